@@ -1,0 +1,373 @@
+"""ctypes wrapper around oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+The oracle is the CPU restatement of the reference's algorithm (see
+ransac_oracle.h).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+PLANE, SPHERE, CYLINDER, CONE = 0, 1, 2, 3
+SCORE_INT64_WRAP, SCORE_F64 = 0, 1
+S_LENGTHC, S_ALLCAND, S_NOFMINSET = 1, 2, 3
+
+
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("outwards", C.c_int32), ("v", C.c_double * 10)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("eps", C.c_double * 4),
+        ("alpha", C.c_double * 4),
+        ("cos_alpha", C.c_double * 4),
+        ("collin_threshold", C.c_double),
+        ("parallelthrdeg", C.c_double),
+        ("cos_parallelthr", C.c_double),
+        ("sphere_par", C.c_double),
+        ("minconeopang", C.c_double),
+        ("prob_det", C.c_double),
+        ("tau", C.c_int64),
+        ("itermax", C.c_int64),
+        ("drawN", C.c_int32),
+        ("minsubsetN", C.c_int32),
+        ("extract_s", C.c_int32),
+        ("terminate_s", C.c_int32),
+        ("n_shape_types", C.c_int32),
+        ("shape_types", C.c_int32 * 8),
+        ("score_mode", C.c_int32),
+        ("sphere_uses_enabled", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class CI(C.Structure):
+    _fields_ = [("min", C.c_double), ("max", C.c_double), ("E", C.c_double)]
+
+
+class Rng(C.Structure):
+    _fields_ = [
+        ("s", C.c_uint64 * 4),
+        ("stream", C.POINTER(C.c_uint64)),
+        ("stream_len", C.c_int64),
+        ("stream_pos", C.c_int64),
+        ("draws", C.c_int64),
+    ]
+
+
+class Extracted(C.Structure):
+    _fields_ = [
+        ("shape", Shape),
+        ("n_inpoints", C.c_int64),
+        ("inpoints", C.POINTER(C.c_int64)),
+        ("score_E", C.c_double),
+        ("iteration", C.c_int64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("shapes", C.POINTER(Extracted)),
+        ("n_shapes", C.c_int64),
+        ("iterations", C.c_int64),
+        ("candidates_scored", C.c_int64),
+        ("scored_left", C.c_int64),
+        ("seconds", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (Makefile in this directory)."""
+    src = os.path.join(_HERE, "ransac_oracle.c")
+    hdr = os.path.join(_HERE, "ransac_oracle.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    dp = C.POINTER(C.c_double)
+    i64p = C.POINTER(C.c_int64)
+    u64p = C.POINTER(C.c_uint64)
+    u8p = C.POINTER(C.c_uint8)
+    i32p = C.POINTER(C.c_int32)
+    sp, pp = C.POINTER(Shape), C.POINTER(Params)
+    sig = {
+        "orc_default_params": (None, [pp]),
+        "orc_params_finalize": (None, [pp]),
+        "orc_shape_finalize": (None, [sp]),
+        "orc_compatible": (C.c_int, [sp, dp, dp, C.c_double, C.c_double]),
+        "orc_confidence_interval": (C.c_int, [C.c_double, C.c_double, C.POINTER(CI)]),
+        "orc_notsoconfident": (CI, [C.c_double, C.c_double]),
+        "orc_isoverlap": (C.c_int, [CI, CI]),
+        "orc_estimatescore": (CI, [C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+        "orc_prob": (C.c_double, [C.c_double, C.c_int64, C.c_int64, C.c_int64]),
+        "orc_cloud_create": (C.c_void_p, [dp, dp, C.c_int64, i64p, C.c_int64]),
+        "orc_cloud_destroy": (None, [C.c_void_p]),
+        "orc_cloud_set_enabled": (None, [C.c_void_p, u64p, C.c_int64]),
+        "orc_cloud_get_enabled": (None, [C.c_void_p, u64p, C.c_int64]),
+        "orc_cloud_enable_all": (None, [C.c_void_p]),
+        "orc_cloud_count_enabled": (C.c_int64, [C.c_void_p]),
+        "orc_scorecandidate": (C.c_int64, [C.c_void_p, sp, pp, i64p, u64p]),
+        "orc_score_batch": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p]),
+        "orc_refit": (C.c_int64, [C.c_void_p, sp, pp, i64p, C.c_int64]),
+        "orc_invalidate": (None, [C.c_void_p, i64p, C.c_int64]),
+        "orc_select_enabled": (C.c_int64, [C.c_void_p, C.c_int64]),
+        "orc_fit": (C.c_int, [C.c_int, dp, dp, C.c_int, pp, sp]),
+        "orc_fit2pointsphere": (C.c_int, [dp, dp, pp, sp]),
+        "orc_fit2pointcylinder": (C.c_int, [dp, dp, pp, sp]),
+        "orc_fit3pointcone": (C.c_int, [dp, dp, sp]),
+        "orc_rodriguesrad": (None, [dp, C.c_double, dp]),
+        "orc_pluscrossprod": (None, [dp, C.c_double, dp]),
+        "orc_rank": (C.c_int, [dp, C.c_int, C.c_int]),
+        "orc_findAABB": (None, [dp, C.c_int64, C.c_int, dp, dp]),
+        "orc_iswithinrectangle": (C.c_int, [dp, dp, dp]),
+        "orc_octree_build": (C.c_void_p, [dp, C.c_int64]),
+        "orc_octree_destroy": (None, [C.c_void_p]),
+        "orc_octree_depth": (C.c_int, [C.c_void_p]),
+        "orc_octree_findleaf": (C.c_int, [C.c_void_p, dp, i32p, C.c_int]),
+        "orc_octree_node_npoints": (C.c_int64, [C.c_void_p, C.c_int32]),
+        "orc_octree_node_points": (i64p, [C.c_void_p, C.c_int32]),
+        "orc_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
+        "orc_rng_next": (C.c_uint64, [C.POINTER(Rng)]),
+        "orc_rng_range": (C.c_int64, [C.POINTER(Rng), C.c_int64]),
+        "orc_ransac": (C.c_int, [C.c_void_p, dp, dp, pp, C.POINTER(Rng), C.c_int, C.POINTER(Result)]),
+        "orc_result_free": (None, [C.POINTER(Result)]),
+        "orc_largestconncomp": (C.c_int64, [u8p, C.c_int32, C.c_int32, C.c_int, i64p, C.c_int64]),
+        "orc_bitmapparameters": (C.c_int, [dp, u8p, i64p, C.c_int64, C.c_double, i32p, i32p, dp, dp, u8p, i64p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "shape_types":
+            p.n_shape_types = len(v)
+            for i, t in enumerate(v):
+                p.shape_types[i] = t
+        elif isinstance(v, (list, tuple, np.ndarray)):
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(p, k, v)
+    lib().orc_params_finalize(C.byref(p))
+    return p
+
+
+def make_shape(kind, outwards, v):
+    s = Shape()
+    s.kind = kind
+    s.outwards = int(bool(outwards))
+    for i, x in enumerate(v):
+        s.v[i] = float(x)
+    lib().orc_shape_finalize(C.byref(s))
+    return s
+
+
+def shapes_array(shapes):
+    arr = (Shape * max(1, len(shapes)))()
+    for i, s in enumerate(shapes):
+        arr[i] = s
+    return arr
+
+
+class Cloud:
+    """Mirror of the pieces of RANSACCloud (octree.jl:37-59) the path reads."""
+
+    def __init__(self, xyz, nrm, subset1_1based):
+        self.xyz = _f64(xyz).reshape(-1, 3)
+        self.nrm = _f64(nrm).reshape(-1, 3)
+        self.subset1 = np.ascontiguousarray(subset1_1based, dtype=np.int64)
+        self.n = self.xyz.shape[0]
+        self.s = self.subset1.shape[0]
+        self.h = lib().orc_cloud_create(_dp(self.xyz), _dp(self.nrm), self.n,
+                                        self.subset1.ctypes.data_as(C.POINTER(C.c_int64)), self.s)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_cloud_destroy(self.h)
+            self.h = None
+
+    @property
+    def nchunks(self):
+        return (self.n + 63) // 64
+
+    def set_enabled(self, chunks):
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64)
+        lib().orc_cloud_set_enabled(self.h, chunks.ctypes.data_as(C.POINTER(C.c_uint64)), chunks.size)
+
+    def get_enabled(self):
+        out = np.zeros(self.nchunks, dtype=np.uint64)
+        lib().orc_cloud_get_enabled(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size)
+        return out
+
+    def enable_all(self):
+        lib().orc_cloud_enable_all(self.h)
+
+    def count_enabled(self):
+        return lib().orc_cloud_count_enabled(self.h)
+
+    def scorecandidate(self, shape, params, want_mask=False):
+        inp = np.zeros(max(1, self.s), dtype=np.int64)
+        w = (self.s + 63) // 64
+        mask = np.zeros(max(1, w), dtype=np.uint64) if want_mask else None
+        cnt = lib().orc_scorecandidate(self.h, C.byref(shape), C.byref(params),
+                                       inp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       mask.ctypes.data_as(C.POINTER(C.c_uint64)) if want_mask else None)
+        return (cnt, inp[:cnt].copy(), mask[:w]) if want_mask else (cnt, inp[:cnt].copy())
+
+    def score_batch(self, shapes, params, want_masks=False):
+        b = len(shapes)
+        arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
+        counts = np.zeros(max(1, b), dtype=np.int32)
+        w = (self.s + 63) // 64
+        masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64) if want_masks else None
+        lib().orc_score_batch(self.h, arr, b, C.byref(params),
+                              counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                              masks.ctypes.data_as(C.POINTER(C.c_uint64)) if want_masks else None)
+        return (counts[:b], masks[:b, :w]) if want_masks else counts[:b]
+
+    def refit(self, shape, params):
+        out = np.zeros(max(1, self.n), dtype=np.int64)
+        cnt = lib().orc_refit(self.h, C.byref(shape), C.byref(params),
+                              out.ctypes.data_as(C.POINTER(C.c_int64)), self.n)
+        return out[:cnt].copy()
+
+    def invalidate(self, idx_1based):
+        idx = np.ascontiguousarray(idx_1based, dtype=np.int64)
+        lib().orc_invalidate(self.h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size)
+
+    def select_enabled(self, k):
+        return lib().orc_select_enabled(self.h, int(k))
+
+    def ransac(self, params, seed=1234, stream=None, octree_depth=1):
+        rng = Rng()
+        lib().orc_rng_seed(C.byref(rng), seed)
+        if stream is not None:
+            stream = np.ascontiguousarray(stream, dtype=np.uint64)
+            rng.stream = stream.ctypes.data_as(C.POINTER(C.c_uint64))
+            rng.stream_len = stream.size
+        res = Result()
+        rc = lib().orc_ransac(self.h, _dp(self.xyz), _dp(self.nrm), C.byref(params),
+                              C.byref(rng), octree_depth, C.byref(res))
+        out = {"rc": rc, "iterations": res.iterations, "candidates_scored": res.candidates_scored,
+               "scored_left": res.scored_left, "seconds": res.seconds, "draws": rng.draws, "shapes": []}
+        for i in range(res.n_shapes):
+            e = res.shapes[i]
+            sh = Shape.from_buffer_copy(bytes(e.shape))
+            idx = np.ctypeslib.as_array(e.inpoints, shape=(max(1, e.n_inpoints),))[: e.n_inpoints].copy()
+            out["shapes"].append({"shape": sh, "inpoints": idx, "score_E": e.score_E, "iteration": e.iteration})
+        lib().orc_result_free(C.byref(res))
+        return out
+
+
+def fit(kind, p, n, params):
+    p, n = _f64(p).reshape(-1, 3), _f64(n).reshape(-1, 3)
+    out = Shape()
+    ok = lib().orc_fit(kind, _dp(p), _dp(n), p.shape[0], C.byref(params), C.byref(out))
+    return out if ok else None
+
+
+def compatible(shape, p, n, eps, cos_alpha):
+    p, n = _f64(p), _f64(n)
+    return bool(lib().orc_compatible(C.byref(shape), _dp(p), _dp(n), eps, cos_alpha))
+
+
+def estimatescore(S1, P, sigma, mode=SCORE_INT64_WRAP):
+    ci = lib().orc_estimatescore(S1, P, sigma, mode)
+    return ci.min, ci.max, ci.E
+
+
+def prob(n, s, N, k):
+    return lib().orc_prob(float(n), int(s), int(N), int(k))
+
+
+def largestconncomp(bitmap_xy, conn8=False):
+    """bitmap_xy: 2-D bool array indexed [x, y] like a Julia BitMatrix.
+    Returns 0-based column-major linear indices of the largest component."""
+    bm = np.asfortranarray(np.asarray(bitmap_xy, dtype=np.uint8))
+    xs, ys = bm.shape
+    flat = np.ascontiguousarray(bm.reshape(-1, order="F"))
+    out = np.zeros(max(1, flat.size), dtype=np.int64)
+    k = lib().orc_largestconncomp(flat.ctypes.data_as(C.POINTER(C.c_uint8)), xs, ys, int(conn8),
+                                  out.ctypes.data_as(C.POINTER(C.c_int64)), out.size)
+    return out[:k].copy()
+
+
+def bitmapparameters(params2d, compat, beta, idsource=None):
+    prm = _f64(params2d).reshape(-1, 2)
+    n = prm.shape[0]
+    comp = np.ascontiguousarray(compat, dtype=np.uint8)
+    ids = None if idsource is None else np.ascontiguousarray(idsource, dtype=np.int64)
+    xs, ys = C.c_int32(), C.c_int32()
+    bx, by = C.c_double(), C.c_double()
+    idp = None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_int64))
+    rc = lib().orc_bitmapparameters(_dp(prm), comp.ctypes.data_as(C.POINTER(C.c_uint8)), idp, n, beta,
+                                    C.byref(xs), C.byref(ys), C.byref(bx), C.byref(by), None, None)
+    if rc:
+        raise AssertionError("max-min should be positive")
+    bitmap = np.zeros(xs.value * ys.value, dtype=np.uint8)
+    idxmap = np.zeros(xs.value * ys.value, dtype=np.int64)
+    lib().orc_bitmapparameters(_dp(prm), comp.ctypes.data_as(C.POINTER(C.c_uint8)), idp, n, beta,
+                               C.byref(xs), C.byref(ys), C.byref(bx), C.byref(by),
+                               bitmap.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               idxmap.ctypes.data_as(C.POINTER(C.c_int64)))
+    shape = (xs.value, ys.value)
+    return bitmap.reshape(shape, order="F").astype(bool), idxmap.reshape(shape, order="F"), (bx.value, by.value)
+
+
+class Octree:
+    def __init__(self, xyz):
+        self.xyz = _f64(xyz).reshape(-1, 3)
+        self.h = lib().orc_octree_build(_dp(self.xyz), self.xyz.shape[0])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_octree_destroy(self.h)
+            self.h = None
+
+    def depth(self):
+        return lib().orc_octree_depth(self.h)
+
+    def findleaf(self, p):
+        p = _f64(p)
+        path = (C.c_int32 * 64)()
+        d = lib().orc_octree_findleaf(self.h, _dp(p), path, 64)
+        return d, list(path[:d])
+
+    def node_points(self, node):
+        n = lib().orc_octree_node_npoints(self.h, node)
+        ptr = lib().orc_octree_node_points(self.h, node)
+        return np.ctypeslib.as_array(ptr, shape=(max(1, n),))[:n].copy()

@@ -1,0 +1,118 @@
+"""Writes reference_known_answers.json: the inputs and expected outputs of the
+reference's own known-answer tests that touch the hot path, transcribed as DATA
+(values only) from /root/reference/test/*.jl.  No reference code is executed or
+stored: Julia is not available in the build container.  Each block
+names the test file:line it was read from.  Run once; the JSON is committed."""
+import json
+import os
+
+F, T = False, True
+out = {}
+
+# test/octree.jl:8-114 -- rectangle = HyperRectangle((0,0,0),(1,1,1))
+out["iswithinrectangle"] = {
+    "source": "test/octree.jl:8-114",
+    "origin": [0.0, 0.0, 0.0], "widths": [1.0, 1.0, 1.0],
+    "cases": [
+        # corner points :10-32
+        [[0, 0, 0], F], [[1, 0, 0], F], [[0, 1, 0], F], [[0, 0, 1], F],
+        [[1, 1, 0], F], [[1, 0, 1], F], [[0, 1, 1], F], [[1, 1, 1], T],
+        # edge midpoints :34-64
+        [[0.5, 0, 0], F], [[0.5, 0, 1], F], [[0, 0.5, 0], F], [[0, 0.5, 1], F],
+        [[1, 0.5, 0], F], [[0.5, 1, 0], F], [[1, 0, 0.5], F], [[0, 0, 0.5], F],
+        [[0, 1, 0.5], F], [[1, 0.5, 1], T], [[0.5, 1, 1], T], [[1, 1, 0.5], T],
+        # face midpoints :66-84
+        [[0.5, 0.5, 0], F], [[0.5, 0, 0.5], F], [[0, 0.5, 0.5], F],
+        [[0.5, 0.5, 1], T], [[0.5, 1, 0.5], T], [[1, 0.5, 0.5], T],
+        # inside points :86-99
+        [[0.5, 0.5, 0.1], T], [[0.5, 0.1, 0.5], T], [[0.1, 0.5, 0.5], T],
+        [[0.5, 0.5, 0.9], T], [[0.5, 0.9, 0.5], T], [[0.9, 0.5, 0.5], T],
+        # outside points :101-114
+        [[0.5, 0.5, -0.1], F], [[0.5, -0.1, 0.5], F], [[-0.1, 0.5, 0.5], F],
+        [[0.5, 0.5, 1.1], F], [[0.5, 1.1, 0.5], F], [[1.1, 0.5, 0.5], F],
+    ],
+}
+
+# test/octree.jl:116-140 -- ps = [SVector(i,j,k)/3 for i in 0:5 for j in 0:5 for k in 0:5]
+out["octree_grid"] = {
+    "source": "test/octree.jl:116-140",
+    "grid_n": 6, "divide_by": 3.0,
+    "query_point_1based": 117,
+    "expected_leaf_depth": 3,
+    "expected_octree_depth": 3,
+    "getnthcell_nothing_levels": [-1, 0, 4, 5],
+}
+
+# test/dummyspheretest.jl:6-49 -- EPSI = 0.1, ALFI = deg2rad(10)
+tn = [[0, -1, 0.0], [0, 0, -1.0], [1, 0, 0.0], [0, 1, 0.0]]
+out["dummysphere"] = {
+    "source": "test/dummyspheretest.jl:6-49",
+    "sphere_eps": 0.1, "sphere_alpha_deg": 10.0,
+    "plane_alpha_rad_is_pi_over_2": True, "collin_threshold": 0.2,
+    "sets": [
+        {"name": "true sphere 1", "v": [[0, -1, 0.0], [0, 0, -1.0], [1, 0, 0.0], [0, 1, 0.0]], "n": tn,
+         "sphere": True, "plane": False,
+         "hand_derived": {"center": [0, 0, 0], "radius": 1.0, "outwards": True}},
+        {"name": "true sphere 2", "v": [[0, -0.99, 0.0], [0, 0, -1.0], [1.01, 0, 0.0], [0, 1, 0.0]], "n": tn,
+         "sphere": True, "sphere_eps_0.01": False, "plane": False},
+        {"name": "false sphere 1", "v": [[0, 1, 0.0], [0, 0, -1.0], [1, 0, 0.0], [0, 1, 0.0]], "n": tn,
+         "sphere": False, "sphere_eps10_alpha_pi2": False, "plane": False},
+    ],
+}
+
+# test/utilitytests.jl:41-65 and src defaults
+out["default_parameters"] = {
+    "source": "test/utilitytests.jl:41-65",
+    "common": {"collin_threshold": 0.2, "parallelthrdeg": 1.0},
+    "iteration": {"drawN": 3, "minsubsetN": 15, "prob_det": 0.9, "tau": 900, "itermax": 1000,
+                  "extract_s": "nofminset", "terminate_s": "nofminset"},
+    "sphere": {"eps": 0.3, "alpha_deg": 5.0, "sphere_par": 0.02},
+    "plane": {"eps": 0.3, "alpha_deg": 5.0},
+    "cylinder": {"eps": 0.3, "alpha_deg": 5.0},
+    "cone": {"eps": 0.3, "alpha_deg": 5.0, "minconeopang_deg": 2.0},
+    "default_shape_order": ["plane", "cone", "cylinder", "sphere"],
+}
+
+# test/utilitytests.jl:116-133 -- pluscrossprod!(A, val, v) == A + val .* crossprodtensor(v)
+out["pluscrossprod"] = {
+    "source": "test/utilitytests.jl:116-133",
+    "property": "A + value*[0 -v3 v2; v3 0 -v1; -v2 v1 0] elementwise-equal",
+    "values": [0.25881904510252074, 1.0, 0.0],  # sin(deg2rad(15)), 1, 0
+}
+
+# test/confidenceintervals.jl:1-26
+out["confidence_interval"] = {
+    "source": "test/confidenceintervals.jl:1-26",
+    "ctor": {"a": 1.0, "b": 3.0, "E": 2.0, "reversed_throws": True},
+    "notsoconfident": {"a": 9.7, "b": 153.9, "min": 9.7, "max": 153.9, "E": 81.8},
+}
+
+# test/parameterspacebitmap.jl:1-55 (test disabled upstream, runtests.jl:38-42).
+# 1-based inclusive ranges [x0, x1, step, y0, y1, step]; idx = values appended per pixel
+out["largestconncomp"] = {
+    "source": "test/parameterspacebitmap.jl:1-55",
+    "size": [150, 150],
+    "dense": {
+        "patches": [
+            {"range": [55, 75, 1, 55, 75, 1], "idx": [1, 2, 3]},
+            {"range": [100, 125, 1, 100, 125, 1], "idx": [-99, -98]},
+            {"range": [130, 140, 1, 130, 140, 1], "idx": [0]},
+        ],
+        "expected_conn4": {"idx": [-99, -98], "repeat": 676},
+        "expected_conn8": {"idx": [-99, -98], "repeat": 676},
+    },
+    "eight": {
+        "patches": [
+            {"range": [55, 73, 1, 55, 73, 1], "idx": [1, 2, 3]},
+            {"range": [100, 126, 2, 100, 126, 2], "idx": [-99, -98]},
+            {"range": [101, 127, 2, 101, 127, 2], "idx": [-99, -98]},
+            {"range": [130, 140, 1, 130, 140, 1], "idx": [0]},
+        ],
+        "expected_conn4": {"idx": [1, 2, 3], "repeat": 361},
+        "expected_conn8": {"idx": [-99, -98], "repeat": 392},
+    },
+}
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("ok")
