@@ -1,0 +1,229 @@
+/*
+ * ransac_hip.h -- C ABI of libransac_hip.so: the MI355X-native (gfx950, HIP)
+ * replacement for the data-parallel hot path of cserteGT3/RANSAC.jl v0.6.0.
+ *
+ * The reference has no FFI; its boundary is Julia multiple dispatch on
+ * FittedShape subtypes (src/fitting.jl:8-66).  Each entry point below names the
+ * reference function it replaces (paths under /root/reference).  A Julia
+ * `ccall` shim (julia/RANSACHIP.jl) or any FFI binds these.
+ *
+ * Conventions
+ *  - every call returns int: 0 = ok, negative = error (RH_E_*); the message is
+ *    available from rh_last_error() on the calling thread;
+ *  - the caller allocates every output; the library never keeps a host pointer
+ *    past the call and never calls back into the host runtime (GC-safe);
+ *  - point indices cross the boundary 1-based int64, like `inpoints::Vector{Int}`
+ *    (src/fitting.jl:81-84);
+ *  - enabled bits use BitVector's layout: uint64 chunks, bit i%64 of chunk i/64,
+ *    LSB first (src/octree.jl:42);
+ *  - one host thread per rh_cloud at a time; calls are synchronous unless the
+ *    name ends in _dev (those enqueue on the cloud's HIP stream);
+ *  - all arithmetic is IEEE binary64 in the reference's operation order
+ *    (no FMA contraction), so inlier sets are bit-identical to the CPU path.
+ *  - there is NO CPU fallback: without a usable HIP device every cloud call
+ *    fails with RH_E_NODEVICE.
+ */
+#ifndef RANSAC_HIP_H
+#define RANSAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_VERSION 100
+
+enum {
+    RH_OK = 0,
+    RH_E_INVALID = -1,   /* bad argument (the reference would hit an @assert) */
+    RH_E_NODEVICE = -2,  /* no HIP device / HIP runtime error */
+    RH_E_NOMEM = -3,
+    RH_E_CAPACITY = -4,  /* caller-provided output too small; *n_out holds the needed size */
+    RH_E_INTERNAL = -5,
+};
+
+/* shape kinds */
+enum { RH_PLANE = 0, RH_SPHERE = 1, RH_CYLINDER = 2, RH_CONE = 3 };
+
+/* POD candidate = the reference's FittedShape structs flattened:
+ *   RH_PLANE    FittedPlane    (src/shapes/plane.jl:8-11)     v[0..2]=point  v[3..5]=normal
+ *   RH_SPHERE   FittedSphere   (src/shapes/sphere.jl:9-13)    v[0..2]=center v[3]=radius
+ *   RH_CYLINDER FittedCylinder (src/shapes/cylinder.jl:11-16) v[0..2]=axis   v[3..5]=center v[6]=radius
+ *   RH_CONE     FittedCone     (src/shapes/cone.jl:11-19)     v[0..2]=apex   v[3..5]=axis   v[6]=opang
+ *                              v[7]=cos(-opang/2), v[8]=sin(-opang/2): computed by the HOST
+ *                              (the reference evaluates them in rodrigues, src/utilities.jl:21-22);
+ *                              rh_shape_finalize fills them with the C libm.
+ * `outwards` is the Bool field of sphere/cylinder/cone; ignored for planes. */
+typedef struct {
+    int32_t kind;
+    int32_t outwards;
+    double v[10];
+} rh_shape;
+
+enum { RH_SCORE_INT64_WRAP = 0, RH_SCORE_F64 = 1 };
+enum { RH_S_LENGTHC = 1, RH_S_ALLCAND = 2, RH_S_NOFMINSET = 3 };
+
+/* Parameters = the reference's nested NamedTuple (src/utilities.jl:332-399 and the
+ * defaultshapeparameters of each shape file), flattened.  Per-kind arrays are
+ * indexed by RH_* kind.  cos_alpha[] / cos_parallelthr are thresholds computed by
+ * the host (rh_params_finalize uses the C libm). */
+typedef struct {
+    double eps[4];             /* <shape>.eps  */
+    double alpha[4];           /* <shape>.alpha (rad) */
+    double cos_alpha[4];       /* cos(alpha): isparallel, src/utilities.jl:115-117 */
+    double collin_threshold;   /* common.collin_threshold */
+    double parallelthrdeg;     /* common.parallelthrdeg */
+    double cos_parallelthr;    /* cosd(parallelthrdeg) */
+    double sphere_par;         /* sphere.sphere_par */
+    double minconeopang;       /* cone.minconeopang */
+    double prob_det;           /* iteration.prob_det */
+    int64_t tau;               /* iteration.tau */
+    int64_t itermax;           /* iteration.itermax */
+    int32_t drawN;             /* iteration.drawN */
+    int32_t minsubsetN;        /* iteration.minsubsetN */
+    int32_t extract_s;         /* iteration.extract_s  (RH_S_*) */
+    int32_t terminate_s;       /* iteration.terminate_s */
+    int32_t n_shape_types;
+    int32_t shape_types[8];    /* iteration.shape_types as RH_* kinds, in order */
+    int32_t score_mode;        /* RH_SCORE_INT64_WRAP = the reference's wrapping Int64 product
+                                  (src/confidenceintervals.jl:54,72); RH_SCORE_F64 = fixed */
+    int32_t sphere_uses_enabled; /* 0 = reference behaviour (src/shapes/sphere.jl:121,131) */
+    int32_t reserved;
+} rh_params;
+
+typedef struct rh_cloud rh_cloud;
+
+/* ---- library ---- */
+int rh_version(void);
+const char *rh_last_error(void);
+int rh_device_count(int *n_out);
+
+/* ---- parameters (src/utilities.jl:332-399; RANSAC.jl:94) ---- */
+void rh_default_params(rh_params *p);
+void rh_params_finalize(rh_params *p);
+void rh_shape_finalize(rh_shape *s);
+
+/* ---- cloud: replaces RANSACCloud (src/octree.jl:37-59, ctors :78-138) ----
+ * xyz_aos / nrm_aos: n x 3 doubles, i.e. Julia's Vector{SVector{3,Float64}} memory
+ * as is; subset1_idx_1based: pc.subsets[1] (the only subset the reference scores,
+ * src/iterations.jl:95).  Transposes to SoA in HBM, stores subset 1 contiguously in
+ * subset order; all points start enabled (src/octree.jl:84). */
+int rh_cloud_create(const double *xyz_aos, const double *nrm_aos, int64_t n,
+                    const int64_t *subset1_idx_1based, int64_t s, int device, rh_cloud **out);
+int rh_cloud_destroy(rh_cloud *c);
+int rh_cloud_info(const rh_cloud *c, int64_t *n, int64_t *s, int *device);
+/* pc.isenabled (BitVector.chunks) in / out; nchunks must be ceil(n/64) */
+int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t nchunks);
+int rh_cloud_get_enabled(rh_cloud *c, uint64_t *chunks, int64_t nchunks);
+int rh_cloud_enable_all(rh_cloud *c);                   /* ransac(pc, params, true): src/iterations.jl:14-21 */
+int rh_cloud_count_enabled(rh_cloud *c, int64_t *out);  /* count(pc.isenabled): src/iterations.jl:75 */
+
+/* ---- hot path ---- */
+
+/* Replaces scorecandidates! (src/fitting.jl:181-190) = B x scorecandidate
+ * (plane.jl:61-71, sphere.jl:118-134, cylinder.jl:172-183, cone.jl:155-167) with one
+ * batched launch per shape kind.  counts_out[b] = number of compatible (and, except
+ * for spheres in reference mode, enabled) points of subset 1.  masks_out (optional):
+ * b rows of ceil(s/64) words; bit j of row i = subset position j is an inpoint of
+ * candidate i, so inpoints = subsets[1][mask] in subset order. */
+int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p,
+                   int32_t *counts_out, uint64_t *masks_out_or_null);
+
+/* Same, all buffers resident in HBM on the cloud's device, enqueued on the cloud's
+ * stream without synchronising (bench / multi-GPU plumbing). d_counts must hold b
+ * int32 (overwritten). */
+int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                       int32_t *d_counts, uint64_t *d_masks_or_null);
+
+/* Replaces refit (plane.jl:137-143, sphere.jl:179-190, cylinder.jl:228-234,
+ * cone.jl:176-182): all enabled compatible points of the WHOLE cloud, ascending
+ * 1-based.  If more than cap are found returns RH_E_CAPACITY with *n_out = needed. */
+int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p,
+             int64_t *idx_out_1based, int64_t cap, int64_t *n_out);
+
+/* Replaces invalidate_indexes! (src/fitting.jl:197-202). */
+int rh_invalidate(rh_cloud *c, const int64_t *idx_1based, int64_t n);
+
+/* Replaces the enabled-cell gather of samplepointcloud4! (src/fitting.jl:405-407,
+ * 415-422) for the root cell: idx_out[i] = the ranks[i]-th enabled point (1-based
+ * rank, ascending index order), 0 if the rank is out of range. */
+int rh_select_enabled(rh_cloud *c, const int64_t *ranks_1based, int32_t k, int64_t *idx_out_1based);
+
+/* ---- host-side pieces of the plugin API (O(1) per minimal set) ---- */
+
+/* fit(::Type{T}, p, n, pc, params) (plane.jl:33-57, sphere.jl:87-114,
+ * cylinder.jl:135-168, cone.jl:123-128).  p, n: lp x 3 AoS.  *fitted = 0 is the
+ * reference's `nothing`. */
+int rh_fit(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm,
+           rh_shape *out, int32_t *fitted);
+
+/* estimatescore / ConfidenceInterval (src/confidenceintervals.jl:71-74, 53-59, 1-6) */
+int rh_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int32_t score_mode,
+                     double *ci_min, double *ci_max, double *ci_E);
+/* prob(n, s, N, k) (src/utilities.jl:262) */
+double rh_prob(double n, int64_t s, int64_t N, int64_t k);
+
+/* ---- driver: replaces ransac(pc, params) (src/iterations.jl:35-162) ---- */
+typedef struct {
+    uint64_t s[4];           /* xoshiro256++ state (rh_rng_seed) */
+    const uint64_t *stream;  /* optional injected raw 64-bit draws, consumed first */
+    int64_t stream_len, stream_pos;
+    int64_t draws;
+} rh_rng;
+void rh_rng_seed(rh_rng *r, uint64_t seed);
+/* rand(1:n) = 1 + floor(next * n / 2^64) */
+int64_t rh_rng_range(rh_rng *r, int64_t n);
+
+typedef struct {
+    rh_shape shape;
+    int64_t n_inpoints;
+    int64_t *inpoints;       /* ascending, 1-based; owned by the result */
+    double score_E;
+    int64_t iteration;
+} rh_extracted;              /* ExtractedShape, src/fitting.jl:81-84 */
+
+typedef struct {
+    rh_extracted *shapes;
+    int64_t n_shapes;
+    int64_t iterations;
+    int64_t candidates_scored;
+    int64_t scored_left;
+    double seconds;          /* wall time of the loop (src/iterations.jl:46,159; not truncated) */
+    double seconds_score;    /* device time in score launches + count read-back */
+    double seconds_extract;  /* refit + invalidate + candidate liveness */
+    double seconds_host;     /* sampling + fit + bookkeeping */
+} rh_result;
+
+/* xyz_aos / nrm_aos: the same host arrays given to rh_cloud_create (read for the
+ * minimal-set fits only).  The cloud's enabled bits are updated in place, like
+ * pc.isenabled. */
+int rh_ransac(rh_cloud *c, const double *xyz_aos, const double *nrm_aos, const rh_params *p,
+              rh_rng *rng, rh_result *out);
+void rh_result_free(rh_result *r);
+
+/* ---- parameter-space bitmap + largest connected component
+ *      (src/parameterspacebitmap.jl:12-60, 69-109; dead code upstream) ----
+ * bitmap: xs*ys bytes, column-major like a Julia BitMatrix (pixel [x,y] at x + xs*y,
+ * 0-based).  conn8 = 0: 4-connectivity (`1:ndims`), 1: `trues(3,3)`.  Writes the
+ * 0-based linear indices (ascending) of the largest component. */
+int rh_largestconncomp(const uint8_t *bitmap, int32_t xs, int32_t ys, int32_t conn8, int device,
+                       int64_t *out, int64_t cap, int64_t *n_out);
+int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int64_t *idsource_or_null,
+                        int64_t n, double beta, int32_t *xs, int32_t *ys, double *betax, double *betay,
+                        uint8_t *bitmap_or_null, int64_t *idxmap_or_null);
+
+/* ---- measurement plumbing (bench.py): HIP events on the cloud's stream ---- */
+int rh_timer_start(rh_cloud *c);
+int rh_timer_stop(rh_cloud *c, float *ms_out); /* synchronises the stream */
+int rh_cloud_sync(rh_cloud *c);
+/* device allocations on the cloud's device for the *_dev entry points */
+int rh_dev_alloc(rh_cloud *c, int64_t bytes, void **d_out);
+int rh_dev_free(rh_cloud *c, void *d);
+int rh_dev_upload(rh_cloud *c, void *d_dst, const void *h_src, int64_t bytes);
+int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

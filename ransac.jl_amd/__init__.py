@@ -1,0 +1,12 @@
+"""ransac.jl_amd -- MI355X-native (gfx950 HIP) hot path of Efficient RANSAC behind the API of
+cserteGT3/RANSAC.jl: FittedShape / RANSACCloud / ransac().  Import as `ransac_jl_amd`."""
+from . import _lib, synth
+from ._lib import (CONE, CYLINDER, PLANE, SPHERE, SCORE_F64, SCORE_INT64_WRAP, RansacHipError, lib)
+from .api import (DEFAULT_PARAMETERS, DEFAULT_SHAPE_DICT, ConfidenceInterval, E, ExtractedShape, FittedCone,
+                  FittedCylinder, FittedPlane, FittedShape, FittedSphere, RANSACCloud, bitmapparameters,
+                  defaultcommonparameters, defaultiterationparameters, defaultparameters,
+                  defaultshapeparameters, estimatescore, fit, invalidate_indexes, largestconncomp,
+                  notsoconfident, params_to_c, prob, ransac, ransacparameters, refit, score_batch,
+                  scorecandidate, select_enabled, shape_from_c, strt)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,123 @@
+"""ctypes binding of libransac_hip.so (include/ransac_hip.h).  Loading fails loudly when the
+HIP library has not been built: there is no CPU fallback in the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libransac_hip.so")
+
+PLANE, SPHERE, CYLINDER, CONE = 0, 1, 2, 3
+KIND_NAMES = {PLANE: "plane", SPHERE: "sphere", CYLINDER: "cylinder", CONE: "cone"}
+SCORE_INT64_WRAP, SCORE_F64 = 0, 1
+S_LENGTHC, S_ALLCAND, S_NOFMINSET = 1, 2, 3
+RH_OK, RH_E_INVALID, RH_E_NODEVICE, RH_E_NOMEM, RH_E_CAPACITY, RH_E_INTERNAL = 0, -1, -2, -3, -4, -5
+
+
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("outwards", C.c_int32), ("v", C.c_double * 10)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("eps", C.c_double * 4), ("alpha", C.c_double * 4), ("cos_alpha", C.c_double * 4),
+        ("collin_threshold", C.c_double), ("parallelthrdeg", C.c_double), ("cos_parallelthr", C.c_double),
+        ("sphere_par", C.c_double), ("minconeopang", C.c_double), ("prob_det", C.c_double),
+        ("tau", C.c_int64), ("itermax", C.c_int64),
+        ("drawN", C.c_int32), ("minsubsetN", C.c_int32), ("extract_s", C.c_int32), ("terminate_s", C.c_int32),
+        ("n_shape_types", C.c_int32), ("shape_types", C.c_int32 * 8),
+        ("score_mode", C.c_int32), ("sphere_uses_enabled", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Rng(C.Structure):
+    _fields_ = [("s", C.c_uint64 * 4), ("stream", C.POINTER(C.c_uint64)), ("stream_len", C.c_int64),
+                ("stream_pos", C.c_int64), ("draws", C.c_int64)]
+
+
+class Extracted(C.Structure):
+    _fields_ = [("shape", Shape), ("n_inpoints", C.c_int64), ("inpoints", C.POINTER(C.c_int64)),
+                ("score_E", C.c_double), ("iteration", C.c_int64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("shapes", C.POINTER(Extracted)), ("n_shapes", C.c_int64), ("iterations", C.c_int64),
+                ("candidates_scored", C.c_int64), ("scored_left", C.c_int64), ("seconds", C.c_double),
+                ("seconds_score", C.c_double), ("seconds_extract", C.c_double), ("seconds_host", C.c_double)]
+
+
+class RansacHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libransac_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_sp, _pp, _vp = C.POINTER(Shape), C.POINTER(Params), C.c_void_p
+
+# every symbol include/ransac_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rh_version": (C.c_int, []),
+    "rh_last_error": (C.c_char_p, []),
+    "rh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rh_default_params": (None, [_pp]),
+    "rh_params_finalize": (None, [_pp]),
+    "rh_shape_finalize": (None, [_sp]),
+    "rh_cloud_create": (C.c_int, [_dp, _dp, C.c_int64, _i64p, C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "rh_cloud_destroy": (C.c_int, [_vp]),
+    "rh_cloud_info": (C.c_int, [_vp, _i64p, _i64p, C.POINTER(C.c_int)]),
+    "rh_cloud_set_enabled": (C.c_int, [_vp, _u64p, C.c_int64]),
+    "rh_cloud_get_enabled": (C.c_int, [_vp, _u64p, C.c_int64]),
+    "rh_cloud_enable_all": (C.c_int, [_vp]),
+    "rh_cloud_count_enabled": (C.c_int, [_vp, _i64p]),
+    "rh_score_batch": (C.c_int, [_vp, _sp, C.c_int32, _pp, _i32p, _u64p]),
+    "rh_score_batch_dev": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp]),
+    "rh_refit": (C.c_int, [_vp, _sp, _pp, _i64p, C.c_int64, _i64p]),
+    "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
+    "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),
+    "rh_fit": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
+    "rh_estimatescore": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp, _dp, _dp]),
+    "rh_prob": (C.c_double, [C.c_double, C.c_int64, C.c_int64, C.c_int64]),
+    "rh_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
+    "rh_rng_range": (C.c_int64, [C.POINTER(Rng), C.c_int64]),
+    "rh_ransac": (C.c_int, [_vp, _dp, _dp, _pp, C.POINTER(Rng), C.POINTER(Result)]),
+    "rh_result_free": (None, [C.POINTER(Result)]),
+    "rh_largestconncomp": (C.c_int, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int, _i64p, C.c_int64, _i64p]),
+    "rh_bitmapparameters": (C.c_int, [_dp, _u8p, _i64p, C.c_int64, C.c_double, _i32p, _i32p, _dp, _dp, _u8p, _i64p]),
+    "rh_timer_start": (C.c_int, [_vp]),
+    "rh_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "rh_cloud_sync": (C.c_int, [_vp]),
+    "rh_dev_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "rh_dev_free": (C.c_int, [_vp, _vp]),
+    "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if libransac_hip.so is missing (run `python -c 'import
+    __graft_entry__ as g; g.build()'` or `python ransac.jl_amd/build.py`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "%s is missing: the HIP extension has not been built and this package has no CPU "
+                "fallback (build it with ransac.jl_amd/build.py)" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != RH_OK:
+        raise RansacHipError(rc, lib().rh_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,481 @@
+"""Host-side mirror of the reference's API for the hot path -- same names, argument meaning
+and error behaviour as cserteGT3/RANSAC.jl v0.6.0 (paths in comments are under
+/root/reference/src), with every data-parallel step routed through the C ABI of
+libransac_hip.so.  Nothing here computes a score or an inlier set on the CPU."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import CONE, CYLINDER, PLANE, SPHERE, check, lib
+
+
+# ------------------------------------------------------------------ shapes ----
+class FittedShape:
+    """abstract supertype of all fitted shapes (fitting.jl:6)"""
+    kind = None
+
+    def to_c(self):
+        raise NotImplementedError
+
+
+def _vec(a):
+    a = np.asarray(a, dtype=np.float64).reshape(3)
+    return a
+
+
+class FittedPlane(FittedShape):  # shapes/plane.jl:8-11
+    kind = PLANE
+
+    def __init__(self, point, normal):
+        self.point, self.normal = _vec(point), _vec(normal)
+
+    def to_c(self):
+        return _mk(PLANE, False, list(self.point) + list(self.normal))
+
+    def __repr__(self):
+        return "FittedPlane(normal: %s, point: %s)" % (self.normal, self.point)
+
+
+class FittedSphere(FittedShape):  # shapes/sphere.jl:9-13
+    kind = SPHERE
+
+    def __init__(self, center, radius, outwards):
+        self.center, self.radius, self.outwards = _vec(center), float(radius), bool(outwards)
+
+    def to_c(self):
+        return _mk(SPHERE, self.outwards, list(self.center) + [self.radius])
+
+    def __repr__(self):
+        return "FittedSphere(center: %s, R: %s, %s)" % (self.center, self.radius, "outwards" if self.outwards else "inwards")
+
+
+class FittedCylinder(FittedShape):  # shapes/cylinder.jl:11-16
+    kind = CYLINDER
+
+    def __init__(self, axis, center, radius, outwards):
+        self.axis, self.center, self.radius, self.outwards = _vec(axis), _vec(center), float(radius), bool(outwards)
+
+    def to_c(self):
+        return _mk(CYLINDER, self.outwards, list(self.axis) + list(self.center) + [self.radius])
+
+    def __repr__(self):
+        return "FittedCylinder(center: %s, axis: %s, R: %s, %s)" % (
+            self.center, self.axis, self.radius, "outwards" if self.outwards else "inwards")
+
+
+class FittedCone(FittedShape):  # shapes/cone.jl:11-19
+    kind = CONE
+
+    def __init__(self, apex, axis, opang, outwards):
+        self.apex, self.axis, self.opang, self.outwards = _vec(apex), _vec(axis), float(opang), bool(outwards)
+
+    def to_c(self):
+        return _mk(CONE, self.outwards, list(self.apex) + list(self.axis) + [self.opang])
+
+    def __repr__(self):
+        return "FittedCone(apex: %s, axis: %s, w: %s, %s)" % (
+            self.apex, self.axis, self.opang, "outwards" if self.outwards else "inwards")
+
+
+def _mk(kind, outwards, v):
+    s = L.Shape()
+    s.kind = kind
+    s.outwards = int(bool(outwards))
+    for i, x in enumerate(v):
+        s.v[i] = float(x)
+    lib().rh_shape_finalize(C.byref(s))
+    return s
+
+
+def shape_from_c(s):
+    v = list(s.v)
+    if s.kind == PLANE:
+        return FittedPlane(v[0:3], v[3:6])
+    if s.kind == SPHERE:
+        return FittedSphere(v[0:3], v[3], bool(s.outwards))
+    if s.kind == CYLINDER:
+        return FittedCylinder(v[0:3], v[3:6], v[6], bool(s.outwards))
+    if s.kind == CONE:
+        return FittedCone(v[0:3], v[3:6], v[6], bool(s.outwards))
+    raise ValueError("unknown kind %d" % s.kind)
+
+
+def strt(x):  # fitting.jl:66; shapes/*.jl `strt`
+    return L.KIND_NAMES[x.kind]
+
+
+DEFAULT_SHAPE_DICT = {"plane": FittedPlane, "cone": FittedCone, "cylinder": FittedCylinder, "sphere": FittedSphere}
+_KIND_OF = {FittedPlane: PLANE, FittedSphere: SPHERE, FittedCylinder: CYLINDER, FittedCone: CONE}
+
+
+class ExtractedShape:  # fitting.jl:81-84
+    def __init__(self, shape, inpoints):
+        self.shape = shape
+        self.inpoints = np.asarray(inpoints, dtype=np.int64)
+
+    def __repr__(self):
+        return "Cand: (%s), %d ps" % (strt(self.shape), len(self.inpoints))
+
+
+class ConfidenceInterval:  # confidenceintervals.jl:1-6
+    def __init__(self, x, y):
+        if x > y:
+            raise ValueError("out of order")
+        self.min, self.max, self.E = float(x), float(y), (float(x) + float(y)) / 2
+
+    def __repr__(self):
+        return "CI: [%s, %s]" % (self.min, self.max)
+
+
+def E(x):  # confidenceintervals.jl:43
+    return x.E
+
+
+def notsoconfident(x, y):  # confidenceintervals.jl:20-22
+    return ConfidenceInterval(min(x, y), max(x, y))
+
+
+def estimatescore(S1length, Plength, sigma, score_mode=L.SCORE_INT64_WRAP):  # confidenceintervals.jl:71-74
+    lo, hi, e = C.c_double(), C.c_double(), C.c_double()
+    check(lib().rh_estimatescore(int(S1length), int(Plength), int(sigma), score_mode,
+                                 C.byref(lo), C.byref(hi), C.byref(e)))
+    ci = ConfidenceInterval.__new__(ConfidenceInterval)
+    ci.min, ci.max, ci.E = lo.value, hi.value, e.value
+    return ci
+
+
+def prob(n, s, N, k):  # utilities.jl:262
+    return lib().rh_prob(float(n), int(s), int(N), int(k))
+
+
+# -------------------------------------------------------------- parameters ----
+def defaultshapeparameters(T):  # shapes/*.jl defaultshapeparameters
+    a = math.radians(5)
+    if T is FittedPlane:
+        return {"plane": {"ϵ": 0.3, "α": a}}
+    if T is FittedSphere:
+        return {"sphere": {"ϵ": 0.3, "α": a, "sphere_par": 0.02}}
+    if T is FittedCylinder:
+        return {"cylinder": {"ϵ": 0.3, "α": a}}
+    if T is FittedCone:
+        return {"cone": {"ϵ": 0.3, "α": a, "minconeopang": math.radians(2)}}
+    raise TypeError(T)
+
+
+def defaultiterationparameters(shape_types):  # utilities.jl:332-347
+    return {"iteration": {"drawN": 3, "minsubsetN": 15, "prob_det": 0.9, "shape_types": list(shape_types),
+                          "τ": 900, "itermax": 1000, "extract_s": "nofminset", "terminate_s": "nofminset"}}
+
+
+def defaultcommonparameters():  # utilities.jl:368-373
+    return {"common": {"collin_threshold": 0.2, "parallelthrdeg": 1.0}}
+
+
+def defaultparameters(shape_types):  # utilities.jl:391-399
+    p = defaultiterationparameters(shape_types)
+    p.update(defaultcommonparameters())
+    for T in shape_types:
+        p.update(defaultshapeparameters(T))
+    return p
+
+
+DEFAULT_PARAMETERS = defaultparameters([FittedPlane, FittedCone, FittedCylinder, FittedSphere])  # RANSAC.jl:94
+
+_ALIASES = {"eps": "ϵ", "epsilon": "ϵ", "alpha": "α", "tau": "τ"}
+
+
+def _norm_keys(d):
+    return {_ALIASES.get(k, k): v for k, v in d.items()}
+
+
+def ransacparameters(p=None, **kwargs):  # utilities.jl:425-464
+    """ransacparameters(; kw...), ransacparameters(p; kw...) or ransacparameters([types]; kw...).
+    Nested dicts stand in for NamedTuples; `eps`/`alpha`/`tau` are accepted for ϵ/α/τ."""
+    if p is None:
+        base = DEFAULT_PARAMETERS
+    elif isinstance(p, (list, tuple)):
+        base = defaultparameters(list(p))
+    else:
+        base = p
+    newp = {k: dict(v) for k, v in base.items()}
+    for a, val in kwargs.items():
+        old = newp.get(a, {})
+        merged = dict(old)
+        merged.update(_norm_keys(val))
+        newp[a] = merged
+    return newp
+
+
+_S = {"lengthC": L.S_LENGTHC, "allcand": L.S_ALLCAND, "nofminset": L.S_NOFMINSET}
+
+
+def params_to_c(params, score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False):
+    """Flatten the nested parameter dict into rh_params.  Shapes absent from the dict keep the
+    library defaults (they are never used: `shape_types` selects what is fitted)."""
+    c = L.Params()
+    lib().rh_default_params(C.byref(c))
+    for name, kind in (("plane", PLANE), ("sphere", SPHERE), ("cylinder", CYLINDER), ("cone", CONE)):
+        if name in params:
+            sp = _norm_keys(params[name])
+            c.eps[kind] = sp.get("ϵ", c.eps[kind])
+            c.alpha[kind] = sp.get("α", c.alpha[kind])
+    if "sphere" in params:
+        c.sphere_par = _norm_keys(params["sphere"]).get("sphere_par", c.sphere_par)
+    if "cone" in params:
+        c.minconeopang = _norm_keys(params["cone"]).get("minconeopang", c.minconeopang)
+    if "common" in params:
+        c.collin_threshold = params["common"].get("collin_threshold", c.collin_threshold)
+        c.parallelthrdeg = params["common"].get("parallelthrdeg", c.parallelthrdeg)
+    if "iteration" in params:
+        it = _norm_keys(params["iteration"])
+        c.drawN = it.get("drawN", c.drawN)
+        c.minsubsetN = it.get("minsubsetN", c.minsubsetN)
+        c.prob_det = it.get("prob_det", c.prob_det)
+        c.tau = int(it.get("τ", c.tau))
+        c.itermax = int(it.get("itermax", c.itermax))
+        c.extract_s = _S[str(it.get("extract_s", "nofminset")).lstrip(":")]
+        c.terminate_s = _S[str(it.get("terminate_s", "nofminset")).lstrip(":")]
+        if "shape_types" in it:
+            st = it["shape_types"]
+            c.n_shape_types = len(st)
+            for i, T in enumerate(st):
+                c.shape_types[i] = _KIND_OF[T] if T in _KIND_OF else int(T)
+    c.score_mode = score_mode
+    c.sphere_uses_enabled = int(bool(sphere_uses_enabled))
+    lib().rh_params_finalize(C.byref(c))
+    return c
+
+
+def _cparams(params):
+    return params if isinstance(params, L.Params) else params_to_c(params)
+
+
+# ------------------------------------------------------------------- cloud ----
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class RANSACCloud:
+    """RANSACCloud(vertices, normals, numofsubsets | subsets) (octree.jl:37-138).  The points,
+    normals, subset 1 and the enabled bits live in HBM on `device`; the host keeps the arrays
+    it was given (for the O(1) minimal-set fits) and the subset index lists."""
+
+    def __init__(self, vertices, normals, subsets, device=0, seed=None):
+        self.vertices = _f64(vertices).reshape(-1, 3)
+        self.normals = _f64(normals).reshape(-1, 3)
+        assert self.vertices.shape == self.normals.shape, "Every point must have a normal."
+        self.size = self.vertices.shape[0]
+        if isinstance(subsets, (int, np.integer)):
+            assert subsets > 0, "At least 1 subset please!"
+            rng = np.random.default_rng(seed)
+            alls = rng.permutation(self.size).astype(np.int64) + 1   # randperm(l): octree.jl:131
+            ssl = self.size // int(subsets)
+            subs = [alls[i * ssl:(i + 1) * ssl] for i in range(int(subsets) - 1)]
+            subs.append(alls[(int(subsets) - 1) * ssl:])
+            subsets = subs
+        self.subsets = [np.ascontiguousarray(s, dtype=np.int64) for s in subsets]
+        self.device = device
+        h = C.c_void_p()
+        s1 = self.subsets[0]
+        check(lib().rh_cloud_create(_p(self.vertices, C.c_double), _p(self.normals, C.c_double), self.size,
+                                    _p(s1, C.c_int64), s1.size, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().rh_cloud_destroy(h)
+            self._h = None
+
+    @property
+    def nchunks(self):
+        return (self.size + 63) // 64
+
+    @property
+    def isenabled(self):
+        """pc.isenabled as a bool array (a copy; write it back with set_enabled)."""
+        ch = np.zeros(max(1, self.nchunks), dtype=np.uint64)
+        check(lib().rh_cloud_get_enabled(self._h, _p(ch, C.c_uint64), self.nchunks))
+        bits = np.unpackbits(ch[: self.nchunks].view(np.uint8), bitorder="little")
+        return bits[: self.size].astype(bool)
+
+    def enabled_chunks(self):
+        ch = np.zeros(max(1, self.nchunks), dtype=np.uint64)
+        check(lib().rh_cloud_get_enabled(self._h, _p(ch, C.c_uint64), self.nchunks))
+        return ch[: self.nchunks]
+
+    def set_enabled(self, mask_or_chunks):
+        a = np.asarray(mask_or_chunks)
+        if a.dtype == np.uint64:
+            ch = np.ascontiguousarray(a)
+        else:
+            bits = np.zeros(self.nchunks * 64, dtype=np.uint8)
+            bits[: self.size] = a.astype(np.uint8)
+            ch = np.packbits(bits, bitorder="little").view(np.uint64)
+        ch = np.ascontiguousarray(ch if ch.size else np.zeros(1, dtype=np.uint64))
+        check(lib().rh_cloud_set_enabled(self._h, _p(ch, C.c_uint64), self.nchunks))
+
+    def enable_all(self):
+        check(lib().rh_cloud_enable_all(self._h))
+
+    def count_enabled(self):
+        out = C.c_int64()
+        check(lib().rh_cloud_count_enabled(self._h, C.byref(out)))
+        return out.value
+
+    def __repr__(self):
+        return "RANSACCloud of size %d & %d subsets" % (self.size, len(self.subsets))
+
+
+# ---------------------------------------------------------------- hot path ----
+def fit(T, p, n, pc, params):
+    """fit(::Type{T}, p, n, pc, params) -> T or None (shapes/*.jl `fit`)."""
+    p, n = _f64(p).reshape(-1, 3), _f64(n).reshape(-1, 3)
+    assert p.shape[0] > 2, "At least 3 point is needed."
+    assert p.shape == n.shape, "Size must be the same."
+    out, ok = L.Shape(), C.c_int32()
+    kind = _KIND_OF[T] if T in _KIND_OF else int(T)
+    check(lib().rh_fit(kind, _p(p, C.c_double), _p(n, C.c_double), p.shape[0], C.byref(_cparams(params)),
+                       C.byref(out), C.byref(ok)))
+    return shape_from_c(out) if ok.value else None
+
+
+def _shape_array(cands):
+    arr = (L.Shape * max(1, len(cands)))()
+    for i, s in enumerate(cands):
+        arr[i] = s if isinstance(s, L.Shape) else s.to_c()
+    return arr
+
+
+def score_batch(pc, candidates, params, want_masks=False):
+    """One launch per shape kind for the whole batch (replaces the loop of scorecandidates!,
+    fitting.jl:181-190).  Returns counts[b] (and masks[b, ceil(S/64)] over subset positions)."""
+    b = len(candidates)
+    arr = candidates if isinstance(candidates, C.Array) else _shape_array(candidates)
+    counts = np.zeros(max(1, b), dtype=np.int32)
+    w = (pc.subsets[0].size + 63) // 64
+    masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64) if want_masks else None
+    check(lib().rh_score_batch(pc._h, arr, b, C.byref(_cparams(params)), _p(counts, C.c_int32),
+                               _p(masks, C.c_uint64) if want_masks else None))
+    if want_masks:
+        if w == 0:
+            return counts[:b], masks[:b, :0]
+        flat = masks.reshape(-1)[: b * w].reshape(b, w) if masks.shape[1] != w else masks[:b]
+        return counts[:b], flat
+    return counts[:b]
+
+
+def scorecandidate(pc, candidate, subsetID, params):
+    """scorecandidate(pc, candidate, subsetID, params) -> (ConfidenceInterval, inpoints)
+    (shapes/plane.jl:61-71 ...).  Only subset 1 lives on the device, as only subset 1 is ever
+    scored by the reference (iterations.jl:95)."""
+    if subsetID != 1:
+        raise ValueError("only subsetID == 1 is resident on the device (iterations.jl:95)")
+    cp = _cparams(params)
+    counts, masks = score_batch(pc, [candidate], cp, want_masks=True)
+    s1 = pc.subsets[0]
+    bits = np.unpackbits(masks[0].view(np.uint8), bitorder="little")[: s1.size].astype(bool)
+    inpoints = s1[bits]
+    assert inpoints.size == counts[0]
+    return estimatescore(s1.size, pc.size, int(counts[0]), cp.score_mode), inpoints
+
+
+def refit(s, pc, params):
+    """refit(s, pc, params) -> ExtractedShape (shapes/plane.jl:137-143 ...)."""
+    out = np.zeros(max(1, pc.size), dtype=np.int64)
+    n = C.c_int64()
+    cs = s if isinstance(s, L.Shape) else s.to_c()
+    check(lib().rh_refit(pc._h, C.byref(cs), C.byref(_cparams(params)), _p(out, C.c_int64), pc.size, C.byref(n)))
+    return ExtractedShape(s if not isinstance(s, L.Shape) else shape_from_c(s), out[: n.value].copy())
+
+
+def invalidate_indexes(pc, indexlist):  # invalidate_indexes!: fitting.jl:197-202
+    idx = np.ascontiguousarray(indexlist, dtype=np.int64)
+    check(lib().rh_invalidate(pc._h, _p(idx, C.c_int64), idx.size))
+
+
+def select_enabled(pc, ranks):
+    """k-th enabled point of the root cell: the `enabled_inds[nexti]` of fitting.jl:405-422."""
+    r = np.ascontiguousarray(ranks, dtype=np.int64)
+    out = np.zeros(max(1, r.size), dtype=np.int64)
+    check(lib().rh_select_enabled(pc._h, _p(r, C.c_int64), r.size, _p(out, C.c_int64)))
+    return out[: r.size]
+
+
+def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=None,
+           score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, return_stats=False):
+    """ransac(pc, params[, setenabled]; reset_rand) -> (Vector{ExtractedShape}, seconds)
+    (iterations.jl:14-21, 35-162).  `reset_rand` reseeds the generator with 1234 like
+    Random.seed!(1234); `stream` injects raw 64-bit draws (rand(1:n) = 1 + floor(u*n/2^64))."""
+    if setenabled:
+        pc.enable_all()
+    cp = params if isinstance(params, L.Params) else params_to_c(params, score_mode, sphere_uses_enabled)
+    rng = L.Rng()
+    lib().rh_rng_seed(C.byref(rng), 1234 if reset_rand else seed)
+    keep = None
+    if stream is not None:
+        keep = np.ascontiguousarray(stream, dtype=np.uint64)
+        rng.stream = _p(keep, C.c_uint64)
+        rng.stream_len = keep.size
+    res = L.Result()
+    check(lib().rh_ransac(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
+                          C.byref(rng), C.byref(res)))
+    extracted = []
+    for i in range(res.n_shapes):
+        e = res.shapes[i]
+        idx = np.ctypeslib.as_array(e.inpoints, shape=(max(1, e.n_inpoints),))[: e.n_inpoints].copy()
+        es = ExtractedShape(shape_from_c(e.shape), idx)
+        es.score_E, es.iteration, es.c_shape = e.score_E, e.iteration, L.Shape.from_buffer_copy(bytes(e.shape))
+        extracted.append(es)
+    stats = {"iterations": res.iterations, "candidates_scored": res.candidates_scored,
+             "scored_left": res.scored_left, "seconds": res.seconds, "seconds_score": res.seconds_score,
+             "seconds_extract": res.seconds_extract, "seconds_host": res.seconds_host, "draws": rng.draws}
+    lib().rh_result_free(C.byref(res))
+    seconds = stats["seconds"]
+    return (extracted, seconds, stats) if return_stats else (extracted, seconds)
+
+
+# ------------------------------------------ parameter-space bitmap (dormant) ----
+def largestconncomp(bimage, indmap=None, connectivity="default", device=0):
+    """largestconncomp(bimage, indmap, conn) (parameterspacebitmap.jl:69-109).  bimage[x, y];
+    connectivity "default" (4) or "eight".  Returns the indmap entries of the largest component
+    (or 0-based column-major linear indices when indmap is None)."""
+    conn8 = {"default": 0, "eight": 1, 4: 0, 8: 1, False: 0, True: 1}[connectivity]
+    bm = np.asarray(bimage, dtype=np.uint8)
+    xs, ys = bm.shape
+    flat = np.ascontiguousarray(bm.reshape(-1, order="F"))
+    out = np.zeros(max(1, flat.size), dtype=np.int64)
+    n = C.c_int64()
+    check(lib().rh_largestconncomp(_p(flat, C.c_uint8), xs, ys, conn8, device, _p(out, C.c_int64), out.size, C.byref(n)))
+    lin = out[: n.value].copy()
+    if indmap is None:
+        return lin
+    res = []
+    for li in lin:
+        v = indmap[int(li) % xs][int(li) // xs]
+        res.extend(v if isinstance(v, (list, tuple, np.ndarray)) else [v])
+    return res
+
+
+def bitmapparameters(parameters, compatibility, beta, idsource=None):  # parameterspacebitmap.jl:12-60
+    prm = _f64(parameters).reshape(-1, 2)
+    comp = np.ascontiguousarray(compatibility, dtype=np.uint8)
+    n = prm.shape[0]
+    assert n == comp.size and (idsource is None or len(idsource) == n), "Everything must have the same length."
+    ids = None if idsource is None else np.ascontiguousarray(idsource, dtype=np.int64)
+    xs, ys, bx, by = C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+    idp = None if ids is None else _p(ids, C.c_int64)
+    check(lib().rh_bitmapparameters(_p(prm, C.c_double), _p(comp, C.c_uint8), idp, n, beta, C.byref(xs), C.byref(ys),
+                                    C.byref(bx), C.byref(by), None, None))
+    bitmap = np.zeros(xs.value * ys.value, dtype=np.uint8)
+    idxmap = np.zeros(xs.value * ys.value, dtype=np.int64)
+    check(lib().rh_bitmapparameters(_p(prm, C.c_double), _p(comp, C.c_uint8), idp, n, beta, C.byref(xs), C.byref(ys),
+                                    C.byref(bx), C.byref(by), _p(bitmap, C.c_uint8), _p(idxmap, C.c_int64)))
+    shp = (xs.value, ys.value)
+    return bitmap.reshape(shp, order="F").astype(bool), idxmap.reshape(shp, order="F"), (bx.value, by.value)

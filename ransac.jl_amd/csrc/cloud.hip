@@ -1,0 +1,515 @@
+// cloud.hip -- C-ABI entry points around the device-resident cloud (include/ransac_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "rh_internal.h"
+
+// ---------------------------------------------------------------- errors ----
+static thread_local char g_err[512] = "";
+
+void rh_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *rh_last_error(void) { return g_err; }
+extern "C" int rh_version(void) { return RH_VERSION; }
+
+extern "C" int rh_device_count(int *n_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_out = 0;
+        rh_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return RH_E_NODEVICE;
+    }
+    *n_out = n;
+    return RH_OK;
+}
+
+int rh_validate_params(const rh_params *p)
+{
+    if (!p) { rh_set_error("params is NULL"); return RH_E_INVALID; }
+    for (int k = 0; k < 4; k++)
+        if (!(p->eps[k] == p->eps[k]) || !(p->cos_alpha[k] == p->cos_alpha[k])) {
+            rh_set_error("params: eps/cos_alpha of kind %d is NaN", k);
+            return RH_E_INVALID;
+        }
+    return RH_OK;
+}
+
+// ------------------------------------------------------------ allocation ----
+template <typename T>
+static int dev_alloc(T **p, int64_t count)
+{
+    *p = nullptr;
+    const size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipSuccess) {
+        rh_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RH_E_NOMEM : RH_E_NODEVICE;
+    }
+    return RH_OK;
+}
+
+int rh_ensure_pin(rh_cloud *c, int64_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return RH_OK;
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr;
+    c->h_pin_cap = 0;
+    int64_t cap = std::max<int64_t>(bytes, 1 << 20);
+    RH_HIP(hipHostMalloc(&c->h_pin, (size_t)cap, hipHostMallocDefault));
+    c->h_pin_cap = cap;
+    return RH_OK;
+}
+
+int rh_ensure_batch(rh_cloud *c, int64_t b)
+{
+    if (b <= c->batch_cap) return RH_OK;
+    RH_HIP(hipStreamSynchronize(c->stream));
+    int64_t cap = std::max<int64_t>(b, std::max<int64_t>(1024, c->batch_cap * 2));
+    (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_counts);
+    c->d_shapes = nullptr; c->d_prep = nullptr; c->d_orig = nullptr; c->d_counts = nullptr;
+    c->batch_cap = 0;
+    RH_TRY(dev_alloc(&c->d_shapes, cap));
+    RH_TRY(dev_alloc(&c->d_prep, 4 * cap));
+    RH_TRY(dev_alloc(&c->d_orig, 4 * cap));
+    RH_TRY(dev_alloc(&c->d_counts, cap));
+    c->batch_cap = cap;
+    return RH_OK;
+}
+
+int rh_ensure_masks(rh_cloud *c, int64_t words)
+{
+    if (words <= c->masks_cap) return RH_OK;
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_masks);
+    c->d_masks = nullptr;
+    c->masks_cap = 0;
+    RH_TRY(dev_alloc(&c->d_masks, words));
+    c->masks_cap = words;
+    return RH_OK;
+}
+
+static void cloud_free(rh_cloud *c)
+{
+    if (!c) return;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->full); (void)hipFree(c->sub); (void)hipFree(c->dis);
+    (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
+    (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
+    (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
+    (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk);
+    (void)hipFree(c->d_counts); (void)hipFree(c->d_masks); (void)hipFree(c->d_ranks);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int set_all_enabled(rh_cloud *c)
+{
+    if (c->nwords > 0) {
+        RH_HIP(hipMemsetAsync(c->enabled, 0xFF, sizeof(uint64_t) * (size_t)c->nwords, c->stream));
+        if (c->n % 64) {
+            const uint64_t last = (~0ULL) >> (64 - c->n % 64);
+            RH_HIP(hipMemcpyAsync(c->enabled + (c->nwords - 1), &last, sizeof last, hipMemcpyHostToDevice, c->stream));
+            RH_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
+    c->select_valid = false;
+    c->n_dis = 0;
+    return RH_OK;
+}
+
+// ------------------------------------------------------------------ cloud ----
+extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, const int64_t *subset1, int64_t s,
+                               int device, rh_cloud **out)
+{
+    if (!out) { rh_set_error("out is NULL"); return RH_E_INVALID; }
+    *out = nullptr;
+    if (n < 0 || s < 0 || (n > 0 && (!xyz || !nrm)) || (s > 0 && !subset1)) {
+        rh_set_error("rh_cloud_create: bad arguments (n=%lld s=%lld)", (long long)n, (long long)s);
+        return RH_E_INVALID;
+    }
+    if (n > (int64_t)0x7FFFF000) { rh_set_error("clouds above 2^31 points are not supported"); return RH_E_INVALID; }
+    for (int64_t j = 0; j < s; j++)
+        if (subset1[j] < 1 || subset1[j] > n) {
+            rh_set_error("subset index %lld at position %lld outside 1..%lld", (long long)subset1[j], (long long)j,
+                         (long long)n);
+            return RH_E_INVALID;
+        }
+    int ndev = 0;
+    RH_TRY(rh_device_count(&ndev));
+    if (ndev <= 0) { rh_set_error("no HIP device is visible; libransac_hip has no CPU fallback"); return RH_E_NODEVICE; }
+    if (device < 0 || device >= ndev) { rh_set_error("device %d out of range (%d visible)", device, ndev); return RH_E_INVALID; }
+    RH_HIP(hipSetDevice(device));
+
+    rh_cloud *c = new (std::nothrow) rh_cloud();
+    if (!c) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
+    c->device = device;
+    c->n = n;
+    c->s = s;
+    c->n_pad = ((n + RH_SC_TILE - 1) / RH_SC_TILE) * RH_SC_TILE;
+    c->s_pad = ((s + RH_SC_TILE - 1) / RH_SC_TILE) * RH_SC_TILE;
+    if (c->n_pad == 0) c->n_pad = RH_SC_TILE;
+    if (c->s_pad == 0) c->s_pad = RH_SC_TILE;
+    c->nwords = (n + 63) / 64;
+    c->swords = (s + 63) / 64;
+    c->nblocks = (c->nwords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
+    c->dis_stride = c->s_pad + RH_SC_TILE;
+
+    int rc = RH_OK;
+    double *t_xyz = nullptr, *t_nrm = nullptr;
+    int32_t *h_idx = nullptr;
+    auto fail = [&](int code) {
+        (void)hipFree(t_xyz); (void)hipFree(t_nrm);
+        delete[] h_idx;
+        cloud_free(c);
+        return code;
+    };
+#define CK(x) do { rc = (x); if (rc != RH_OK) return fail(rc); } while (0)
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); return fail(RH_E_NODEVICE); } } while (0)
+    CKH(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CKH(hipEventCreate(&c->ev0));
+    CKH(hipEventCreate(&c->ev1));
+    CK(dev_alloc(&c->full, 6 * c->n_pad));
+    CK(dev_alloc(&c->sub, 6 * c->s_pad));
+    CK(dev_alloc(&c->dis, 6 * c->dis_stride));
+    CK(dev_alloc(&c->sub_idx0, s));
+    CK(dev_alloc(&c->enabled, c->nwords));
+    CK(dev_alloc(&c->sub_enabled, c->swords));
+    CK(dev_alloc(&c->d_ndis, 1));
+    CK(dev_alloc(&c->refit_mask, c->nwords));
+    CK(dev_alloc(&c->block_sums, c->nblocks + 2));
+    CK(dev_alloc(&c->word_prefix, c->nwords + 1));
+    CK(dev_alloc(&c->idx_out, n));
+    CK(dev_alloc(&c->d_total, 1));
+    CK(dev_alloc(&c->d_nk, 4));
+    CKH(hipMemsetAsync(c->full, 0, sizeof(double) * 6 * (size_t)c->n_pad, c->stream));
+    CKH(hipMemsetAsync(c->sub, 0, sizeof(double) * 6 * (size_t)c->s_pad, c->stream));
+    CKH(hipMemsetAsync(c->dis, 0, sizeof(double) * 6 * (size_t)c->dis_stride, c->stream));
+    CKH(hipMemsetAsync(c->d_total, 0, sizeof(int32_t), c->stream));
+
+    if (n > 0) {
+        CK(dev_alloc(&t_xyz, 3 * n));
+        CK(dev_alloc(&t_nrm, 3 * n));
+        CKH(hipMemcpyAsync(t_xyz, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        CKH(hipMemcpyAsync(t_nrm, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
+        if (s > 0) {
+            h_idx = new (std::nothrow) int32_t[(size_t)s];
+            if (!h_idx) { rh_set_error("out of host memory"); return fail(RH_E_NOMEM); }
+            for (int64_t j = 0; j < s; j++) h_idx[j] = (int32_t)(subset1[j] - 1);
+            CKH(hipMemcpyAsync(c->sub_idx0, h_idx, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
+            CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, c->sub_idx0, s, c->sub, c->s_pad));
+        }
+    }
+    CK(set_all_enabled(c));
+    CKH(hipStreamSynchronize(c->stream));
+#undef CK
+#undef CKH
+    (void)hipFree(t_xyz);
+    (void)hipFree(t_nrm);
+    delete[] h_idx;
+    *out = c;
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_destroy(rh_cloud *c)
+{
+    cloud_free(c);
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_info(const rh_cloud *c, int64_t *n, int64_t *s, int *device)
+{
+    if (!c) { rh_set_error("cloud is NULL"); return RH_E_INVALID; }
+    if (n) *n = c->n;
+    if (s) *s = c->s;
+    if (device) *device = c->device;
+    return RH_OK;
+}
+
+static int enter(rh_cloud *c)
+{
+    if (!c) { rh_set_error("cloud is NULL"); return RH_E_INVALID; }
+    RH_HIP(hipSetDevice(c->device));
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t nchunks)
+{
+    RH_TRY(enter(c));
+    if (nchunks != c->nwords || (nchunks > 0 && !chunks)) {
+        rh_set_error("rh_cloud_set_enabled: nchunks=%lld, expected %lld", (long long)nchunks, (long long)c->nwords);
+        return RH_E_INVALID;
+    }
+    if (c->nwords > 0) {
+        RH_HIP(hipMemcpyAsync(c->enabled, chunks, sizeof(uint64_t) * (size_t)nchunks, hipMemcpyHostToDevice, c->stream));
+        if (c->n % 64) {   // BitVector keeps the unused tail bits zero; enforce it
+            const uint64_t last = chunks[nchunks - 1] & ((~0ULL) >> (64 - c->n % 64));
+            RH_HIP(hipMemcpyAsync(c->enabled + (nchunks - 1), &last, sizeof last, hipMemcpyHostToDevice, c->stream));
+        }
+        RH_HIP(hipStreamSynchronize(c->stream));
+    }
+    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    c->select_valid = false;
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_get_enabled(rh_cloud *c, uint64_t *chunks, int64_t nchunks)
+{
+    RH_TRY(enter(c));
+    if (nchunks != c->nwords || (nchunks > 0 && !chunks)) {
+        rh_set_error("rh_cloud_get_enabled: nchunks=%lld, expected %lld", (long long)nchunks, (long long)c->nwords);
+        return RH_E_INVALID;
+    }
+    if (c->nwords > 0) {
+        RH_HIP(hipMemcpyAsync(chunks, c->enabled, sizeof(uint64_t) * (size_t)nchunks, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_enable_all(rh_cloud *c)
+{
+    RH_TRY(enter(c));
+    RH_TRY(set_all_enabled(c));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_count_enabled(rh_cloud *c, int64_t *out)
+{
+    RH_TRY(enter(c));
+    if (!out) { rh_set_error("out is NULL"); return RH_E_INVALID; }
+    return rhk_count_enabled(c, out);
+}
+
+// ---------------------------------------------------------------- scoring ----
+static inline const uint64_t *enabled_for_kind(const rh_cloud *c, int kind, const rh_params *p)
+{
+    // sphere.jl:121,131: the sphere scorer builds `ens` and never applies it
+    if (kind == RH_SPHERE && !p->sphere_uses_enabled) return nullptr;
+    return c->sub_enabled;
+}
+
+extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, int32_t *counts_out,
+                              uint64_t *masks_out)
+{
+    RH_TRY(enter(c));
+    RH_TRY(rh_validate_params(p));
+    if (b < 0 || (b > 0 && (!shapes || !counts_out))) { rh_set_error("rh_score_batch: bad arguments"); return RH_E_INVALID; }
+    if (b == 0) return RH_OK;
+    int32_t nk[4] = { 0, 0, 0, 0 };
+    for (int32_t i = 0; i < b; i++) {
+        if (shapes[i].kind < 0 || shapes[i].kind > 3) {
+            rh_set_error("candidate %d has unknown kind %d", i, shapes[i].kind);
+            return RH_E_INVALID;
+        }
+        nk[shapes[i].kind]++;
+    }
+    RH_TRY(rh_ensure_batch(c, b));
+    const int64_t stage_bytes = (int64_t)b * (sizeof(rh_shape) + sizeof(int32_t)) + 64;
+    RH_TRY(rh_ensure_pin(c, stage_bytes));
+    rh_shape *h_sorted = (rh_shape *)c->h_pin;
+    int32_t *h_orig = (int32_t *)((char *)c->h_pin + (size_t)b * sizeof(rh_shape));
+    int32_t off[4], fill[4];
+    off[0] = 0;
+    for (int k = 1; k < 4; k++) off[k] = off[k - 1] + nk[k - 1];
+    for (int k = 0; k < 4; k++) fill[k] = off[k];
+    for (int32_t i = 0; i < b; i++) {   // stable counting sort by kind
+        const int k = shapes[i].kind;
+        h_sorted[fill[k]] = shapes[i];
+        h_orig[fill[k]] = i;
+        fill[k]++;
+    }
+    RH_HIP(hipMemcpyAsync(c->d_shapes, h_sorted, sizeof(rh_shape) * (size_t)b, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemcpyAsync(c->d_nk, nk, sizeof nk, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
+    RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep));
+    uint64_t *d_masks = nullptr;
+    if (masks_out) {
+        RH_TRY(rh_ensure_masks(c, (int64_t)b * c->swords));
+        d_masks = c->d_masks;
+    }
+    for (int k = 0; k < 4; k++) {
+        if (nk[k] == 0) continue;
+        RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), c->d_prep + off[k],
+                              c->d_orig + off[k], c->d_nk + k, nk[k], p->eps[k], p->cos_alpha[k], c->d_counts,
+                              d_masks, c->swords));
+    }
+    RH_HIP(hipMemcpyAsync(counts_out, c->d_counts, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
+    if (masks_out && c->swords > 0)
+        RH_HIP(hipMemcpyAsync(masks_out, d_masks, sizeof(uint64_t) * (size_t)b * (size_t)c->swords,
+                              hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                                  int32_t *d_counts, uint64_t *d_masks)
+{
+    RH_TRY(enter(c));
+    RH_TRY(rh_validate_params(p));
+    if (b < 0 || (b > 0 && (!d_shapes || !d_counts))) { rh_set_error("rh_score_batch_dev: bad arguments"); return RH_E_INVALID; }
+    if (b == 0) return RH_OK;
+    RH_TRY(rh_ensure_batch(c, b));
+    RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
+    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, c->d_nk, c->batch_cap));
+    for (int k = 0; k < 4; k++)
+        RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), c->d_prep + (int64_t)k * c->batch_cap,
+                              c->d_orig + (int64_t)k * c->batch_cap, c->d_nk + k, b, p->eps[k], p->cos_alpha[k],
+                              d_counts, d_masks, c->swords));
+    return RH_OK;
+}
+
+// ------------------------------------------------------------------ refit ----
+extern "C" int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p, int64_t *idx_out, int64_t cap,
+                        int64_t *n_out)
+{
+    RH_TRY(enter(c));
+    RH_TRY(rh_validate_params(p));
+    if (!shape || !n_out || cap < 0 || (cap > 0 && !idx_out)) { rh_set_error("rh_refit: bad arguments"); return RH_E_INVALID; }
+    if (shape->kind < 0 || shape->kind > 3) { rh_set_error("unknown shape kind %d", shape->kind); return RH_E_INVALID; }
+    *n_out = 0;
+    rh_prep P;
+    rh_prep_host(*shape, &P);
+    c->select_valid = false;   // block_sums / d_total are shared with the select directory
+    RH_TRY(rhk_refit_mask(c, P, shape->kind, p->eps[shape->kind], p->cos_alpha[shape->kind]));
+    RH_TRY(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
+    int32_t total = 0;
+    RH_HIP(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    *n_out = total;
+    if (total > cap) {
+        rh_set_error("rh_refit: %d inliers, capacity %lld", total, (long long)cap);
+        return RH_E_CAPACITY;
+    }
+    if (total > 0) {
+        RH_HIP(hipMemcpyAsync(idx_out, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return RH_OK;
+}
+
+extern "C" int rh_invalidate(rh_cloud *c, const int64_t *idx, int64_t n)
+{
+    RH_TRY(enter(c));
+    if (n < 0 || (n > 0 && !idx)) { rh_set_error("rh_invalidate: bad arguments"); return RH_E_INVALID; }
+    if (n == 0) return RH_OK;
+    if (n > c->n) {   // idx_out is the staging buffer; longer lists (duplicates) go in pieces
+        for (int64_t o = 0; o < n; o += c->n) RH_TRY(rh_invalidate(c, idx + o, std::min<int64_t>(c->n, n - o)));
+        return RH_OK;
+    }
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 1 || idx[k] > c->n) {
+            rh_set_error("rh_invalidate: index %lld outside 1..%lld", (long long)idx[k], (long long)c->n);
+            return RH_E_INVALID;   // the reference would throw a BoundsError
+        }
+    RH_HIP(hipMemcpyAsync(c->idx_out, idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    RH_TRY(rhk_invalidate_idx(c, c->idx_out, n));
+    RH_TRY(rhk_rebuild_sub_enabled(c, true, false));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    c->select_valid = false;
+    return RH_OK;
+}
+
+extern "C" int rh_select_enabled(rh_cloud *c, const int64_t *ranks, int32_t k, int64_t *idx_out)
+{
+    RH_TRY(enter(c));
+    if (k < 0 || (k > 0 && (!ranks || !idx_out))) { rh_set_error("rh_select_enabled: bad arguments"); return RH_E_INVALID; }
+    if (k == 0) return RH_OK;
+    if (c->nwords == 0) { for (int i = 0; i < k; i++) idx_out[i] = 0; return RH_OK; }
+    if (k > c->ranks_cap) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_ranks);
+        c->d_ranks = nullptr;
+        c->ranks_cap = 0;
+        RH_TRY(dev_alloc(&c->d_ranks, 2 * (int64_t)k));
+        c->ranks_cap = k;
+    }
+    if (!c->select_valid) RH_TRY(rhk_build_select(c));
+    RH_HIP(hipMemcpyAsync(c->d_ranks, ranks, sizeof(int64_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
+    RH_TRY(rhk_select(c, c->d_ranks, k, c->d_ranks + c->ranks_cap));
+    RH_HIP(hipMemcpyAsync(idx_out, c->d_ranks + c->ranks_cap, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+// ------------------------------------------------------------ measurement ----
+extern "C" int rh_timer_start(rh_cloud *c)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipEventRecord(c->ev0, c->stream));
+    return RH_OK;
+}
+
+extern "C" int rh_timer_stop(rh_cloud *c, float *ms_out)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipEventRecord(c->ev1, c->stream));
+    RH_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    RH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms_out) *ms_out = ms;
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_sync(rh_cloud *c)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+extern "C" int rh_dev_alloc(rh_cloud *c, int64_t bytes, void **d_out)
+{
+    RH_TRY(enter(c));
+    if (!d_out || bytes < 0) { rh_set_error("rh_dev_alloc: bad arguments"); return RH_E_INVALID; }
+    char *p = nullptr;
+    RH_TRY(dev_alloc(&p, bytes));
+    *d_out = p;
+    return RH_OK;
+}
+
+extern "C" int rh_dev_free(rh_cloud *c, void *d)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    RH_HIP(hipFree(d));
+    return RH_OK;
+}
+
+extern "C" int rh_dev_upload(rh_cloud *c, void *d_dst, const void *h_src, int64_t bytes)
+{
+    RH_TRY(enter(c));
+    if (bytes <= 0) return RH_OK;
+    RH_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+extern "C" int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes)
+{
+    RH_TRY(enter(c));
+    if (bytes <= 0) return RH_OK;
+    RH_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}

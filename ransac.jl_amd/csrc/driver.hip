@@ -1,0 +1,458 @@
+// driver.hip -- rh_ransac: the reference's ransac() loop (src/iterations.jl:35-162) with the
+// data-parallel steps on the GPU.
+//
+// Host: RNG, minimal-set sampling (samplepointcloud4!, src/fitting.jl:383-430), fits, score
+// statistics, best-candidate bookkeeping.  Device: batched scoring of every candidate an
+// iteration produced (one launch per shape kind instead of src/fitting.jl:181-190's sequential
+// loop -- legal because nothing inside an iteration reads a score before iterations.jl:99 is
+// done), the full-cloud refit scan, enabled-bit maintenance and candidate liveness.
+//
+// Candidate store.  The reference keeps every scored candidate with its inlier index list and
+// deletes, at each extraction, every candidate that owns a now-disabled point
+// (removeinvalidshapes!, src/fitting.jl:209-221).  Index lists do not scale to thousands of
+// candidates per iteration, so liveness is RECOMPUTED: a stored candidate is invalid iff it is
+// compatible with some subset-1 point that is disabled now and was part of its inlier list:
+//   plane / cylinder / cone (inliers = compatible & enabled at score time): the points disabled
+//     by THIS extraction suffice -- earlier extractions already removed their victims;
+//   sphere in reference mode (inliers ignore the enabled bit, sphere.jl:121,131): every
+//     disabled subset-1 point.
+// Both are one more run of the score kernel over the append-only list of disabled subset-1
+// points (rh_cloud::dis), new points at the tail.
+//
+// Octree.  In the reference the level argmax at src/fitting.jl:401 is always 1 because the
+// RANSACCloud constructor swaps levelweight/levelscore (src/octree.jl:44-45 vs :84; SURVEY.md
+// 0.5), so every minimal set is drawn from the root cell = all enabled points in ascending
+// order, and levelscore never influences a result.  The driver therefore samples from the
+// enabled set directly and keeps no octree.
+#include <math.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rh_internal.h"
+
+namespace {
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// host mirror of pc.isenabled with a rank directory for "k-th enabled point"
+struct EnabledMirror {
+    std::vector<uint64_t> w;
+    std::vector<int64_t> dir;   // enabled count before each 64-word block
+    int64_t n = 0, count = 0;
+    bool dir_ok = false;
+    static constexpr int64_t BLK = 64;
+
+    bool test(int64_t i0) const { return (w[(size_t)(i0 >> 6)] >> (i0 & 63)) & 1ULL; }
+    void recount()
+    {
+        count = 0;
+        for (uint64_t x : w) count += __builtin_popcountll(x);
+        dir_ok = false;
+    }
+    void clear(const int64_t *idx1, int64_t k)
+    {
+        for (int64_t j = 0; j < k; j++) {
+            const int64_t i0 = idx1[j] - 1;
+            uint64_t &x = w[(size_t)(i0 >> 6)];
+            const uint64_t bit = 1ULL << (i0 & 63);
+            if (x & bit) { x &= ~bit; count--; }
+        }
+        dir_ok = false;
+    }
+    void build()
+    {
+        const int64_t nb = (int64_t)w.size() / BLK + 1;
+        dir.assign((size_t)nb + 1, 0);
+        int64_t acc = 0;
+        for (int64_t b = 0; b < nb; b++) {
+            dir[(size_t)b] = acc;
+            const int64_t lo = b * BLK, hi = std::min<int64_t>(lo + BLK, (int64_t)w.size());
+            for (int64_t i = lo; i < hi; i++) acc += __builtin_popcountll(w[(size_t)i]);
+        }
+        dir[(size_t)nb] = acc;
+        dir_ok = true;
+    }
+    // 1-based rank -> 1-based index of the k-th enabled point (ascending)
+    int64_t select(int64_t k)
+    {
+        if (!dir_ok) build();
+        const int64_t nb = (int64_t)dir.size() - 1;
+        if (k < 1 || k > dir[(size_t)nb]) return 0;
+        int64_t lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) / 2;
+            if (dir[(size_t)mid] < k) lo = mid; else hi = mid;
+        }
+        int64_t rem = k - dir[(size_t)lo];
+        for (int64_t i = lo * BLK; i < (int64_t)w.size(); i++) {
+            const int pc = __builtin_popcountll(w[(size_t)i]);
+            if (rem <= pc) {
+                uint64_t x = w[(size_t)i];
+                for (int64_t r = 1; r < rem; r++) x &= x - 1;
+                return i * 64 + __builtin_ctzll(x) + 1;
+            }
+            rem -= pc;
+        }
+        return 0;
+    }
+};
+
+struct Stored {
+    rh_shape shape;
+    double E;
+    int32_t slot;   // index in the device store of its kind
+};
+
+// device-resident store of prepared candidates, one growable array per kind
+struct DeviceStore {
+    rh_prep *prep[4] = { nullptr, nullptr, nullptr, nullptr };
+    int64_t cap[4] = { 0, 0, 0, 0 };
+    int32_t n[4] = { 0, 0, 0, 0 };
+    int32_t *iota = nullptr;      // 0..iota_cap-1
+    int64_t iota_cap = 0;
+    int32_t *counts = nullptr;    // liveness / score counts, iota_cap entries
+    int32_t *d_idx = nullptr;     // gather lists
+    int32_t *d_nk = nullptr;      // one int per launch slot (8)
+    rh_shape *d_shapes = nullptr;
+    int64_t shapes_cap = 0;
+};
+
+int store_free(rh_cloud *c, DeviceStore &st)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 4; k++) (void)hipFree(st.prep[k]);
+    (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
+    (void)hipFree(st.d_shapes);
+    return RH_OK;
+}
+
+int store_reserve(rh_cloud *c, DeviceStore &st, int kind, int64_t need)
+{
+    if (need <= st.cap[kind]) return RH_OK;
+    const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(4096, st.cap[kind] * 2));
+    rh_prep *np = nullptr;
+    RH_HIP(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)cap));
+    if (st.n[kind] > 0)
+        RH_HIP(hipMemcpyAsync(np, st.prep[kind], sizeof(rh_prep) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(st.prep[kind]);
+    st.prep[kind] = np;
+    st.cap[kind] = cap;
+    return RH_OK;
+}
+
+int store_reserve_aux(rh_cloud *c, DeviceStore &st, int64_t need)
+{
+    if (need <= st.iota_cap) return RH_OK;
+    const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(4096, st.iota_cap * 2));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx);
+    st.iota = st.counts = st.d_idx = nullptr;
+    RH_HIP(hipMalloc((void **)&st.iota, sizeof(int32_t) * (size_t)cap));
+    RH_HIP(hipMalloc((void **)&st.counts, sizeof(int32_t) * (size_t)cap));
+    RH_HIP(hipMalloc((void **)&st.d_idx, sizeof(int32_t) * (size_t)cap));
+    RH_TRY(rhk_iota(c, st.iota, (int32_t)cap, 0));
+    st.iota_cap = cap;
+    return RH_OK;
+}
+
+}  // namespace
+
+extern "C" void rh_result_free(rh_result *r)
+{
+    if (!r) return;
+    for (int64_t i = 0; i < r->n_shapes; i++) free(r->shapes[i].inpoints);
+    free(r->shapes);
+    memset(r, 0, sizeof *r);
+}
+
+extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng,
+                         rh_result *out)
+{
+    if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
+    memset(out, 0, sizeof *out);
+    RH_TRY(rh_validate_params(p));
+    if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
+    if (p->drawN < 2 || p->drawN > 16) {   // @assert drawN > 1: src/fitting.jl:386
+        rh_set_error("rh_ransac: drawN=%d outside 2..16", p->drawN);
+        return RH_E_INVALID;
+    }
+    if (p->n_shape_types < 0 || p->n_shape_types > 8) { rh_set_error("rh_ransac: bad n_shape_types"); return RH_E_INVALID; }
+    for (int t = 0; t < p->n_shape_types; t++)
+        if (p->shape_types[t] < 0 || p->shape_types[t] > 3) { rh_set_error("rh_ransac: bad shape type"); return RH_E_INVALID; }
+    if (p->extract_s < 1 || p->extract_s > 3 || p->terminate_s < 1 || p->terminate_s > 3) {
+        rh_set_error("rh_ransac: extract_s / terminate_s must be 1..3");
+        return RH_E_INVALID;
+    }
+    RH_HIP(hipSetDevice(c->device));
+    const double t_start = now_s();
+    const int drawN = p->drawN;
+
+    EnabledMirror en;
+    en.n = c->n;
+    en.w.assign((size_t)c->nwords, 0);
+    if (c->nwords > 0) RH_TRY(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
+    en.recount();
+    // the disabled list must describe the cloud as it is now (points disabled before the call)
+    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
+    int32_t ndis = 0;
+    RH_HIP(hipMemcpyAsync(&ndis, c->d_ndis, sizeof ndis, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    c->n_dis = ndis;
+    c->select_valid = false;
+
+    DeviceStore st;
+    std::vector<Stored> store;              // scoredshapes, reference order
+    std::vector<rh_shape> cands;            // this iteration's candidates
+    std::vector<rh_shape> sorted;
+    std::vector<int32_t> orig, counts_h, idx_h;
+    std::vector<int64_t> sd((size_t)drawN);
+    std::vector<double> fp(3 * (size_t)drawN), fn(3 * (size_t)drawN);
+    std::vector<rh_extracted> extracted;
+    int64_t countcandidates[4] = { 0, 0, 0, 0 };
+    int64_t best = -1;                      // index into store of the running first maximum
+    double t_score = 0, t_extract = 0;
+    int rc = RH_OK;
+    RH_HIP(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
+
+#define RUN(x) do { rc = (x); if (rc != RH_OK) goto fail; } while (0)
+#define RUNH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); rc = RH_E_NODEVICE; goto fail; } } while (0)
+
+    int64_t k;
+    for (k = 1; k <= p->itermax; k++) {
+        if (en.count < p->tau) break;   // iterations.jl:75
+        // ---- sample + fit (host): iterations.jl:80-91 ----
+        cands.clear();
+        for (int i = 0; i < p->minsubsetN; i++) {
+            // samplepointcloud4!: fitting.jl:388-428 on the root cell
+            int64_t r1 = rh_rng_range(rng, c->n);
+            while (!en.test(r1 - 1)) r1 = rh_rng_range(rng, c->n);
+            if (en.count < drawN) continue;
+            sd[0] = r1;
+            for (int q = 1; q < drawN; q++) {
+                int64_t pick = en.select(rh_rng_range(rng, en.count));
+                if (pick == sd[0]) pick = en.select(rh_rng_range(rng, en.count));   // one redraw: fitting.jl:416-419
+                sd[(size_t)q] = pick;
+            }
+            bool distinct = true;   // allisdifferent: utilities.jl:285-295
+            for (int a = 1; a < drawN && distinct; a++)
+                for (int b = 0; b < a; b++)
+                    if (sd[(size_t)a] == sd[(size_t)b]) { distinct = false; break; }
+            if (!distinct) continue;
+            for (int q = 0; q < drawN; q++) {
+                memcpy(&fp[3 * (size_t)q], xyz + 3 * (sd[(size_t)q] - 1), 24);
+                memcpy(&fn[3 * (size_t)q], nrm + 3 * (sd[(size_t)q] - 1), 24);
+            }
+            for (int t = 0; t < p->n_shape_types; t++) {   // forcefitshapes!: fitting.jl:165-173
+                rh_shape fitted;
+                int32_t ok = 0;
+                RUN(rh_fit(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));
+                if (ok) cands.push_back(fitted);
+            }
+        }
+        const int32_t ncand = (int32_t)cands.size();
+        countcandidates[2] += ncand;
+
+        // ---- score the whole batch on the device: fitting.jl:181-190 ----
+        if (ncand > 0) {
+            const double t0 = now_s();
+            int32_t nk[4] = { 0, 0, 0, 0 }, off[4], fill[4];
+            for (const rh_shape &s : cands) nk[s.kind]++;
+            off[0] = 0;
+            for (int q = 1; q < 4; q++) off[q] = off[q - 1] + nk[q - 1];
+            for (int q = 0; q < 4; q++) fill[q] = off[q];
+            sorted.resize((size_t)ncand);
+            orig.resize((size_t)ncand);
+            for (int32_t i = 0; i < ncand; i++) {
+                const int q = cands[(size_t)i].kind;
+                sorted[(size_t)fill[q]] = cands[(size_t)i];
+                orig[(size_t)fill[q]] = i;
+                fill[q]++;
+            }
+            if (ncand > st.shapes_cap) {
+                RUNH(hipStreamSynchronize(c->stream));
+                (void)hipFree(st.d_shapes);
+                st.d_shapes = nullptr;
+                st.shapes_cap = std::max<int64_t>(ncand, 1024);
+                RUNH(hipMalloc((void **)&st.d_shapes, sizeof(rh_shape) * (size_t)st.shapes_cap));
+            }
+            RUN(store_reserve_aux(c, st, ncand));
+            for (int q = 0; q < 4; q++) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + nk[q]));
+            RUNH(hipMemcpyAsync(st.d_shapes, sorted.data(), sizeof(rh_shape) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
+            RUNH(hipMemcpyAsync(st.d_idx, orig.data(), sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
+            RUNH(hipMemcpyAsync(st.d_nk, nk, sizeof nk, hipMemcpyHostToDevice, c->stream));
+            RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)ncand, c->stream));
+            for (int q = 0; q < 4; q++) {
+                if (nk[q] == 0) continue;
+                rh_prep *tail = st.prep[q] + st.n[q];   // prepared records persist in the store
+                RUN(rhk_prep_sorted(c, st.d_shapes + off[q], nk[q], tail));
+                const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
+                RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q],
+                                   p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+            }
+            counts_h.resize((size_t)ncand);
+            RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+            RUNH(hipStreamSynchronize(c->stream));
+            t_score += now_s() - t0;
+            // record in candidate order (recordscore!: fitting.jl:114-119)
+            int32_t slot_next[4] = { st.n[0], st.n[1], st.n[2], st.n[3] };
+            // slots were assigned in sorted order = candidate order within a kind (stable sort)
+            for (int32_t i = 0; i < ncand; i++) {
+                const rh_shape &s = cands[(size_t)i];
+                double lo, hi, E;
+                RUN(rh_estimatescore(c->s, c->n, counts_h[(size_t)i], p->score_mode, &lo, &hi, &E));
+                Stored rec;
+                rec.shape = s;
+                rec.E = E;
+                rec.slot = slot_next[s.kind]++;
+                store.push_back(rec);
+                // findhighestscore (fitting.jl:140-151) incrementally: first maximum, strict >
+                if (best < 0) best = (int64_t)store.size() - 1;
+                else if (E > store[(size_t)best].E) best = (int64_t)store.size() - 1;
+            }
+            for (int q = 0; q < 4; q++) st.n[q] += nk[q];
+        }
+        countcandidates[3] = k * p->minsubsetN;
+        countcandidates[1] = (int64_t)store.size();
+
+        if (!store.empty()) {
+            const double scr = store[(size_t)best].E;
+            const double ppp = rh_prob(scr, countcandidates[p->extract_s], c->n, drawN);
+            if (ppp > p->prob_det) {   // iterations.jl:123
+                const double t0 = now_s();
+                // refit: full-cloud scan + ascending compaction (plane.jl:137-143 ...)
+                const rh_shape bestshape = store[(size_t)best].shape;
+                rh_prep P;
+                rh_prep_host(bestshape, &P);
+                RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
+                RUN(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
+                int32_t total = 0;
+                RUNH(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+                // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
+                RUN(rhk_andnot_enabled(c, c->refit_mask));
+                RUN(rhk_rebuild_sub_enabled(c, true, false));
+                int32_t ndis_new = 0;
+                RUNH(hipMemcpyAsync(&ndis_new, c->d_ndis, sizeof ndis_new, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipStreamSynchronize(c->stream));
+                rh_extracted ex;
+                memset(&ex, 0, sizeof ex);
+                ex.shape = bestshape;
+                ex.n_inpoints = total;
+                ex.inpoints = (int64_t *)malloc(sizeof(int64_t) * (size_t)std::max<int32_t>(total, 1));
+                if (!ex.inpoints) { rh_set_error("out of host memory"); rc = RH_E_NOMEM; goto fail; }
+                if (total > 0)
+                    RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipStreamSynchronize(c->stream));
+                ex.score_E = scr;
+                ex.iteration = k;
+                extracted.push_back(ex);
+                en.clear(ex.inpoints, total);
+                const int64_t ndis_old = c->n_dis;
+                c->n_dis = ndis_new;
+
+                // deleteat!(scoredshapes, best.index): iterations.jl:136
+                store.erase(store.begin() + best);
+                // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
+                std::vector<char> dead_slot[4];
+                for (int q = 0; q < 4; q++) {
+                    dead_slot[q].assign((size_t)st.n[q], 1);   // slots not referenced by `store` are dead
+                }
+                for (const Stored &r : store) dead_slot[r.shape.kind][(size_t)r.slot] = 0;
+                int64_t maxn = 0;
+                for (int q = 0; q < 4; q++) maxn = std::max<int64_t>(maxn, st.n[q]);
+                RUN(store_reserve_aux(c, st, maxn));
+                for (int q = 0; q < 4; q++) {
+                    if (st.n[q] == 0) continue;
+                    const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                    const int64_t first = all_disabled ? 0 : ndis_old;
+                    const int64_t cnt = (int64_t)ndis_new - first;
+                    if (cnt > 0) {
+                        RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)st.n[q], c->stream));
+                        RUNH(hipMemcpyAsync(st.d_nk + 4 + q, &st.n[q], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                        RUN(rhk_score_kind(c, q, c->dis + first, c->dis_stride, cnt, nullptr, st.prep[q], st.iota,
+                                           st.d_nk + 4 + q, st.n[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+                        counts_h.resize((size_t)st.n[q]);
+                        RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)st.n[q], hipMemcpyDeviceToHost, c->stream));
+                        RUNH(hipStreamSynchronize(c->stream));
+                        for (int32_t sl = 0; sl < st.n[q]; sl++)
+                            if (counts_h[(size_t)sl] > 0) dead_slot[q][(size_t)sl] = 1;
+                    }
+                }
+                // drop dead candidates on the host (order preserved), compact the device store
+                {
+                    std::vector<int32_t> remap[4];
+                    for (int q = 0; q < 4; q++) {
+                        remap[q].assign((size_t)st.n[q], -1);
+                        idx_h.clear();
+                        for (int32_t sl = 0; sl < st.n[q]; sl++)
+                            if (!dead_slot[q][(size_t)sl]) {
+                                remap[q][(size_t)sl] = (int32_t)idx_h.size();
+                                idx_h.push_back(sl);
+                            }
+                        const int32_t alive = (int32_t)idx_h.size();
+                        if (alive != st.n[q]) {
+                            if (alive > 0) {
+                                rh_prep *np = nullptr;
+                                RUNH(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)st.cap[q]));
+                                RUNH(hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream));
+                                rc = rhk_gather_prep(c, st.prep[q], st.d_idx, alive, np);
+                                RUNH(hipStreamSynchronize(c->stream));
+                                (void)hipFree(st.prep[q]);
+                                st.prep[q] = np;
+                                if (rc != RH_OK) goto fail;
+                            }
+                            st.n[q] = alive;
+                        }
+                    }
+                    size_t wpos = 0;
+                    for (size_t i = 0; i < store.size(); i++) {
+                        const int q = store[i].shape.kind;
+                        const int32_t ns = remap[q][(size_t)store[i].slot];
+                        if (ns < 0) continue;
+                        store[wpos] = store[i];
+                        store[wpos].slot = ns;
+                        wpos++;
+                    }
+                    store.resize(wpos);
+                }
+                // the running maximum must be recomputed over the survivors
+                best = -1;
+                for (size_t i = 0; i < store.size(); i++)
+                    if (best < 0 || store[i].E > store[(size_t)best].E) best = (int64_t)i;
+                t_extract += now_s() - t0;
+            }
+        }
+        // updatelevelweight (octree.jl:198-205) only ever produces NaN weights: no effect (header)
+        if (rh_prob((double)p->tau, countcandidates[p->terminate_s], c->n, drawN) > p->prob_det) { k++; break; }
+    }
+    out->iterations = std::min<int64_t>(k - 1, p->itermax);
+    out->candidates_scored = countcandidates[2];
+    out->scored_left = (int64_t)store.size();
+    out->n_shapes = (int64_t)extracted.size();
+    out->shapes = (rh_extracted *)malloc(sizeof(rh_extracted) * std::max<size_t>(extracted.size(), 1));
+    if (!out->shapes) { rh_set_error("out of host memory"); rc = RH_E_NOMEM; goto fail; }
+    for (size_t i = 0; i < extracted.size(); i++) out->shapes[i] = extracted[i];
+    extracted.clear();
+    store_free(c, st);
+    c->select_valid = false;
+    out->seconds = now_s() - t_start;
+    out->seconds_score = t_score;
+    out->seconds_extract = t_extract;
+    out->seconds_host = out->seconds - t_score - t_extract;
+    return RH_OK;
+
+fail:
+    for (rh_extracted &e : extracted) free(e.inpoints);
+    store_free(c, st);
+    return rc;
+#undef RUN
+#undef RUNH
+}

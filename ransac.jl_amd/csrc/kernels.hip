@@ -1,0 +1,722 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the RANSAC hot path.
+//
+// Numerics contract: IEEE binary64, the reference's operation order, NO fused
+// multiply-add (built with -ffp-contract=off), correctly rounded sqrt and divide.
+// Each per-point test cites the reference function it restates (paths under
+// /root/reference/src).  StaticArrays semantics: dot = (a1*b1 + a2*b2) + a3*b3,
+// norm = sqrt of the same sum of squares, normalize(a) = (1/norm(a)) * a.
+//
+// Layout: points are structure-of-arrays, six planes (x y z nx ny nz) of `stride`
+// doubles; lane i of a wave reads element base+i of each plane (512-B coalesced
+// loads).  Candidate constants are wave-uniform: they are read with scalar loads
+// into SGPRs, the per-point math runs on the FP64 vector ALU, inlier counts come
+// from 64-bit wave ballots + s_bcnt1 (no cross-lane reduction tree).
+
+#include "rh_internal.h"
+
+namespace {
+
+// Each test returns the WAVE's 64-bit result mask (bit l = lane l's point is compatible): the
+// two comparisons are balloted separately and ANDed on the scalar unit.
+#define WB(cond) __builtin_amdgcn_ballot_w64(cond)
+
+// ------------------------------------------------------------------ tests ----
+// plane: compatiblesPlane shapes/plane.jl:114-130 (+ project2plane :82-95), isparallel utilities.jl:115-117
+__device__ __forceinline__ uint64_t test_plane(const rh_prep &P, double px, double py, double pz, double nx,
+                                           double ny, double nz, double eps, double cosa)
+{
+    const double vx = px - P.f[0], vy = py - P.f[1], vz = pz - P.f[2];
+    const double d = (P.f[6] * vx + P.f[7] * vy) + P.f[8] * vz;
+    const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
+    return WB(dn > cosa) & WB(fabs(d) < eps);
+}
+
+// sphere: compatiblesSphere shapes/sphere.jl:144-172.  Inward case: normalize(o-p) = -normalize(p-o)
+// and dot(-u, n) = -dot(u, n) exactly (round-to-nearest is odd-symmetric), hence sgn * dot.
+__device__ __forceinline__ uint64_t test_sphere(const rh_prep &P, double px, double py, double pz, double nx,
+                                            double ny, double nz, double eps, double cosa)
+{
+    const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
+    const double nr = sqrt((dx * dx + dy * dy) + dz * dz);
+    const double inv = 1.0 / nr;
+    const double ux = inv * dx, uy = inv * dy, uz = inv * dz;
+    const double dt = (ux * nx + uy * ny) + uz * nz;
+    return WB(P.f[4] * dt > cosa) & WB(fabs(nr - P.f[3]) < eps);
+}
+
+// cylinder: compatiblesCylinder shapes/cylinder.jl:194-221
+__device__ __forceinline__ uint64_t test_cylinder(const rh_prep &P, double px, double py, double pz, double nx,
+                                              double ny, double nz, double eps, double cosa)
+{
+    const double ax = P.f[0], ay = P.f[1], az = P.f[2];
+    const double cx = P.f[3], cy = P.f[4], cz = P.f[5];
+    const double tx = px - cx, ty = py - cy, tz = pz - cz;
+    const double sd = (ax * tx + ay * ty) + az * tz;
+    // curr_norm = p - a*dot(a, p-c) - c
+    const double qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
+    const double nr = sqrt((qx * qx + qy * qy) + qz * qz);
+    const double inv = 1.0 / nr;
+    const double ux = inv * qx, uy = inv * qy, uz = inv * qz;
+    const double dt = (ux * nx + uy * ny) + uz * nz;
+    // the reference nests the two tests (cylinder.jl:209-214); their conjunction is the same bit
+    return WB(fabs(nr - P.f[6]) < eps) & WB(P.f[7] * dt > cosa);
+}
+
+// cone: compatiblesCone shapes/cone.jl:132-153, project2cone :68-85,
+// rodriguesrad/rodrigues/pluscrossprod! utilities.jl:61-64,19-24,32-43
+__device__ __forceinline__ uint64_t test_cone(const rh_prep &P, double px, double py, double pz, double nx,
+                                          double ny, double nz, double eps, double cosa)
+{
+    const double ax = P.f[3], ay = P.f[4], az = P.f[5];
+    const double c = P.f[6], s = P.f[7];
+    // to_point = apex - p; to_pointn = normalize(to_point)
+    const double tx = P.f[0] - px, ty = P.f[1] - py, tz = P.f[2] - pz;
+    double inv = 1.0 / sqrt((tx * tx + ty * ty) + tz * tz);
+    const double tnx = inv * tx, tny = inv * ty, tnz = inv * tz;
+    // rot_ax = normalize(cross(axis, to_pointn))
+    double kx = ay * tnz - az * tny, ky = az * tnx - ax * tnz, kz = ax * tny - ay * tnx;
+    inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+    const double rx = inv * kx, ry = inv * ky, rz = inv * kz;
+    // comp_n = normalize(cross(axis, rot_ax))
+    kx = ay * rz - az * ry; ky = az * rx - ax * rz; kz = ax * ry - ay * rx;
+    inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+    const double mx = inv * kx, my = inv * ky, mz = inv * kz;
+    // rodriguesrad re-normalizes the axis
+    inv = 1.0 / sqrt((rx * rx + ry * ry) + rz * rz);
+    const double vx = inv * rx, vy = inv * ry, vz = inv * rz;
+    // R = v v' + cos .* (I - v v'), then pluscrossprod!(R, sin, v)
+    const double nxx = vx * vx, nxy = vx * vy, nxz = vx * vz, nyy = vy * vy, nyz = vy * vz, nzz = vz * vz;
+    const double R00 = nxx + c * (1.0 - nxx);
+    double R01 = nxy + c * (0.0 - nxy);
+    double R02 = nxz + c * (0.0 - nxz);
+    double R10 = R01;
+    const double R11 = nyy + c * (1.0 - nyy);
+    double R12 = nyz + c * (0.0 - nyz);
+    double R20 = R02;
+    double R21 = R12;
+    const double R22 = nzz + c * (1.0 - nzz);
+    R01 -= s * vz; R02 += s * vy;
+    R10 += s * vz; R12 -= s * vx;
+    R20 -= s * vy; R21 += s * vx;
+    // current_normal = normalize(R * comp_n)
+    kx = (R00 * mx + R01 * my) + R02 * mz;
+    ky = (R10 * mx + R11 * my) + R12 * mz;
+    kz = (R20 * mx + R21 * my) + R22 * mz;
+    inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+    const double gx = inv * kx, gy = inv * ky, gz = inv * kz;
+    // dist = dot(-current_normal, -to_point)
+    const double dist = ((-gx) * (-tx) + (-gy) * (-ty)) + (-gz) * (-tz);
+    const double dt = (gx * nx + gy * ny) + gz * nz;
+    return WB(P.f[8] * dt > cosa) & WB(fabs(dist) < eps);
+}
+
+template <int KIND>
+__device__ __forceinline__ uint64_t test_point(const rh_prep &P, double px, double py, double pz, double nx,
+                                           double ny, double nz, double eps, double cosa)
+{
+    if (KIND == RH_PLANE) return test_plane(P, px, py, pz, nx, ny, nz, eps, cosa);
+    if (KIND == RH_SPHERE) return test_sphere(P, px, py, pz, nx, ny, nz, eps, cosa);
+    if (KIND == RH_CYLINDER) return test_cylinder(P, px, py, pz, nx, ny, nz, eps, cosa);
+    return test_cone(P, px, py, pz, nx, ny, nz, eps, cosa);
+}
+
+__device__ __forceinline__ uint64_t valid_mask(int64_t base, int64_t s)
+{
+    const int64_t left = s - base;
+    return left >= 64 ? ~0ULL : (left <= 0 ? 0ULL : ((1ULL << left) - 1ULL));
+}
+
+// -------------------------------------------------------------- prep ------
+__device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
+{
+#pragma unroll
+    for (int i = 0; i < 12; i++) o.f[i] = 0.0;
+    const double sgn = s.outwards ? 1.0 : -1.0;
+    switch (s.kind) {
+    case RH_PLANE: {
+        for (int i = 0; i < 6; i++) o.f[i] = s.v[i];
+        const double a = s.v[3], b = s.v[4], c = s.v[5];
+        const double inv = 1.0 / sqrt((a * a + b * b) + c * c);   // o_z = normalize(plane.normal)
+        o.f[6] = inv * a; o.f[7] = inv * b; o.f[8] = inv * c;
+        break;
+    }
+    case RH_SPHERE:
+        for (int i = 0; i < 4; i++) o.f[i] = s.v[i];
+        o.f[4] = sgn;
+        break;
+    case RH_CYLINDER:
+        for (int i = 0; i < 7; i++) o.f[i] = s.v[i];
+        o.f[7] = sgn;
+        break;
+    default:
+        for (int i = 0; i < 6; i++) o.f[i] = s.v[i];
+        o.f[6] = s.v[7];   // cos(-opang/2)
+        o.f[7] = s.v[8];   // sin(-opang/2)
+        o.f[8] = sgn;
+        break;
+    }
+}
+
+__global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b) prep_one(shapes[i], prep[i]);
+}
+
+// unknown kinds (device-resident batch): bin by kind with one atomic per candidate
+__global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
+                                   int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b) return;
+    const rh_shape s = shapes[i];
+    if (s.kind < 0 || s.kind > 3) return;   // counts[i] stays 0
+    const int slot = atomicAdd(&nk[s.kind], 1);
+    prep_one(s, prep[(int64_t)s.kind * cap + slot]);
+    orig[(int64_t)s.kind * cap + slot] = i;
+}
+
+// ------------------------------------------------------------- score ------
+// grid.x = point splits, grid.y = candidate tiles of RH_SC_CT.  A wave owns
+// RH_SC_WAVE_PTS contiguous points per tile (PPT x 64, PPT points per lane in
+// registers) and walks the block's candidates; per candidate it issues PPT tests per
+// lane, PPT ballots, and one LDS atomic with the wave's popcount.
+template <int KIND, bool MASK>
+__global__ void __launch_bounds__(RH_SC_THREADS)
+score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
+             const uint64_t *__restrict__ enabled_words, const rh_prep *__restrict__ prep,
+             const int32_t *__restrict__ orig, const int32_t *__restrict__ nk_ptr, double eps, double cosa,
+             int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride)
+{
+    const int nk = *nk_ptr;
+    const int c0 = blockIdx.y * RH_SC_CT;
+    if (c0 >= nk) return;
+    const int nc = min(RH_SC_CT, nk - c0);
+
+    __shared__ int32_t lcnt[RH_SC_CT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < RH_SC_CT) lcnt[tid] = 0;
+    __syncthreads();
+
+    const double *__restrict__ X = pts, *__restrict__ Y = pts + stride, *__restrict__ Z = pts + 2 * stride;
+    const double *__restrict__ NX = pts + 3 * stride, *__restrict__ NY = pts + 4 * stride,
+                 *__restrict__ NZ = pts + 5 * stride;
+    const int64_t ntiles = (s + RH_SC_TILE - 1) / RH_SC_TILE;
+    const int64_t swords = (s + 63) >> 6;
+    static_assert(RH_SC_CT == 64, "one lane per candidate of the tile");
+    int acc = 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * RH_SC_TILE + (int64_t)wave * RH_SC_WAVE_PTS;
+        double px[RH_SC_PPT], py[RH_SC_PPT], pz[RH_SC_PPT], qx[RH_SC_PPT], qy[RH_SC_PPT], qz[RH_SC_PPT];
+        uint64_t en[RH_SC_PPT];
+#pragma unroll
+        for (int p = 0; p < RH_SC_PPT; p++) {
+            const int64_t i = wbase + p * 64 + lane;
+            px[p] = X[i]; py[p] = Y[i]; pz[p] = Z[i];
+            qx[p] = NX[i]; qy[p] = NY[i]; qz[p] = NZ[i];
+            const int64_t gb = wbase + p * 64;
+            uint64_t v = valid_mask(gb, s);
+            if (enabled_words != nullptr && v != 0) v &= enabled_words[gb >> 6];
+            en[p] = v;
+        }
+        // candidate constants: scalar loads, software-prefetched one candidate ahead
+        rh_prep P = prep[c0];
+        for (int c = 0; c < nc; c++) {
+            const rh_prep Pn = prep[c0 + min(c + 1, nc - 1)];
+            uint64_t bw[RH_SC_PPT];
+            int n = 0;
+#pragma unroll
+            for (int p = 0; p < RH_SC_PPT; p++) {
+                bw[p] = test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & en[p];
+                n += __popcll(bw[p]);
+            }
+            acc += (lane == c) ? n : 0;   // lane c keeps candidate c0+c's count (RH_SC_CT == 64)
+            if (MASK) {
+                const int64_t w0 = wbase >> 6;
+                if (lane < RH_SC_PPT && w0 + lane < swords) {
+                    uint64_t v = bw[0];
+#pragma unroll
+                    for (int p = 1; p < RH_SC_PPT; p++) v = (lane == p) ? bw[p] : v;
+                    masks[(int64_t)orig[c0 + c] * mask_stride + w0 + lane] = v;
+                }
+            }
+            P = Pn;
+        }
+    }
+    if (acc != 0) atomicAdd(&lcnt[lane], acc);
+    __syncthreads();
+    if (tid < nc) {
+        const int v = lcnt[tid];
+        if (v != 0) atomicAdd(&counts[orig[c0 + tid]], v);
+    }
+}
+
+// ------------------------------------------------------------- refit ------
+// One candidate (kernarg -> SGPRs), the whole cloud in original order.  Each wave owns
+// 64-point words; mask word = ballot & enabled word; all-disabled words are skipped
+// without touching the point planes.  Per-1024-word popcount sums feed the compaction.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+refit_mask_kernel(const double *__restrict__ pts, int64_t stride, int64_t n, int64_t nwords,
+                  const uint64_t *__restrict__ enabled, const rh_prep P, double eps, double cosa,
+                  uint64_t *__restrict__ mask_out, int32_t *__restrict__ block_sums)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const double *__restrict__ X = pts, *__restrict__ Y = pts + stride, *__restrict__ Z = pts + 2 * stride;
+    const double *__restrict__ NX = pts + 3 * stride, *__restrict__ NY = pts + 4 * stride,
+                 *__restrict__ NZ = pts + 5 * stride;
+    for (int64_t w = wave0; w < nwords; w += nwaves) {
+        const uint64_t en = enabled[w] & valid_mask(w << 6, n);
+        uint64_t b = 0;
+        if (en != 0) {
+            const int64_t i = (w << 6) + lane;
+            b = test_point<KIND>(P, X[i], Y[i], Z[i], NX[i], NY[i], NZ[i], eps, cosa) & en;
+        }
+        if (lane == 0) {
+            mask_out[w] = b;
+            if (b != 0) atomicAdd(&block_sums[w / RH_WORDS_PER_BLOCK], __popcll(b));
+        }
+    }
+}
+
+// popcount sums per RH_WORDS_PER_BLOCK words (used for the select directory)
+__global__ void __launch_bounds__(256)
+block_popc_kernel(const uint64_t *__restrict__ words, int64_t nwords, int32_t *__restrict__ block_sums)
+{
+    __shared__ int32_t red[4];
+    const int64_t base = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
+    int acc = 0;
+    for (int k = threadIdx.x; k < RH_WORDS_PER_BLOCK; k += 256) {
+        const int64_t w = base + k;
+        if (w < nwords) acc += __popcll(words[w]);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// single-block exclusive scan of block_sums[0..nb) in place; block_sums[nb] and *total = grand total
+__global__ void __launch_bounds__(1024)
+scan_block_sums_kernel(int32_t *__restrict__ block_sums, int64_t nb, int32_t *__restrict__ total)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < nb ? block_sums[i] : 0;
+        int inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += wsum[k];
+        const int carry = carry_s;
+        if (i < nb) block_sums[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        block_sums[nb] = carry_s;
+        *total = carry_s;
+    }
+}
+
+// block b expands mask words [b*1024, (b+1)*1024): ascending 1-based indices
+__global__ void __launch_bounds__(256)
+expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ block_prefix,
+                   int64_t *__restrict__ idx_out, int64_t cap, int32_t *__restrict__ word_prefix_out)
+{
+    __shared__ int32_t off[RH_WORDS_PER_BLOCK];
+    __shared__ int32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
+    // each thread owns 4 consecutive words
+    int pc[4], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t w = base + threadIdx.x * 4 + k;
+        pc[k] = w < nwords ? __popcll(mask[w]) : 0;
+        tsum += pc[k];
+    }
+    int inc = tsum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wave; k++) woff += wsum[k];
+    int run = block_prefix[blockIdx.x] + woff + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        off[threadIdx.x * 4 + k] = run;
+        const int64_t w = base + threadIdx.x * 4 + k;
+        if (word_prefix_out != nullptr && w < nwords) word_prefix_out[w] = run;
+        run += pc[k];
+    }
+    __syncthreads();
+    if (idx_out == nullptr) return;
+    for (int k = wave; k < RH_WORDS_PER_BLOCK; k += 4) {
+        const int64_t w = base + k;
+        if (w >= nwords) break;
+        const uint64_t m = mask[w];
+        if (m == 0) continue;
+        if ((m >> lane) & 1ULL) {
+            const int64_t pos = (int64_t)off[k] + __popcll(m & ((1ULL << lane) - 1ULL));
+            if (pos < cap) idx_out[pos] = (w << 6) + lane + 1;
+        }
+    }
+}
+
+// ------------------------------------------------- enabled maintenance ----
+__global__ void invalidate_idx_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t npoints,
+                                      uint64_t *__restrict__ enabled)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t i0 = idx[k] - 1;
+    if (i0 < 0 || i0 >= npoints) return;
+    atomicAnd((unsigned long long *)&enabled[i0 >> 6], ~(1ULL << (i0 & 63)));
+}
+
+__global__ void andnot_kernel(uint64_t *__restrict__ enabled, const uint64_t *__restrict__ mask, int64_t nwords)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) enabled[w] &= ~mask[w];
+}
+
+// sub_enabled bit j = enabled[sub_idx0[j]]; optionally append the points whose bit went 1 -> 0
+// (or, with reset, every disabled point) to the disabled-subset-1 list used by the liveness pass.
+__global__ void __launch_bounds__(256)
+rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ sub_idx0, int64_t s,
+                           uint64_t *__restrict__ sub_enabled, const double *__restrict__ sub, int64_t sub_stride,
+                           double *__restrict__ dis, int64_t dis_stride, int32_t *__restrict__ ndis, int append,
+                           int reset)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = j >> 6;
+    bool bit = false;
+    if (j < s) {
+        const int32_t i0 = sub_idx0[j];
+        bit = (enabled[i0 >> 6] >> (i0 & 63)) & 1ULL;
+    }
+    const uint64_t neww = __builtin_amdgcn_ballot_w64(bit);
+    const uint64_t valid = valid_mask(w << 6, s);
+    if (valid == 0) return;
+    const uint64_t oldw = reset ? valid : sub_enabled[w];
+    if (lane == 0) sub_enabled[w] = neww;
+    if (!append) return;
+    const uint64_t gone = oldw & ~neww & valid;
+    if (gone == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(ndis, __popcll(gone));
+    base = __shfl(base, 0);
+    if ((gone >> lane) & 1ULL) {
+        const int64_t pos = base + __popcll(gone & ((1ULL << lane) - 1ULL));
+#pragma unroll
+        for (int k = 0; k < 6; k++) dis[k * dis_stride + pos] = sub[k * sub_stride + j];
+    }
+}
+
+__global__ void select_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ word_prefix,
+                              int64_t nwords, int32_t total, const int64_t *__restrict__ ranks, int32_t k,
+                              int64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int64_t r = ranks[i];
+    if (r < 1 || r > total) { out[i] = 0; return; }
+    // last word w with word_prefix[w] < r
+    int64_t lo = 0, hi = nwords;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (word_prefix[mid] < r) lo = mid; else hi = mid;
+    }
+    uint64_t m = enabled[lo];
+    int rem = (int)(r - word_prefix[lo]);
+    for (int t = 1; t < rem; t++) m &= m - 1;
+    out[i] = (lo << 6) + __ffsll((unsigned long long)m);
+}
+
+// AoS (Vector{SVector{3,Float64}}) -> SoA planes, optionally gathering through an index list
+__global__ void transpose_kernel(const double *__restrict__ xyz, const double *__restrict__ nrm,
+                                 const int32_t *__restrict__ gather, int64_t count, double *__restrict__ dst,
+                                 int64_t stride)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int64_t i = gather ? gather[j] : j;
+    dst[j] = xyz[3 * i];
+    dst[stride + j] = xyz[3 * i + 1];
+    dst[2 * stride + j] = xyz[3 * i + 2];
+    dst[3 * stride + j] = nrm[3 * i];
+    dst[4 * stride + j] = nrm[3 * i + 1];
+    dst[5 * stride + j] = nrm[3 * i + 2];
+}
+
+__global__ void iota_kernel(int32_t *d, int32_t n, int32_t base)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = base + i;
+}
+
+__global__ void gather_prep_kernel(const rh_prep *__restrict__ src, const int32_t *__restrict__ idx, int32_t n,
+                                   rh_prep *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+template <int KIND>
+int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, const uint64_t *en,
+                 const rh_prep *prep, const int32_t *orig, const int32_t *nk, int32_t nk_bound, double eps,
+                 double cosa, int32_t *counts, uint64_t *masks, int64_t mask_stride)
+{
+    const int ctiles = cdiv(nk_bound, RH_SC_CT);
+    const int64_t ntiles = (s + RH_SC_TILE - 1) / RH_SC_TILE;
+    if (ctiles == 0 || ntiles == 0) return RH_OK;
+    // ~8192 blocks keeps all 256 CUs (8 XCDs x 32) busy with several waves per SIMD; blocks that
+    // share a candidate tile differ in blockIdx.x, so consecutive ids (dealt round-robin over the
+    // XCDs) stream different point tiles against the same SGPR-resident candidates.
+    int64_t splits = 8192 / ctiles;
+    if (splits < 1) splits = 1;
+    if (splits > ntiles) splits = ntiles;
+    dim3 grid((unsigned)splits, (unsigned)ctiles);
+    if (masks)
+        hipLaunchKernelGGL((score_kernel<KIND, true>), grid, dim3(RH_SC_THREADS), 0, c->stream, pts, stride, s, en,
+                           prep, orig, nk, eps, cosa, counts, masks, mask_stride);
+    else
+        hipLaunchKernelGGL((score_kernel<KIND, false>), grid, dim3(RH_SC_THREADS), 0, c->stream, pts, stride, s, en,
+                           prep, orig, nk, eps, cosa, counts, masks, mask_stride);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+}  // namespace
+
+// host twin of prep_one (used when the candidate is passed by value as a kernel argument)
+void rh_prep_host(const rh_shape &s, rh_prep *o)
+{
+    for (int i = 0; i < 12; i++) o->f[i] = 0.0;
+    const double sgn = s.outwards ? 1.0 : -1.0;
+    switch (s.kind) {
+    case RH_PLANE: {
+        for (int i = 0; i < 6; i++) o->f[i] = s.v[i];
+        const double a = s.v[3], b = s.v[4], c = s.v[5];
+        const double inv = 1.0 / __builtin_sqrt((a * a + b * b) + c * c);
+        o->f[6] = inv * a; o->f[7] = inv * b; o->f[8] = inv * c;
+        break;
+    }
+    case RH_SPHERE:
+        for (int i = 0; i < 4; i++) o->f[i] = s.v[i];
+        o->f[4] = sgn;
+        break;
+    case RH_CYLINDER:
+        for (int i = 0; i < 7; i++) o->f[i] = s.v[i];
+        o->f[7] = sgn;
+        break;
+    default:
+        for (int i = 0; i < 6; i++) o->f[i] = s.v[i];
+        o->f[6] = s.v[7];
+        o->f[7] = s.v[8];
+        o->f[8] = sgn;
+        break;
+    }
+}
+
+int rhk_transpose_aos(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, const int32_t *d_gather,
+                      int64_t count, double *dst, int64_t dst_stride)
+{
+    (void)n;
+    if (count == 0) return RH_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, d_xyz, d_nrm, d_gather,
+                       count, dst, dst_stride);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep)
+{
+    if (b == 0) return RH_OK;
+    hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
+                    int32_t *d_nk, int64_t cap)
+{
+    RH_HIP(hipMemsetAsync(d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    if (b == 0) return RH_OK;
+    hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
+                       d_nk, cap);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s, const uint64_t *en,
+                   const rh_prep *d_prep, const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps,
+                   double cosa, int32_t *d_counts, uint64_t *d_masks, int64_t mask_stride)
+{
+    switch (kind) {
+    case RH_PLANE: return launch_score<RH_PLANE>(c, pts, stride, s, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks, mask_stride);
+    case RH_SPHERE: return launch_score<RH_SPHERE>(c, pts, stride, s, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks, mask_stride);
+    case RH_CYLINDER: return launch_score<RH_CYLINDER>(c, pts, stride, s, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks, mask_stride);
+    case RH_CONE: return launch_score<RH_CONE>(c, pts, stride, s, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks, mask_stride);
+    }
+    rh_set_error("unknown shape kind %d", kind);
+    return RH_E_INVALID;
+}
+
+int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa)
+{
+    RH_HIP(hipMemsetAsync(c->block_sums, 0, sizeof(int32_t) * (size_t)(c->nblocks + 1), c->stream));
+    if (c->nwords == 0) return RH_OK;
+    int64_t blocks = cdiv(c->nwords, 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    dim3 grid((unsigned)blocks), blk(256);
+#define RH_LAUNCH_REFIT(K)                                                                                        \
+    hipLaunchKernelGGL((refit_mask_kernel<K>), grid, blk, 0, c->stream, c->full, c->n_pad, c->n, c->nwords,       \
+                       c->enabled, P, eps, cosa, c->refit_mask, c->block_sums)
+    switch (kind) {
+    case RH_PLANE: RH_LAUNCH_REFIT(RH_PLANE); break;
+    case RH_SPHERE: RH_LAUNCH_REFIT(RH_SPHERE); break;
+    case RH_CYLINDER: RH_LAUNCH_REFIT(RH_CYLINDER); break;
+    case RH_CONE: RH_LAUNCH_REFIT(RH_CONE); break;
+    default: rh_set_error("unknown shape kind %d", kind); return RH_E_INVALID;
+    }
+#undef RH_LAUNCH_REFIT
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// block_sums must already hold the per-block popcounts of `mask`
+int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
+                     int32_t *d_total)
+{
+    const int64_t nb = (nwords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, d_total);
+    RH_HIP(hipGetLastError());
+    if (nb == 0) return RH_OK;
+    hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, mask, nwords, c->block_sums,
+                       idx_out, cap, (int32_t *)nullptr);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
+{
+    if (n == 0) return RH_OK;
+    hipLaunchKernelGGL(invalidate_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_idx, n, c->n, c->enabled);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask)
+{
+    if (c->nwords == 0) return RH_OK;
+    hipLaunchKernelGGL(andnot_kernel, dim3(cdiv(c->nwords, 256)), dim3(256), 0, c->stream, c->enabled, mask, c->nwords);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_rebuild_sub_enabled(rh_cloud *c, bool append, bool reset)
+{
+    if (reset) {
+        RH_HIP(hipMemsetAsync(c->d_ndis, 0, sizeof(int32_t), c->stream));
+    }
+    if (c->s == 0) return RH_OK;
+    hipLaunchKernelGGL(rebuild_sub_enabled_kernel, dim3(cdiv(c->s, 256)), dim3(256), 0, c->stream, c->enabled,
+                       c->sub_idx0, c->s, c->sub_enabled, c->sub, c->s_pad, c->dis, c->dis_stride, c->d_ndis,
+                       append ? 1 : 0, reset ? 1 : 0);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_build_select(rh_cloud *c)
+{
+    if (c->nwords == 0) { c->select_valid = true; return RH_OK; }
+    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
+                       c->block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
+    hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
+                       c->block_sums, (int64_t *)nullptr, (int64_t)0, c->word_prefix);
+    RH_HIP(hipGetLastError());
+    c->select_valid = true;
+    return RH_OK;
+}
+
+int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out)
+{
+    if (k == 0) return RH_OK;
+    int32_t total = 0;
+    RH_HIP(hipMemcpyAsync(&total, c->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(select_kernel, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->enabled, c->word_prefix,
+                       c->nwords, total, d_ranks, k, d_out);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_count_enabled(rh_cloud *c, int64_t *out)
+{
+    *out = 0;
+    if (c->nwords == 0) return RH_OK;
+    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
+                       c->block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
+    RH_HIP(hipGetLastError());
+    int32_t total = 0;
+    RH_HIP(hipMemcpyAsync(&total, c->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    *out = total;
+    c->select_valid = false;   // block_sums was clobbered
+    return RH_OK;
+}
+
+int rhk_iota(rh_cloud *c, int32_t *d, int32_t n, int32_t base)
+{
+    if (n == 0) return RH_OK;
+    hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d, n, base);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32_t n, rh_prep *dst)
+{
+    if (n == 0) return RH_OK;
+    hipLaunchKernelGGL(gather_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, src, d_idx, n, dst);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// mask (nwords 64-bit words) -> ascending 1-based set-bit positions; ws_block_sums needs nb+2 ints
+int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
+                        int64_t *idx_out, int64_t cap, int32_t *d_total)
+{
+    const int64_t nb = (nwords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
+    if (nb > 0) hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, stream, mask, nwords, ws_block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, ws_block_sums, nb, d_total);
+    if (nb > 0)
+        hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, mask, nwords, ws_block_sums,
+                           idx_out, cap, (int32_t *)nullptr);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}

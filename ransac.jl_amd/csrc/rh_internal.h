@@ -1,0 +1,130 @@
+// rh_internal.h -- internal declarations of libransac_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "ransac_hip.h"
+
+// ---- error plumbing -------------------------------------------------------
+void rh_set_error(const char *fmt, ...);
+
+#define RH_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            rh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                         __LINE__);                                                         \
+            return RH_E_NODEVICE;                                                           \
+        }                                                                                   \
+    } while (0)
+
+#define RH_TRY(call)                 \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != RH_OK) return rc_; \
+    } while (0)
+
+// ---- device-side candidate record ------------------------------------------
+// Per-candidate constants hoisted out of the per-point loop.  Every hoisted value is
+// a pure function of the candidate computed with the same IEEE operations the
+// reference evaluates per call, so hoisting does not change a single bit.
+//   plane    f[0..2]=point  f[3..5]=normal f[6..8]=normalize(normal)   (plane.jl:85)
+//   sphere   f[0..2]=center f[3]=R  f[4]=sgn
+//   cylinder f[0..2]=axis   f[3..5]=center f[6]=R f[7]=sgn
+//   cone     f[0..2]=apex   f[3..5]=axis   f[6]=cos(-w/2) f[7]=sin(-w/2) f[8]=sgn
+// sgn = +1.0 (outwards) / -1.0 (inwards); multiplying by it is exact.
+struct rh_prep {
+    double f[12];
+};
+
+// score kernel geometry (kernels.hip)
+constexpr int RH_SC_THREADS = 256;
+constexpr int RH_SC_PPT = 4;                             // points per lane
+constexpr int RH_SC_WAVE_PTS = 64 * RH_SC_PPT;           // contiguous points per wave per tile
+constexpr int RH_SC_TILE = RH_SC_THREADS * RH_SC_PPT;    // points per block per tile
+constexpr int RH_SC_CT = 64;                             // candidates per block
+constexpr int RH_WORDS_PER_BLOCK = 1024;                 // scan granularity (64-bit words)
+
+// ---- the cloud --------------------------------------------------------------
+struct rh_cloud {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t n = 0, s = 0;
+    int64_t n_pad = 0, s_pad = 0;      // padded to RH_SC_TILE
+    int64_t nwords = 0, swords = 0;    // ceil(n/64), ceil(s/64)
+    int64_t nblocks = 0;               // ceil(nwords / RH_WORDS_PER_BLOCK)
+
+    // HBM layout: six SoA planes of n_pad (resp. s_pad) doubles: x y z nx ny nz
+    double *full = nullptr;            // full cloud, original order
+    double *sub = nullptr;             // subset 1, subset order
+    double *dis = nullptr;             // disabled subset-1 points (append-only), capacity s_pad + tile
+    int64_t dis_stride = 0;
+    int32_t *sub_idx0 = nullptr;       // [s] 0-based original index of subset position j
+    uint64_t *enabled = nullptr;       // [nwords]  pc.isenabled chunks
+    uint64_t *sub_enabled = nullptr;   // [swords]  enabled bits gathered into subset order
+    int32_t *d_ndis = nullptr;         // device counter: entries in dis
+    int64_t n_dis = 0;                 // host mirror
+
+    // refit / select workspaces
+    uint64_t *refit_mask = nullptr;    // [nwords]
+    int32_t *block_sums = nullptr;     // [nblocks + 1]
+    int32_t *word_prefix = nullptr;    // [nwords + 1] exclusive prefix of popcount(enabled) (select)
+    bool select_valid = false;
+    int64_t *idx_out = nullptr;        // [n] compacted indices
+    int32_t *d_total = nullptr;        // scalar
+
+    // batch workspaces (grown on demand)
+    int64_t batch_cap = 0;
+    rh_shape *d_shapes = nullptr;      // [batch_cap]
+    rh_prep *d_prep = nullptr;         // [4 * batch_cap], kind-major
+    int32_t *d_orig = nullptr;         // [4 * batch_cap]
+    int32_t *d_nk = nullptr;           // [4]
+    int32_t *d_counts = nullptr;       // [batch_cap]
+    uint64_t *d_masks = nullptr;       // grown on demand
+    int64_t masks_cap = 0;
+    int64_t *d_ranks = nullptr;        // select in/out
+    int64_t ranks_cap = 0;
+
+    // pinned staging
+    void *h_pin = nullptr;
+    int64_t h_pin_cap = 0;
+};
+
+// ---- kernel launchers (kernels.hip) -----------------------------------------
+int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_nrm, int64_t n,
+                      const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
+int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
+                    int32_t *d_nk, int64_t cap);
+// score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
+// launch for an upper bound of nk_bound candidates
+int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s,
+                   const uint64_t *enabled_words_or_null, const rh_prep *d_prep, const int32_t *d_orig,
+                   const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
+                   uint64_t *d_masks_or_null, int64_t mask_stride);
+int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa);
+int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
+                     int32_t *d_total);
+int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n);
+int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask);
+int rhk_rebuild_sub_enabled(rh_cloud *c, bool append_newly_disabled, bool reset_list);
+int rhk_build_select(rh_cloud *c);
+int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out);
+int rhk_count_enabled(rh_cloud *c, int64_t *out);
+int rhk_iota(rh_cloud *c, int32_t *d, int32_t n, int32_t base);
+int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32_t n, rh_prep *dst);
+
+int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
+                        int64_t *idx_out, int64_t cap, int32_t *d_total);
+
+void rh_prep_host(const rh_shape &s, rh_prep *out);
+
+// ---- host helpers (cloud.hip) -----------------------------------------------
+int rh_ensure_batch(rh_cloud *c, int64_t b);
+int rh_ensure_masks(rh_cloud *c, int64_t words);
+int rh_ensure_pin(rh_cloud *c, int64_t bytes);
+int rh_validate_params(const rh_params *p);

@@ -1,0 +1,321 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle on the same seeded
+inputs.  Integer / index outputs must be bit-exact (counts, masks, inlier index lists)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import ransac_jl_amd as R
+from oracle import oracle as orc
+from ransac_jl_amd import _lib as L
+from ransac_jl_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def to_orc_params(cp):
+    return orc.Params.from_buffer_copy(bytes(cp))
+
+
+def to_orc_shapes(arr, b):
+    out = (orc.Shape * max(1, b))()
+    C.memmove(out, arr, C.sizeof(L.Shape) * b)
+    return out
+
+
+def make_candidates(truth, b, seed, kinds=None):
+    cands = synth.jittered_candidates(truth, b, seed=seed)
+    tcls = {"plane": R.FittedPlane, "sphere": R.FittedSphere, "cylinder": R.FittedCylinder, "cone": R.FittedCone}
+    out = []
+    for name, outw, v in cands:
+        if name == "plane":
+            out.append(R.FittedPlane(v[0:3], v[3:6]))
+        elif name == "sphere":
+            out.append(R.FittedSphere(v[0:3], v[3], outw))
+        elif name == "cylinder":
+            out.append(R.FittedCylinder(v[0:3], v[3:6], v[6], outw))
+        else:
+            out.append(R.FittedCone(v[0:3], v[3:6], v[6], outw))
+    return out
+
+
+def shape_array(cands):
+    arr = (L.Shape * max(1, len(cands)))()
+    for i, s in enumerate(cands):
+        arr[i] = s.to_c()
+    return arr
+
+
+@pytest.fixture(scope="module")
+def small_scene():
+    prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder", "cone", "cone"]
+    xyz, nrm, truth = synth.make_cloud(60_000, prim, 0.2, seed=11)
+    subs = synth.make_subsets(60_000, 3, seed=11)
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    return pc, oc, truth
+
+
+def test_score_counts_and_masks_all_kinds(small_scene):
+    pc, oc, truth = small_scene
+    cp = R.params_to_c(R.ransacparameters())
+    cands = make_candidates(truth, 203, seed=1)       # 203: ragged last candidate tile
+    arr = shape_array(cands)
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc_shapes(arr, len(cands)), to_orc_params(cp), want_masks=True)
+    assert counts.sum() > 10000                          # the batch really hits the primitives
+    assert np.array_equal(counts, ocounts)
+    assert np.array_equal(masks, omasks)                 # bit-exact inlier sets in subset order
+    for k in (L.PLANE, L.SPHERE, L.CYLINDER, L.CONE):
+        sel = [i for i, c in enumerate(cands) if c.kind == k]
+        assert len(sel) > 10 and counts[sel].max() > 500, "kind %d never scored inliers" % k
+    # counts without masks go through the other kernel instantiation
+    assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
+
+
+def test_scorecandidate_mirror_returns_reference_tuple(small_scene):
+    pc, oc, truth = small_scene
+    params = R.ransacparameters()
+    cp = R.params_to_c(params)
+    for cand in make_candidates(truth, 8, seed=2):
+        ci, inpoints = R.scorecandidate(pc, cand, 1, params)
+        cnt, oin = oc.scorecandidate(orc.Shape.from_buffer_copy(bytes(cand.to_c())), to_orc_params(cp))
+        assert np.array_equal(inpoints, oin)             # subset order, 1-based original indices
+        assert (ci.min, ci.max, ci.E) == orc.estimatescore(oc.s, oc.n, cnt)
+    with pytest.raises(ValueError):
+        R.scorecandidate(pc, cand, 2, params)
+
+
+def test_score_respects_enabled_bits_and_sphere_quirk(small_scene):
+    pc, oc, truth = small_scene
+    rng = np.random.default_rng(3)
+    mask = rng.random(pc.size) < 0.6
+    pc.set_enabled(mask)
+    oc.set_enabled(pc.enabled_chunks())
+    assert pc.count_enabled() == int(mask.sum()) == oc.count_enabled()
+    assert np.array_equal(pc.isenabled, mask)
+    cands = make_candidates(truth, 64, seed=4)
+    arr = shape_array(cands)
+    for fixed in (0, 1):
+        cp = R.params_to_c(R.ransacparameters(), sphere_uses_enabled=bool(fixed))
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        ocounts, omasks = oc.score_batch(to_orc_shapes(arr, 64), to_orc_params(cp), want_masks=True)
+        assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    # Q4 (sphere.jl:121,131): in reference mode sphere counts ignore the enabled bits
+    pc.enable_all(); oc.enable_all()
+    cp = R.params_to_c(R.ransacparameters())
+    full = R.score_batch(pc, arr, cp)
+    pc.set_enabled(mask)
+    part = R.score_batch(pc, arr, cp)
+    for i, c in enumerate(cands):
+        if c.kind == L.SPHERE:
+            assert part[i] == full[i]
+        elif full[i] > 100:
+            assert part[i] < full[i]
+    pc.enable_all(); oc.enable_all()
+
+
+def test_refit_invalidate_select(small_scene):
+    pc, oc, truth = small_scene
+    pc.enable_all(); oc.enable_all()
+    params = R.ransacparameters()
+    cp = R.params_to_c(params)
+    op = to_orc_params(cp)
+    rng = np.random.default_rng(5)
+    for cand in make_candidates(truth, 8, seed=6):
+        ex = R.refit(cand, pc, params)
+        oidx = oc.refit(orc.Shape.from_buffer_copy(bytes(cand.to_c())), op)
+        assert np.array_equal(ex.inpoints, oidx)         # ascending original indices
+        assert np.all(np.diff(ex.inpoints) > 0)
+        R.invalidate_indexes(pc, ex.inpoints)
+        oc.invalidate(oidx)
+        assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
+        n_en = pc.count_enabled()
+        assert n_en == oc.count_enabled()
+        ranks = np.concatenate([[1, n_en, n_en + 1, 0], rng.integers(1, n_en + 1, 50)])
+        got = R.select_enabled(pc, ranks)
+        exp = np.array([oc.select_enabled(int(r)) for r in ranks])
+        assert np.array_equal(got, exp)
+        # scoring after the extraction sees the new enabled bits
+        arr = shape_array([cand])
+        assert np.array_equal(R.score_batch(pc, arr, cp), oc.score_batch(to_orc_shapes(arr, 1), op))
+    # refit with too small a buffer reports the needed size
+    cs = make_candidates(truth, 1, seed=7)[0].to_c()
+    pc.enable_all()
+    n = C.c_int64()
+    small = np.zeros(4, dtype=np.int64)
+    rc = R.lib().rh_refit(pc._h, C.byref(cs), C.byref(cp), small.ctypes.data_as(C.POINTER(C.c_int64)), 4, C.byref(n))
+    assert rc == L.RH_E_CAPACITY and n.value > 4
+    oc.enable_all()
+
+
+@pytest.mark.parametrize("n,s", [(1, 1), (63, 63), (64, 64), (65, 33), (1023, 1023), (1025, 1025), (5000, 777)])
+def test_ragged_sizes(n, s):
+    rng = np.random.default_rng(n * 7 + s)
+    xyz, nrm, truth = synth.make_cloud(n, ["plane", "sphere"], 0.1, seed=n)
+    sub = (rng.permutation(n)[:s] + 1).astype(np.int64)
+    pc = R.RANSACCloud(xyz, nrm, [sub])
+    oc = orc.Cloud(xyz, nrm, sub)
+    cp = R.params_to_c(R.ransacparameters(plane={"ϵ": 2.0}, sphere={"ϵ": 2.0}))
+    cands = make_candidates(truth, 5, seed=n)
+    arr = shape_array(cands)
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc_shapes(arr, 5), to_orc_params(cp), want_masks=True)
+    assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    for c in cands:
+        ex = R.refit(c, pc, cp)
+        assert np.array_equal(ex.inpoints, oc.refit(orc.Shape.from_buffer_copy(bytes(c.to_c())), to_orc_params(cp)))
+
+
+def test_empty_batch_and_bad_arguments(small_scene):
+    pc, oc, truth = small_scene
+    cp = R.params_to_c(R.ransacparameters())
+    assert R.score_batch(pc, [], cp).size == 0
+    bad = L.Shape()
+    bad.kind = 9
+    with pytest.raises(R.RansacHipError) as e:
+        R.score_batch(pc, (L.Shape * 1)(bad), cp)
+    assert e.value.code == L.RH_E_INVALID
+    with pytest.raises(R.RansacHipError):
+        R.invalidate_indexes(pc, [0])
+    with pytest.raises(R.RansacHipError):
+        R.invalidate_indexes(pc, [pc.size + 1])
+    with pytest.raises(R.RansacHipError):      # subset index out of range
+        R.RANSACCloud(np.zeros((4, 3)), np.zeros((4, 3)), [np.array([5], dtype=np.int64)])
+
+
+def test_points_on_cone_axis_are_incompatible():
+    # cone.jl:68-85: a point on the axis gives NaN -> incompatible
+    apex, axis = np.array([0.0, 0, 0]), np.array([0.0, 0, 1.0])
+    pts = np.array([[0, 0, 5.0], [0, 0, 0.0], [3.0, 0, 3.0], [-3.0, 0, 3.0]])
+    nrm = np.array([[0, 0, 1.0], [0, 0, 1.0], [math.sqrt(.5), 0, -math.sqrt(.5)], [-math.sqrt(.5), 0, -math.sqrt(.5)]])
+    sub = np.array([1, 2, 3, 4], dtype=np.int64)
+    pc, oc = R.RANSACCloud(pts, nrm, [sub]), orc.Cloud(pts, nrm, sub)
+    cone = R.FittedCone(apex, axis, math.pi / 2, True)
+    cp = R.params_to_c(R.ransacparameters())
+    counts, masks = R.score_batch(pc, [cone], cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc_shapes(shape_array([cone]), 1), to_orc_params(cp), want_masks=True)
+    assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    assert int(masks[0, 0]) == 0b1100
+
+
+def run_both(xyz, nrm, subs, params, seed, **kw):
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    cp = R.params_to_c(params, **kw)
+    got, secs, stats = R.ransac(pc, cp, seed=seed, return_stats=True)
+    exp = oc.ransac(to_orc_params(cp), seed=seed)
+    assert exp["rc"] == 0
+    return pc, oc, got, exp, stats
+
+
+def assert_same_run(pc, oc, got, exp, stats):
+    assert stats["iterations"] == exp["iterations"]
+    assert stats["candidates_scored"] == exp["candidates_scored"]
+    assert stats["scored_left"] == exp["scored_left"]
+    assert stats["draws"] == exp["draws"]                 # same RNG consumption
+    assert len(got) == len(exp["shapes"])
+    for g, e in zip(got, exp["shapes"]):
+        assert bytes(g.c_shape) == bytes(e["shape"])      # parameters bit-identical (bar is 1e-5 rel)
+        assert np.array_equal(g.inpoints, e["inpoints"])  # identical inlier index sets
+        assert g.score_E == e["score_E"] and g.iteration == e["iteration"]
+    assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
+
+
+def test_ransac_cfg1_end_to_end():
+    """BASELINE configs[0]: 50k plane+sphere, the reference's defaults, faithful mode
+    (wrapping Int64 score, sphere ignores enabled): same minimal-set stream in => identical
+    extracted shapes and index sets out."""
+    c = synth.config("cfg1")
+    subs = synth.make_subsets(50000, c["r"], c["seed"])
+    params = R.ransacparameters([R.FittedPlane, R.FittedSphere])
+    pc, oc, got, exp, stats = run_both(c["xyz"], c["nrm"], subs, params, seed=1234)
+    assert len(got) == 2 and {R.strt(g.shape) for g in got} == {"plane", "sphere"}
+    assert sorted(len(g.inpoints) for g in got) == [25000, 25000]
+    assert_same_run(pc, oc, got, exp, stats)
+
+
+@pytest.mark.parametrize("seed,fixed", [(1, False), (2, False), (3, True)])
+def test_ransac_multi_primitive_all_kinds(seed, fixed):
+    """Many extractions with surviving / dying stored candidates of every kind: exercises the
+    recomputed candidate liveness (driver.hip) against the oracle's stored index lists."""
+    prim = ["plane", "sphere", "cylinder", "cone", "plane", "sphere"]
+    xyz, nrm, truth = synth.make_cloud(24_000, prim, 0.05, seed=40 + seed)
+    subs = synth.make_subsets(24_000, 2, seed=seed)
+    params = R.ransacparameters(iteration={"minsubsetN": 60, "τ": 300, "itermax": 40, "prob_det": 0.5})
+    kw = dict(score_mode=L.SCORE_F64, sphere_uses_enabled=True) if fixed else {}
+    pc, oc, got, exp, stats = run_both(xyz, nrm, subs, params, seed=seed, **kw)
+    assert len(got) >= 3
+    assert_same_run(pc, oc, got, exp, stats)
+
+
+def test_ransac_injected_stream_and_preexisting_disabled_points():
+    xyz, nrm, truth = synth.make_cloud(12_000, ["plane", "sphere", "cylinder"], 0.1, seed=77)
+    subs = synth.make_subsets(12_000, 2, seed=77)
+    pc, oc = R.RANSACCloud(xyz, nrm, subs), orc.Cloud(xyz, nrm, subs[0])
+    dis = np.random.default_rng(1).random(12_000) < 0.15
+    pc.set_enabled(~dis)
+    oc.set_enabled(pc.enabled_chunks())
+    stream = np.random.default_rng(2).integers(0, 2 ** 63, size=500, dtype=np.uint64) * np.uint64(2)
+    cp = R.params_to_c(R.ransacparameters(iteration={"minsubsetN": 40, "τ": 200, "itermax": 25, "prob_det": 0.5}))
+    got, secs, stats = R.ransac(pc, cp, seed=9, stream=stream, return_stats=True)
+    exp = oc.ransac(to_orc_params(cp), seed=9, stream=stream)
+    assert len(got) >= 1
+    assert_same_run(pc, oc, got, exp, stats)
+    # ransac(pc, params, true) re-enables everything first (iterations.jl:14-21)
+    got2, _ = R.ransac(pc, cp, setenabled=True, seed=9)
+    oc.enable_all()
+    exp2 = oc.ransac(to_orc_params(cp), seed=9)
+    assert [bytes(g.c_shape) for g in got2] == [bytes(e["shape"]) for e in exp2["shapes"]]
+
+
+def test_largestconncomp_known_answers(golden):  # test/parameterspacebitmap.jl:1-55
+    from test_oracle_golden import build_cc_case
+    g = golden["largestconncomp"]
+    for case in ("dense", "eight"):
+        bm, idx = build_cc_case(g["size"], g[case]["patches"])
+        indmap = [[idx.get((x, y), []) for y in range(bm.shape[1])] for x in range(bm.shape[0])]
+        for conn, key in (("default", "expected_conn4"), ("eight", "expected_conn8")):
+            exp = g[case][key]
+            assert R.largestconncomp(bm, indmap, conn) == exp["idx"] * exp["repeat"]
+
+
+@pytest.mark.parametrize("shape,density,seed", [((1, 1), 1.0, 0), ((7, 300), 0.55, 1), ((257, 129), 0.45, 2),
+                                                 ((640, 480), 0.6, 3), ((64, 64), 0.0, 4), ((300, 300), 1.0, 5)])
+def test_largestconncomp_random_bitmaps(shape, density, seed):
+    bm = np.random.default_rng(seed).random(shape) < density
+    for conn8 in (False, True):
+        got = R.largestconncomp(bm, None, "eight" if conn8 else "default")
+        assert np.array_equal(got, orc.largestconncomp(bm, conn8=conn8))
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE configs[1] at full size (1M points, r = 32, B = 4096): size-independent
+    properties, plus an oracle spot check on a slice of the batch."""
+    c = synth.config("cfg2")
+    n = c["xyz"].shape[0]
+    subs = synth.make_subsets(n, c["r"], c["seed"])
+    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
+    cp = R.params_to_c(R.ransacparameters())
+    cands = make_candidates(c["truth"], 4096, seed=8)
+    arr = shape_array(cands)
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    pop = np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1)
+    assert np.array_equal(pop, counts)                    # checksum of checksums
+    assert np.array_equal(R.score_batch(pc, arr, cp), counts)   # idempotent, both instantiations
+    assert counts.max() <= subs[0].size and counts.sum() > 4096 * 100
+    oc = orc.Cloud(c["xyz"], c["nrm"], subs[0])
+    sel = list(range(0, 4096, 97))
+    sub_arr = shape_array([cands[i] for i in sel])
+    assert np.array_equal(oc.score_batch(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp)), counts[sel])
+    # refit: ascending, all enabled before, none after invalidation, disjoint extractions
+    seen = np.zeros(n, dtype=bool)
+    for cand in cands[:6]:
+        ex = R.refit(cand, pc, cp)
+        assert np.all(np.diff(ex.inpoints) > 0) and not seen[ex.inpoints - 1].any()
+        seen[ex.inpoints - 1] = True
+        R.invalidate_indexes(pc, ex.inpoints)
+        assert R.refit(cand, pc, cp).inpoints.size == 0
+    assert pc.count_enabled() == n - int(seen.sum())
+    assert np.array_equal(pc.isenabled, ~seen)
