@@ -141,7 +141,7 @@ def test_refit_invalidate_select(small_scene):
         arr = shape_array([cand])
         assert np.array_equal(R.score_batch(pc, arr, cp), oc.score_batch(to_orc_shapes(arr, 1), op))
     # refit with too small a buffer reports the needed size
-    cs = make_candidates(truth, 1, seed=7)[0].to_c()
+    cs = R.FittedPlane(truth[0]["point"], truth[0]["normal"]).to_c()
     pc.enable_all()
     n = C.c_int64()
     small = np.zeros(4, dtype=np.int64)
