@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- candidates scored / s (+ shapes / s) on the BASELINE.json workload.
+
+A "step" = one pass of the hot path over one batch: B = 4096 candidate shapes (ground-truth
+primitives jittered by 1 %) scored against subset 1 (S = N/32 points) of the
+10M-point, 40-primitive, 30 %-outlier synthetic cloud (BASELINE.json configs[2], the config the
+metric is quoted on), everything resident in HBM when the timed region starts.  With --gpus N
+every rank holds a replica of the cloud, scores its own 4096-candidate slice of a global
+N x 4096 batch and one RCCL int32 sum all-reduce per step gives every rank every score
+(weak scaling; value = candidates all ranks scored / max-over-ranks time).
+
+One JSON line on rank 0.  Extra objects: `roofline` (dominant score kernel, HIP events on the
+library's stream), `roofline_valu` (FP64 vector-ALU view of the same kernel -- the batched
+score is ALU-bound), `roofline_refit` (the HBM-bound full-cloud scan),
+`cpu_baseline` (the oracle, 1 thread, bounded sample), `end_to_end` (rh_ransac on the same cloud).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
+SCORE_BYTES_PER_TEST = 48.25   # 6 x 8 B point+normal + 1 bit enabled + 1 bit mask
+REFIT_BYTES_PER_POINT = 48.125
+# FP64 vector instructions per (candidate, point) test in score_kernel's inner loop, counted from
+# the gfx950 ISA of this build: v_add/v_mul/v_fma/v_cmp/v_rcp/v_rsq ... _f64
+VALU_F64_PER_TEST = {"plane": 15, "sphere": 45, "cylinder": 59, "cone": 247}
+# useful flops per test in the reference's arithmetic
+FLOPS_PER_TEST = {"plane": 13, "sphere": 20, "cylinder": 34, "cone": 140}
+KINDS = ["plane", "sphere", "cylinder", "cone"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="cloud size (default: BASELINE cfg3)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
+    ap.add_argument("--e2e-seconds", type=float, default=25.0)
+    return ap.parse_args()
+
+
+def shapes_to_c(R, L, cands):
+    arr = (L.Shape * max(1, len(cands)))()
+    kmap = {"plane": L.PLANE, "sphere": L.SPHERE, "cylinder": L.CYLINDER, "cone": L.CONE}
+    for i, (name, outw, v) in enumerate(cands):
+        arr[i].kind = kmap[name]
+        arr[i].outwards = int(outw)
+        for j, x in enumerate(v):
+            arr[i].v[j] = float(x)
+        R.lib().rh_shape_finalize(C.byref(arr[i]))
+    return arr
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+
+    import ransac_jl_amd as R
+    from ransac_jl_amd import _lib as L
+    from ransac_jl_amd import dist as rdist
+    from ransac_jl_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    lib = R.lib()
+
+    # ---- workload: BASELINE cfg3 (cfg4 when sharded) -----------------------------------
+    n = args.points
+    prim = ["plane"] * 16 + ["sphere"] * 12 + ["cylinder"] * 12
+    t0 = time.time()
+    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=3)
+    subs = synth.make_subsets(n, 32, seed=3)
+    S = subs[0].size
+    pc = R.RANSACCloud(xyz, nrm, subs, device=local_rank)
+    t_setup = time.time() - t0
+    params = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder])
+    cp = R.params_to_c(params, score_mode=L.SCORE_F64)   # Int64 score wraps at this size
+
+    b_global = B_PER_GPU * world
+    cands = synth.jittered_candidates(truth, b_global, seed=0)
+    arr = shapes_to_c(R, L, cands)
+    batch = rdist.DeviceBatch(pc, arr, b_global)
+    counts = torch.zeros(b_global, dtype=torch.int32, device="cuda")
+    local = rdist.gpu_local_score(pc, batch, cp)
+    lo, hi = rdist.shard_bounds(b_global, rank, world)
+
+    def step():
+        if world > 1:
+            rdist.score_batch_sharded(b_global, rank, world, local, counts)
+        else:   # no collective, no host sync inside the timed region
+            L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp),
+                                           C.c_void_p(counts.data_ptr()), None))
+
+    def fence():
+        L.check(lib.rh_cloud_sync(pc._h))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    L.check(lib.rh_timer_start(pc._h))
+    for _ in range(args.steps):
+        step()
+    ev_ms = C.c_float()
+    L.check(lib.rh_timer_stop(pc._h, C.byref(ev_ms)))
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = b_global * args.steps / dt
+    counts_h = counts.cpu().numpy()
+
+    out = {
+        "metric": "candidates_scored_per_sec", "value": value, "unit": "candidates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cfg3: 10M-point 40-primitive cloud, 30% outliers, r=32 subsets, "
+                               "B=4096 candidates/GPU/step" if n == 10_000_000 else "custom",
+                   "points": n, "subset_points": int(S), "candidates_per_step": b_global,
+                   "kinds": "plane/sphere/cylinder (cycled over the 40 ground-truth primitives, 1% jitter)",
+                   "score_mode": "f64", "parallelism": "candidate-sharded x%d, int32 sum all-reduce" % world},
+        "tests_per_sec": value * S,
+    }
+
+    if rank == 0:
+        # ---- per-kind kernel time (HIP events) and rooflines -----------------------------
+        per_kind = {}
+        reps = 10
+        acc = [0.0] * 4
+        msk = (C.c_float * 4)()
+        for _ in range(reps):   # the same launches as the timed steps, bracketed by events per kind
+            L.check(lib.rh_score_batch_dev_timed(pc._h, batch.slice_ptr(lo), hi - lo, C.byref(cp),
+                                                 C.c_void_p(counts.data_ptr() + 4 * lo), None, msk))
+            for k in range(4):
+                acc[k] += msk[k]
+        for ki, k in enumerate(KINDS):
+            nk = sum(1 for c in cands[lo:hi] if c[0] == k)
+            if nk:
+                per_kind[k] = {"candidates": nk, "ms_per_launch": acc[ki] / reps}
+        dom = max(per_kind, key=lambda k: per_kind[k]["ms_per_launch"])
+        d = per_kind[dom]
+        tests = d["candidates"] * S
+        sec = d["ms_per_launch"] * 1e-3
+        alg_bytes = tests * SCORE_BYTES_PER_TEST + d["candidates"] * (64 + 4)
+        out["roofline"] = {
+            "kernel": "score_kernel<%s>" % dom, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "algorithmic bytes = 48.25 B x (candidate, point) tests; the batched kernel re-uses each "
+                    "point across the candidate tile from registers, so it is FP64-ALU-bound and this "
+                    "fraction exceeds 1 by design (SURVEY.md 8d) -- see roofline_valu",
+        }
+        issue = VALU_F64_PER_TEST[dom] * tests / 64 * 4          # SIMD cycles at 4 cycles per wave64 f64 op
+        out["roofline_valu"] = {
+            "kernel": "score_kernel<%s>" % dom, "bound": "fp64_valu",
+            "achieved": FLOPS_PER_TEST[dom] * tests / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": FLOPS_PER_TEST[dom] * tests / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "valu_issue_frac": issue / (1024 * 2.4e9 * sec),
+            "note": "achieved = reference flops/test x tests / time (no FMA allowed: bit-exact parity caps this at "
+                    "half the FMA peak); valu_issue_frac = f64 vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x time)",
+        }
+        out["per_kind"] = per_kind
+        out["event_ms_per_step"] = ev_ms.value / args.steps
+
+        # refit scan: HBM-bound
+        t = truth[0]
+        plane = R.FittedPlane(t["point"], t["normal"]).to_c()
+        idx = np.zeros(n, dtype=np.int64)
+        nout = C.c_int64()
+        L.check(lib.rh_refit(pc._h, C.byref(plane), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            L.check(lib.rh_refit(pc._h, C.byref(plane), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
+        t_refit = (time.perf_counter() - t0) / 5
+        rbytes = n * REFIT_BYTES_PER_POINT + 8 * nout.value
+        out["roofline_refit"] = {"kernel": "refit_mask_kernel<plane>+compaction (host wall incl. D2H of the index list)",
+                                 "bound": "hbm", "achieved": rbytes / t_refit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": rbytes / t_refit / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "ms": 1e3 * t_refit, "inliers": int(nout.value)}
+
+        # ---- cpu_baseline: the oracle (port of the reference's single-threaded path) ------
+        if not args.no_cpu:
+            from oracle import oracle as orc
+            oc = orc.Cloud(xyz, nrm, subs[0])
+            nb = 768
+            oarr = (orc.Shape * nb)()
+            C.memmove(oarr, arr, C.sizeof(L.Shape) * nb)
+            op = orc.Params.from_buffer_copy(bytes(cp))
+            t0 = time.perf_counter()
+            oc_counts = oc.score_batch(oarr, op)
+            t_cpu = time.perf_counter() - t0
+            if not np.array_equal(oc_counts, counts_h[:nb]):
+                raise SystemExit("PARITY FAILURE: GPU counts differ from the oracle on the cpu_baseline sample")
+            out["cpu_baseline"] = {"value": nb / t_cpu, "unit": "candidates/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d candidates of the same batch on the same subset (S=%d), "
+                                             "%.1f s; counts checked equal to the GPU's" % (nb, S, t_cpu),
+                                   "host_cpus": os.cpu_count()}
+            del oc
+
+        # ---- end to end: shapes / s of the whole ransac() loop on the same cloud ----------
+        if not args.no_e2e:
+            e2e = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
+                                     iteration={"minsubsetN": 4096, "itermax": 1, "τ": 900, "prob_det": 0.9})
+            ecp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True)
+            # time-boxed: calibrate seconds/iteration on 8 iterations, then ONE call sized to the budget
+            pc.enable_all()
+            ecp.itermax = 8
+            _, _, st = R.ransac(pc, ecp, seed=99, return_stats=True)
+            per_iter = max(st["seconds"] / max(1, st["iterations"]), 1e-4)
+            pc.enable_all()
+            ecp.itermax = max(16, int(args.e2e_seconds / per_iter))
+            t0 = time.perf_counter()
+            got, secs, st = R.ransac(pc, ecp, seed=1234, return_stats=True)
+            shapes, iters, cand_scored = len(got), st["iterations"], st["candidates_scored"]
+            agg = {kk: st[kk] for kk in ("seconds_score", "seconds_extract", "seconds_host")}
+            t_e2e = time.perf_counter() - t0
+            out["end_to_end"] = {"metric": "shapes_per_sec", "value": shapes / t_e2e, "shapes": shapes, "seconds": t_e2e,
+                                 "iterations": iters, "minimal_sets": iters * 4096, "candidates_scored": cand_scored,
+                                 "breakdown_s": agg,
+                                 "itermax": int(ecp.itermax), "largest_shapes": sorted((len(g.inpoints) for g in got), reverse=True)[:5],
+                                 "note": "one rh_ransac call, minsubsetN=4096, itermax sized to ~%gs; root-cell sampling "
+                                         "like the reference, f64 score mode" % args.e2e_seconds}
+        out["setup_seconds"] = t_setup
+        print(json.dumps(out))
+    batch.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,6 +214,11 @@ int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int
                         uint8_t *bitmap_or_null, int64_t *idxmap_or_null);
 
 /* ---- measurement plumbing (bench.py): HIP events on the cloud's stream ---- */
+/* rh_score_batch_dev with a HIP event recorded on the cloud's stream before each of the four
+ * per-kind score launches and after the last; waits for the batch and returns the elapsed
+ * milliseconds of each kind's kernel (0 for kinds without candidates ~ an empty launch). */
+int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                             int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_kind_out /* [4] */);
 int rh_timer_start(rh_cloud *c);
 int rh_timer_stop(rh_cloud *c, float *ms_out); /* synchronises the stream */
 int rh_cloud_sync(rh_cloud *c);

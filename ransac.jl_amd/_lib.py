@@ -75,6 +75,7 @@ SIGNATURES = {
     "rh_cloud_count_enabled": (C.c_int, [_vp, _i64p]),
     "rh_score_batch": (C.c_int, [_vp, _sp, C.c_int32, _pp, _i32p, _u64p]),
     "rh_score_batch_dev": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp]),
+    "rh_score_batch_dev_timed": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp, C.POINTER(C.c_float)]),
     "rh_refit": (C.c_int, [_vp, _sp, _pp, _i64p, C.c_int64, _i64p]),
     "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
     "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),

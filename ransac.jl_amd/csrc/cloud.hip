@@ -114,6 +114,8 @@ static void cloud_free(rh_cloud *c)
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int k = 0; k < 5; k++)
+        if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -185,6 +187,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CKH(hipEventCreate(&c->ev0));
     CKH(hipEventCreate(&c->ev1));
+    for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
     CK(dev_alloc(&c->full, 6 * c->n_pad));
     CK(dev_alloc(&c->sub, 6 * c->s_pad));
     CK(dev_alloc(&c->dis, 6 * c->dis_stride));
@@ -362,21 +365,42 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     return RH_OK;
 }
 
-extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
-                                  int32_t *d_counts, uint64_t *d_masks)
+static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                                int32_t *d_counts, uint64_t *d_masks, float *ms_kind)
 {
     RH_TRY(enter(c));
     RH_TRY(rh_validate_params(p));
     if (b < 0 || (b > 0 && (!d_shapes || !d_counts))) { rh_set_error("rh_score_batch_dev: bad arguments"); return RH_E_INVALID; }
+    if (ms_kind) for (int k = 0; k < 4; k++) ms_kind[k] = 0.f;
     if (b == 0) return RH_OK;
     RH_TRY(rh_ensure_batch(c, b));
     RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
     RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, c->d_nk, c->batch_cap));
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
+        if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
         RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), c->d_prep + (int64_t)k * c->batch_cap,
                               c->d_orig + (int64_t)k * c->batch_cap, c->d_nk + k, b, p->eps[k], p->cos_alpha[k],
                               d_counts, d_masks, c->swords));
+    }
+    if (ms_kind) {
+        RH_HIP(hipEventRecord(c->evk[4], c->stream));
+        RH_HIP(hipEventSynchronize(c->evk[4]));
+        for (int k = 0; k < 4; k++) RH_HIP(hipEventElapsedTime(&ms_kind[k], c->evk[k], c->evk[k + 1]));
+    }
     return RH_OK;
+}
+
+extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                                  int32_t *d_counts, uint64_t *d_masks)
+{
+    return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr);
+}
+
+extern "C" int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                                        int32_t *d_counts, uint64_t *d_masks, float *ms_kind_out)
+{
+    if (!ms_kind_out) { rh_set_error("rh_score_batch_dev_timed: ms_kind_out is NULL"); return RH_E_INVALID; }
+    return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, ms_kind_out);
 }
 
 // ------------------------------------------------------------------ refit ----

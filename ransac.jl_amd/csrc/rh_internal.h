@@ -53,6 +53,7 @@ struct rh_cloud {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // per-kind launch brackets
     int64_t n = 0, s = 0;
     int64_t n_pad = 0, s_pad = 0;      // padded to RH_SC_TILE
     int64_t nwords = 0, swords = 0;    // ceil(n/64), ceil(s/64)
