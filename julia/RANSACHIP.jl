@@ -1,0 +1,209 @@
+# RANSACHIP.jl -- the `ccall` shim a RANSAC.jl maintainer adds to route the hot path of
+# RANSAC.jl v0.6.0 through libransac_hip.so (include/ransac_hip.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia runtime.  It is written
+# against RANSAC.jl v0.6.0's source (src/fitting.jl, src/iterations.jl, src/shapes/*.jl) and the
+# C ABI; struct layouts below must stay in sync with include/ransac_hip.h (tests/test_abi.py pins
+# sizeof(rh_shape) == 88 and the rh_params field offsets on the C side).
+#
+# Usage:
+#   using RANSAC, RANSACHIP
+#   pc  = RANSACCloud(vs, ns, 32)
+#   hpc = RANSACHIP.HIPCloud(pc)                      # uploads once; pc stays the source of truth on the host
+#   extracted, secs = RANSACHIP.ransac(hpc, params)   # same loop as RANSAC.ransac, GPU hot path
+module RANSACHIP
+
+using RANSAC
+using RANSAC: FittedShape, FittedPlane, FittedSphere, FittedCylinder, FittedCone,
+              ExtractedShape, IterationCandidates, ConfidenceInterval, E,
+              recordscore!, findhighestscore, forcefitshapes!, samplepointcloud4!,
+              chooseS, prob, updatelevelweight, strt
+using StaticArrays
+
+const LIB = get(ENV, "RANSAC_HIP_LIB", joinpath(@__DIR__, "..", "ransac.jl_amd", "libransac_hip.so"))
+
+const RH_PLANE, RH_SPHERE, RH_CYLINDER, RH_CONE = Cint(0), Cint(1), Cint(2), Cint(3)
+
+# typedef struct { int32_t kind; int32_t outwards; double v[10]; } rh_shape;   (88 bytes)
+struct RhShape
+    kind::Cint
+    outwards::Cint
+    v::NTuple{10,Cdouble}
+end
+
+# rh_params, field for field (include/ransac_hip.h)
+struct RhParams
+    eps::NTuple{4,Cdouble}
+    alpha::NTuple{4,Cdouble}
+    cos_alpha::NTuple{4,Cdouble}
+    collin_threshold::Cdouble
+    parallelthrdeg::Cdouble
+    cos_parallelthr::Cdouble
+    sphere_par::Cdouble
+    minconeopang::Cdouble
+    prob_det::Cdouble
+    tau::Int64
+    itermax::Int64
+    drawN::Cint
+    minsubsetN::Cint
+    extract_s::Cint
+    terminate_s::Cint
+    n_shape_types::Cint
+    shape_types::NTuple{8,Cint}
+    score_mode::Cint
+    sphere_uses_enabled::Cint
+    reserved::Cint
+end
+
+lasterror() = unsafe_string(ccall((:rh_last_error, LIB), Cstring, ()))
+check(rc) = rc == 0 ? nothing : error("libransac_hip error $rc: $(lasterror())")
+
+pad10(xs...) = ntuple(i -> i <= length(xs) ? Cdouble(xs[i]) : 0.0, 10)
+
+# FittedShape -> rh_shape.  cos/sin(-opang/2) are computed HERE, with Julia's libm, exactly as
+# rodrigues() would (src/utilities.jl:21-22), so the device sees the reference's own constants.
+toC(s::FittedPlane) = RhShape(RH_PLANE, 0, pad10(s.point..., s.normal...))
+toC(s::FittedSphere) = RhShape(RH_SPHERE, s.outwards, pad10(s.center..., s.radius))
+toC(s::FittedCylinder) = RhShape(RH_CYLINDER, s.outwards, pad10(s.axis..., s.center..., s.radius))
+toC(s::FittedCone) = RhShape(RH_CONE, s.outwards,
+    pad10(s.apex..., s.axis..., s.opang, cos(-s.opang/2), sin(-s.opang/2)))
+
+kindof(::Type{<:FittedPlane}) = RH_PLANE
+kindof(::Type{<:FittedSphere}) = RH_SPHERE
+kindof(::Type{<:FittedCylinder}) = RH_CYLINDER
+kindof(::Type{<:FittedCone}) = RH_CONE
+
+# nested NamedTuple (src/utilities.jl:332-399) -> rh_params; thresholds use Julia's cos / cosd
+function toC(p::NamedTuple; score_mode = 0, sphere_uses_enabled = 0)
+    get2(nt, k, d) = haskey(nt, k) ? getfield(nt, k) : d
+    sh(name) = get2(p, name, (ϵ = 0.3, α = deg2rad(5)))
+    order = (:plane, :sphere, :cylinder, :cone)                       # RH_* kind order
+    eps = ntuple(i -> Cdouble(sh(order[i]).ϵ), 4)
+    alp = ntuple(i -> Cdouble(sh(order[i]).α), 4)
+    it, co = p.iteration, p.common
+    sym = Dict(:lengthC => 1, :allcand => 2, :nofminset => 3)
+    st = [kindof(T) for T in it.shape_types]
+    RhParams(eps, alp, ntuple(i -> cos(alp[i]), 4),
+        co.collin_threshold, co.parallelthrdeg, cosd(co.parallelthrdeg),
+        get2(get2(p, :sphere, NamedTuple()), :sphere_par, 0.02),
+        get2(get2(p, :cone, NamedTuple()), :minconeopang, deg2rad(2)),
+        it.prob_det, it.τ, it.itermax, it.drawN, it.minsubsetN,
+        sym[it.extract_s], sym[it.terminate_s], length(st),
+        ntuple(i -> i <= length(st) ? st[i] : Cint(0), 8), score_mode, sphere_uses_enabled, 0)
+end
+
+"Device-resident twin of a RANSACCloud; `pc` stays authoritative for fits and sampling."
+mutable struct HIPCloud{P}
+    pc::P
+    handle::Ptr{Cvoid}
+    function HIPCloud(pc; device = 0)
+        # Vector{SVector{3,Float64}} is n x 3 contiguous doubles: passed as is (zero copy on the host side)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        s1 = pc.subsets[1]
+        GC.@preserve pc check(ccall((:rh_cloud_create, LIB), Cint,
+            (Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Int64, Cint, Ptr{Ptr{Cvoid}}),
+            pointer(reinterpret(Float64, pc.vertices)), pointer(reinterpret(Float64, pc.normals)),
+            pc.size, s1, length(s1), device, h))
+        obj = new{typeof(pc)}(pc, h[])
+        push_enabled!(obj)
+        finalizer(o -> ccall((:rh_cloud_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
+    end
+end
+
+# pc.isenabled::BitVector -> device (same chunk layout)
+push_enabled!(h::HIPCloud) = check(ccall((:rh_cloud_set_enabled, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{UInt64}, Int64), h.handle, h.pc.isenabled.chunks, length(h.pc.isenabled.chunks)))
+
+"""
+Replacement for `scorecandidates!` (src/fitting.jl:181-190): ONE batched call instead of a
+sequential loop.  Legal because nothing reads a score before the loop ends (iterations.jl:99).
+`inpoints` are rebuilt from the returned bit masks (subset order), so `IterationCandidates` and
+`removeinvalidshapes!` keep working unchanged.
+"""
+function scorecandidates!(h::HIPCloud, ic::IterationCandidates, candidates, subsetID, params, octree_levels;
+                          cparams = toC(params))
+    @assert subsetID == 1 "only subset 1 is resident on the device (iterations.jl:95)"
+    pc = h.pc
+    b = length(candidates)
+    if b > 0
+        shapes = RhShape[toC(c) for c in candidates]
+        counts = Vector{Int32}(undef, b)
+        s1 = pc.subsets[1]
+        w = cld(length(s1), 64)
+        masks = Matrix{UInt64}(undef, w, b)               # column i = row i of the C array
+        check(ccall((:rh_score_batch, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{RhShape}, Int32, Ref{RhParams}, Ptr{Int32}, Ptr{UInt64}),
+            h.handle, shapes, b, cparams, counts, masks))
+        for i in 1:b
+            bits = BitVector(undef, length(s1))
+            copyto!(bits.chunks, view(masks, :, i))
+            ip = s1[bits]
+            sc = RANSAC.estimatescore(length(s1), pc.size, length(ip))
+            pc.levelscore[octree_levels[i]] += E(sc)
+            recordscore!(ic, candidates[i], sc, ip)
+        end
+    end
+    empty!(candidates); empty!(octree_levels)
+    return nothing
+end
+
+"Replacement for `refit` (src/shapes/*.jl): full-cloud scan on the device, ascending indices."
+function refit(s::FittedShape, h::HIPCloud, params; cparams = toC(params))
+    idx = Vector{Int}(undef, h.pc.size)
+    n = Ref{Int64}(0)
+    check(ccall((:rh_refit, LIB), Cint,
+        (Ptr{Cvoid}, Ref{RhShape}, Ref{RhParams}, Ptr{Int64}, Int64, Ptr{Int64}),
+        h.handle, toC(s), cparams, idx, length(idx), n))
+    resize!(idx, n[])
+    return ExtractedShape(s, idx)
+end
+
+"Replacement for `invalidate_indexes!` (src/fitting.jl:197-202): host bits and device bits."
+function invalidate_indexes!(h::HIPCloud, indexlist)
+    RANSAC.invalidate_indexes!(h.pc, indexlist)
+    check(ccall((:rh_invalidate, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), h.handle, indexlist, length(indexlist)))
+end
+
+"""
+`ransac(pc, params)` (src/iterations.jl:35-162) with the three hot calls swapped; sampling, `fit`,
+`findhighestscore`, `prob`, `removeinvalidshapes!` are the reference's own functions.
+"""
+function ransac(h::HIPCloud, params; reset_rand = false)
+    pc = h.pc
+    reset_rand && RANSAC.Random.seed!(1234)
+    it = params.iteration
+    cparams = toC(params)
+    push_enabled!(h)
+    start_time = time_ns()
+    candidates = FittedShape[]; scoredshapes = IterationCandidates(); extracted = ExtractedShape[]
+    levels = Int[]; sd = Vector{Int}(undef, it.drawN); countcandidates = [0, 0, 0]
+    for k in 1:it.itermax
+        count(pc.isenabled) < it.τ && break
+        for i in 1:it.minsubsetN
+            res = samplepointcloud4!(sd, pc, params)
+            res[1] || continue
+            forcefitshapes!(view(pc.vertices, sd), view(pc.normals, sd), params, candidates, levels, res[2], pc)
+        end
+        countcandidates[2] += length(candidates)
+        scorecandidates!(h, scoredshapes, candidates, 1, params, levels; cparams = cparams)
+        countcandidates[3] = k * it.minsubsetN
+        countcandidates[1] = length(scoredshapes)
+        if length(scoredshapes) > 0
+            best = findhighestscore(scoredshapes)
+            bestshape = scoredshapes.shapes[best.index]
+            scr = E(scoredshapes.scores[best.index])
+            if prob(scr, chooseS(countcandidates, it.extract_s), pc.size, it.drawN) > it.prob_det
+                ex = refit(bestshape, h, params; cparams = cparams)
+                invalidate_indexes!(h, ex.inpoints)
+                push!(extracted, ex)
+                deleteat!(scoredshapes, best.index)
+                RANSAC.removeinvalidshapes!(pc, scoredshapes)
+            end
+        end
+        updatelevelweight(pc)
+        prob(it.τ, chooseS(countcandidates, it.terminate_s), pc.size, it.drawN) > it.prob_det && break
+    end
+    return extracted, trunc((time_ns() - start_time) / 1_000_000_000, digits = 2)
+end
+
+end # module
