@@ -12,6 +12,8 @@
 // into SGPRs, the per-point math runs on the FP64 vector ALU, inlier counts come
 // from 64-bit wave ballots + s_bcnt1 (no cross-lane reduction tree).
 
+#include <stdlib.h>
+
 #include "rh_internal.h"
 
 namespace {
@@ -163,17 +165,31 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
     if (i < b) prep_one(shapes[i], prep[i]);
 }
 
-// unknown kinds (device-resident batch): bin by kind with one atomic per candidate
+// unknown kinds (device-resident batch): bin by kind, one atomic per (wave, kind)
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b) return;
-    const rh_shape s = shapes[i];
-    if (s.kind < 0 || s.kind > 3) return;   // counts[i] stays 0
-    const int slot = atomicAdd(&nk[s.kind], 1);
-    prep_one(s, prep[(int64_t)s.kind * cap + slot]);
-    orig[(int64_t)s.kind * cap + slot] = i;
+    const int lane = threadIdx.x & 63;
+    rh_shape s;
+    int kind = -1;
+    if (i < b) {
+        s = shapes[i];
+        if (s.kind >= 0 && s.kind <= 3) kind = s.kind;   // anything else: counts[i] stays 0
+    }
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t m = WB(kind == k);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&nk[k], __popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+    }
+    if (kind < 0) return;
+    prep_one(s, prep[(int64_t)kind * cap + slot]);
+    orig[(int64_t)kind * cap + slot] = i;
 }
 
 // ------------------------------------------------------------- score ------
@@ -258,11 +274,13 @@ score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
 // One candidate (kernarg -> SGPRs), the whole cloud in original order.  Each wave owns
 // 64-point words; mask word = ballot & enabled word; all-disabled words are skipped
 // without touching the point planes.  Per-1024-word popcount sums feed the compaction.
+constexpr int RH_RF_WPW = 4;   // 64-point words per wave per iteration (24 loads in flight per lane)
+
 template <int KIND>
 __global__ void __launch_bounds__(256)
 refit_mask_kernel(const double *__restrict__ pts, int64_t stride, int64_t n, int64_t nwords,
                   const uint64_t *__restrict__ enabled, const rh_prep P, double eps, double cosa,
-                  uint64_t *__restrict__ mask_out, int32_t *__restrict__ block_sums)
+                  uint64_t *__restrict__ mask_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -270,16 +288,27 @@ refit_mask_kernel(const double *__restrict__ pts, int64_t stride, int64_t n, int
     const double *__restrict__ X = pts, *__restrict__ Y = pts + stride, *__restrict__ Z = pts + 2 * stride;
     const double *__restrict__ NX = pts + 3 * stride, *__restrict__ NY = pts + 4 * stride,
                  *__restrict__ NZ = pts + 5 * stride;
-    for (int64_t w = wave0; w < nwords; w += nwaves) {
-        const uint64_t en = enabled[w] & valid_mask(w << 6, n);
-        uint64_t b = 0;
-        if (en != 0) {
-            const int64_t i = (w << 6) + lane;
-            b = test_point<KIND>(P, X[i], Y[i], Z[i], NX[i], NY[i], NZ[i], eps, cosa) & en;
+    const int64_t ngroups = (nwords + RH_RF_WPW - 1) / RH_RF_WPW;
+    for (int64_t g = wave0; g < ngroups; g += nwaves) {
+        const int64_t w0 = g * RH_RF_WPW;
+        uint64_t en[RH_RF_WPW];
+        double px[RH_RF_WPW], py[RH_RF_WPW], pz[RH_RF_WPW], qx[RH_RF_WPW], qy[RH_RF_WPW], qz[RH_RF_WPW];
+#pragma unroll
+        for (int k = 0; k < RH_RF_WPW; k++) {
+            const int64_t w = w0 + k;
+            en[k] = w < nwords ? (enabled[w] & valid_mask(w << 6, n)) : 0ULL;
         }
-        if (lane == 0) {
-            mask_out[w] = b;
-            if (b != 0) atomicAdd(&block_sums[w / RH_WORDS_PER_BLOCK], __popcll(b));
+#pragma unroll
+        for (int k = 0; k < RH_RF_WPW; k++) {
+            // an all-disabled word re-reads the (L2-hot) first line of the planes instead of streaming its 3 KB
+            const int64_t i = (en[k] != 0 ? ((w0 + k) << 6) : (int64_t)0) + lane;
+            px[k] = X[i]; py[k] = Y[i]; pz[k] = Z[i];
+            qx[k] = NX[i]; qy[k] = NY[i]; qz[k] = NZ[i];
+        }
+#pragma unroll
+        for (int k = 0; k < RH_RF_WPW; k++) {
+            const uint64_t b = test_point<KIND>(P, px[k], py[k], pz[k], qx[k], qy[k], qz[k], eps, cosa) & en[k];
+            if (lane == 0 && w0 + k < nwords) mask_out[w0 + k] = b;
         }
     }
 }
@@ -334,21 +363,23 @@ scan_block_sums_kernel(int32_t *__restrict__ block_sums, int64_t nb, int32_t *__
     }
 }
 
-// block b expands mask words [b*1024, (b+1)*1024): ascending 1-based indices
+// block b expands mask words [b*1024, (b+1)*1024): ascending 1-based indices.  Each thread owns
+// 4 consecutive words: block-wide exclusive scan of their popcounts, then every thread writes the
+// set bits of its own words (shape masks are sparse: a few bits per word).
 __global__ void __launch_bounds__(256)
 expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ block_prefix,
                    int64_t *__restrict__ idx_out, int64_t cap, int32_t *__restrict__ word_prefix_out)
 {
-    __shared__ int32_t off[RH_WORDS_PER_BLOCK];
     __shared__ int32_t wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
-    // each thread owns 4 consecutive words
+    uint64_t m[4];
     int pc[4], tsum = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int64_t w = base + threadIdx.x * 4 + k;
-        pc[k] = w < nwords ? __popcll(mask[w]) : 0;
+        m[k] = w < nwords ? mask[w] : 0ULL;
+        pc[k] = __popcll(m[k]);
         tsum += pc[k];
     }
     int inc = tsum;
@@ -360,24 +391,21 @@ expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int3
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < wave; k++) woff += wsum[k];
-    int run = block_prefix[blockIdx.x] + woff + inc - tsum;
+    int64_t run = (int64_t)block_prefix[blockIdx.x] + woff + inc - tsum;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        off[threadIdx.x * 4 + k] = run;
         const int64_t w = base + threadIdx.x * 4 + k;
-        if (word_prefix_out != nullptr && w < nwords) word_prefix_out[w] = run;
-        run += pc[k];
-    }
-    __syncthreads();
-    if (idx_out == nullptr) return;
-    for (int k = wave; k < RH_WORDS_PER_BLOCK; k += 4) {
-        const int64_t w = base + k;
-        if (w >= nwords) break;
-        const uint64_t m = mask[w];
-        if (m == 0) continue;
-        if ((m >> lane) & 1ULL) {
-            const int64_t pos = (int64_t)off[k] + __popcll(m & ((1ULL << lane) - 1ULL));
-            if (pos < cap) idx_out[pos] = (w << 6) + lane + 1;
+        if (word_prefix_out != nullptr && w < nwords) word_prefix_out[w] = (int32_t)run;
+        if (idx_out != nullptr) {
+            uint64_t bits = m[k];
+            while (bits) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (run < cap) idx_out[run] = (w << 6) + b + 1;
+                run++;
+            }
+        } else {
+            run += pc[k];
         }
     }
 }
@@ -492,10 +520,12 @@ int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, cons
     const int ctiles = cdiv(nk_bound, RH_SC_CT);
     const int64_t ntiles = (s + RH_SC_TILE - 1) / RH_SC_TILE;
     if (ctiles == 0 || ntiles == 0) return RH_OK;
-    // ~8192 blocks keeps all 256 CUs (8 XCDs x 32) busy with several waves per SIMD; blocks that
+    // Blocks that
     // share a candidate tile differ in blockIdx.x, so consecutive ids (dealt round-robin over the
     // XCDs) stream different point tiles against the same SGPR-resident candidates.
-    int64_t splits = 8192 / ctiles;
+    static int env_blocks = -1;
+    if (env_blocks < 0) { const char *e = getenv("RH_SCORE_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
+    int64_t splits = (env_blocks > 0 ? env_blocks : 65536) / ctiles;   // one tile per block unless the grid gets huge: best balance (measured)
     if (splits < 1) splits = 1;
     if (splits > ntiles) splits = ntiles;
     dim3 grid((unsigned)splits, (unsigned)ctiles);
@@ -510,6 +540,9 @@ int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, cons
 }
 
 }  // namespace
+
+int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
+                        int64_t *idx_out, int64_t cap, int32_t *d_total);
 
 // host twin of prep_one (used when the candidate is passed by value as a kernel argument)
 void rh_prep_host(const rh_shape &s, rh_prep *o)
@@ -587,14 +620,16 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
 
 int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa)
 {
-    RH_HIP(hipMemsetAsync(c->block_sums, 0, sizeof(int32_t) * (size_t)(c->nblocks + 1), c->stream));
     if (c->nwords == 0) return RH_OK;
-    int64_t blocks = cdiv(c->nwords, 4);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    static int env_blocks = -1;
+    if (env_blocks < 0) { const char *e = getenv("RH_REFIT_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
+    int64_t blocks = cdiv(c->nwords, 4 * RH_RF_WPW);
+    const int64_t cap = env_blocks > 0 ? env_blocks : 256 * 8;
+    if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), blk(256);
 #define RH_LAUNCH_REFIT(K)                                                                                        \
     hipLaunchKernelGGL((refit_mask_kernel<K>), grid, blk, 0, c->stream, c->full, c->n_pad, c->n, c->nwords,       \
-                       c->enabled, P, eps, cosa, c->refit_mask, c->block_sums)
+                       c->enabled, P, eps, cosa, c->refit_mask)
     switch (kind) {
     case RH_PLANE: RH_LAUNCH_REFIT(RH_PLANE); break;
     case RH_SPHERE: RH_LAUNCH_REFIT(RH_SPHERE); break;
@@ -607,18 +642,10 @@ int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double c
     return RH_OK;
 }
 
-// block_sums must already hold the per-block popcounts of `mask`
 int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
                      int32_t *d_total)
 {
-    const int64_t nb = (nwords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, d_total);
-    RH_HIP(hipGetLastError());
-    if (nb == 0) return RH_OK;
-    hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, mask, nwords, c->block_sums,
-                       idx_out, cap, (int32_t *)nullptr);
-    RH_HIP(hipGetLastError());
-    return RH_OK;
+    return rhk_compact_generic(c->stream, mask, nwords, c->block_sums, idx_out, cap, d_total);
 }
 
 int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
