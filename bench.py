@@ -175,9 +175,10 @@ def main():
             "kernel": "score_kernel<%s>" % dom, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "algorithmic bytes = 48.25 B x (candidate, point) tests; the batched kernel re-uses each "
-                    "point across the candidate tile from registers, so it is FP64-ALU-bound and this "
-                    "fraction exceeds 1 by design (SURVEY.md 8d) -- see roofline_valu",
+            "note": "EFFECTIVE rate on algorithmic bytes = 48.25 B x (candidate, point) tests (SURVEY.md 8d). The "
+                    "kernel never streams those bytes: points are staged once per tile and re-used across the "
+                    "candidate batch, and box tests on Morton-ordered 64-point groups reject most (candidate, "
+                    "group) pairs, so frac > 1 by design; measured HBM traffic is in profiles/ (PMC)",
         }
         issue = VALU_F64_PER_TEST[dom] * tests / 64 * 4          # SIMD cycles at 4 cycles per wave64 f64 op
         out["roofline_valu"] = {
@@ -185,10 +186,13 @@ def main():
             "achieved": FLOPS_PER_TEST[dom] * tests / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": FLOPS_PER_TEST[dom] * tests / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_issue_frac": issue / (1024 * 2.4e9 * sec),
-            "note": "achieved = reference flops/test x tests / time (no FMA allowed: bit-exact parity caps this at "
-                    "half the FMA peak); valu_issue_frac = f64 vector instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x time)",
+            "note": "EFFECTIVE: reference flops/test x ALGORITHMIC tests / time (no FMA allowed: bit-exact parity "
+                    "caps real work at half the FMA peak). valu_issue_frac = f64 vector instructions the brute-force "
+                    "kernel would issue x 4 cycles / (1024 SIMDs x 2.4 GHz x time): > 1 means the culled kernel "
+                    "skipped that share of the per-point tests (RH_SCORE_PATH=brute measures the un-culled kernel)",
         }
         out["per_kind"] = per_kind
+        out["score_path"] = os.environ.get("RH_SCORE_PATH", "groups (culled)")
         out["event_ms_per_step"] = ev_ms.value / args.steps
 
         # refit scan: HBM-bound

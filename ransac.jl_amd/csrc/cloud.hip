@@ -3,8 +3,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "rh_internal.h"
 
@@ -100,6 +104,30 @@ int rh_ensure_masks(rh_cloud *c, int64_t words)
     return RH_OK;
 }
 
+static int ensure_masks_int(rh_cloud *c, int64_t words)
+{
+    if (words <= c->masks_int_cap) return RH_OK;
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_masks_int);
+    c->d_masks_int = nullptr;
+    c->masks_int_cap = 0;
+    RH_TRY(dev_alloc(&c->d_masks_int, words));
+    c->masks_int_cap = words;
+    return RH_OK;
+}
+
+// 63-bit Morton code of a point inside the subset's bounding box (21 bits per axis)
+static inline uint64_t spread21(uint64_t v)
+{
+    v &= 0x1FFFFFULL;
+    v = (v | (v << 32)) & 0x1F00000000FFFFULL;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFULL;
+    v = (v | (v << 8)) & 0x100F00F00F00F00FULL;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+
 static void cloud_free(rh_cloud *c)
 {
     if (!c) return;
@@ -107,6 +135,7 @@ static void cloud_free(rh_cloud *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->full); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
+    (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
     (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk);
@@ -192,6 +221,17 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->sub, 6 * c->s_pad));
     CK(dev_alloc(&c->dis, 6 * c->dis_stride));
     CK(dev_alloc(&c->sub_idx0, s));
+    CK(dev_alloc(&c->sub_perm, s));
+    c->ngroups = (s + 63) / 64;
+    c->ng_pad = ((c->ngroups + RH_G2_TG - 1) / RH_G2_TG) * RH_G2_TG + RH_G2_TG;
+    CK(dev_alloc(&c->gb, 7 * c->ng_pad));
+    CKH(hipMemsetAsync(c->gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
+    {
+        const char *e = getenv("RH_SCORE_PATH");   // "brute" / "groups" force a path (tests, A/B runs)
+        c->use_groups = s >= RH_G2_MIN_POINTS;
+        if (e && e[0] == 'b') c->use_groups = false;
+        if (e && e[0] == 'g') c->use_groups = s > 0;
+    }
     CK(dev_alloc(&c->enabled, c->nwords));
     CK(dev_alloc(&c->sub_enabled, c->swords));
     CK(dev_alloc(&c->d_ndis, 1));
@@ -213,11 +253,47 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
         CKH(hipMemcpyAsync(t_nrm, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
         if (s > 0) {
-            h_idx = new (std::nothrow) int32_t[(size_t)s];
+            // internal order of subset 1 = Morton order of its points: 64 consecutive points are
+            // spatially compact, which is what the culled score kernel's per-group boxes need
+            h_idx = new (std::nothrow) int32_t[2 * (size_t)s];
             if (!h_idx) { rh_set_error("out of host memory"); return fail(RH_E_NOMEM); }
-            for (int64_t j = 0; j < s; j++) h_idx[j] = (int32_t)(subset1[j] - 1);
+            double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 }, mag = 0;
+            bool first = true;
+            for (int64_t j = 0; j < s; j++) {
+                const double *pp = xyz + 3 * (subset1[j] - 1);
+                for (int k = 0; k < 3; k++) {
+                    const double v = pp[k];
+                    if (!(v == v) || v - v != 0) continue;   // NaN / inf do not shape the box
+                    if (first || v < lo[k]) lo[k] = v;
+                    if (first || v > hi[k]) hi[k] = v;
+                    if (fabs(v) > mag) mag = fabs(v);
+                }
+                first = false;
+            }
+            c->coord_mag = mag;
+            std::vector<std::pair<uint64_t, int32_t>> keys((size_t)s);
+            for (int64_t j = 0; j < s; j++) {
+                const double *pp = xyz + 3 * (subset1[j] - 1);
+                uint64_t code = 0;
+                for (int k = 0; k < 3; k++) {
+                    const double ext = hi[k] - lo[k];
+                    double t = ext > 0 ? (pp[k] - lo[k]) / ext : 0.0;
+                    if (!(t >= 0)) t = 0;
+                    if (t > 1) t = 1;
+                    code |= spread21((uint64_t)(t * 2097151.0)) << k;
+                }
+                keys[(size_t)j] = std::make_pair(code, (int32_t)j);
+            }
+            std::sort(keys.begin(), keys.end());
+            int32_t *h_perm = h_idx + s;
+            for (int64_t i = 0; i < s; i++) {
+                h_perm[i] = keys[(size_t)i].second;
+                h_idx[i] = (int32_t)(subset1[h_perm[i]] - 1);
+            }
             CKH(hipMemcpyAsync(c->sub_idx0, h_idx, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
+            CKH(hipMemcpyAsync(c->sub_perm, h_perm, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
             CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, c->sub_idx0, s, c->sub, c->s_pad));
+            CK(rhk_group_bounds(c));
         }
     }
     CK(set_all_enabled(c));
@@ -311,6 +387,17 @@ static inline const uint64_t *enabled_for_kind(const rh_cloud *c, int kind, cons
     return c->sub_enabled;
 }
 
+// score candidates of one kind against subset 1; masks (optional) come out in INTERNAL order
+static int score_kind_subset(rh_cloud *c, int k, const rh_params *p, const rh_prep *d_prep, const int32_t *d_orig,
+                             const int32_t *d_nk, int32_t nk_bound, int32_t *d_counts, uint64_t *d_masks_int)
+{
+    if (c->use_groups)
+        return rhk_score_kind_groups(c, k, enabled_for_kind(c, k, p), d_prep, d_orig, d_nk, nk_bound, p->eps[k],
+                                     p->cos_alpha[k], d_counts, d_masks_int);
+    return rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), d_prep, d_orig, d_nk, nk_bound,
+                          p->eps[k], p->cos_alpha[k], d_counts, d_masks_int, c->swords);
+}
+
 extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, int32_t *counts_out,
                               uint64_t *masks_out)
 {
@@ -346,19 +433,22 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     RH_HIP(hipMemcpyAsync(c->d_nk, nk, sizeof nk, hipMemcpyHostToDevice, c->stream));
     RH_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
     RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep));
-    uint64_t *d_masks = nullptr;
-    if (masks_out) {
+    uint64_t *d_masks = nullptr, *d_masks_int = nullptr;
+    if (masks_out && c->swords > 0) {
         RH_TRY(rh_ensure_masks(c, (int64_t)b * c->swords));
+        RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
         d_masks = c->d_masks;
+        d_masks_int = c->d_masks_int;
+        RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     for (int k = 0; k < 4; k++) {
         if (nk[k] == 0) continue;
-        RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), c->d_prep + off[k],
-                              c->d_orig + off[k], c->d_nk + k, nk[k], p->eps[k], p->cos_alpha[k], c->d_counts,
-                              d_masks, c->swords));
+        RH_TRY(score_kind_subset(c, k, p, c->d_prep + off[k], c->d_orig + off[k], c->d_nk + k, nk[k], c->d_counts,
+                                 d_masks_int));
     }
+    if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     RH_HIP(hipMemcpyAsync(counts_out, c->d_counts, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
-    if (masks_out && c->swords > 0)
+    if (d_masks)
         RH_HIP(hipMemcpyAsync(masks_out, d_masks, sizeof(uint64_t) * (size_t)b * (size_t)c->swords,
                               hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
@@ -376,12 +466,18 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     RH_TRY(rh_ensure_batch(c, b));
     RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
     RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, c->d_nk, c->batch_cap));
+    uint64_t *d_masks_int = nullptr;
+    if (d_masks && c->swords > 0) {
+        RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
+        d_masks_int = c->d_masks_int;
+        RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+    }
     for (int k = 0; k < 4; k++) {
         if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
-        RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), c->d_prep + (int64_t)k * c->batch_cap,
-                              c->d_orig + (int64_t)k * c->batch_cap, c->d_nk + k, b, p->eps[k], p->cos_alpha[k],
-                              d_counts, d_masks, c->swords));
+        RH_TRY(score_kind_subset(c, k, p, c->d_prep + (int64_t)k * c->batch_cap, c->d_orig + (int64_t)k * c->batch_cap,
+                                 c->d_nk + k, b, d_counts, d_masks_int));
     }
+    if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     if (ms_kind) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[4]));

@@ -295,8 +295,12 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
                 rh_prep *tail = st.prep[q] + st.n[q];   // prepared records persist in the store
                 RUN(rhk_prep_sorted(c, st.d_shapes + off[q], nk[q], tail));
                 const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
-                RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q],
-                                   p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+                if (c->use_groups)
+                    RUN(rhk_score_kind_groups(c, q, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q], p->eps[q],
+                                              p->cos_alpha[q], st.counts, nullptr));
+                else
+                    RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q],
+                                       p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
             }
             counts_h.resize((size_t)ncand);
             RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));

@@ -270,6 +270,274 @@ score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
     }
 }
 
+// ------------------------------------------------- culled score (groups) ----
+// Subset 1 is stored in Morton order; every 64 consecutive points form a group with an
+// axis-aligned box (centre c, half extents h, radius hr = |h|).  A block stages a tile of
+// RH_G2_TG groups in LDS.  Per 64-candidate chunk a wave runs
+//   stage 1 (lane = candidate): one conservative box test per (candidate, group) -> survivor bits;
+//   stage 2 (lane = point):     the exact per-point test only for surviving pairs.
+// A pair is skipped ONLY when the box proves that no point of the group can pass the distance
+// half of the test, with a slack (1e-9 x coordinate magnitude) that is >= 10^5 x the rounding
+// error of the per-point distance, so counts and masks are bit-identical to the brute-force
+// kernel.  Every comparison is written so that NaN means "do not skip".
+__device__ __forceinline__ double box_slack(const rh_prep &P, double coord_mag)
+{
+    return 1e-9 * (1.0 + coord_mag + fabs(P.f[0]) + fabs(P.f[1]) + fabs(P.f[2]) + fabs(P.f[3]) + fabs(P.f[4]) +
+                   fabs(P.f[5]) + fabs(P.f[6]));
+}
+
+template <int KIND>
+__device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, double cy, double cz, double hx, double hy,
+                                         double hz, double hr, double eps, double slack)
+{
+    if (KIND == RH_PLANE) {
+        // d(p) = dot(o_z, p - point) is affine: over the box it stays within d(c) +- sum |o_z_i| h_i
+        const double d = (P.f[6] * (cx - P.f[0]) + P.f[7] * (cy - P.f[1])) + P.f[8] * (cz - P.f[2]);
+        const double ext = (fabs(P.f[6]) * hx + fabs(P.f[7]) * hy) + fabs(P.f[8]) * hz;
+        return fabs(d) > (ext + eps) + slack;
+    }
+    if (KIND == RH_SPHERE) {
+        // |p - o| lies between the min and max distance from o to the box
+        const double ax = fabs(cx - P.f[0]), ay = fabs(cy - P.f[1]), az = fabs(cz - P.f[2]);
+        const double nx = fmax(ax - hx, 0.0), ny = fmax(ay - hy, 0.0), nz = fmax(az - hz, 0.0);
+        const double fx = ax + hx, fy = ay + hy, fz = az + hz;
+        const double dmin = sqrt((nx * nx + ny * ny) + nz * nz), dmax = sqrt((fx * fx + fy * fy) + fz * fz);
+        return (dmin > (P.f[3] + eps) + slack) | (dmax < (P.f[3] - eps) - slack);
+    }
+    if (KIND == RH_CYLINDER) {
+        // q(p) = (I - a a')(p - c0) is linear: |q(p) - q(c)| <= max(1, |1 - |a|^2|) * |p - c|
+        const double ax = P.f[0], ay = P.f[1], az = P.f[2];
+        const double tx = cx - P.f[3], ty = cy - P.f[4], tz = cz - P.f[5];
+        const double sd = (ax * tx + ay * ty) + az * tz;
+        const double qx = (cx - ax * sd) - P.f[3], qy = (cy - ay * sd) - P.f[4], qz = (cz - az * sd) - P.f[5];
+        const double rho = sqrt((qx * qx + qy * qy) + qz * qz);
+        const double a2 = (ax * ax + ay * ay) + az * az;
+        const double lip = fmax(1.0, fabs(1.0 - a2)) * hr;
+        return (rho - lip > (P.f[6] + eps) + slack) | (rho + lip < (P.f[6] - eps) - slack);
+    }
+    // cone: dist(p) = cos(w/2) rho(p) +- sin(w/2) h(p) (rho, h = radial / axial coordinate of p - apex;
+    // the axis only enters through normalized cross products) is 1-Lipschitz in p
+    {
+        const double ax = P.f[3], ay = P.f[4], az = P.f[5];
+        const double c = P.f[6], s = P.f[7];
+        const double tx = P.f[0] - cx, ty = P.f[1] - cy, tz = P.f[2] - cz;
+        double inv = 1.0 / sqrt((tx * tx + ty * ty) + tz * tz);
+        const double tnx = inv * tx, tny = inv * ty, tnz = inv * tz;
+        double kx = ay * tnz - az * tny, ky = az * tnx - ax * tnz, kz = ax * tny - ay * tnx;
+        inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+        const double rx = inv * kx, ry = inv * ky, rz = inv * kz;
+        kx = ay * rz - az * ry; ky = az * rx - ax * rz; kz = ax * ry - ay * rx;
+        inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+        const double mx = inv * kx, my = inv * ky, mz = inv * kz;
+        // Rodrigues rotation of m about r by the angle whose cos/sin are (c, s): m c + (r x m) s + r (r.m)(1-c)
+        const double ux = ry * mz - rz * my, uy = rz * mx - rx * mz, uz = rx * my - ry * mx;
+        const double rm = (rx * mx + ry * my) + rz * mz;
+        const double gx = (mx * c + ux * s) + rx * rm * (1.0 - c);
+        const double gy = (my * c + uy * s) + ry * rm * (1.0 - c);
+        const double gz = (mz * c + uz * s) + rz * rm * (1.0 - c);
+        const double gn = sqrt((gx * gx + gy * gy) + gz * gz);
+        const double dist = ((gx * tx + gy * ty) + gz * tz) / gn;
+        // a centre on / next to the axis makes the frame ill-conditioned: never skip there
+        const double ta = sqrt((tx * tx + ty * ty) + tz * tz);
+        const double sinang = sqrt(((ay * tnz - az * tny) * (ay * tnz - az * tny) + (az * tnx - ax * tnz) * (az * tnx - ax * tnz)) +
+                                   (ax * tny - ay * tnx) * (ax * tny - ay * tnx));
+        const double an = sqrt((ax * ax + ay * ay) + az * az);
+        const bool well = (sinang > 1e-6 * an) & (ta > 0.0);
+        return well & (fabs(dist) > ((hr + eps) + slack) + 1e-6 * (hr + fabs(dist)));
+    }
+}
+
+typedef uint32_t rh_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t rh_u32x8 __attribute__((ext_vector_type(8)));
+typedef double rh_f64x2 __attribute__((ext_vector_type(2)));
+
+// Scalar prefetch of one 96-byte candidate record.  hipcc sinks an ordinary scalar load down to
+// its first use (behind the whole group loop), exposing its latency once per candidate; the asm
+// pair issues it here and waits for it there.  SMEM and LDS share lgkmcnt, so the compiler's own
+// waits for LDS reads can only make this wait a no-op, never unsafe.
+__device__ __forceinline__ void sprefetch_issue(const rh_prep *p, rh_u32x16 &lo, rh_u32x8 &hi)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");   // early-clobber: the data may land before the 2nd issue
+}
+__device__ __forceinline__ void sprefetch_wait(rh_u32x16 &lo, rh_u32x8 &hi, rh_prep &out)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)::"memory");
+    union { uint32_t u[2]; double d; } cv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { cv.u[0] = lo[2 * i]; cv.u[1] = lo[2 * i + 1]; out.f[i] = cv.d; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cv.u[0] = hi[2 * i]; cv.u[1] = hi[2 * i + 1]; out.f[8 + i] = cv.d; }
+}
+
+template <int KIND, bool MASK, int NT>
+__global__ void __launch_bounds__(NT)
+score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
+                    const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
+                    int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
+                    const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
+                    int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+{
+    // points of the tile as three 16-byte planes (x,y) (z,nx) (ny,nz): one ds_read_b128 each per test.
+    // Disabled / out-of-range points are staged with x = NaN: every distance test is then false, so
+    // the inner loop needs no enabled word.
+    __shared__ rh_f64x2 lp[3][RH_G2_TILE];
+    __shared__ double lb[7][RH_G2_TG];
+    __shared__ uint64_t len[RH_G2_TG];
+    __shared__ int next_chunk;
+
+    const int nk = *nk_ptr;
+    const int nchunks = (nk + 63) >> 6;
+    const int cpb = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int chunk_lo = (int)blockIdx.y * cpb;
+    const int chunk_hi = min(nchunks, chunk_lo + cpb);
+    if (chunk_lo >= chunk_hi) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t g0 = (int64_t)blockIdx.x * RH_G2_TG;
+    const int64_t p0 = g0 * 64;
+    const double qnan = __builtin_nan("");
+#pragma unroll
+    for (int i = 0; i < RH_G2_TILE / NT; i++) {
+        const int li = tid + i * NT;
+        const int64_t gi = p0 + li;
+        uint64_t v = valid_mask((gi >> 6) << 6, s);
+        if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
+        const bool on = (v >> (gi & 63)) & 1ULL;
+        rh_f64x2 a, b, c;
+        a.x = on ? pts[gi] : qnan;
+        a.y = pts[stride + gi];
+        b.x = pts[2 * stride + gi];
+        b.y = pts[3 * stride + gi];
+        c.x = pts[4 * stride + gi];
+        c.y = pts[5 * stride + gi];
+        lp[0][li] = a; lp[1][li] = b; lp[2][li] = c;
+    }
+    if (tid < 7 * RH_G2_TG) {   // one thread per (bound component, group): the loads go out together
+        const int k = tid / RH_G2_TG, gl = tid % RH_G2_TG;
+        const int64_t g = g0 + gl;
+        lb[k][gl] = g < ngroups ? gb[k * gstride + g] : 0.0;
+    } else if (tid >= 128 && tid < 128 + RH_G2_TG) {
+        const int64_t g = g0 + (tid - 128);
+        uint64_t v = valid_mask(g << 6, s);
+        if (enabled_words != nullptr && v != 0) v &= enabled_words[g];
+        len[tid - 128] = v;
+    }
+    if (tid == 0) next_chunk = chunk_lo;
+    __syncthreads();
+
+    for (;;) {
+        int chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&next_chunk, 1);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        if (chunk >= chunk_hi) break;
+        const int cbase = chunk << 6;
+        const int ci = cbase + lane;
+
+        // ---- stage 1: lane = candidate, one box test per group of the tile
+        unsigned surv = 0;
+        if (ci < nk) {
+            const rh_prep Pl = prep[ci];
+            const double slack = box_slack(Pl, coord_mag);
+#pragma unroll 4
+            for (int g = 0; g < RH_G2_TG; g++) {
+                if (len[g] == 0) continue;
+                const bool skip = box_skip<KIND>(Pl, lb[0][g], lb[1][g], lb[2][g], lb[3][g], lb[4][g], lb[5][g],
+                                                 lb[6][g], eps, slack);
+                surv |= skip ? 0u : (1u << g);
+            }
+            if (dbg == 2) surv = (1u << RH_G2_TG) - 1u;
+        }
+        if (dbg == 1) surv = 0;
+
+        // ---- stage 2: lane = point, exact test for the surviving (candidate, group) pairs
+        uint64_t todo = WB(surv != 0);
+        int acc = 0;
+        if (todo != 0) {
+            int l = __builtin_ctzll(todo);
+            rh_u32x16 nlo;
+            rh_u32x8 nhi;
+            rh_prep P;
+            sprefetch_issue(&prep[cbase + l], nlo, nhi);
+            sprefetch_wait(nlo, nhi, P);
+            for (;;) {
+                todo &= todo - 1;
+                const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
+                sprefetch_issue(&prep[cbase + ln], nlo, nhi);   // lands while this candidate's groups run
+                unsigned rem = __builtin_amdgcn_readlane(surv, l);
+                int n = 0;
+                while (rem != 0) {
+                    const int g = __builtin_ctz(rem);
+                    rem &= rem - 1;
+                    const int i = (g << 6) + lane;
+                    const rh_f64x2 a = lp[0][i], b = lp[1][i], c = lp[2][i];
+                    const uint64_t m = test_point<KIND>(P, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
+                    n += __popcll(m);
+                    if (MASK) {
+                        if (lane == 0 && m != 0) masks[(int64_t)orig[cbase + l] * mask_stride + g0 + g] = m;
+                    }
+                }
+                acc = (lane == l) ? n : acc;
+                sprefetch_wait(nlo, nhi, P);
+                if (todo == 0) break;
+                l = ln;
+            }
+        }
+        if (acc != 0) atomicAdd(&counts[orig[ci]], acc);
+    }
+}
+
+// one wave per 64-point group: axis-aligned box of its valid points
+__global__ void __launch_bounds__(256)
+group_bounds_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, int64_t ngroups,
+                    double *__restrict__ gb, int64_t gstride)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const int64_t i = (g << 6) + lane;
+    const bool valid = i < s;
+    const int64_t ii = valid ? i : (g << 6);   // the first point of a group is always valid
+    double mn[3], mx[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double v = pts[k * stride + ii];
+        mn[k] = v; mx[k] = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fmin(mn[k], __shfl_xor(mn[k], off));
+            mx[k] = fmax(mx[k], __shfl_xor(mx[k], off));
+        }
+    }
+    if (lane == 0) {
+        double h2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double c = 0.5 * mn[k] + 0.5 * mx[k];
+            const double h = fmax(mx[k] - c, c - mn[k]) * 1.0000000000000009;
+            gb[k * gstride + g] = c;
+            gb[(3 + k) * gstride + g] = h;
+            h2 += h * h;
+        }
+        gb[6 * gstride + g] = sqrt(h2) * 1.0000000000000009;
+    }
+}
+
+// masks in internal (Morton) order -> subset order; `out` must be zeroed
+__global__ void unpermute_masks_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ perm, int64_t swords,
+                                       int64_t total_words, uint64_t *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_words) return;
+    uint64_t m = in[t];
+    const int64_t row = t / swords, w = t - row * swords;
+    while (m != 0) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const int32_t j = perm[(w << 6) + b];
+        atomicOr((unsigned long long *)&out[row * swords + (j >> 6)], 1ULL << (j & 63));
+    }
+}
+
 // ------------------------------------------------------------- refit ------
 // One candidate (kernarg -> SGPRs), the whole cloud in original order.  Each wave owns
 // 64-point words; mask word = ballot & enabled word; all-disabled words are skipped
@@ -744,6 +1012,75 @@ int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords
     if (nb > 0)
         hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, mask, nwords, ws_block_sums,
                            idx_out, cap, (int32_t *)nullptr);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+template <int KIND>
+static int launch_score_groups(rh_cloud *c, const uint64_t *en, const rh_prep *prep, const int32_t *orig,
+                               const int32_t *nk, int32_t nk_bound, double eps, double cosa, int32_t *counts,
+                               uint64_t *masks)
+{
+    const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
+    const int nchunks = cdiv(nk_bound, 64);
+    if (ntiles == 0 || nchunks == 0) return RH_OK;
+    static int env_blocks = -1;
+    if (env_blocks < 0) { const char *e = getenv("RH_G2_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
+    // candidate rows: enough blocks to fill the chip several times over, at least ~8 chunks per block
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
+    static int env_cpb = -1;
+    if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
+    const int min_cpb = env_cpb > 0 ? env_cpb : 8;     // at least this many 64-candidate chunks per block (measured best)
+    int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
+    if (rows < 1) rows = 1;
+    if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
+    if (rows < 1) rows = 1;
+    dim3 grid((unsigned)ntiles, (unsigned)rows);
+    static int nt = -1;
+    if (nt < 0) { const char *e = getenv("RH_G2_NT"); nt = e ? atoi(e) : 256; }
+#define RH_G2_LAUNCH(M, NT)                                                                                          \
+    hipLaunchKernelGGL((score_groups_kernel<KIND, M, NT>), grid, dim3(NT), 0, c->stream, c->sub, c->s_pad, c->s, en, \
+                       c->gb, c->ng_pad, c->ngroups, prep, orig, nk, eps, cosa, c->coord_mag, counts, masks, c->swords, dbg)
+    if (masks) RH_G2_LAUNCH(true, 256);
+    else if (nt == 1024) RH_G2_LAUNCH(false, 1024);
+    else if (nt == 512) RH_G2_LAUNCH(false, 512);
+    else RH_G2_LAUNCH(false, 256);
+#undef RH_G2_LAUNCH
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_prep *d_prep, const int32_t *d_orig,
+                          const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
+                          uint64_t *d_masks_int)
+{
+    switch (kind) {
+    case RH_PLANE: return launch_score_groups<RH_PLANE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_SPHERE: return launch_score_groups<RH_SPHERE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_CYLINDER: return launch_score_groups<RH_CYLINDER>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_CONE: return launch_score_groups<RH_CONE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    }
+    rh_set_error("unknown shape kind %d", kind);
+    return RH_E_INVALID;
+}
+
+int rhk_group_bounds(rh_cloud *c)
+{
+    if (c->ngroups == 0) return RH_OK;
+    hipLaunchKernelGGL(group_bounds_kernel, dim3(cdiv(c->ngroups, 4)), dim3(256), 0, c->stream, c->sub, c->s_pad, c->s,
+                       c->ngroups, c->gb, c->ng_pad);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out)
+{
+    const int64_t total = (int64_t)b * c->swords;
+    if (total == 0) return RH_OK;
+    RH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * (size_t)total, c->stream));
+    hipLaunchKernelGGL(unpermute_masks_kernel, dim3(cdiv(total, 256)), dim3(256), 0, c->stream, d_in, c->sub_perm,
+                       c->swords, total, d_out);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

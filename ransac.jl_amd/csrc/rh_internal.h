@@ -47,6 +47,9 @@ constexpr int RH_SC_WAVE_PTS = 64 * RH_SC_PPT;           // contiguous points pe
 constexpr int RH_SC_TILE = RH_SC_THREADS * RH_SC_PPT;    // points per block per tile
 constexpr int RH_SC_CT = 64;                             // candidates per block
 constexpr int RH_WORDS_PER_BLOCK = 1024;                 // scan granularity (64-bit words)
+constexpr int RH_G2_TG = 4;                              // 64-point groups per LDS tile of the culled score kernel
+constexpr int RH_G2_TILE = RH_G2_TG * 64;
+constexpr int64_t RH_G2_MIN_POINTS = 8192;               // below this the brute-force kernel is used
 
 // ---- the cloud --------------------------------------------------------------
 struct rh_cloud {
@@ -67,6 +70,11 @@ struct rh_cloud {
     int32_t *sub_idx0 = nullptr;       // [s] 0-based original index of subset position j
     uint64_t *enabled = nullptr;       // [nwords]  pc.isenabled chunks
     uint64_t *sub_enabled = nullptr;   // [swords]  enabled bits gathered into subset order
+    int32_t *sub_perm = nullptr;       // [s] internal (Morton) position -> subset position j
+    double *gb = nullptr;              // 7 planes x ng_pad: box centre cx cy cz, half extents hx hy hz, radius hr
+    int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
+    double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
+    bool use_groups = false;           // culled scoring path available (s large enough)
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
 
@@ -87,6 +95,8 @@ struct rh_cloud {
     int32_t *d_counts = nullptr;       // [batch_cap]
     uint64_t *d_masks = nullptr;       // grown on demand
     int64_t masks_cap = 0;
+    uint64_t *d_masks_int = nullptr;   // masks in internal order (before un-permuting)
+    int64_t masks_int_cap = 0;
     int64_t *d_ranks = nullptr;        // select in/out
     int64_t ranks_cap = 0;
 
@@ -107,6 +117,12 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
                    const uint64_t *enabled_words_or_null, const rh_prep *d_prep, const int32_t *d_orig,
                    const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
                    uint64_t *d_masks_or_null, int64_t mask_stride);
+// culled path over c->sub (Morton order + per-group boxes); masks (optional) are in INTERNAL order
+int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_or_null, const rh_prep *d_prep,
+                          const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
+                          int32_t *d_counts, uint64_t *d_masks_int_or_null);
+int rhk_group_bounds(rh_cloud *c);
+int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out);
 int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa);
 int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
                      int32_t *d_total);

@@ -14,6 +14,20 @@ from ransac_jl_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", params=["groups", "brute"], autouse=True)
+def score_path(request):
+    """Every test runs against both scoring kernels: the culled one (Morton groups + box tests)
+    and the brute-force one.  The path is chosen when a cloud is created."""
+    import os
+    old = os.environ.get("RH_SCORE_PATH")
+    os.environ["RH_SCORE_PATH"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("RH_SCORE_PATH", None)
+    else:
+        os.environ["RH_SCORE_PATH"] = old
+
+
 def to_orc_params(cp):
     return orc.Params.from_buffer_copy(bytes(cp))
 
@@ -48,7 +62,7 @@ def shape_array(cands):
 
 
 @pytest.fixture(scope="module")
-def small_scene():
+def small_scene(score_path):
     prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder", "cone", "cone"]
     xyz, nrm, truth = synth.make_cloud(60_000, prim, 0.2, seed=11)
     subs = synth.make_subsets(60_000, 3, seed=11)
