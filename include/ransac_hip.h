@@ -89,7 +89,9 @@ typedef struct {
     int32_t score_mode;        /* RH_SCORE_INT64_WRAP = the reference's wrapping Int64 product
                                   (src/confidenceintervals.jl:54,72); RH_SCORE_F64 = fixed */
     int32_t sphere_uses_enabled; /* 0 = reference behaviour (src/shapes/sphere.jl:121,131) */
-    int32_t reserved;
+    int32_t sampling_streams;  /* 0 = one sequential random stream (the reference's structure, host-side
+                                  sampling); 1 = one stream per (iteration, minimal set), a pure function
+                                  of (seed, k, j): sampling + plane/sphere/cylinder fits run on the device */
 } rh_params;
 
 typedef struct rh_cloud rh_cloud;

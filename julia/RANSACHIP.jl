@@ -52,7 +52,7 @@ struct RhParams
     shape_types::NTuple{8,Cint}
     score_mode::Cint
     sphere_uses_enabled::Cint
-    reserved::Cint
+    sampling_streams::Cint
 end
 
 lasterror() = unsafe_string(ccall((:rh_last_error, LIB), Cstring, ()))

@@ -43,7 +43,7 @@ class Params(C.Structure):
         ("shape_types", C.c_int32 * 8),
         ("score_mode", C.c_int32),
         ("sphere_uses_enabled", C.c_int32),
-        ("reserved", C.c_int32),
+        ("sampling_streams", C.c_int32),
     ]
 
 

@@ -923,6 +923,24 @@ int64_t orc_rng_range(orc_rng *r, int64_t n)
     return 1 + (int64_t)(((unsigned __int128)orc_rng_next(r) * (unsigned __int128)(uint64_t)n) >> 64);
 }
 
+/* sampling_streams = 1: one splitmix64 stream per (iteration k, minimal set j) */
+static uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+typedef struct { orc_rng *seq; uint64_t x; int per_set; } draw_src;
+
+static int64_t draw_range(draw_src *d, int64_t n)
+{
+    if (!d->per_set) return orc_rng_range(d->seq, n);
+    d->seq->draws++;
+    d->x += 0x9E3779B97F4A7C15ULL;
+    return 1 + (int64_t)(((unsigned __int128)mix64(d->x) * (unsigned __int128)(uint64_t)n) >> 64);
+}
+
 /* ---------------------------------------------------------------- driver */
 
 /* Julia argmax over a Float64 vector: NaN is the maximum; first occurrence wins */
@@ -936,17 +954,17 @@ static int jl_argmax(const double *a, int n)
 
 /* samplepointcloud4!: fitting.jl:383-430 with the root cell (the
  * argmax at :401 is always 1, asserted by the caller).  sd: 1-based indices. */
-static int sample4(const orc_cloud *c, const orc_params *p, orc_rng *rng, int64_t n_enabled, int64_t *sd)
+static int sample4(const orc_cloud *c, const orc_params *p, draw_src *rng, int64_t n_enabled, int64_t *sd)
 {
-    int64_t r1 = orc_rng_range(rng, c->n);
-    while (!is_enabled(c, r1 - 1)) r1 = orc_rng_range(rng, c->n);
+    int64_t r1 = draw_range(rng, c->n);
+    while (!is_enabled(c, r1 - 1)) r1 = draw_range(rng, c->n);
     if (n_enabled < p->drawN) return 0; /* (false, 0) */
     sd[0] = r1;
     for (int k = 1; k < p->drawN; k++) {
-        int64_t nexti = orc_rng_range(rng, n_enabled);
+        int64_t nexti = draw_range(rng, n_enabled);
         int64_t cand = orc_select_enabled(c, nexti);
         if (sd[0] == cand) {
-            nexti = orc_rng_range(rng, n_enabled); /* try oncemore: fitting.jl:416-419 */
+            nexti = draw_range(rng, n_enabled); /* try oncemore: fitting.jl:416-419 */
             cand = orc_select_enabled(c, nexti);
         }
         sd[k] = cand;
@@ -1027,7 +1045,11 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
         int64_t n_enabled = orc_cloud_count_enabled(c);
         if (n_enabled < p->tau) break; /* iterations.jl:75 */
         for (int i = 0; i < p->minsubsetN; i++) {
-            if (!sample4(c, p, rng, n_enabled, sd)) continue;
+            draw_src src = { rng, 0, p->sampling_streams };
+            if (p->sampling_streams)
+                src.x = mix64(rng->s[0] + (uint64_t)k * 0xD1B54A32D192ED03ULL) ^
+                        mix64((uint64_t)i * 0x8CB92BA72F3D8DD7ULL + 0x2545F4914F6CDD1DULL);
+            if (!sample4(c, p, &src, n_enabled, sd)) continue;
             /* fitting.jl:401: argmax(levelweight[1:max_depth]) must be 1 */
             int lvl = jl_argmax(levelweight, octree_depth) + 1;
             if (lvl != 1) { rc = -2; goto done; }

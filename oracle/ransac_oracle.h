@@ -78,7 +78,8 @@ typedef struct {
     int32_t shape_types[8];    /* ORC_* kinds in iteration.shape_types order */
     int32_t score_mode;        /* ORC_SCORE_INT64_WRAP (faithful) or ORC_SCORE_F64 */
     int32_t sphere_uses_enabled; /* 0 = faithful Q4 (sphere.jl:121,131), 1 = fixed */
-    int32_t reserved;
+    int32_t sampling_streams;  /* 0 = one sequential stream (reference structure); 1 = one stream per
+                                  (iteration, minimal set): pure function of (seed, k, j) */
 } orc_params;
 
 void orc_default_params(orc_params *p);

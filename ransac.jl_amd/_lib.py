@@ -25,7 +25,7 @@ class Params(C.Structure):
         ("tau", C.c_int64), ("itermax", C.c_int64),
         ("drawN", C.c_int32), ("minsubsetN", C.c_int32), ("extract_s", C.c_int32), ("terminate_s", C.c_int32),
         ("n_shape_types", C.c_int32), ("shape_types", C.c_int32 * 8),
-        ("score_mode", C.c_int32), ("sphere_uses_enabled", C.c_int32), ("reserved", C.c_int32),
+        ("score_mode", C.c_int32), ("sphere_uses_enabled", C.c_int32), ("sampling_streams", C.c_int32),
     ]
 
 

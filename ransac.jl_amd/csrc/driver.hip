@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "fit_shared.h"
 #include "rh_internal.h"
 
 namespace {
@@ -174,6 +175,427 @@ extern "C" void rh_result_free(rh_result *r)
     memset(r, 0, sizeof *r);
 }
 
+
+namespace {
+
+#define RUN(x) do { int rc_ = (x); if (rc_ != RH_OK) return rc_; } while (0)
+#define RUNH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); return RH_E_NODEVICE; } } while (0)
+
+struct Driver {
+    rh_cloud *c;
+    const rh_params *p;
+    const double *xyz, *nrm;
+    rh_rng *rng;
+    int drawN;
+
+    EnabledMirror en;
+    DeviceStore st;
+    std::vector<Stored> store;              // scoredshapes, reference order
+    std::vector<rh_extracted> extracted;
+    int64_t cc[4] = { 0, 0, 0, 0 };         // countcandidates (1-based like the reference)
+    int64_t best = -1;                      // index into store of the running first maximum
+    double t_score = 0, t_extract = 0, t_sample = 0;
+    int64_t iterations = 0;
+    bool terminated = false;
+
+    // scratch
+    std::vector<rh_shape> sorted;
+    std::vector<int32_t> orig, counts_h, idx_h;
+    std::vector<int64_t> sd;
+    std::vector<double> fp, fn;
+
+    // device sampler buffers
+    rh_cand_entry *d_entries = nullptr;
+    int32_t entries_cap = 0;
+    int32_t *d_count = nullptr, *d_gave_up = nullptr;
+    unsigned long long *d_draws = nullptr;
+    int32_t draws_cap = 0;
+
+    ~Driver()
+    {
+        for (rh_extracted &e : extracted) free(e.inpoints);
+        store_free(c, st);
+        (void)hipFree(d_entries); (void)hipFree(d_count); (void)hipFree(d_gave_up); (void)hipFree(d_draws);
+    }
+
+    int init()
+    {
+        drawN = p->drawN;
+        sd.resize((size_t)drawN);
+        fp.resize(3 * (size_t)drawN);
+        fn.resize(3 * (size_t)drawN);
+        en.n = c->n;
+        en.w.assign((size_t)c->nwords, 0);
+        if (c->nwords > 0) RUN(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
+        en.recount();
+        // the disabled list must describe the cloud as it is now (points disabled before the call)
+        RUN(rhk_rebuild_sub_enabled(c, true, true));
+        int32_t ndis = 0;
+        RUNH(hipMemcpyAsync(&ndis, c->d_ndis, sizeof ndis, hipMemcpyDeviceToHost, c->stream));
+        RUNH(hipStreamSynchronize(c->stream));
+        c->n_dis = ndis;
+        c->select_valid = false;
+        RUNH(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
+        return RH_OK;
+    }
+
+    // forcefitshapes! (fitting.jl:165-173) for one sampled minimal set
+    int fit_set(std::vector<rh_shape> &cands)
+    {
+        for (int q = 0; q < drawN; q++) {
+            memcpy(&fp[3 * (size_t)q], xyz + 3 * (sd[(size_t)q] - 1), 24);
+            memcpy(&fn[3 * (size_t)q], nrm + 3 * (sd[(size_t)q] - 1), 24);
+        }
+        for (int t = 0; t < p->n_shape_types; t++) {
+            rh_shape fitted;
+            int32_t ok = 0;
+            RUN(rh_fit(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));
+            if (ok) cands.push_back(fitted);
+        }
+        return RH_OK;
+    }
+
+    // one iteration's minimal sets on the host: sequential stream (mode 0) or per-set streams (mode 1)
+    int sample_iteration_host(int64_t k, std::vector<rh_shape> &cands)
+    {
+        cands.clear();
+        if (p->sampling_streams) en.build();
+        for (int i = 0; i < p->minsubsetN; i++) {
+            if (p->sampling_streams) {
+                uint64_t x = rhfit::set_stream_init(rng->s[0], (uint64_t)k, (uint64_t)i);
+                uint32_t nd = 0;
+                bool gave_up = false;
+                const bool ok = rhfit::sample_minimal_set(en, c->n, en.count, drawN, &x, sd.data(), &nd, &gave_up);
+                rng->draws += nd;
+                if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
+                if (!ok) continue;
+            } else {
+                // samplepointcloud4!: fitting.jl:388-428 on the root cell
+                int64_t r1 = rh_rng_range(rng, c->n);
+                while (!en.test(r1 - 1)) r1 = rh_rng_range(rng, c->n);
+                if (en.count < drawN) continue;
+                sd[0] = r1;
+                for (int q = 1; q < drawN; q++) {
+                    int64_t pick = en.select(rh_rng_range(rng, en.count));
+                    if (pick == sd[0]) pick = en.select(rh_rng_range(rng, en.count));   // one redraw: fitting.jl:416-419
+                    sd[(size_t)q] = pick;
+                }
+                bool distinct = true;   // allisdifferent: utilities.jl:285-295
+                for (int a = 1; a < drawN && distinct; a++)
+                    for (int b = 0; b < a; b++)
+                        if (sd[(size_t)a] == sd[(size_t)b]) { distinct = false; break; }
+                if (!distinct) continue;
+            }
+            RUN(fit_set(cands));
+        }
+        return RH_OK;
+    }
+
+    // stable sort by kind + upload; fills off/nk
+    int upload_sorted(const rh_shape *cands, int32_t ncand, int32_t nk[4], int32_t off[4])
+    {
+        int32_t fill[4];
+        for (int q = 0; q < 4; q++) nk[q] = 0;
+        for (int32_t i = 0; i < ncand; i++) nk[cands[i].kind]++;
+        off[0] = 0;
+        for (int q = 1; q < 4; q++) off[q] = off[q - 1] + nk[q - 1];
+        for (int q = 0; q < 4; q++) fill[q] = off[q];
+        sorted.resize((size_t)ncand);
+        orig.resize((size_t)ncand);
+        for (int32_t i = 0; i < ncand; i++) {
+            const int q = cands[i].kind;
+            sorted[(size_t)fill[q]] = cands[i];
+            orig[(size_t)fill[q]] = i;
+            fill[q]++;
+        }
+        if (ncand > st.shapes_cap) {
+            RUNH(hipStreamSynchronize(c->stream));
+            (void)hipFree(st.d_shapes);
+            st.d_shapes = nullptr;
+            st.shapes_cap = std::max<int64_t>(ncand, 1024);
+            RUNH(hipMalloc((void **)&st.d_shapes, sizeof(rh_shape) * (size_t)st.shapes_cap));
+        }
+        RUN(store_reserve_aux(c, st, ncand));
+        RUNH(hipMemcpyAsync(st.d_shapes, sorted.data(), sizeof(rh_shape) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
+        RUNH(hipMemcpyAsync(st.d_idx, orig.data(), sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
+        RUNH(hipMemcpyAsync(st.d_nk, nk, sizeof(int32_t) * 4, hipMemcpyHostToDevice, c->stream));
+        return RH_OK;
+    }
+
+    // scorecandidates! (fitting.jl:181-190) for a batch: counts in candidate order.  One launch
+    // per shape kind -- nothing reads a score before the loop ends (iterations.jl:99).
+    int score(const rh_shape *cands, int32_t ncand, std::vector<int32_t> &counts)
+    {
+        counts.assign((size_t)ncand, 0);
+        if (ncand == 0) return RH_OK;
+        const double t0 = now_s();
+        int32_t nk[4], off[4];
+        RUN(upload_sorted(cands, ncand, nk, off));
+        RUN(rh_ensure_batch(c, ncand));
+        RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)ncand, c->stream));
+        RUN(rhk_prep_sorted(c, st.d_shapes, ncand, c->d_prep));
+        for (int q = 0; q < 4; q++) {
+            if (nk[q] == 0) continue;
+            const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
+            if (c->use_groups)
+                RUN(rhk_score_kind_groups(c, q, enw, c->d_prep + off[q], st.d_idx + off[q], st.d_nk + q, nk[q], p->eps[q],
+                                          p->cos_alpha[q], st.counts, nullptr));
+            else
+                RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, c->d_prep + off[q], st.d_idx + off[q], st.d_nk + q,
+                                   nk[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+        }
+        RUNH(hipMemcpyAsync(counts.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
+        RUNH(hipStreamSynchronize(c->stream));
+        t_score += now_s() - t0;
+        return RH_OK;
+    }
+
+    // recordscore! (fitting.jl:114-119) in candidate order + prepared records into the device store
+    int record(const rh_shape *cands, int32_t ncand, const int32_t *counts)
+    {
+        if (ncand == 0) return RH_OK;
+        int32_t nk[4], off[4];
+        RUN(upload_sorted(cands, ncand, nk, off));
+        for (int q = 0; q < 4; q++) {
+            if (nk[q] == 0) continue;
+            RUN(store_reserve(c, st, q, (int64_t)st.n[q] + nk[q]));
+            RUN(rhk_prep_sorted(c, st.d_shapes + off[q], nk[q], st.prep[q] + st.n[q]));
+        }
+        int32_t slot_next[4] = { st.n[0], st.n[1], st.n[2], st.n[3] };
+        for (int32_t i = 0; i < ncand; i++) {   // slots follow candidate order within a kind (stable sort)
+            double lo, hi, E;
+            RUN(rh_estimatescore(c->s, c->n, counts[i], p->score_mode, &lo, &hi, &E));
+            Stored rec;
+            rec.shape = cands[i];
+            rec.E = E;
+            rec.slot = slot_next[cands[i].kind]++;
+            store.push_back(rec);
+            // findhighestscore (fitting.jl:140-151) incrementally: first maximum, strict >
+            if (best < 0) best = (int64_t)store.size() - 1;
+            else if (E > store[(size_t)best].E) best = (int64_t)store.size() - 1;
+        }
+        for (int q = 0; q < 4; q++) st.n[q] += nk[q];
+        return RH_OK;
+    }
+
+    // iterations.jl:106-140: extract the best candidate if its detection probability is high enough
+    int maybe_extract(int64_t k, bool *did)
+    {
+        *did = false;
+        if (store.empty()) return RH_OK;
+        const double scr = store[(size_t)best].E;
+        const double ppp = rh_prob(scr, cc[p->extract_s], c->n, drawN);
+        if (!(ppp > p->prob_det)) return RH_OK;   // iterations.jl:123
+        const double t0 = now_s();
+        // refit: full-cloud scan + ascending compaction (plane.jl:137-143 ...)
+        const rh_shape bestshape = store[(size_t)best].shape;
+        rh_prep P;
+        rh_prep_host(bestshape, &P);
+        RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
+        RUN(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
+        int32_t total = 0;
+        RUNH(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
+        RUN(rhk_andnot_enabled(c, c->refit_mask));
+        RUN(rhk_rebuild_sub_enabled(c, true, false));
+        c->select_valid = false;
+        int32_t ndis_new = 0;
+        RUNH(hipMemcpyAsync(&ndis_new, c->d_ndis, sizeof ndis_new, hipMemcpyDeviceToHost, c->stream));
+        RUNH(hipStreamSynchronize(c->stream));
+        rh_extracted ex;
+        memset(&ex, 0, sizeof ex);
+        ex.shape = bestshape;
+        ex.n_inpoints = total;
+        ex.inpoints = (int64_t *)malloc(sizeof(int64_t) * (size_t)std::max<int32_t>(total, 1));
+        if (!ex.inpoints) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
+        extracted.push_back(ex);   // owned from here on
+        if (total > 0)
+            RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        RUNH(hipStreamSynchronize(c->stream));
+        extracted.back().score_E = scr;
+        extracted.back().iteration = k;
+        en.clear(ex.inpoints, total);
+        const int64_t ndis_old = c->n_dis;
+        c->n_dis = ndis_new;
+
+        // deleteat!(scoredshapes, best.index): iterations.jl:136
+        store.erase(store.begin() + best);
+        // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
+        std::vector<char> dead_slot[4];
+        for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 1);   // unreferenced slots are dead
+        for (const Stored &r : store) dead_slot[r.shape.kind][(size_t)r.slot] = 0;
+        int64_t maxn = 0;
+        for (int q = 0; q < 4; q++) maxn = std::max<int64_t>(maxn, st.n[q]);
+        RUN(store_reserve_aux(c, st, maxn));
+        for (int q = 0; q < 4; q++) {
+            if (st.n[q] == 0) continue;
+            const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+            const int64_t first = all_disabled ? 0 : ndis_old;
+            const int64_t cnt = (int64_t)ndis_new - first;
+            if (cnt <= 0) continue;
+            RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)st.n[q], c->stream));
+            RUNH(hipMemcpyAsync(st.d_nk + 4 + q, &st.n[q], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            RUN(rhk_score_kind(c, q, c->dis + first, c->dis_stride, cnt, nullptr, st.prep[q], st.iota, st.d_nk + 4 + q,
+                               st.n[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+            counts_h.resize((size_t)st.n[q]);
+            RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)st.n[q], hipMemcpyDeviceToHost, c->stream));
+            RUNH(hipStreamSynchronize(c->stream));
+            for (int32_t sl = 0; sl < st.n[q]; sl++)
+                if (counts_h[(size_t)sl] > 0) dead_slot[q][(size_t)sl] = 1;
+        }
+        // drop dead candidates on the host (order preserved), compact the device store
+        std::vector<int32_t> remap[4];
+        for (int q = 0; q < 4; q++) {
+            remap[q].assign((size_t)st.n[q], -1);
+            idx_h.clear();
+            for (int32_t sl = 0; sl < st.n[q]; sl++)
+                if (!dead_slot[q][(size_t)sl]) {
+                    remap[q][(size_t)sl] = (int32_t)idx_h.size();
+                    idx_h.push_back(sl);
+                }
+            const int32_t alive = (int32_t)idx_h.size();
+            if (alive != st.n[q]) {
+                if (alive > 0) {
+                    rh_prep *np = nullptr;
+                    RUNH(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)st.cap[q]));
+                    hipError_t e1 = hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream);
+                    int rc2 = e1 == hipSuccess ? rhk_gather_prep(c, st.prep[q], st.d_idx, alive, np) : RH_E_NODEVICE;
+                    hipError_t e2 = hipStreamSynchronize(c->stream);
+                    (void)hipFree(st.prep[q]);
+                    st.prep[q] = np;
+                    if (rc2 != RH_OK || e2 != hipSuccess) { rh_set_error("candidate store compaction failed"); return RH_E_NODEVICE; }
+                }
+                st.n[q] = alive;
+            }
+        }
+        size_t wpos = 0;
+        for (size_t i = 0; i < store.size(); i++) {
+            const int q = store[i].shape.kind;
+            const int32_t ns = remap[q][(size_t)store[i].slot];
+            if (ns < 0) continue;
+            store[wpos] = store[i];
+            store[wpos].slot = ns;
+            wpos++;
+        }
+        store.resize(wpos);
+        // the running maximum must be recomputed over the survivors
+        best = -1;
+        for (size_t i = 0; i < store.size(); i++)
+            if (best < 0 || store[i].E > store[(size_t)best].E) best = (int64_t)i;
+        t_extract += now_s() - t0;
+        *did = true;
+        return RH_OK;
+    }
+
+    // everything of iteration k after the candidates exist: iterations.jl:98-156.
+    // Returns through *stop whether the loop ends after this iteration.
+    int finish_iteration(int64_t k, const rh_shape *cands, int32_t ncand, const int32_t *counts, bool *did_extract, bool *stop)
+    {
+        cc[2] += ncand;
+        RUN(record(cands, ncand, counts));
+        cc[3] = k * p->minsubsetN;
+        cc[1] = (int64_t)store.size();
+        RUN(maybe_extract(k, did_extract));
+        // updatelevelweight (octree.jl:198-205) only ever produces NaN weights: no effect (header)
+        *stop = rh_prob((double)p->tau, cc[p->terminate_s], c->n, drawN) > p->prob_det;
+        iterations = k;
+        return RH_OK;
+    }
+
+    int run_sequential()
+    {
+        std::vector<rh_shape> cands;
+        std::vector<int32_t> counts;
+        for (int64_t k = 1; k <= p->itermax; k++) {
+            if (en.count < p->tau) break;   // iterations.jl:75
+            const double t0 = now_s();
+            RUN(sample_iteration_host(k, cands));
+            t_sample += now_s() - t0;
+            RUN(score(cands.data(), (int32_t)cands.size(), counts));
+            bool did = false, stop = false;
+            RUN(finish_iteration(k, cands.data(), (int32_t)cands.size(), counts.data(), &did, &stop));
+            if (stop) break;
+        }
+        return RH_OK;
+    }
+
+    // sampling_streams = 1 with every shape type fittable on the device: iterations are sampled,
+    // fitted and scored SPECULATIVELY in windows (the enabled bits only change at an extraction, and
+    // a set's draws are a pure function of (seed, k, j)); the host replays the window in order and,
+    // when an extraction happens at iteration kk, throws the rest of the window away and resumes at
+    // kk + 1 -- bit-identical to the sequential loop.
+    int run_streams_device()
+    {
+        const int64_t sets_budget = 1 << 20;
+        int64_t K = std::max<int64_t>(1, std::min<int64_t>(128, sets_budget / std::max(1, p->minsubsetN)));
+        RUNH(hipMalloc((void **)&d_count, sizeof(int32_t)));
+        RUNH(hipMalloc((void **)&d_gave_up, sizeof(int32_t)));
+        draws_cap = (int32_t)K;
+        RUNH(hipMalloc((void **)&d_draws, sizeof(unsigned long long) * (size_t)draws_cap));
+        entries_cap = 1 << 16;
+        RUNH(hipMalloc((void **)&d_entries, sizeof(rh_cand_entry) * (size_t)entries_cap));
+        std::vector<rh_cand_entry> entries;
+        std::vector<unsigned long long> draws((size_t)K);
+        std::vector<rh_shape> cands;
+        std::vector<int32_t> counts;
+        const int T = p->n_shape_types;
+        int64_t k = 1;
+        while (k <= p->itermax) {
+            if (en.count < p->tau) break;
+            const int32_t W = (int32_t)std::min<int64_t>(K, p->itermax - k + 1);
+            const double t0 = now_s();
+            int32_t cnt = 0, gave_up = 0;
+            for (;;) {
+                RUN(rhk_sample_fit(c, p, rng->s[0], k, W, (int32_t)en.count, d_entries, entries_cap, d_count, d_draws, d_gave_up));
+                RUNH(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipMemcpyAsync(&gave_up, d_gave_up, sizeof gave_up, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipMemcpyAsync(draws.data(), d_draws, sizeof(unsigned long long) * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipStreamSynchronize(c->stream));
+                if (cnt <= entries_cap) break;
+                (void)hipFree(d_entries);   // the list overflowed: grow it and draw the window again
+                d_entries = nullptr;
+                entries_cap = cnt + cnt / 4;
+                RUNH(hipMalloc((void **)&d_entries, sizeof(rh_cand_entry) * (size_t)entries_cap));
+            }
+            if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
+            entries.resize((size_t)cnt);
+            if (cnt > 0) {
+                RUNH(hipMemcpyAsync(entries.data(), d_entries, sizeof(rh_cand_entry) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipStreamSynchronize(c->stream));
+                std::sort(entries.begin(), entries.end(),
+                          [](const rh_cand_entry &a, const rh_cand_entry &b) { return a.slot < b.slot; });
+            }
+            t_sample += now_s() - t0;
+            cands.resize((size_t)cnt);
+            for (int32_t i = 0; i < cnt; i++) cands[(size_t)i] = entries[(size_t)i].shape;
+            RUN(score(cands.data(), cnt, counts));
+            // replay the window in iteration order
+            int32_t pos = 0;
+            bool stop = false, did = false;
+            int32_t it = 0;
+            for (; it < W; it++) {
+                const int64_t kk = k + it;
+                if (en.count < p->tau) { stop = true; break; }   // iterations.jl:75 (only after an extraction)
+                const int64_t slot_end = (int64_t)(it + 1) * p->minsubsetN * T;
+                int32_t e = pos;
+                while (e < cnt && entries[(size_t)e].slot < slot_end) e++;
+                rng->draws += (int64_t)draws[(size_t)it];
+                RUN(finish_iteration(kk, cands.data() + pos, e - pos, counts.data() + pos, &did, &stop));
+                pos = e;
+                if (stop || did) { it++; break; }
+            }
+            k += it;
+            if (stop) break;
+        }
+        return RH_OK;
+    }
+};
+
+#undef RUN
+#undef RUNH
+
+}  // namespace
+
 extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng,
                          rh_result *out)
 {
@@ -192,271 +614,30 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
         rh_set_error("rh_ransac: extract_s / terminate_s must be 1..3");
         return RH_E_INVALID;
     }
+    if (p->minsubsetN < 0) { rh_set_error("rh_ransac: minsubsetN < 0"); return RH_E_INVALID; }
     RH_HIP(hipSetDevice(c->device));
     const double t_start = now_s();
-    const int drawN = p->drawN;
 
-    EnabledMirror en;
-    en.n = c->n;
-    en.w.assign((size_t)c->nwords, 0);
-    if (c->nwords > 0) RH_TRY(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
-    en.recount();
-    // the disabled list must describe the cloud as it is now (points disabled before the call)
-    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
-    int32_t ndis = 0;
-    RH_HIP(hipMemcpyAsync(&ndis, c->d_ndis, sizeof ndis, hipMemcpyDeviceToHost, c->stream));
-    RH_HIP(hipStreamSynchronize(c->stream));
-    c->n_dis = ndis;
-    c->select_valid = false;
+    Driver d;
+    d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
+    RH_TRY(d.init());
+    bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;
+    for (int t = 0; t < p->n_shape_types; t++)
+        if (p->shape_types[t] == RH_CONE) device_sampler = false;   // the cone fit needs libm acos/cos/sin: host
+    RH_TRY(device_sampler ? d.run_streams_device() : d.run_sequential());
 
-    DeviceStore st;
-    std::vector<Stored> store;              // scoredshapes, reference order
-    std::vector<rh_shape> cands;            // this iteration's candidates
-    std::vector<rh_shape> sorted;
-    std::vector<int32_t> orig, counts_h, idx_h;
-    std::vector<int64_t> sd((size_t)drawN);
-    std::vector<double> fp(3 * (size_t)drawN), fn(3 * (size_t)drawN);
-    std::vector<rh_extracted> extracted;
-    int64_t countcandidates[4] = { 0, 0, 0, 0 };
-    int64_t best = -1;                      // index into store of the running first maximum
-    double t_score = 0, t_extract = 0;
-    int rc = RH_OK;
-    RH_HIP(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
-
-#define RUN(x) do { rc = (x); if (rc != RH_OK) goto fail; } while (0)
-#define RUNH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); rc = RH_E_NODEVICE; goto fail; } } while (0)
-
-    int64_t k;
-    for (k = 1; k <= p->itermax; k++) {
-        if (en.count < p->tau) break;   // iterations.jl:75
-        // ---- sample + fit (host): iterations.jl:80-91 ----
-        cands.clear();
-        for (int i = 0; i < p->minsubsetN; i++) {
-            // samplepointcloud4!: fitting.jl:388-428 on the root cell
-            int64_t r1 = rh_rng_range(rng, c->n);
-            while (!en.test(r1 - 1)) r1 = rh_rng_range(rng, c->n);
-            if (en.count < drawN) continue;
-            sd[0] = r1;
-            for (int q = 1; q < drawN; q++) {
-                int64_t pick = en.select(rh_rng_range(rng, en.count));
-                if (pick == sd[0]) pick = en.select(rh_rng_range(rng, en.count));   // one redraw: fitting.jl:416-419
-                sd[(size_t)q] = pick;
-            }
-            bool distinct = true;   // allisdifferent: utilities.jl:285-295
-            for (int a = 1; a < drawN && distinct; a++)
-                for (int b = 0; b < a; b++)
-                    if (sd[(size_t)a] == sd[(size_t)b]) { distinct = false; break; }
-            if (!distinct) continue;
-            for (int q = 0; q < drawN; q++) {
-                memcpy(&fp[3 * (size_t)q], xyz + 3 * (sd[(size_t)q] - 1), 24);
-                memcpy(&fn[3 * (size_t)q], nrm + 3 * (sd[(size_t)q] - 1), 24);
-            }
-            for (int t = 0; t < p->n_shape_types; t++) {   // forcefitshapes!: fitting.jl:165-173
-                rh_shape fitted;
-                int32_t ok = 0;
-                RUN(rh_fit(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));
-                if (ok) cands.push_back(fitted);
-            }
-        }
-        const int32_t ncand = (int32_t)cands.size();
-        countcandidates[2] += ncand;
-
-        // ---- score the whole batch on the device: fitting.jl:181-190 ----
-        if (ncand > 0) {
-            const double t0 = now_s();
-            int32_t nk[4] = { 0, 0, 0, 0 }, off[4], fill[4];
-            for (const rh_shape &s : cands) nk[s.kind]++;
-            off[0] = 0;
-            for (int q = 1; q < 4; q++) off[q] = off[q - 1] + nk[q - 1];
-            for (int q = 0; q < 4; q++) fill[q] = off[q];
-            sorted.resize((size_t)ncand);
-            orig.resize((size_t)ncand);
-            for (int32_t i = 0; i < ncand; i++) {
-                const int q = cands[(size_t)i].kind;
-                sorted[(size_t)fill[q]] = cands[(size_t)i];
-                orig[(size_t)fill[q]] = i;
-                fill[q]++;
-            }
-            if (ncand > st.shapes_cap) {
-                RUNH(hipStreamSynchronize(c->stream));
-                (void)hipFree(st.d_shapes);
-                st.d_shapes = nullptr;
-                st.shapes_cap = std::max<int64_t>(ncand, 1024);
-                RUNH(hipMalloc((void **)&st.d_shapes, sizeof(rh_shape) * (size_t)st.shapes_cap));
-            }
-            RUN(store_reserve_aux(c, st, ncand));
-            for (int q = 0; q < 4; q++) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + nk[q]));
-            RUNH(hipMemcpyAsync(st.d_shapes, sorted.data(), sizeof(rh_shape) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
-            RUNH(hipMemcpyAsync(st.d_idx, orig.data(), sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
-            RUNH(hipMemcpyAsync(st.d_nk, nk, sizeof nk, hipMemcpyHostToDevice, c->stream));
-            RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)ncand, c->stream));
-            for (int q = 0; q < 4; q++) {
-                if (nk[q] == 0) continue;
-                rh_prep *tail = st.prep[q] + st.n[q];   // prepared records persist in the store
-                RUN(rhk_prep_sorted(c, st.d_shapes + off[q], nk[q], tail));
-                const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
-                if (c->use_groups)
-                    RUN(rhk_score_kind_groups(c, q, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q], p->eps[q],
-                                              p->cos_alpha[q], st.counts, nullptr));
-                else
-                    RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, tail, st.d_idx + off[q], st.d_nk + q, nk[q],
-                                       p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
-            }
-            counts_h.resize((size_t)ncand);
-            RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
-            RUNH(hipStreamSynchronize(c->stream));
-            t_score += now_s() - t0;
-            // record in candidate order (recordscore!: fitting.jl:114-119)
-            int32_t slot_next[4] = { st.n[0], st.n[1], st.n[2], st.n[3] };
-            // slots were assigned in sorted order = candidate order within a kind (stable sort)
-            for (int32_t i = 0; i < ncand; i++) {
-                const rh_shape &s = cands[(size_t)i];
-                double lo, hi, E;
-                RUN(rh_estimatescore(c->s, c->n, counts_h[(size_t)i], p->score_mode, &lo, &hi, &E));
-                Stored rec;
-                rec.shape = s;
-                rec.E = E;
-                rec.slot = slot_next[s.kind]++;
-                store.push_back(rec);
-                // findhighestscore (fitting.jl:140-151) incrementally: first maximum, strict >
-                if (best < 0) best = (int64_t)store.size() - 1;
-                else if (E > store[(size_t)best].E) best = (int64_t)store.size() - 1;
-            }
-            for (int q = 0; q < 4; q++) st.n[q] += nk[q];
-        }
-        countcandidates[3] = k * p->minsubsetN;
-        countcandidates[1] = (int64_t)store.size();
-
-        if (!store.empty()) {
-            const double scr = store[(size_t)best].E;
-            const double ppp = rh_prob(scr, countcandidates[p->extract_s], c->n, drawN);
-            if (ppp > p->prob_det) {   // iterations.jl:123
-                const double t0 = now_s();
-                // refit: full-cloud scan + ascending compaction (plane.jl:137-143 ...)
-                const rh_shape bestshape = store[(size_t)best].shape;
-                rh_prep P;
-                rh_prep_host(bestshape, &P);
-                RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
-                RUN(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
-                int32_t total = 0;
-                RUNH(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
-                // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
-                RUN(rhk_andnot_enabled(c, c->refit_mask));
-                RUN(rhk_rebuild_sub_enabled(c, true, false));
-                int32_t ndis_new = 0;
-                RUNH(hipMemcpyAsync(&ndis_new, c->d_ndis, sizeof ndis_new, hipMemcpyDeviceToHost, c->stream));
-                RUNH(hipStreamSynchronize(c->stream));
-                rh_extracted ex;
-                memset(&ex, 0, sizeof ex);
-                ex.shape = bestshape;
-                ex.n_inpoints = total;
-                ex.inpoints = (int64_t *)malloc(sizeof(int64_t) * (size_t)std::max<int32_t>(total, 1));
-                if (!ex.inpoints) { rh_set_error("out of host memory"); rc = RH_E_NOMEM; goto fail; }
-                if (total > 0)
-                    RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
-                RUNH(hipStreamSynchronize(c->stream));
-                ex.score_E = scr;
-                ex.iteration = k;
-                extracted.push_back(ex);
-                en.clear(ex.inpoints, total);
-                const int64_t ndis_old = c->n_dis;
-                c->n_dis = ndis_new;
-
-                // deleteat!(scoredshapes, best.index): iterations.jl:136
-                store.erase(store.begin() + best);
-                // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
-                std::vector<char> dead_slot[4];
-                for (int q = 0; q < 4; q++) {
-                    dead_slot[q].assign((size_t)st.n[q], 1);   // slots not referenced by `store` are dead
-                }
-                for (const Stored &r : store) dead_slot[r.shape.kind][(size_t)r.slot] = 0;
-                int64_t maxn = 0;
-                for (int q = 0; q < 4; q++) maxn = std::max<int64_t>(maxn, st.n[q]);
-                RUN(store_reserve_aux(c, st, maxn));
-                for (int q = 0; q < 4; q++) {
-                    if (st.n[q] == 0) continue;
-                    const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
-                    const int64_t first = all_disabled ? 0 : ndis_old;
-                    const int64_t cnt = (int64_t)ndis_new - first;
-                    if (cnt > 0) {
-                        RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)st.n[q], c->stream));
-                        RUNH(hipMemcpyAsync(st.d_nk + 4 + q, &st.n[q], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-                        RUN(rhk_score_kind(c, q, c->dis + first, c->dis_stride, cnt, nullptr, st.prep[q], st.iota,
-                                           st.d_nk + 4 + q, st.n[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
-                        counts_h.resize((size_t)st.n[q]);
-                        RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)st.n[q], hipMemcpyDeviceToHost, c->stream));
-                        RUNH(hipStreamSynchronize(c->stream));
-                        for (int32_t sl = 0; sl < st.n[q]; sl++)
-                            if (counts_h[(size_t)sl] > 0) dead_slot[q][(size_t)sl] = 1;
-                    }
-                }
-                // drop dead candidates on the host (order preserved), compact the device store
-                {
-                    std::vector<int32_t> remap[4];
-                    for (int q = 0; q < 4; q++) {
-                        remap[q].assign((size_t)st.n[q], -1);
-                        idx_h.clear();
-                        for (int32_t sl = 0; sl < st.n[q]; sl++)
-                            if (!dead_slot[q][(size_t)sl]) {
-                                remap[q][(size_t)sl] = (int32_t)idx_h.size();
-                                idx_h.push_back(sl);
-                            }
-                        const int32_t alive = (int32_t)idx_h.size();
-                        if (alive != st.n[q]) {
-                            if (alive > 0) {
-                                rh_prep *np = nullptr;
-                                RUNH(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)st.cap[q]));
-                                RUNH(hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream));
-                                rc = rhk_gather_prep(c, st.prep[q], st.d_idx, alive, np);
-                                RUNH(hipStreamSynchronize(c->stream));
-                                (void)hipFree(st.prep[q]);
-                                st.prep[q] = np;
-                                if (rc != RH_OK) goto fail;
-                            }
-                            st.n[q] = alive;
-                        }
-                    }
-                    size_t wpos = 0;
-                    for (size_t i = 0; i < store.size(); i++) {
-                        const int q = store[i].shape.kind;
-                        const int32_t ns = remap[q][(size_t)store[i].slot];
-                        if (ns < 0) continue;
-                        store[wpos] = store[i];
-                        store[wpos].slot = ns;
-                        wpos++;
-                    }
-                    store.resize(wpos);
-                }
-                // the running maximum must be recomputed over the survivors
-                best = -1;
-                for (size_t i = 0; i < store.size(); i++)
-                    if (best < 0 || store[i].E > store[(size_t)best].E) best = (int64_t)i;
-                t_extract += now_s() - t0;
-            }
-        }
-        // updatelevelweight (octree.jl:198-205) only ever produces NaN weights: no effect (header)
-        if (rh_prob((double)p->tau, countcandidates[p->terminate_s], c->n, drawN) > p->prob_det) { k++; break; }
-    }
-    out->iterations = std::min<int64_t>(k - 1, p->itermax);
-    out->candidates_scored = countcandidates[2];
-    out->scored_left = (int64_t)store.size();
-    out->n_shapes = (int64_t)extracted.size();
-    out->shapes = (rh_extracted *)malloc(sizeof(rh_extracted) * std::max<size_t>(extracted.size(), 1));
-    if (!out->shapes) { rh_set_error("out of host memory"); rc = RH_E_NOMEM; goto fail; }
-    for (size_t i = 0; i < extracted.size(); i++) out->shapes[i] = extracted[i];
-    extracted.clear();
-    store_free(c, st);
+    out->iterations = d.iterations;
+    out->candidates_scored = d.cc[2];
+    out->scored_left = (int64_t)d.store.size();
+    out->n_shapes = (int64_t)d.extracted.size();
+    out->shapes = (rh_extracted *)malloc(sizeof(rh_extracted) * std::max<size_t>(d.extracted.size(), 1));
+    if (!out->shapes) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
+    for (size_t i = 0; i < d.extracted.size(); i++) out->shapes[i] = d.extracted[i];
+    d.extracted.clear();   // ownership of the index lists moved to the result
     c->select_valid = false;
     out->seconds = now_s() - t_start;
-    out->seconds_score = t_score;
-    out->seconds_extract = t_extract;
-    out->seconds_host = out->seconds - t_score - t_extract;
+    out->seconds_score = d.t_score;
+    out->seconds_extract = d.t_extract;
+    out->seconds_host = d.t_sample;
     return RH_OK;
-
-fail:
-    for (rh_extracted &e : extracted) free(e.inpoints);
-    store_free(c, st);
-    return rc;
-#undef RUN
-#undef RUNH
 }

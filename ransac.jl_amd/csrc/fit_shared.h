@@ -1,0 +1,252 @@
+// fit_shared.h -- minimal-set fits for plane / sphere / cylinder and the per-set random stream,
+// compiled for BOTH host and device (hipcc, -ffp-contract=off): only + - * / sqrt fabs and
+// comparisons are used, so the two sides produce bit-identical candidates.  The cone fit needs
+// acos/cos/sin (libm) and LAPACK-like rank / solve: it stays host-only in fit.cpp.
+// Paths in comments are under /root/reference/src.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "ransac_hip.h"
+
+#if defined(__HIPCC__)
+#define RH_HD __host__ __device__ inline
+#else
+#define RH_HD inline
+#endif
+
+namespace rhfit {
+
+// StaticArrays-style 3-vector: dot / norm sum left to right, normalize multiplies by 1/norm
+struct Vec {
+    double x, y, z;
+    RH_HD Vec() : x(0), y(0), z(0) {}
+    RH_HD Vec(double a, double b, double c) : x(a), y(b), z(c) {}
+    RH_HD explicit Vec(const double *p) : x(p[0]), y(p[1]), z(p[2]) {}
+    RH_HD Vec operator+(const Vec &o) const { return Vec(x + o.x, y + o.y, z + o.z); }
+    RH_HD Vec operator-(const Vec &o) const { return Vec(x - o.x, y - o.y, z - o.z); }
+    RH_HD Vec operator-() const { return Vec(-x, -y, -z); }
+    RH_HD Vec operator*(double s) const { return Vec(x * s, y * s, z * s); }
+    RH_HD Vec operator/(double s) const { return Vec(x / s, y / s, z / s); }
+    RH_HD void store(double *p) const { p[0] = x; p[1] = y; p[2] = z; }
+};
+RH_HD Vec operator*(double s, const Vec &v) { return Vec(s * v.x, s * v.y, s * v.z); }
+RH_HD double dot(const Vec &a, const Vec &b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RH_HD double norm(const Vec &a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); }
+RH_HD Vec normalize(const Vec &a) { return (1.0 / norm(a)) * a; }
+RH_HD Vec cross(const Vec &a, const Vec &b)
+{
+    return Vec(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+struct Vec2 {
+    double x, y;
+};
+
+
+// ---- plane.jl:33-57 ----
+RH_HD bool fit_plane(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+{
+    const Vec p1(p), p2(p + 3), p3(p + 6);
+    const Vec crossv = normalize(cross(p2 - p1, p3 - p1));
+    if (norm(crossv) < prm.collin_threshold) return false;
+    const double thr = prm.cos_alpha[RH_PLANE];
+    bool same = true, opposite = true;
+    for (int i = 0; i < lp; i++) {
+        const double dotp = dot(crossv, normalize(Vec(n + 3 * i)));
+        same = same && (dotp > thr);
+        opposite = opposite && (dotp < -thr);
+    }
+    if (!same && !opposite) return false;
+    out->kind = RH_PLANE;
+    p1.store(out->v);
+    (same ? crossv : -1.0 * crossv).store(out->v + 3);
+    return true;
+}
+
+// ---- sphere.jl:29-75 ----
+RH_HD void fit2pointsphere(const double *v, const double *n, const rh_params &prm, Vec *center, double *radius)
+{
+    const Vec v1(v), v2(v + 3), n1(n), n2raw(n + 3);
+    const Vec n1n = normalize(n1), n2n = normalize(n2raw);
+    if (fabs(dot(n1n, n2n)) > prm.cos_parallelthr) {
+        *center = (v1 + v2) / 2;
+        *radius = norm(*center - v1);
+        return;
+    }
+    const Vec g = v2 - v1;
+    const Vec h = cross(n2n, g);
+    const Vec k = cross(n2n, n1n);
+    const double nk = norm(k), nh = norm(h);
+    if (nk < prm.sphere_par || nh < prm.sphere_par) {
+        const Vec n2 = cross(n2n, cross(n1n, n2n));
+        const Vec n1b = cross(n1n, cross(n2n, n1n));
+        const Vec c1 = v1 + (dot(v2 - v1, n2) / dot(n1, n2)) * n1;
+        const Vec c2 = v2 + (dot(v1 - v2, n1b) / dot(n2raw, n1b)) * n2raw;
+        *center = (c1 + c2) / 2;
+        *radius = (norm(v1 - *center) + norm(v1 - *center)) / 2;
+    } else if (dot(h, k) > 0) {
+        *center = v1 + (nh / nk) * n1n;
+        *radius = norm(*center - v1);
+    } else {
+        *center = v1 - (nh / nk) * n1n;
+        *radius = norm(*center - v1);
+    }
+}
+
+// ---- sphere.jl:87-114 ----
+RH_HD bool fit_sphere(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+{
+    Vec center;
+    double radius;
+    fit2pointsphere(p, n, prm, &center, &radius);
+    const double thr = prm.cos_alpha[RH_SPHERE], eps = prm.eps[RH_SPHERE];
+    bool vert = true, same = true, opposite = true;
+    for (int i = 0; i < lp; i++) {
+        const Vec pi(p + 3 * i);
+        vert = vert && (fabs(norm(pi - center) - radius) < eps);
+        const double dotp = dot(normalize(pi - center), normalize(Vec(n + 3 * i)));
+        same = same && (dotp > thr);
+        opposite = opposite && (dotp < -thr);
+    }
+    if (!vert || (!same && !opposite)) return false;
+    out->kind = RH_SPHERE;
+    out->outwards = same ? 1 : 0;
+    center.store(out->v);
+    out->v[3] = radius;
+    return true;
+}
+
+// ---- cylinder.jl:46-59 (project2plane), :61-85 (projectto2d), :87-101 ----
+RH_HD Vec cyl_project2plane(const Vec &n, const Vec &w) { return w + n * (dot(-n, w) / dot(n, n)); }
+
+RH_HD Vec2 cyl_projectto2d(const Vec &xa, const Vec &ya, const Vec &za, const Vec &p1)
+{
+    const double xx = xa.x, xy = xa.y, xz = xa.z, yx = ya.x, yy = ya.y, yz = ya.z;
+    const double zx = za.x, zy = za.y, zz = za.z, px = p1.x, py = p1.y, pz = p1.z;
+    Vec2 r;
+    r.x = -((-(pz * yy * zx) + py * yz * zx + pz * yx * zy - px * yz * zy - py * yx * zz + px * yy * zz) /
+            (xz * yy * zx - xy * yz * zx - xz * yx * zy + xx * yz * zy + xy * yx * zz - xx * yy * zz));
+    r.y = -((pz * xy * zx - py * xz * zx - pz * xx * zy + px * xz * zy + py * xx * zz - px * xy * zz) /
+            (xz * yy * zx - xy * yz * zx - xz * yx * zy + xx * yz * zy + xy * yx * zz - xx * yy * zz));
+    return r;
+}
+
+// ---- cylinder.jl:34-125 ----
+RH_HD bool fit2pointcylinder(const double *p, const double *n, const rh_params &prm, Vec *axis, Vec *center, double *radius,
+                       bool *outw)
+{
+    const Vec p1(p), p2(p + 3), n1(n), n2(n + 3);
+    if (fabs(dot(n1, n2)) > prm.cos_parallelthr) return false;
+    const Vec an = normalize(cross(n1, n2));
+    const Vec xax = normalize(cyl_project2plane(an, p1));
+    const Vec yax = normalize(cross(an, xax));
+    const Vec2 a = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1));
+    const Vec2 b = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1 + n1));
+    const Vec2 c = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2));
+    const Vec2 d = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2 + n2));
+    const Vec2 amb = { a.x - b.x, a.y - b.y }, cmd = { c.x - d.x, c.y - d.y };
+    const double d1 = a.x * b.y - a.y * b.x;       // det([a'; b'])
+    const double d2 = c.x * d.y - c.y * d.x;
+    const double d3 = amb.x * cmd.y - amb.y * cmd.x;
+    const Vec2 ic = { (d1 * cmd.x - d2 * amb.x) / d3, (d1 * cmd.y - d2 * amb.y) / d3 };
+    const Vec cc = ic.x * xax + ic.y * yax;
+    const double r1 = norm((p1 - cc) - an * dot(an, p1 - cc));
+    const double r2 = norm((p2 - cc) - an * dot(an, p2 - cc));
+    *axis = an;
+    *center = cc;
+    *radius = (r1 + r2) / 2;
+    *outw = ((b.x - a.x) * (a.x - ic.x) + (b.y - a.y) * (a.y - ic.y)) > 0;
+    return true;
+}
+
+// ---- cylinder.jl:135-168 ----
+RH_HD bool fit_cylinder(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+{
+    Vec axis, center;
+    double radius;
+    bool outw;
+    if (!fit2pointcylinder(p, n, prm, &axis, &center, &radius, &outw)) return false;
+    const double thr = prm.cos_alpha[RH_CYLINDER], eps = prm.eps[RH_CYLINDER];
+    bool vert = true, same = true, opposite = true;
+    for (int i = 0; i < lp; i++) {
+        const Vec pi(p + 3 * i);
+        const Vec cn = (pi - axis * dot(axis, pi - center)) - center;
+        vert = vert && (fabs(norm(cn) - radius) < eps);
+        const double dotp = dot(normalize(cn), Vec(n + 3 * i));
+        same = same && (dotp > thr);
+        opposite = opposite && (dotp < -thr);
+    }
+    if (!vert || (!same && !opposite)) return false;
+    out->kind = RH_CYLINDER;
+    out->outwards = same ? 1 : 0;
+    axis.store(out->v);
+    center.store(out->v + 3);
+    out->v[6] = radius;
+    return true;
+}
+
+
+// ---- per-minimal-set random stream (sampling_streams = 1) ------------------------------------
+// One splitmix64 stream per (iteration k, minimal set j), a pure function of (seed, k, j): every
+// set can be drawn independently -- on the device, in any order -- with the same result.
+RH_HD uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+RH_HD uint64_t set_stream_init(uint64_t seed, uint64_t k, uint64_t j)
+{
+    return mix64(seed + k * 0xD1B54A32D192ED03ULL) ^ mix64(j * 0x8CB92BA72F3D8DD7ULL + 0x2545F4914F6CDD1DULL);
+}
+RH_HD uint64_t set_stream_next(uint64_t *x)
+{
+    *x += 0x9E3779B97F4A7C15ULL;
+    return mix64(*x);
+}
+RH_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+    return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+}
+// rand(1:n) = 1 + floor(u * n / 2^64)
+RH_HD int64_t set_stream_range(uint64_t *x, int64_t n) { return 1 + (int64_t)mulhi64(set_stream_next(x), (uint64_t)n); }
+
+}  // namespace rhfit
+
+namespace rhfit {
+
+// samplepointcloud4! (src/fitting.jl:383-430) on the root cell, drawing from a per-set stream.
+// En provides test(i0) and select(rank) over the enabled bits.  Returns false for the
+// reference's (false, 0) / (false, 1) outcomes.  *ndraws counts rand() calls.
+template <class En>
+RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN, uint64_t *x, int64_t *sd,
+                              uint32_t *ndraws, bool *gave_up)
+{
+    if (n_enabled <= 0) return false;   // the reference would spin forever at fitting.jl:393
+    int64_t r1 = set_stream_range(x, n);
+    uint32_t nd = 1;
+    while (!en.test(r1 - 1)) {
+        r1 = set_stream_range(x, n);
+        if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+    }
+    *ndraws += nd;
+    if (n_enabled < drawN) return false;
+    sd[0] = r1;
+    for (int q = 1; q < drawN; q++) {
+        int64_t pick = en.select(set_stream_range(x, n_enabled));
+        ++*ndraws;
+        if (pick == sd[0]) {   // one redraw: fitting.jl:416-419
+            pick = en.select(set_stream_range(x, n_enabled));
+            ++*ndraws;
+        }
+        sd[q] = pick;
+    }
+    for (int a = 1; a < drawN; a++)   // allisdifferent: utilities.jl:285-295
+        for (int b = 0; b < a; b++)
+            if (sd[a] == sd[b]) return false;
+    return true;
+}
+
+}  // namespace rhfit

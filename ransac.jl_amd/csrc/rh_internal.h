@@ -138,6 +138,15 @@ int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32
 int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
                         int64_t *idx_out, int64_t cap, int32_t *d_total);
 
+// device-side sampling + fitting (sampler.hip)
+struct rh_cand_entry {
+    int64_t slot;     // ((iteration - k0) * minsubsetN + set) * n_shape_types + type index
+    rh_shape shape;
+};
+int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
+                   rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws,
+                   int32_t *d_gave_up);
+
 void rh_prep_host(const rh_shape &s, rh_prep *out);
 
 // ---- host helpers (cloud.hip) -----------------------------------------------

@@ -1,0 +1,105 @@
+// sampler.hip -- device-side minimal-set sampling + fitting (sampling_streams = 1).
+// One thread per (iteration, minimal set): draws the set from its own splitmix64 stream
+// (fit_shared.h), gathers the points, runs the plane / sphere / cylinder fits in the order of
+// iteration.shape_types (forcefitshapes!, src/fitting.jl:165-173) and appends every fitted
+// candidate, tagged with its slot = ((iteration, set), shape type), to a compact list.  The host
+// sorts the list by slot, which restores the reference's candidate order exactly.
+#include "fit_shared.h"
+#include "rh_internal.h"
+
+namespace {
+
+struct DevEnabled {
+    const uint64_t *w;
+    const int32_t *prefix;   // exclusive popcount prefix per word
+    int64_t nwords;
+    int32_t total;
+    __device__ bool test(int64_t i0) const { return (w[i0 >> 6] >> (i0 & 63)) & 1ULL; }
+    __device__ int64_t select(int64_t r) const
+    {
+        if (r < 1 || r > total) return 0;
+        int64_t lo = 0, hi = nwords;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] < r) lo = mid; else hi = mid;
+        }
+        uint64_t m = w[lo];
+        const int rem = (int)(r - prefix[lo]);
+        for (int t = 1; t < rem; t++) m &= m - 1;
+        return (lo << 6) + __ffsll((unsigned long long)m);
+    }
+};
+
+constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the host sampler
+
+__global__ void __launch_bounds__(128)
+sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, DevEnabled en, int32_t n_enabled,
+                  const rh_params prm, uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out,
+                  int32_t cap, int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
+                  int32_t *__restrict__ gave_up_flag)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n_iters * prm.minsubsetN;
+    if (t >= total) return;
+    const int32_t it = (int32_t)(t / prm.minsubsetN);
+    const int32_t j = (int32_t)(t - (int64_t)it * prm.minsubsetN);
+    uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
+    int64_t sd[RH_MAX_DRAWN];
+    uint32_t nd = 0;
+    bool gave_up = false;
+    const int drawN = prm.drawN;
+    const bool ok = rhfit::sample_minimal_set(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+    atomicAdd(&draws_per_iter[it], (unsigned long long)nd);
+    if (gave_up) atomicExch(gave_up_flag, 1);
+    if (!ok) return;
+    double fp[3 * RH_MAX_DRAWN], fn[3 * RH_MAX_DRAWN];
+    for (int q = 0; q < drawN; q++) {
+        const int64_t i0 = sd[q] - 1;
+        for (int k = 0; k < 3; k++) {
+            fp[3 * q + k] = full[k * stride + i0];
+            fn[3 * q + k] = full[(3 + k) * stride + i0];
+        }
+    }
+    for (int ti = 0; ti < prm.n_shape_types; ti++) {
+        rh_shape s;
+        for (int q = 0; q < 10; q++) s.v[q] = 0.0;
+        s.kind = -1;
+        s.outwards = 0;
+        bool fitted = false;
+        switch (prm.shape_types[ti]) {
+        case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
+        case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
+        case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
+        default: break;   // cones are fitted on the host (libm): the driver never sends them here
+        }
+        if (!fitted) continue;
+        const int32_t pos = atomicAdd(out_count, 1);
+        if (pos < cap) {
+            out[pos].slot = (int64_t)t * prm.n_shape_types + ti;
+            out[pos].shape = s;
+        }
+    }
+}
+
+}  // namespace
+
+int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
+                   rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws, int32_t *d_gave_up)
+{
+    if (prm->drawN > RH_MAX_DRAWN) { rh_set_error("device sampler supports drawN <= %d", RH_MAX_DRAWN); return RH_E_INVALID; }
+    if (!c->select_valid) RH_TRY(rhk_build_select(c));
+    RH_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
+    RH_HIP(hipMemsetAsync(d_gave_up, 0, sizeof(int32_t), c->stream));
+    RH_HIP(hipMemsetAsync(d_draws, 0, sizeof(unsigned long long) * (size_t)n_iters, c->stream));
+    const int64_t total = (int64_t)n_iters * prm->minsubsetN;
+    if (total == 0) return RH_OK;
+    DevEnabled en;
+    en.w = c->enabled;
+    en.prefix = c->word_prefix;
+    en.nwords = c->nwords;
+    en.total = n_enabled;
+    hipLaunchKernelGGL(sample_fit_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full, c->n_pad,
+                       c->n, en, n_enabled, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}

@@ -264,6 +264,29 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
     assert_same_run(pc, oc, got, exp, stats)
 
 
+@pytest.mark.parametrize("prims,kinds,seed", [
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11),   # device sampler + speculation
+    (["plane", "sphere", "cylinder", "cone"], "all", 12),                             # cone present: host sampler
+    (["plane", "plane"], "p", 13),
+])
+def test_ransac_per_set_streams(prims, kinds, seed):
+    """sampling_streams = 1: sampling + fitting on the device, iterations speculated in windows;
+    must equal the oracle's strictly sequential loop over the same per-set streams."""
+    xyz, nrm, truth = synth.make_cloud(30_000, prims, 0.1, seed=60 + seed)
+    subs = synth.make_subsets(30_000, 2, seed=seed)
+    types = {"psc": [R.FittedPlane, R.FittedSphere, R.FittedCylinder], "p": [R.FittedPlane],
+             "all": [R.FittedPlane, R.FittedCone, R.FittedCylinder, R.FittedSphere]}[kinds]
+    params = R.ransacparameters(types, iteration={"minsubsetN": 50, "τ": 300, "itermax": 300, "prob_det": 0.6})
+    pc, oc, got, exp, stats = run_both(xyz, nrm, subs, params, seed=seed, score_mode=L.SCORE_F64,
+                                       sphere_uses_enabled=True, sampling_streams=1)
+    assert len(got) >= 2
+    assert_same_run(pc, oc, got, exp, stats)
+    # and it differs from the sequential-stream run (different draws), while both find the big shapes
+    pc2 = R.RANSACCloud(xyz, nrm, subs)
+    got0, _ = R.ransac(pc2, R.params_to_c(params, score_mode=L.SCORE_F64, sphere_uses_enabled=True), seed=seed)
+    assert len(got0) >= 2
+
+
 def test_ransac_injected_stream_and_preexisting_disabled_points():
     xyz, nrm, truth = synth.make_cloud(12_000, ["plane", "sphere", "cylinder"], 0.1, seed=77)
     subs = synth.make_subsets(12_000, 2, seed=77)
