@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--points", type=int, default=10_000_000, help="cloud size (default: BASELINE cfg3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
-    ap.add_argument("--e2e-seconds", type=float, default=25.0)
+    ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
+    ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     return ap.parse_args()
 
 
@@ -80,10 +81,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("RH_BENCH_SHARE_GPU0"):   # rehearsal of the N > 1 flow on a one-GPU box (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RH_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     lib = R.lib()
 
     # ---- workload: BASELINE cfg3 (cfg4 when sharded) -----------------------------------
@@ -172,7 +179,7 @@ def main():
         sec = d["ms_per_launch"] * 1e-3
         alg_bytes = tests * SCORE_BYTES_PER_TEST + d["candidates"] * (64 + 4)
         out["roofline"] = {
-            "kernel": "score_kernel<%s>" % dom, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
+            "kernel": "score_groups_kernel<%s>" % dom, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": alg_bytes,
             "note": "EFFECTIVE rate on algorithmic bytes = 48.25 B x (candidate, point) tests (SURVEY.md 8d). The "
@@ -182,7 +189,7 @@ def main():
         }
         issue = VALU_F64_PER_TEST[dom] * tests / 64 * 4          # SIMD cycles at 4 cycles per wave64 f64 op
         out["roofline_valu"] = {
-            "kernel": "score_kernel<%s>" % dom, "bound": "fp64_valu",
+            "kernel": "score_groups_kernel<%s>" % dom, "bound": "fp64_valu",
             "achieved": FLOPS_PER_TEST[dom] * tests / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": FLOPS_PER_TEST[dom] * tests / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_issue_frac": issue / (1024 * 2.4e9 * sec),
@@ -233,27 +240,48 @@ def main():
         # ---- end to end: shapes / s of the whole ransac() loop on the same cloud ----------
         if not args.no_e2e:
             e2e = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
-                                     iteration={"minsubsetN": 4096, "itermax": 1, "τ": 900, "prob_det": 0.9})
+                                     iteration={"minsubsetN": 4096, "itermax": args.e2e_iters, "τ": 900, "prob_det": 0.9})
             ecp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
-            # time-boxed: calibrate seconds/iteration on 8 iterations, then ONE call sized to the budget
             pc.enable_all()
-            ecp.itermax = 8
-            _, _, st = R.ransac(pc, ecp, seed=99, return_stats=True)
-            per_iter = max(st["seconds"] / max(1, st["iterations"]), 1e-4)
+            ecp.itermax = 4
+            R.ransac(pc, ecp, seed=99)                      # warm-up (allocations, first launches)
             pc.enable_all()
-            ecp.itermax = max(16, int(args.e2e_seconds / per_iter))
+            ecp.itermax = args.e2e_iters
             t0 = time.perf_counter()
             got, secs, st = R.ransac(pc, ecp, seed=1234, return_stats=True)
-            shapes, iters, cand_scored = len(got), st["iterations"], st["candidates_scored"]
-            agg = {kk: st[kk] for kk in ("seconds_score", "seconds_extract", "seconds_host")}
             t_e2e = time.perf_counter() - t0
-            out["end_to_end"] = {"metric": "shapes_per_sec", "value": shapes / t_e2e, "shapes": shapes, "seconds": t_e2e,
-                                 "iterations": iters, "minimal_sets": iters * 4096, "candidates_scored": cand_scored,
-                                 "breakdown_s": agg,
-                                 "itermax": int(ecp.itermax), "largest_shapes": sorted((len(g.inpoints) for g in got), reverse=True)[:5],
-                                 "note": "one rh_ransac call, minsubsetN=4096, itermax sized to ~%gs; root-cell sampling "
-                                         "like the reference, f64 score mode, per-set random streams: sampling + fits + scoring on the device, "
-                                         "iterations speculated in windows of 128" % args.e2e_seconds}
+            last_it = max([g.iteration for g in got], default=0)
+            out["end_to_end"] = {"metric": "shapes_per_sec", "value": len(got) / t_e2e, "shapes": len(got), "seconds": t_e2e,
+                                 "iterations": st["iterations"], "minimal_sets": st["iterations"] * 4096,
+                                 "minimal_sets_per_sec": st["iterations"] * 4096 / t_e2e,
+                                 "candidates_scored": st["candidates_scored"], "last_extraction_iteration": last_it,
+                                 "breakdown_s": {"sample_fit": st["seconds_host"], "score": st["seconds_score"],
+                                                 "extract": st["seconds_extract"]},
+                                 "largest_shapes": sorted((len(g.inpoints) for g in got), reverse=True)[:5],
+                                 "note": "one rh_ransac call: minsubsetN=4096, itermax=%d, root-cell sampling like the "
+                                         "reference, f64 score mode, per-set random streams (sampling + fits + scoring on "
+                                         "the device, iterations speculated in windows of 128)" % args.e2e_iters}
+            if not args.no_cpu:
+                # CPU side of the same loop on a bounded prefix, and a parity check of that prefix
+                from oracle import oracle as orc
+                nit = args.e2e_cpu_iters
+                ecp.itermax = nit
+                pc.enable_all()
+                gp, _, sp = R.ransac(pc, ecp, seed=1234, return_stats=True)
+                oc = orc.Cloud(xyz, nrm, subs[0])
+                t0 = time.perf_counter()
+                eo = oc.ransac(orc.Params.from_buffer_copy(bytes(ecp)), seed=1234)
+                t_cpu = time.perf_counter() - t0
+                same = (len(gp) == len(eo["shapes"]) and sp["draws"] == eo["draws"] and
+                        all(bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
+                            for g, e in zip(gp, eo["shapes"])))
+                if not same:
+                    raise SystemExit("PARITY FAILURE: rh_ransac differs from the oracle on the %d-iteration prefix" % nit)
+                out["end_to_end"]["cpu_baseline"] = {
+                    "kind": "port", "cores": 1, "iterations": nit, "seconds": t_cpu,
+                    "minimal_sets_per_sec": nit * 4096 / t_cpu, "shapes": len(eo["shapes"]),
+                    "sample": "the oracle's ransac() on the first %d iterations of the same run; extracted shapes, "
+                              "index sets and draw counts checked identical to rh_ransac's" % nit}
         out["setup_seconds"] = t_setup
         print(json.dumps(out))
     batch.free()

@@ -9,4 +9,6 @@ from .api import (DEFAULT_PARAMETERS, DEFAULT_SHAPE_DICT, ConfidenceInterval, E,
                   notsoconfident, params_to_c, prob, ransac, ransacparameters, refit, score_batch,
                   scorecandidate, select_enabled, shape_from_c, strt)
 
+from .io import exportJSON, readconfig, toDict
+
 __all__ = [n for n in dir() if not n.startswith("_")]
