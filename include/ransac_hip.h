@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 100
+#define RH_VERSION 101
 
 enum {
     RH_OK = 0,
@@ -92,6 +92,12 @@ typedef struct {
     int32_t sampling_streams;  /* 0 = one sequential random stream (the reference's structure, host-side
                                   sampling); 1 = one stream per (iteration, minimal set), a pure function
                                   of (seed, k, j): sampling + plane/sphere/cylinder fits run on the device */
+    int32_t octree_sampling;   /* 0 = every minimal set from the root cell: the reference's live behaviour
+                                  (constructor bug); 1 = what docs/src/ransac.md:73-96 describes:
+                                  a level is drawn from the level distribution and the other points come from
+                                  the first point's cell at that level (linear Morton octree; needs
+                                  sampling_streams = 1) */
+    int32_t octree_max_depth;  /* depth cap of the linear octree (default 10) */
 } rh_params;
 
 typedef struct rh_cloud rh_cloud;

@@ -53,6 +53,8 @@ struct RhParams
     score_mode::Cint
     sphere_uses_enabled::Cint
     sampling_streams::Cint
+    octree_sampling::Cint
+    octree_max_depth::Cint
 end
 
 lasterror() = unsafe_string(ccall((:rh_last_error, LIB), Cstring, ()))
@@ -89,7 +91,7 @@ function toC(p::NamedTuple; score_mode = 0, sphere_uses_enabled = 0)
         get2(get2(p, :cone, NamedTuple()), :minconeopang, deg2rad(2)),
         it.prob_det, it.τ, it.itermax, it.drawN, it.minsubsetN,
         sym[it.extract_s], sym[it.terminate_s], length(st),
-        ntuple(i -> i <= length(st) ? st[i] : Cint(0), 8), score_mode, sphere_uses_enabled, 0)
+        ntuple(i -> i <= length(st) ? st[i] : Cint(0), 8), score_mode, sphere_uses_enabled, 0, 0, 10)
 end
 
 "Device-resident twin of a RANSACCloud; `pc` stays authoritative for fits and sampling."

@@ -44,6 +44,8 @@ class Params(C.Structure):
         ("score_mode", C.c_int32),
         ("sphere_uses_enabled", C.c_int32),
         ("sampling_streams", C.c_int32),
+        ("octree_sampling", C.c_int32),
+        ("octree_max_depth", C.c_int32),
     ]
 
 

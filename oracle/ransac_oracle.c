@@ -71,6 +71,7 @@ void orc_default_params(orc_params *p)
     p->shape_types[3] = ORC_SPHERE;
     p->score_mode = ORC_SCORE_INT64_WRAP;
     p->sphere_uses_enabled = 0;
+    p->octree_max_depth = 10;
     orc_params_finalize(p);
 }
 
@@ -943,6 +944,200 @@ static int64_t draw_range(draw_src *d, int64_t n)
 
 /* ---------------------------------------------------------------- driver */
 
+/* ---- fixed-behaviour sampling: level-weighted cells of a linear (Morton) octree ------------
+ * What docs/src/ransac.md:73-96 describes and the live reference never does: the
+ * first point is uniform over the enabled points; a level l is drawn from the level distribution
+ * P; the other points are drawn uniformly from the enabled points of the level-l cell that holds
+ * the first point.  Cells are cubes of the cloud's bounding cube; with the points sorted by
+ * Morton code a cell is a contiguous range, so "k-th enabled point of the cell" is a rank/select
+ * on the Morton-ordered enabled bits.  This is OUR specification (nothing in the reference runs
+ * it); the product must match it bit for bit. */
+typedef struct {
+    int64_t n, nwords;
+    int depth;
+    uint64_t *code;   /* sorted Morton codes */
+    int32_t *perm;    /* Morton position -> original index0 */
+    int32_t *pos;     /* original index0 -> Morton position */
+    uint64_t *men;    /* enabled bits in Morton order */
+    int32_t *prefix;  /* exclusive popcount prefix per word of men (+ total at [nwords]) */
+} lin_octree;
+
+static uint64_t spread21(uint64_t v)
+{
+    v &= 0x1FFFFFULL;
+    v = (v | (v << 32)) & 0x1F00000000FFFFULL;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFULL;
+    v = (v | (v << 8)) & 0x100F00F00F00F00FULL;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+
+typedef struct { uint64_t code; int32_t idx; } code_idx;
+static int cmp_code_idx(const void *a, const void *b)
+{
+    const code_idx *x = (const code_idx *)a, *y = (const code_idx *)b;
+    if (x->code != y->code) return x->code < y->code ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+static void lo_rebuild_prefix(lin_octree *o)
+{
+    int32_t acc = 0;
+    for (int64_t w = 0; w < o->nwords; w++) { o->prefix[w] = acc; acc += __builtin_popcountll(o->men[w]); }
+    o->prefix[o->nwords] = acc;
+}
+
+static lin_octree *lo_build(const orc_cloud *c, int max_depth)
+{
+    lin_octree *o = (lin_octree *)calloc(1, sizeof *o);
+    int64_t n = c->n;
+    o->n = n;
+    o->nwords = (n + 63) / 64;
+    o->code = (uint64_t *)malloc(8 * (size_t)(n ? n : 1));
+    o->perm = (int32_t *)malloc(4 * (size_t)(n ? n : 1));
+    o->pos = (int32_t *)malloc(4 * (size_t)(n ? n : 1));
+    o->men = (uint64_t *)calloc((size_t)(o->nwords ? o->nwords : 1), 8);
+    o->prefix = (int32_t *)calloc((size_t)(o->nwords + 1), 4);
+    double lo[3], hi[3];
+    orc_findAABB(c->xyz, n, 3, lo, hi);
+    double size = 0;
+    for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > size) size = hi[k] - lo[k];
+    size = size * (1 + 1e-9);
+    if (!(size > 0)) size = 1;
+    code_idx *ci = (code_idx *)malloc(sizeof(code_idx) * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t code = 0;
+        for (int k = 0; k < 3; k++) {
+            double t = (c->xyz[3 * i + k] - lo[k]) / size;
+            double q = t * 2097152.0;
+            uint64_t qi = !(q >= 0) ? 0 : (q >= 2097151.0 ? 2097151ULL : (uint64_t)q);
+            code |= spread21(qi) << k;
+        }
+        ci[i].code = code;
+        ci[i].idx = (int32_t)i;
+    }
+    qsort(ci, (size_t)n, sizeof(code_idx), cmp_code_idx);
+    for (int64_t i = 0; i < n; i++) { o->code[i] = ci[i].code; o->perm[i] = ci[i].idx; o->pos[ci[i].idx] = (int32_t)i; }
+    free(ci);
+    /* depth: first level whose fullest cell holds <= 8 points (octree.jl:163-165), capped */
+    if (max_depth < 1) max_depth = 1;
+    if (max_depth > 21) max_depth = 21;
+    o->depth = max_depth;
+    for (int l = 1; l <= max_depth; l++) {
+        int shift = 3 * (21 - (l - 1));
+        int64_t run = 0, best = 0;
+        uint64_t prev = 0;
+        for (int64_t i = 0; i < n; i++) {
+            uint64_t key = shift >= 63 ? 0 : (o->code[i] >> shift);
+            if (i == 0 || key != prev) { run = 0; prev = key; }
+            if (++run > best) best = run;
+        }
+        if (best <= 8) { o->depth = l; break; }
+    }
+    for (int64_t i = 0; i < n; i++)
+        if (is_enabled(c, i)) o->men[o->pos[i] >> 6] |= 1ULL << (o->pos[i] & 63);
+    lo_rebuild_prefix(o);
+    return o;
+}
+
+static void lo_free(lin_octree *o)
+{
+    if (!o) return;
+    free(o->code); free(o->perm); free(o->pos); free(o->men); free(o->prefix); free(o);
+}
+
+static int64_t lo_lower_bound(const lin_octree *o, uint64_t key)
+{
+    int64_t lo = 0, hi = o->n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (o->code[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+static int64_t lo_rank(const lin_octree *o, int64_t i) /* enabled among Morton positions < i */
+{
+    if (i >= o->n) return o->prefix[o->nwords];
+    return o->prefix[i >> 6] + __builtin_popcountll(o->men[i >> 6] & ((1ULL << (i & 63)) - 1ULL));
+}
+
+static int64_t lo_select(const lin_octree *o, int64_t r) /* Morton position of the r-th (1-based) enabled */
+{
+    int64_t lo = 0, hi = o->nwords;
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (o->prefix[mid] < r) lo = mid; else hi = mid;
+    }
+    uint64_t m = o->men[lo];
+    for (int64_t t = 1; t < r - o->prefix[lo]; t++) m &= m - 1;
+    return lo * 64 + __builtin_ctzll(m);
+}
+
+static uint64_t draw_raw(draw_src *d)
+{
+    if (!d->per_set) return orc_rng_next(d->seq);
+    d->seq->draws++;
+    d->x += 0x9E3779B97F4A7C15ULL;
+    return mix64(d->x);
+}
+
+/* one minimal set, level-weighted; returns 1 and the level, or 0 */
+static int sample_octree(const orc_cloud *c, const lin_octree *o, const double *P, const orc_params *p,
+                         draw_src *rng, int64_t n_enabled, int64_t *sd, int *level_out)
+{
+    if (n_enabled <= 0) return 0;
+    int64_t r1 = draw_range(rng, c->n);
+    while (!is_enabled(c, r1 - 1)) r1 = draw_range(rng, c->n);
+    double u = (double)(draw_raw(rng) >> 11) * (1.0 / 9007199254740992.0);
+    int level = o->depth;
+    double acc = 0;
+    for (int l = 0; l < o->depth; l++) {
+        acc += P[l];
+        if (u < acc) { level = l + 1; break; }
+    }
+    *level_out = level;
+    int shift = 3 * (21 - (level - 1));
+    int64_t lo, hi;
+    if (shift >= 63) { lo = 0; hi = o->n; }
+    else {
+        uint64_t key = o->code[o->pos[r1 - 1]] >> shift;
+        lo = lo_lower_bound(o, key << shift);
+        hi = (key + 1) << shift == 0 ? o->n : lo_lower_bound(o, (key + 1) << shift);
+        if (((key + 1) << shift) >> shift != key + 1) hi = o->n; /* top cell: no overflow */
+    }
+    int64_t base = lo_rank(o, lo), ne = lo_rank(o, hi) - base;
+    if (ne < p->drawN) return 0;
+    sd[0] = r1;
+    for (int q = 1; q < p->drawN; q++) {
+        int64_t pick = (int64_t)o->perm[lo_select(o, base + draw_range(rng, ne))] + 1;
+        if (pick == sd[0]) pick = (int64_t)o->perm[lo_select(o, base + draw_range(rng, ne))] + 1;
+        sd[q] = pick;
+    }
+    for (int i = 1; i < p->drawN; i++)
+        for (int j = 0; j < i; j++)
+            if (sd[i] == sd[j]) return 0;
+    return 1;
+}
+
+/* level distribution update (octree.jl:198-205 with the intended initialisation); kept unchanged
+ * while no score has been collected or if the formula leaves the simplex */
+static void update_level_probs(double *P, const double *sigma, int d)
+{
+    double w = 0, Pn[32];
+    for (int i = 0; i < d; i++) w += sigma[i] / P[i];
+    if (!(w > 0) || d > 32) return;
+    double sum = 0;
+    for (int i = 0; i < d; i++) {
+        Pn[i] = 0.9 * sigma[i] / (w * P[i]) + (1 - 0.9) / d;
+        if (!(Pn[i] >= 0)) return;
+        sum += Pn[i];
+    }
+    if (!(sum > 0)) return;
+    for (int i = 0; i < d; i++) P[i] = Pn[i];
+}
+
 /* Julia argmax over a Float64 vector: NaN is the maximum; first occurrence wins */
 static int jl_argmax(const double *a, int n)
 {
@@ -1040,6 +1235,13 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
     int64_t *refit_idx = (int64_t *)malloc(8 * (size_t)(c->n ? c->n : 1));
     int rc = 0;
 
+    lin_octree *oct = NULL;
+    double octP[32], octS[32];
+    if (p->octree_sampling) {
+        oct = lo_build(c, p->octree_max_depth);
+        for (int i = 0; i < oct->depth; i++) { octP[i] = 1.0 / oct->depth; octS[i] = 0; }
+    }
+
     int64_t k;
     for (k = 1; k <= p->itermax; k++) {
         int64_t n_enabled = orc_cloud_count_enabled(c);
@@ -1049,10 +1251,15 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
             if (p->sampling_streams)
                 src.x = mix64(rng->s[0] + (uint64_t)k * 0xD1B54A32D192ED03ULL) ^
                         mix64((uint64_t)i * 0x8CB92BA72F3D8DD7ULL + 0x2545F4914F6CDD1DULL);
-            if (!sample4(c, p, &src, n_enabled, sd)) continue;
-            /* fitting.jl:401: argmax(levelweight[1:max_depth]) must be 1 */
-            int lvl = jl_argmax(levelweight, octree_depth) + 1;
-            if (lvl != 1) { rc = -2; goto done; }
+            int lvl;
+            if (oct) {
+                if (!sample_octree(c, oct, octP, p, &src, n_enabled, sd, &lvl)) continue;
+            } else {
+                if (!sample4(c, p, &src, n_enabled, sd)) continue;
+                /* fitting.jl:401: argmax(levelweight[1:max_depth]) must be 1 */
+                lvl = jl_argmax(levelweight, octree_depth) + 1;
+                if (lvl != 1) { rc = -2; goto done; }
+            }
             for (int q = 0; q < p->drawN; q++) {
                 memcpy(fp + 3 * q, &c->xyz[3 * (sd[q] - 1)], 24);
                 memcpy(fn + 3 * q, &c->nrm[3 * (sd[q] - 1)], 24);
@@ -1076,7 +1283,8 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
             uint64_t *mask = (uint64_t *)malloc(8 * (size_t)(w ? w : 1));
             int64_t cnt = orc_scorecandidate(c, &cands[i], p, NULL, mask);
             orc_ci sc = orc_estimatescore(c->s, c->n, cnt, p->score_mode);
-            levelscore[levels[i] - 1] += sc.E;
+            if (oct) octS[levels[i] - 1] += sc.E;
+            else levelscore[levels[i] - 1] += sc.E;
             store_push(&st, &cands[i], sc, mask);
         }
         ncand = 0;
@@ -1095,6 +1303,13 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
                 orc_shape bestshape = st.shapes[ind];
                 int64_t ne = orc_refit(c, &bestshape, p, refit_idx, c->n);
                 orc_invalidate(c, refit_idx, ne);
+                if (oct) {
+                    for (int64_t q = 0; q < ne; q++) {
+                        int32_t mp = oct->pos[refit_idx[q] - 1];
+                        oct->men[mp >> 6] &= ~(1ULL << (mp & 63));
+                    }
+                    lo_rebuild_prefix(oct);
+                }
                 if (out->n_shapes == ext_cap) {
                     ext_cap = ext_cap ? ext_cap * 2 : 16;
                     out->shapes = (orc_extracted *)realloc(out->shapes, sizeof(orc_extracted) * (size_t)ext_cap);
@@ -1129,7 +1344,8 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
             }
         }
         /* updatelevelweight: octree.jl:198-205, x = 9//10 */
-        {
+        if (oct) update_level_probs(octP, octS, oct->depth);
+        else {
             double wsum = 0;
             for (int i = 0; i < octree_depth; i++) wsum += levelscore[i] / levelweight[i];
             for (int i = 0; i < octree_depth; i++)
@@ -1147,6 +1363,7 @@ done:
     free(st.shapes); free(st.scores); free(st.masks);
     free(cands); free(levels); free(sd); free(fp); free(fn); free(refit_idx);
     free(levelweight); free(levelscore);
+    lo_free(oct);
     out->seconds = now_s() - t0;
     return rc;
 }

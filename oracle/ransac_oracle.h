@@ -80,6 +80,9 @@ typedef struct {
     int32_t sphere_uses_enabled; /* 0 = faithful Q4 (sphere.jl:121,131), 1 = fixed */
     int32_t sampling_streams;  /* 0 = one sequential stream (reference structure); 1 = one stream per
                                   (iteration, minimal set): pure function of (seed, k, j) */
+    int32_t octree_sampling;   /* 0 = root cell always (the reference's live behaviour);
+                                  1 = level-weighted sampling on a linear octree (docs/src/ransac.md:73-96) */
+    int32_t octree_max_depth;  /* depth cap of the linear octree (default 10) */
 } orc_params;
 
 void orc_default_params(orc_params *p);

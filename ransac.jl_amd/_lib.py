@@ -26,6 +26,7 @@ class Params(C.Structure):
         ("drawN", C.c_int32), ("minsubsetN", C.c_int32), ("extract_s", C.c_int32), ("terminate_s", C.c_int32),
         ("n_shape_types", C.c_int32), ("shape_types", C.c_int32 * 8),
         ("score_mode", C.c_int32), ("sphere_uses_enabled", C.c_int32), ("sampling_streams", C.c_int32),
+        ("octree_sampling", C.c_int32), ("octree_max_depth", C.c_int32),
     ]
 
 

@@ -211,7 +211,8 @@ def ransacparameters(p=None, **kwargs):  # utilities.jl:425-464
 _S = {"lengthC": L.S_LENGTHC, "allcand": L.S_ALLCAND, "nofminset": L.S_NOFMINSET}
 
 
-def params_to_c(params, score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0):
+def params_to_c(params, score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0,
+                octree_sampling=False, octree_max_depth=10):
     """Flatten the nested parameter dict into rh_params.  Shapes absent from the dict keep the
     library defaults (they are never used: `shape_types` selects what is fitted)."""
     c = L.Params()
@@ -245,6 +246,8 @@ def params_to_c(params, score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False
     c.score_mode = score_mode
     c.sphere_uses_enabled = int(bool(sphere_uses_enabled))
     c.sampling_streams = int(sampling_streams)
+    c.octree_sampling = int(bool(octree_sampling))
+    c.octree_max_depth = int(octree_max_depth)
     lib().rh_params_finalize(C.byref(c))
     return c
 
@@ -410,13 +413,14 @@ def select_enabled(pc, ranks):
 
 
 def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=None,
-           score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0, return_stats=False):
+           score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0, octree_sampling=False,
+           return_stats=False):
     """ransac(pc, params[, setenabled]; reset_rand) -> (Vector{ExtractedShape}, seconds)
     (iterations.jl:14-21, 35-162).  `reset_rand` reseeds the generator with 1234 like
     Random.seed!(1234); `stream` injects raw 64-bit draws (rand(1:n) = 1 + floor(u*n/2^64))."""
     if setenabled:
         pc.enable_all()
-    cp = params if isinstance(params, L.Params) else params_to_c(params, score_mode, sphere_uses_enabled, sampling_streams)
+    cp = params if isinstance(params, L.Params) else params_to_c(params, score_mode, sphere_uses_enabled, sampling_streams, octree_sampling)
     rng = L.Rng()
     lib().rh_rng_seed(C.byref(rng), 1234 if reset_rand else seed)
     keep = None

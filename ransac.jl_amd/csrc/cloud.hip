@@ -136,6 +136,8 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
+    (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
+    (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
     (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk);
@@ -163,6 +165,77 @@ static int set_all_enabled(rh_cloud *c)
     c->select_valid = false;
     c->n_dis = 0;
     return RH_OK;
+}
+
+// linear (Morton) octree of the full cloud: codes in the bounding CUBE, sorted by (code, index);
+// depth = first level whose fullest cell holds <= 8 points (src/octree.jl:163-165), capped.
+int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth)
+{
+    if (max_depth < 1) max_depth = 1;
+    if (max_depth > 21) max_depth = 21;
+    if (c->oct_built && c->oct_max_depth == max_depth) return rhk_oct_sync_enabled(c);
+    const int64_t n = c->n;
+    double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3 && n > 0; k++) { lo[k] = xyz[k]; hi[k] = xyz[k]; }
+    for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {   // findAABB: src/utilities.jl:125-136
+            const double a = xyz[3 * i + k];
+            lo[k] = lo[k] > a ? a : lo[k];
+            hi[k] = hi[k] < a ? a : hi[k];
+        }
+    double size = 0;
+    for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > size) size = hi[k] - lo[k];
+    size = size * (1 + 1e-9);
+    if (!(size > 0)) size = 1;
+    std::vector<std::pair<uint64_t, int32_t>> keys((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t code = 0;
+        for (int k = 0; k < 3; k++) {
+            const double t = (xyz[3 * i + k] - lo[k]) / size;
+            const double q = t * 2097152.0;
+            const uint64_t qi = !(q >= 0) ? 0 : (q >= 2097151.0 ? 2097151ULL : (uint64_t)q);
+            code |= spread21(qi) << k;
+        }
+        keys[(size_t)i] = std::make_pair(code, (int32_t)i);
+    }
+    std::sort(keys.begin(), keys.end());
+    c->h_oct_code.resize((size_t)n);
+    c->h_oct_perm.resize((size_t)n);
+    c->h_oct_pos.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        c->h_oct_code[(size_t)i] = keys[(size_t)i].first;
+        c->h_oct_perm[(size_t)i] = keys[(size_t)i].second;
+        c->h_oct_pos[(size_t)keys[(size_t)i].second] = (int32_t)i;
+    }
+    int depth = max_depth;
+    for (int l = 1; l <= max_depth; l++) {
+        const int shift = 3 * (21 - (l - 1));
+        int64_t run = 0, best = 0;
+        uint64_t prev = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const uint64_t key = shift >= 63 ? 0 : (c->h_oct_code[(size_t)i] >> shift);
+            if (i == 0 || key != prev) { run = 0; prev = key; }
+            if (++run > best) best = run;
+        }
+        if (best <= 8) { depth = l; break; }
+    }
+    if (!c->oct_code) {
+        RH_TRY(dev_alloc(&c->oct_code, n));
+        RH_TRY(dev_alloc(&c->oct_perm, n));
+        RH_TRY(dev_alloc(&c->oct_pos, n));
+        RH_TRY(dev_alloc(&c->oct_men, c->nwords));
+        RH_TRY(dev_alloc(&c->oct_prefix, c->nwords + 1));
+    }
+    if (n > 0) {
+        RH_HIP(hipMemcpyAsync(c->oct_code, c->h_oct_code.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        RH_HIP(hipMemcpyAsync(c->oct_perm, c->h_oct_perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        RH_HIP(hipMemcpyAsync(c->oct_pos, c->h_oct_pos.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        RH_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->oct_depth = depth;
+    c->oct_max_depth = max_depth;
+    c->oct_built = true;
+    return rhk_oct_sync_enabled(c);
 }
 
 // ------------------------------------------------------------------ cloud ----

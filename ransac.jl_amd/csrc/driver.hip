@@ -198,6 +198,14 @@ struct Driver {
     int64_t iterations = 0;
     bool terminated = false;
 
+    // level-weighted octree sampling (octree_sampling = 1)
+    bool octree = false;
+    int od = 1;                              // octree depth
+    double oP[32], oS[32];                   // level distribution / summed scores per level
+    std::vector<uint64_t> men;               // host mirror: enabled bits in Morton order
+    std::vector<int32_t> mprefix;
+    std::vector<double> Pwin;
+
     // scratch
     std::vector<rh_shape> sorted;
     std::vector<int32_t> orig, counts_h, idx_h;
@@ -236,7 +244,34 @@ struct Driver {
         c->n_dis = ndis;
         c->select_valid = false;
         RUNH(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
+        octree = p->octree_sampling != 0;
+        if (octree) {
+            RUN(rh_octree_ensure(c, xyz, p->octree_max_depth));
+            od = c->oct_depth;
+            for (int i = 0; i < od; i++) { oP[i] = 1.0 / od; oS[i] = 0.0; }
+            men.assign((size_t)c->nwords, 0);
+            for (int64_t i = 0; i < c->n; i++)
+                if (en.test(i)) { const int32_t mp = c->h_oct_pos[(size_t)i]; men[(size_t)(mp >> 6)] |= 1ULL << (mp & 63); }
+            rebuild_mprefix();
+        }
         return RH_OK;
+    }
+
+    void rebuild_mprefix()
+    {
+        mprefix.resize((size_t)c->nwords + 1);
+        int32_t acc = 0;
+        for (int64_t w = 0; w < c->nwords; w++) { mprefix[(size_t)w] = acc; acc += __builtin_popcountll(men[(size_t)w]); }
+        mprefix[(size_t)c->nwords] = acc;
+    }
+
+    rhfit::OctView host_octview() const
+    {
+        rhfit::OctView oc;
+        oc.code = c->h_oct_code.data(); oc.perm = c->h_oct_perm.data(); oc.pos = c->h_oct_pos.data();
+        oc.men = men.data(); oc.prefix = mprefix.data();
+        oc.n = c->n; oc.nwords = c->nwords; oc.depth = od;
+        return oc;
     }
 
     // forcefitshapes! (fitting.jl:165-173) for one sampled minimal set
@@ -256,19 +291,29 @@ struct Driver {
     }
 
     // one iteration's minimal sets on the host: sequential stream (mode 0) or per-set streams (mode 1)
-    int sample_iteration_host(int64_t k, std::vector<rh_shape> &cands)
+    int sample_iteration_host(int64_t k, std::vector<rh_shape> &cands, std::vector<int32_t> &levels)
     {
         cands.clear();
+        levels.clear();
         if (p->sampling_streams) en.build();
+        const rhfit::OctView oc = octree ? host_octview() : rhfit::OctView();
         for (int i = 0; i < p->minsubsetN; i++) {
             if (p->sampling_streams) {
                 uint64_t x = rhfit::set_stream_init(rng->s[0], (uint64_t)k, (uint64_t)i);
                 uint32_t nd = 0;
                 bool gave_up = false;
-                const bool ok = rhfit::sample_minimal_set(en, c->n, en.count, drawN, &x, sd.data(), &nd, &gave_up);
+                int level = 1;
+                const bool ok = octree ? rhfit::sample_minimal_set_octree(en, oc, oP, c->n, en.count, drawN, &x, sd.data(), &nd,
+                                                                          &gave_up, &level)
+                                       : rhfit::sample_minimal_set(en, c->n, en.count, drawN, &x, sd.data(), &nd, &gave_up);
                 rng->draws += nd;
                 if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
                 if (!ok) continue;
+                const size_t before = cands.size();
+                RUN(fit_set(cands));
+                levels.resize(cands.size(), level);
+                (void)before;
+                continue;
             } else {
                 // samplepointcloud4!: fitting.jl:388-428 on the root cell
                 int64_t r1 = rh_rng_range(rng, c->n);
@@ -287,6 +332,7 @@ struct Driver {
                 if (!distinct) continue;
             }
             RUN(fit_set(cands));
+            levels.resize(cands.size(), 1);
         }
         return RH_OK;
     }
@@ -351,7 +397,7 @@ struct Driver {
     }
 
     // recordscore! (fitting.jl:114-119) in candidate order + prepared records into the device store
-    int record(const rh_shape *cands, int32_t ncand, const int32_t *counts)
+    int record(const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts)
     {
         if (ncand == 0) return RH_OK;
         int32_t nk[4], off[4];
@@ -370,6 +416,7 @@ struct Driver {
             rec.E = E;
             rec.slot = slot_next[cands[i].kind]++;
             store.push_back(rec);
+            if (octree) oS[levels[i] - 1] += E;   // pc.levelscore[level] += E(sc): fitting.jl:184
             // findhighestscore (fitting.jl:140-151) incrementally: first maximum, strict >
             if (best < 0) best = (int64_t)store.size() - 1;
             else if (E > store[(size_t)best].E) best = (int64_t)store.size() - 1;
@@ -398,6 +445,7 @@ struct Driver {
         // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
         RUN(rhk_andnot_enabled(c, c->refit_mask));
         RUN(rhk_rebuild_sub_enabled(c, true, false));
+        if (octree) RUN(rhk_oct_clear_mask(c, c->refit_mask));
         c->select_valid = false;
         int32_t ndis_new = 0;
         RUNH(hipMemcpyAsync(&ndis_new, c->d_ndis, sizeof ndis_new, hipMemcpyDeviceToHost, c->stream));
@@ -415,6 +463,13 @@ struct Driver {
         extracted.back().score_E = scr;
         extracted.back().iteration = k;
         en.clear(ex.inpoints, total);
+        if (octree) {
+            for (int32_t q = 0; q < total; q++) {
+                const int32_t mp = c->h_oct_pos[(size_t)(ex.inpoints[q] - 1)];
+                men[(size_t)(mp >> 6)] &= ~(1ULL << (mp & 63));
+            }
+            rebuild_mprefix();
+        }
         const int64_t ndis_old = c->n_dis;
         c->n_dis = ndis_new;
 
@@ -489,14 +544,16 @@ struct Driver {
 
     // everything of iteration k after the candidates exist: iterations.jl:98-156.
     // Returns through *stop whether the loop ends after this iteration.
-    int finish_iteration(int64_t k, const rh_shape *cands, int32_t ncand, const int32_t *counts, bool *did_extract, bool *stop)
+    int finish_iteration(int64_t k, const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts,
+                         bool *did_extract, bool *stop)
     {
         cc[2] += ncand;
-        RUN(record(cands, ncand, counts));
+        RUN(record(cands, levels, ncand, counts));
         cc[3] = k * p->minsubsetN;
         cc[1] = (int64_t)store.size();
         RUN(maybe_extract(k, did_extract));
-        // updatelevelweight (octree.jl:198-205) only ever produces NaN weights: no effect (header)
+        // updatelevelweight (octree.jl:198-205): in the reference it only ever produces NaN weights (header)
+        if (octree) rhfit::update_level_probs(oP, oS, od);
         *stop = rh_prob((double)p->tau, cc[p->terminate_s], c->n, drawN) > p->prob_det;
         iterations = k;
         return RH_OK;
@@ -505,15 +562,15 @@ struct Driver {
     int run_sequential()
     {
         std::vector<rh_shape> cands;
-        std::vector<int32_t> counts;
+        std::vector<int32_t> counts, levels;
         for (int64_t k = 1; k <= p->itermax; k++) {
             if (en.count < p->tau) break;   // iterations.jl:75
             const double t0 = now_s();
-            RUN(sample_iteration_host(k, cands));
+            RUN(sample_iteration_host(k, cands, levels));
             t_sample += now_s() - t0;
             RUN(score(cands.data(), (int32_t)cands.size(), counts));
             bool did = false, stop = false;
-            RUN(finish_iteration(k, cands.data(), (int32_t)cands.size(), counts.data(), &did, &stop));
+            RUN(finish_iteration(k, cands.data(), levels.data(), (int32_t)cands.size(), counts.data(), &did, &stop));
             if (stop) break;
         }
         return RH_OK;
@@ -537,16 +594,37 @@ struct Driver {
         std::vector<rh_cand_entry> entries;
         std::vector<unsigned long long> draws((size_t)K);
         std::vector<rh_shape> cands;
-        std::vector<int32_t> counts;
+        std::vector<int32_t> counts, levels;
         const int T = p->n_shape_types;
         int64_t k = 1;
         while (k <= p->itermax) {
             if (en.count < p->tau) break;
             const int32_t W = (int32_t)std::min<int64_t>(K, p->itermax - k + 1);
             const double t0 = now_s();
+            const double *d_P = nullptr;
+            if (octree) {
+                // the level distribution of every iteration of the window, assuming no candidate is
+                // scored inside it (the window is cut at the first iteration that has one)
+                Pwin.resize((size_t)W * (size_t)od);
+                double Pw[32];
+                for (int i = 0; i < od; i++) Pw[i] = oP[i];
+                for (int32_t it = 0; it < W; it++) {
+                    for (int i = 0; i < od; i++) Pwin[(size_t)it * od + i] = Pw[i];
+                    rhfit::update_level_probs(Pw, oS, od);
+                }
+                if ((int64_t)Pwin.size() > c->oct_P_cap) {
+                    RUNH(hipStreamSynchronize(c->stream));
+                    (void)hipFree(c->oct_P);
+                    c->oct_P = nullptr;
+                    c->oct_P_cap = (int64_t)K * 32;
+                    RUNH(hipMalloc((void **)&c->oct_P, sizeof(double) * (size_t)c->oct_P_cap));
+                }
+                RUNH(hipMemcpyAsync(c->oct_P, Pwin.data(), sizeof(double) * Pwin.size(), hipMemcpyHostToDevice, c->stream));
+                d_P = c->oct_P;
+            }
             int32_t cnt = 0, gave_up = 0;
             for (;;) {
-                RUN(rhk_sample_fit(c, p, rng->s[0], k, W, (int32_t)en.count, d_entries, entries_cap, d_count, d_draws, d_gave_up));
+                RUN(rhk_sample_fit(c, p, rng->s[0], k, W, (int32_t)en.count, d_P, d_entries, entries_cap, d_count, d_draws, d_gave_up));
                 RUNH(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
                 RUNH(hipMemcpyAsync(&gave_up, d_gave_up, sizeof gave_up, hipMemcpyDeviceToHost, c->stream));
                 RUNH(hipMemcpyAsync(draws.data(), d_draws, sizeof(unsigned long long) * (size_t)W, hipMemcpyDeviceToHost, c->stream));
@@ -566,8 +644,19 @@ struct Driver {
                           [](const rh_cand_entry &a, const rh_cand_entry &b) { return a.slot < b.slot; });
             }
             t_sample += now_s() - t0;
+            if (octree && cnt > 0) {
+                // candidates after the first candidate-bearing iteration were drawn from a stale level
+                // distribution: drop them before scoring (they are re-drawn in the next window)
+                const int64_t per_it = (int64_t)p->minsubsetN * T;
+                const int64_t first_it = entries[0].slot / per_it;
+                int32_t keep = 0;
+                while (keep < cnt && entries[(size_t)keep].slot / per_it == first_it) keep++;
+                cnt = keep;
+                entries.resize((size_t)cnt);
+            }
             cands.resize((size_t)cnt);
-            for (int32_t i = 0; i < cnt; i++) cands[(size_t)i] = entries[(size_t)i].shape;
+            levels.resize((size_t)cnt);
+            for (int32_t i = 0; i < cnt; i++) { cands[(size_t)i] = entries[(size_t)i].shape; levels[(size_t)i] = entries[(size_t)i].level; }
             RUN(score(cands.data(), cnt, counts));
             // replay the window in iteration order
             int32_t pos = 0;
@@ -580,9 +669,10 @@ struct Driver {
                 int32_t e = pos;
                 while (e < cnt && entries[(size_t)e].slot < slot_end) e++;
                 rng->draws += (int64_t)draws[(size_t)it];
-                RUN(finish_iteration(kk, cands.data() + pos, e - pos, counts.data() + pos, &did, &stop));
+                RUN(finish_iteration(kk, cands.data() + pos, levels.data() + pos, e - pos, counts.data() + pos, &did, &stop));
+                const bool cut = octree && e > pos;   // new scores change the level distribution
                 pos = e;
-                if (stop || did) { it++; break; }
+                if (stop || did || cut) { it++; break; }
             }
             k += it;
             if (stop) break;
@@ -615,6 +705,10 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
         return RH_E_INVALID;
     }
     if (p->minsubsetN < 0) { rh_set_error("rh_ransac: minsubsetN < 0"); return RH_E_INVALID; }
+    if (p->octree_sampling && !p->sampling_streams) {
+        rh_set_error("rh_ransac: octree_sampling needs sampling_streams = 1");
+        return RH_E_INVALID;
+    }
     RH_HIP(hipSetDevice(c->device));
     const double t_start = now_s();
 

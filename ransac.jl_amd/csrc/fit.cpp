@@ -231,6 +231,7 @@ extern "C" void rh_default_params(rh_params *p)
     p->shape_types[3] = RH_SPHERE;
     p->score_mode = RH_SCORE_INT64_WRAP;
     p->sphere_uses_enabled = 0;
+    p->octree_max_depth = 10;
     rh_params_finalize(p);
 }
 

@@ -250,3 +250,116 @@ RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN, u
 }
 
 }  // namespace rhfit
+
+namespace rhfit {
+
+// ---- level-weighted sampling on a linear (Morton) octree: octree_sampling = 1 -------------------
+// View over the octree arrays (host or device pointers).  Points are sorted by 63-bit Morton code
+// in the cloud's bounding cube; the level-l cell of a point is the range of codes sharing its top
+// 3(l-1) bits, so cell populations are rank differences on the Morton-ordered enabled bits.
+struct OctView {
+    const uint64_t *code;     // [n] sorted codes
+    const int32_t *perm;      // [n] Morton position -> original index0
+    const int32_t *pos;       // [n] original index0 -> Morton position
+    const uint64_t *men;      // enabled bits in Morton order
+    const int32_t *prefix;    // exclusive popcount prefix per word of men; [nwords] = total
+    int64_t n, nwords;
+    int depth;
+
+    RH_HD int64_t lower_bound(uint64_t key) const
+    {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (code[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+    RH_HD int64_t rank(int64_t i) const
+    {
+        if (i >= n) return prefix[nwords];
+        uint64_t m = men[i >> 6] & ((1ULL << (i & 63)) - 1ULL);
+        int c = 0;
+        while (m) { m &= m - 1; c++; }
+        return prefix[i >> 6] + c;
+    }
+    RH_HD int64_t select(int64_t r) const
+    {
+        int64_t lo = 0, hi = nwords;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] < r) lo = mid; else hi = mid;
+        }
+        uint64_t m = men[lo];
+        for (int64_t t = 1; t < r - prefix[lo]; t++) m &= m - 1;
+        int b = 0;
+        while (!((m >> b) & 1ULL)) b++;
+        return lo * 64 + b;
+    }
+};
+
+template <class En>
+RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P, int64_t n, int64_t n_enabled,
+                                     int drawN, uint64_t *x, int64_t *sd, uint32_t *ndraws, bool *gave_up, int *level_out)
+{
+    *level_out = 1;
+    if (n_enabled <= 0) return false;
+    int64_t r1 = set_stream_range(x, n);
+    uint32_t nd = 1;
+    while (!en.test(r1 - 1)) {
+        r1 = set_stream_range(x, n);
+        if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+    }
+    const double u = (double)(set_stream_next(x) >> 11) * (1.0 / 9007199254740992.0);
+    *ndraws += nd + 1;
+    int level = oc.depth;
+    double acc = 0;
+    for (int l = 0; l < oc.depth; l++) {
+        acc += P[l];
+        if (u < acc) { level = l + 1; break; }
+    }
+    *level_out = level;
+    const int shift = 3 * (21 - (level - 1));
+    int64_t lo, hi;
+    if (shift >= 63) { lo = 0; hi = oc.n; }
+    else {
+        const uint64_t key = oc.code[oc.pos[r1 - 1]] >> shift;
+        lo = oc.lower_bound(key << shift);
+        hi = (((key + 1) << shift) >> shift != key + 1) ? oc.n : oc.lower_bound((key + 1) << shift);
+    }
+    const int64_t base = oc.rank(lo), ne = oc.rank(hi) - base;
+    if (ne < drawN) return false;
+    sd[0] = r1;
+    for (int q = 1; q < drawN; q++) {
+        int64_t pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
+        ++*ndraws;
+        if (pick == sd[0]) {
+            pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
+            ++*ndraws;
+        }
+        sd[q] = pick;
+    }
+    for (int a = 1; a < drawN; a++)
+        for (int b = 0; b < a; b++)
+            if (sd[a] == sd[b]) return false;
+    return true;
+}
+
+// level distribution update (src/octree.jl:198-205, x = 9/10) with the initialisation the docs
+// describe; left unchanged while no score has been collected or if the formula leaves the simplex
+inline void update_level_probs(double *P, const double *sigma, int d)
+{
+    double w = 0, Pn[32];
+    for (int i = 0; i < d; i++) w += sigma[i] / P[i];
+    if (!(w > 0) || d > 32) return;
+    double sum = 0;
+    for (int i = 0; i < d; i++) {
+        Pn[i] = 0.9 * sigma[i] / (w * P[i]) + (1 - 0.9) / d;
+        if (!(Pn[i] >= 0)) return;
+        sum += Pn[i];
+    }
+    if (!(sum > 0)) return;
+    for (int i = 0; i < d; i++) P[i] = Pn[i];
+}
+
+}  // namespace rhfit

@@ -765,6 +765,35 @@ __global__ void transpose_kernel(const double *__restrict__ xyz, const double *_
     dst[5 * stride + j] = nrm[3 * i + 2];
 }
 
+// men[pos[i]] = enabled[i] for every point: one thread per Morton position
+__global__ void oct_gather_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ perm,
+                                          int64_t n, uint64_t *__restrict__ men)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = false;
+    if (j < n) {
+        const int32_t i0 = perm[j];
+        bit = (enabled[i0 >> 6] >> (i0 & 63)) & 1ULL;
+    }
+    const uint64_t w = __builtin_amdgcn_ballot_w64(bit);
+    if ((threadIdx.x & 63) == 0 && (j >> 6) < (n + 63) / 64) men[j >> 6] = w;
+}
+
+// clear in `men` the Morton positions of the points set in an original-order mask
+__global__ void oct_clear_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ pos,
+                                      uint64_t *__restrict__ men)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t m = mask[w];
+    while (m != 0) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const int32_t mp = pos[(w << 6) + b];
+        atomicAnd((unsigned long long *)&men[mp >> 6], ~(1ULL << (mp & 63)));
+    }
+}
+
 __global__ void iota_kernel(int32_t *d, int32_t n, int32_t base)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1083,4 +1112,37 @@ int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *
                        c->swords, total, d_out);
     RH_HIP(hipGetLastError());
     return RH_OK;
+}
+
+// exclusive popcount prefix per word (+ total at [nwords]); clobbers c->block_sums / c->d_total
+int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t *prefix_out)
+{
+    if (nwords == 0) return RH_OK;
+    const int64_t nb = (nwords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
+    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, words, nwords, c->block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, c->d_total);
+    hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, words, nwords, c->block_sums,
+                       (int64_t *)nullptr, (int64_t)0, prefix_out);
+    RH_HIP(hipMemcpyAsync(prefix_out + nwords, c->d_total, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    RH_HIP(hipGetLastError());
+    c->select_valid = false;
+    return RH_OK;
+}
+
+int rhk_oct_sync_enabled(rh_cloud *c)
+{
+    if (c->n == 0) return RH_OK;
+    hipLaunchKernelGGL(oct_gather_enabled_kernel, dim3(cdiv(c->nwords * 64, 256)), dim3(256), 0, c->stream, c->enabled,
+                       c->oct_perm, c->n, c->oct_men);
+    RH_HIP(hipGetLastError());
+    return rhk_word_prefix(c, c->oct_men, c->nwords, c->oct_prefix);
+}
+
+int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask)
+{
+    if (c->nwords == 0) return RH_OK;
+    hipLaunchKernelGGL(oct_clear_mask_kernel, dim3(cdiv(c->nwords, 256)), dim3(256), 0, c->stream, mask, c->nwords,
+                       c->oct_pos, c->oct_men);
+    RH_HIP(hipGetLastError());
+    return rhk_word_prefix(c, c->oct_men, c->nwords, c->oct_prefix);
 }

@@ -78,6 +78,19 @@ struct rh_cloud {
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
 
+    // linear (Morton) octree of the FULL cloud for octree_sampling = 1, built on first use
+    bool oct_built = false;
+    int oct_depth = 0, oct_max_depth = 0;
+    uint64_t *oct_code = nullptr;      // [n] sorted Morton codes (device)
+    int32_t *oct_perm = nullptr;       // [n] Morton position -> original index0
+    int32_t *oct_pos = nullptr;        // [n] original index0 -> Morton position
+    uint64_t *oct_men = nullptr;       // [nwords] enabled bits in Morton order
+    int32_t *oct_prefix = nullptr;     // [nwords + 1]
+    double *oct_P = nullptr;           // level distributions of a speculation window
+    int64_t oct_P_cap = 0;
+    std::vector<uint64_t> h_oct_code;  // host twins (host-side sampling, enabled mirror)
+    std::vector<int32_t> h_oct_perm, h_oct_pos;
+
     // refit / select workspaces
     uint64_t *refit_mask = nullptr;    // [nwords]
     int32_t *block_sums = nullptr;     // [nblocks + 1]
@@ -141,11 +154,18 @@ int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords
 // device-side sampling + fitting (sampler.hip)
 struct rh_cand_entry {
     int64_t slot;     // ((iteration - k0) * minsubsetN + set) * n_shape_types + type index
+    int32_t level;    // octree level the set was drawn from (1 = root)
+    int32_t pad;
     rh_shape shape;
 };
+// d_P: null (root-cell sampling) or n_iters x oct_depth level distributions
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws,
-                   int32_t *d_gave_up);
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, int32_t *d_count,
+                   unsigned long long *d_draws, int32_t *d_gave_up);
+int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth);   // cloud.hip
+int rhk_oct_sync_enabled(rh_cloud *c);                                  // men = permuted enabled; prefix
+int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask);             // clear the bits of an original-order mask
+int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t *prefix_out);
 
 void rh_prep_host(const rh_shape &s, rh_prep *out);
 

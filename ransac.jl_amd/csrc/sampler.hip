@@ -34,7 +34,8 @@ constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the ho
 
 __global__ void __launch_bounds__(128)
 sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, DevEnabled en, int32_t n_enabled,
-                  const rh_params prm, uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out,
+                  const rhfit::OctView oc, const double *__restrict__ Pwin, const rh_params prm, uint64_t seed,
+                  int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out,
                   int32_t cap, int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
                   int32_t *__restrict__ gave_up_flag)
 {
@@ -48,7 +49,11 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
     uint32_t nd = 0;
     bool gave_up = false;
     const int drawN = prm.drawN;
-    const bool ok = rhfit::sample_minimal_set(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+    int level = 1;
+    const bool ok = Pwin != nullptr
+                        ? rhfit::sample_minimal_set_octree(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled, drawN,
+                                                           &x, sd, &nd, &gave_up, &level)
+                        : rhfit::sample_minimal_set(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
     atomicAdd(&draws_per_iter[it], (unsigned long long)nd);
     if (gave_up) atomicExch(gave_up_flag, 1);
     if (!ok) return;
@@ -76,6 +81,8 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
         const int32_t pos = atomicAdd(out_count, 1);
         if (pos < cap) {
             out[pos].slot = (int64_t)t * prm.n_shape_types + ti;
+            out[pos].level = level;
+            out[pos].pad = 0;
             out[pos].shape = s;
         }
     }
@@ -84,7 +91,8 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
 }  // namespace
 
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws, int32_t *d_gave_up)
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws,
+                   int32_t *d_gave_up)
 {
     if (prm->drawN > RH_MAX_DRAWN) { rh_set_error("device sampler supports drawN <= %d", RH_MAX_DRAWN); return RH_E_INVALID; }
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
@@ -98,8 +106,11 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     en.prefix = c->word_prefix;
     en.nwords = c->nwords;
     en.total = n_enabled;
+    rhfit::OctView oc;
+    oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
+    oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     hipLaunchKernelGGL(sample_fit_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full, c->n_pad,
-                       c->n, en, n_enabled, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up);
+                       c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -287,6 +287,31 @@ def test_ransac_per_set_streams(prims, kinds, seed):
     assert len(got0) >= 2
 
 
+@pytest.mark.parametrize("prims,kinds,seed", [
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder", "plane", "sphere"], "psc", 21),   # device sampler
+    (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22),                                        # host sampler
+])
+def test_ransac_octree_sampling(prims, kinds, seed):
+    """octree_sampling = 1 (fixed behaviour, docs/src/ransac.md:73-96): level-weighted cells of a
+    linear octree, level distribution updated from the scores -- device windows vs the oracle's
+    sequential loop, identical shapes / index sets / draw counts."""
+    xyz, nrm, truth = synth.make_cloud(40_000, prims, 0.25, seed=80 + seed)
+    subs = synth.make_subsets(40_000, 4, seed=seed)
+    types = {"psc": [R.FittedPlane, R.FittedSphere, R.FittedCylinder],
+             "all": [R.FittedPlane, R.FittedCone, R.FittedCylinder, R.FittedSphere]}[kinds]
+    params = R.ransacparameters(types, iteration={"minsubsetN": 40, "τ": 300, "itermax": 200, "prob_det": 0.6})
+    kw = dict(score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
+    pc, oc, got, exp, stats = run_both(xyz, nrm, subs, params, seed=seed, octree_sampling=True, **kw)
+    assert len(got) >= 4
+    assert_same_run(pc, oc, got, exp, stats)
+    # local sampling produces far more candidates per minimal set than root-cell sampling
+    pc2 = R.RANSACCloud(xyz, nrm, subs)
+    _, _, st_root = R.ransac(pc2, R.params_to_c(params, **kw), seed=seed, return_stats=True)
+    assert stats["candidates_scored"] > 5 * max(1, st_root["candidates_scored"])
+    with pytest.raises(R.RansacHipError):   # needs per-set streams
+        R.ransac(pc2, R.params_to_c(params, octree_sampling=True), seed=seed)
+
+
 def test_ransac_injected_stream_and_preexisting_disabled_points():
     xyz, nrm, truth = synth.make_cloud(12_000, ["plane", "sphere", "cylinder"], 0.1, seed=77)
     subs = synth.make_subsets(12_000, 2, seed=77)
