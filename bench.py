@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
+    ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
     return ap.parse_args()
 
 
@@ -261,6 +262,24 @@ def main():
                                  "note": "one rh_ransac call: minsubsetN=4096, itermax=%d, root-cell sampling like the "
                                          "reference, f64 score mode, per-set random streams (sampling + fits + scoring on "
                                          "the device, iterations speculated in windows of 128)" % args.e2e_iters}
+            # fixed behaviour: level-weighted octree sampling (docs/src/ransac.md:73-96)
+            ocp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1,
+                                octree_sampling=True)
+            pc.enable_all()
+            ocp.itermax = 4
+            R.ransac(pc, ocp, seed=99)                      # builds + caches the linear octree (setup)
+            pc.enable_all()
+            ocp.itermax = args.e2e_octree_iters
+            t0 = time.perf_counter()
+            goto_, _, sto = R.ransac(pc, ocp, seed=1234, return_stats=True)
+            t_oct = time.perf_counter() - t0
+            out["end_to_end_octree"] = {
+                "metric": "shapes_per_sec", "value": len(goto_) / t_oct, "shapes": len(goto_), "seconds": t_oct,
+                "iterations": sto["iterations"], "candidates_scored": sto["candidates_scored"],
+                "last_extraction_iteration": max([g.iteration for g in goto_], default=0),
+                "breakdown_s": {"sample_fit": sto["seconds_host"], "score": sto["seconds_score"], "extract": sto["seconds_extract"]},
+                "note": "same cloud, octree_sampling=1 (level-weighted cells of a linear Morton octree; not what the "
+                        "reference executes, SURVEY.md 0.5), minsubsetN=4096, itermax=%d" % args.e2e_octree_iters}
             if not args.no_cpu:
                 # CPU side of the same loop on a bounded prefix, and a parity check of that prefix
                 from oracle import oracle as orc

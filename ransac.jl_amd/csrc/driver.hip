@@ -584,7 +584,9 @@ struct Driver {
     int run_streams_device()
     {
         const int64_t sets_budget = 1 << 20;
-        int64_t K = std::max<int64_t>(1, std::min<int64_t>(128, sets_budget / std::max(1, p->minsubsetN)));
+        const int64_t Kmax = std::max<int64_t>(1, std::min<int64_t>(128, sets_budget / std::max(1, p->minsubsetN)));
+        int64_t K = Kmax;        // window length in use; adapted to how often windows get cut short
+        int64_t Kcur = octree ? 1 : Kmax;
         RUNH(hipMalloc((void **)&d_count, sizeof(int32_t)));
         RUNH(hipMalloc((void **)&d_gave_up, sizeof(int32_t)));
         draws_cap = (int32_t)K;
@@ -599,7 +601,7 @@ struct Driver {
         int64_t k = 1;
         while (k <= p->itermax) {
             if (en.count < p->tau) break;
-            const int32_t W = (int32_t)std::min<int64_t>(K, p->itermax - k + 1);
+            const int32_t W = (int32_t)std::min<int64_t>(Kcur, p->itermax - k + 1);
             const double t0 = now_s();
             const double *d_P = nullptr;
             if (octree) {
@@ -676,6 +678,10 @@ struct Driver {
             }
             k += it;
             if (stop) break;
+            // a window cut short wasted its tail: halve; a window used to the end: double
+            if (it < W) Kcur = std::max<int64_t>(1, std::min<int64_t>(Kcur, it) / 2 + (it > 1 ? 0 : 0));
+            else Kcur = std::min<int64_t>(K, Kcur * 2);
+            if (Kcur < 1) Kcur = 1;
         }
         return RH_OK;
     }

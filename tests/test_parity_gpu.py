@@ -182,6 +182,25 @@ def test_ragged_sizes(n, s):
         assert np.array_equal(ex.inpoints, oc.refit(orc.Shape.from_buffer_copy(bytes(c.to_c())), to_orc_params(cp)))
 
 
+def test_empty_cloud_and_empty_subset():
+    cp = R.params_to_c(R.ransacparameters())
+    pc0 = R.RANSACCloud(np.zeros((0, 3)), np.zeros((0, 3)), [np.zeros(0, dtype=np.int64)])
+    assert pc0.count_enabled() == 0
+    plane = R.FittedPlane([0, 0, 0.0], [0, 0, 1.0])
+    assert list(R.score_batch(pc0, [plane], cp)) == [0]
+    assert R.refit(plane, pc0, cp).inpoints.size == 0
+    got, _ = R.ransac(pc0, cp, seed=1)
+    assert got == []
+    # points but an empty subset 1: every score is 0, refit still scans the cloud
+    xyz = np.array([[0, 0, 0.0], [1, 0, 0.1], [0, 1, -0.1], [5, 5, 5.0]])
+    nrm = np.array([[0, 0, 1.0]] * 4)
+    pc1 = R.RANSACCloud(xyz, nrm, [np.zeros(0, dtype=np.int64)])
+    counts, masks = R.score_batch(pc1, [plane], cp, want_masks=True)
+    assert list(counts) == [0] and masks.shape == (1, 0)
+    assert list(R.refit(plane, pc1, cp).inpoints) == [1, 2, 3]
+    assert list(R.select_enabled(pc1, [1, 4, 5])) == [1, 4, 0]
+
+
 def test_empty_batch_and_bad_arguments(small_scene):
     pc, oc, truth = small_scene
     cp = R.params_to_c(R.ransacparameters())
