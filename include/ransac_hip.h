@@ -150,6 +150,15 @@ int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const r
 int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p,
              int64_t *idx_out_1based, int64_t cap, int64_t *n_out);
 
+/* Least-squares refit -- the step of the paper the reference leaves out (docs/src/ransac.md:163-168;
+ * its `refit` returns the shape unchanged).  NOT part of parity runs.  Selects the enabled points
+ * compatible with `shape` at 3*eps, then fits: plane = total least squares; sphere / cylinder / cone
+ * = Gauss-Newton on the geometric distance (normal equations accumulated on the device with f64
+ * MFMA, solved on the host).  rms = root mean square distance of the selected points (for the
+ * iterative kinds: before the last step). */
+int rh_refit_lsq(rh_cloud *c, const rh_shape *shape, const rh_params *p, int32_t max_iter, rh_shape *out,
+                 int64_t *n_used, double *rms, int32_t *iters_done);
+
 /* Replaces invalidate_indexes! (src/fitting.jl:197-202). */
 int rh_invalidate(rh_cloud *c, const int64_t *idx_1based, int64_t n);
 

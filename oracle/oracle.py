@@ -130,6 +130,7 @@ def lib():
         "orc_score_batch": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p]),
         "orc_refit": (C.c_int64, [C.c_void_p, sp, pp, i64p, C.c_int64]),
         "orc_invalidate": (None, [C.c_void_p, i64p, C.c_int64]),
+        "orc_refit_lsq": (C.c_int, [C.c_void_p, sp, pp, C.c_int, sp, i64p, dp, i32p]),
         "orc_select_enabled": (C.c_int64, [C.c_void_p, C.c_int64]),
         "orc_fit": (C.c_int, [C.c_int, dp, dp, C.c_int, pp, sp]),
         "orc_fit2pointsphere": (C.c_int, [dp, dp, pp, sp]),
@@ -266,6 +267,14 @@ class Cloud:
         cnt = lib().orc_refit(self.h, C.byref(shape), C.byref(params),
                               out.ctypes.data_as(C.POINTER(C.c_int64)), self.n)
         return out[:cnt].copy()
+
+    def refit_lsq(self, shape, params, max_iter=10):
+        out, n, rms, it = Shape(), C.c_int64(), C.c_double(), C.c_int32()
+        rc = lib().orc_refit_lsq(self.h, C.byref(shape), C.byref(params), max_iter, C.byref(out), C.byref(n),
+                                 C.byref(rms), C.byref(it))
+        if rc:
+            raise RuntimeError("orc_refit_lsq failed: %d" % rc)
+        return out, n.value, rms.value, it.value
 
     def invalidate(self, idx_1based):
         idx = np.ascontiguousarray(idx_1based, dtype=np.int64)

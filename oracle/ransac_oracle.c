@@ -397,6 +397,163 @@ void orc_invalidate(orc_cloud *c, const int64_t *idx, int64_t n)
     c->dir_valid = 0;
 }
 
+/* ---- least-squares refit (specification shared with ransac.jl_amd/csrc/lsq.hip) ---- */
+static void lsq_unit(double *v) { double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= n; v[1] /= n; v[2] /= n; }
+
+static void lsq_frame(const double a[3], double e1[3], double e2[3])
+{
+    int k = 0;
+    if (fabs(a[1]) < fabs(a[k])) k = 1;
+    if (fabs(a[2]) < fabs(a[k])) k = 2;
+    double t[3] = { 0, 0, 0 };
+    t[k] = 1.0;
+    e1[0] = a[1] * t[2] - a[2] * t[1]; e1[1] = a[2] * t[0] - a[0] * t[2]; e1[2] = a[0] * t[1] - a[1] * t[0];
+    lsq_unit(e1);
+    e2[0] = a[1] * e1[2] - a[2] * e1[1]; e2[1] = a[2] * e1[0] - a[0] * e1[2]; e2[2] = a[0] * e1[1] - a[1] * e1[0];
+    lsq_unit(e2);
+}
+
+static int lsq_solve(int m, const double *A, const double *b, double *x)
+{
+    double M[8][9];
+    for (int i = 0; i < m; i++) { for (int j = 0; j < m; j++) M[i][j] = A[i * 8 + j]; M[i][m] = b[i]; }
+    for (int k = 0; k < m; k++) {
+        int piv = k;
+        for (int i = k + 1; i < m; i++) if (fabs(M[i][k]) > fabs(M[piv][k])) piv = i;
+        if (M[piv][k] == 0.0 || !(M[piv][k] == M[piv][k])) return 0;
+        if (piv != k) for (int j = 0; j <= m; j++) { double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+        for (int i = k + 1; i < m; i++) {
+            double l = M[i][k] / M[k][k];
+            for (int j = k; j <= m; j++) M[i][j] -= l * M[k][j];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double s = M[i][m];
+        for (int j = i + 1; j < m; j++) s -= M[i][j] * x[j];
+        x[i] = s / M[i][i];
+    }
+    return 1;
+}
+
+static void lsq_eig3(double S[3][3], double evec[3][3], double eval[3])
+{
+    double V[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (S[p][q] == 0.0) continue;
+                double theta = (S[q][q] - S[p][p]) / (2 * S[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; k++) { double a = S[k][p], b = S[k][q]; S[k][p] = c * a - s * b; S[k][q] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { double a = S[p][k], b = S[q][k]; S[p][k] = c * a - s * b; S[q][k] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+            }
+    }
+    for (int i = 0; i < 3; i++) { eval[i] = S[i][i]; for (int k = 0; k < 3; k++) evec[i][k] = V[k][i]; }
+}
+
+int orc_refit_lsq(const orc_cloud *c, const orc_shape *shape, const orc_params *p, int max_iter, orc_shape *out,
+                  int64_t *n_used, double *rms, int *iters_done)
+{
+    int kind = shape->kind;
+    if (max_iter < 1) max_iter = 1;
+    double eps3 = 3.0 * p->eps[kind], cosa = p->cos_alpha[kind];
+    uint8_t *sel = (uint8_t *)calloc((size_t)(c->n ? c->n : 1), 1);
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < c->n; i++)
+        if (is_enabled(c, i) && compat(shape, V(&c->xyz[3 * i]), V(&c->nrm[3 * i]), eps3, cosa)) { sel[i] = 1; cnt++; }
+    if (cnt < 8) { free(sel); return -1; }
+    orc_shape cur = *shape;
+    double last = 0;
+    int it;
+    for (it = 0; it < max_iter; it++) {
+        double M[64];
+        memset(M, 0, sizeof M);
+        double e1[3] = { 0, 0, 0 }, e2[3] = { 0, 0, 0 }, cph = 0, sph = 0;
+        if (kind == ORC_CYLINDER) lsq_frame(&cur.v[0], e1, e2);
+        if (kind == ORC_CONE) { lsq_frame(&cur.v[3], e1, e2); cph = cos(cur.v[6] / 2); sph = sin(cur.v[6] / 2); }
+        for (int64_t i = 0; i < c->n; i++) {
+            if (!sel[i]) continue;
+            double row[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            const double *pp = &c->xyz[3 * i];
+            if (kind == ORC_PLANE) {
+                row[0] = pp[0] - cur.v[0]; row[1] = pp[1] - cur.v[1]; row[2] = pp[2] - cur.v[2]; row[3] = 1.0;
+            } else if (kind == ORC_SPHERE) {
+                double dx = pp[0] - cur.v[0], dy = pp[1] - cur.v[1], dz = pp[2] - cur.v[2];
+                double nr = sqrt(dx * dx + dy * dy + dz * dz), inv = 1.0 / nr;
+                row[0] = -dx * inv; row[1] = -dy * inv; row[2] = -dz * inv; row[3] = -1.0; row[4] = nr - cur.v[3];
+            } else {
+                const double *o = kind == ORC_CYLINDER ? &cur.v[3] : &cur.v[0];
+                const double *a = kind == ORC_CYLINDER ? &cur.v[0] : &cur.v[3];
+                double tx = pp[0] - o[0], ty = pp[1] - o[1], tz = pp[2] - o[2];
+                double h = a[0] * tx + a[1] * ty + a[2] * tz;
+                double qx = tx - a[0] * h, qy = ty - a[1] * h, qz = tz - a[2] * h;
+                double rho = sqrt(qx * qx + qy * qy + qz * qz), inv = 1.0 / rho;
+                double ux = qx * inv, uy = qy * inv, uz = qz * inv;
+                double u1 = ux * e1[0] + uy * e1[1] + uz * e1[2], u2 = ux * e2[0] + uy * e2[1] + uz * e2[2];
+                if (kind == ORC_CYLINDER) {
+                    row[0] = -u1; row[1] = -u2; row[2] = -h * u1; row[3] = -h * u2; row[4] = -1.0; row[5] = rho - cur.v[6];
+                } else {
+                    double t1 = tx * e1[0] + ty * e1[1] + tz * e1[2], t2 = tx * e2[0] + ty * e2[1] + tz * e2[2];
+                    row[0] = -ux * cph + a[0] * sph; row[1] = -uy * cph + a[1] * sph; row[2] = -uz * cph + a[2] * sph;
+                    row[3] = -h * u1 * cph - t1 * sph; row[4] = -h * u2 * cph - t2 * sph;
+                    row[5] = -rho * sph - h * cph; row[6] = rho * cph - h * sph;
+                }
+            }
+            for (int a2 = 0; a2 < 8; a2++) for (int b2 = 0; b2 < 8; b2++) M[a2 * 8 + b2] += row[a2] * row[b2];
+        }
+        if (kind == ORC_PLANE) {
+            double N = M[3 * 8 + 3];
+            double sv[3] = { M[0 * 8 + 3], M[1 * 8 + 3], M[2 * 8 + 3] }, S[3][3], evec[3][3], eval[3];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i][j] = M[i * 8 + j] - sv[i] * sv[j] / N;
+            lsq_eig3(S, evec, eval);
+            int mn = 0;
+            for (int i = 1; i < 3; i++) if (eval[i] < eval[mn]) mn = i;
+            double nn[3] = { evec[mn][0], evec[mn][1], evec[mn][2] };
+            lsq_unit(nn);
+            if (nn[0] * shape->v[3] + nn[1] * shape->v[4] + nn[2] * shape->v[5] < 0) for (int i = 0; i < 3; i++) nn[i] = -nn[i];
+            for (int i = 0; i < 3; i++) { cur.v[i] = cur.v[i] + sv[i] / N; cur.v[3 + i] = nn[i]; }
+            last = sqrt((eval[mn] > 0 ? eval[mn] : 0.0) / N);
+            it++;
+            break;
+        }
+        int m = kind == ORC_SPHERE ? 4 : (kind == ORC_CYLINDER ? 5 : 6);
+        double A[64], b[8], x[8], tr = 0;
+        for (int i = 0; i < m; i++) tr += M[i * 8 + i];
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < m; j++) A[i * 8 + j] = M[i * 8 + j];
+            A[i * 8 + i] += 1e-12 * tr;
+            b[i] = -M[i * 8 + m];
+        }
+        last = M[m * 8 + m];
+        if (!lsq_solve(m, A, b, x)) { free(sel); return -2; }
+        if (kind == ORC_SPHERE) { for (int i = 0; i < 4; i++) cur.v[i] += x[i]; }
+        else if (kind == ORC_CYLINDER) {
+            for (int i = 0; i < 3; i++) { cur.v[3 + i] += x[0] * e1[i] + x[1] * e2[i]; cur.v[i] += x[2] * e1[i] + x[3] * e2[i]; }
+            lsq_unit(&cur.v[0]);
+            cur.v[6] += x[4];
+        } else {
+            for (int i = 0; i < 3; i++) { cur.v[i] += x[i]; cur.v[3 + i] += x[3] * e1[i] + x[4] * e2[i]; }
+            lsq_unit(&cur.v[3]);
+            cur.v[6] += 2 * x[5];
+        }
+        double step = 0;
+        for (int i = 0; i < m; i++) step += x[i] * x[i];
+        if (sqrt(step) < 1e-11) { it++; break; }
+    }
+    if (kind != ORC_PLANE) last = cnt > 0 ? sqrt(last / (double)cnt) : 0.0;
+    orc_shape_finalize(&cur);
+    *out = cur;
+    if (n_used) *n_used = cnt;
+    if (rms) *rms = last;
+    if (iters_done) *iters_done = it;
+    free(sel);
+    return 0;
+}
+
 static void build_dir(orc_cloud *c)
 {
     int64_t acc = 0, nb = c->nchunks / DIR_BLOCK + 1;

@@ -124,6 +124,10 @@ void orc_score_batch(const orc_cloud *c, const orc_shape *s, int32_t b, const or
 int64_t orc_refit(const orc_cloud *c, const orc_shape *s, const orc_params *p,
                   int64_t *idx_out, int64_t cap);
 void orc_invalidate(orc_cloud *c, const int64_t *idx_1based, int64_t n);
+/* least-squares refit (our specification; the reference has none): same selection, model and
+ * Gauss-Newton steps as rh_refit_lsq, sums taken sequentially in index order */
+int orc_refit_lsq(const orc_cloud *c, const orc_shape *s, const orc_params *p, int max_iter, orc_shape *out,
+                  int64_t *n_used, double *rms, int *iters_done);
 /* k-th (1-based) enabled point in ascending index order, 1-based; 0 if none */
 int64_t orc_select_enabled(const orc_cloud *c, int64_t k);
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "rh_score_batch_dev": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp]),
     "rh_score_batch_dev_timed": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp, C.POINTER(C.c_float)]),
     "rh_refit": (C.c_int, [_vp, _sp, _pp, _i64p, C.c_int64, _i64p]),
+    "rh_refit_lsq": (C.c_int, [_vp, _sp, _pp, C.c_int32, _sp, _i64p, _dp, _i32p]),
     "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
     "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),
     "rh_fit": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),

@@ -399,6 +399,16 @@ def refit(s, pc, params):
     return ExtractedShape(s if not isinstance(s, L.Shape) else shape_from_c(s), out[: n.value].copy())
 
 
+def refit_lsq(s, pc, params, max_iter=10):
+    """Least-squares refit of `s` to its compatible points within 3*eps (the step the reference omits,
+    docs/src/ransac.md:163-168).  Returns (shape, n_used, rms, iterations)."""
+    out, n, rms, it = L.Shape(), C.c_int64(), C.c_double(), C.c_int32()
+    cs = s if isinstance(s, L.Shape) else s.to_c()
+    check(lib().rh_refit_lsq(pc._h, C.byref(cs), C.byref(_cparams(params)), max_iter, C.byref(out), C.byref(n),
+                             C.byref(rms), C.byref(it)))
+    return shape_from_c(out), n.value, rms.value, it.value
+
+
 def invalidate_indexes(pc, indexlist):  # invalidate_indexes!: fitting.jl:197-202
     idx = np.ascontiguousarray(indexlist, dtype=np.int64)
     check(lib().rh_invalidate(pc._h, _p(idx, C.c_int64), idx.size))

@@ -351,6 +351,50 @@ def test_ransac_injected_stream_and_preexisting_disabled_points():
     assert [bytes(g.c_shape) for g in got2] == [bytes(e["shape"]) for e in exp2["shapes"]]
 
 
+def test_refit_lsq_recovers_primitives_and_matches_oracle(small_scene):
+    """Least-squares refit (f64 MFMA normal equations).  No reference behaviour exists (the reference's
+    refit returns the shape unchanged), so the oracle's sequential twin is the specification: floating
+    point sums differ only in order -> parameters agree to 1e-8 relative; and the refit pulls a 1 %-jittered
+    candidate back onto the ground-truth primitive."""
+    pc, oc, truth = small_scene
+    pc.enable_all(); oc.enable_all()
+    params = R.ransacparameters()
+    cp = R.params_to_c(params)
+    op = to_orc_params(cp)
+    cands = make_candidates(truth, 16, seed=3)
+    seen = set()
+    for cand, t in zip(cands, truth * 2):
+        if cand.kind != L.PLANE:
+            cand.outwards = True      # the synthetic primitives' normals point outwards
+        got, n, rms, it = R.refit_lsq(cand, pc, cp, max_iter=12)
+        exp, on, orms, oit = oc.refit_lsq(orc.Shape.from_buffer_copy(bytes(cand.to_c())), op, max_iter=12)
+        assert n == on and n > 500, (R.strt(cand), n, on)
+        gv, ev = np.array(list(got.to_c().v)), np.array(list(exp.v))
+        assert np.allclose(gv, ev, rtol=1e-8, atol=1e-9), (R.strt(cand), gv, ev)
+        assert abs(rms - orms) <= 1e-9 + 1e-6 * orms
+        assert rms < 0.05          # synthetic noise sigma = 0.02
+        seen.add(got.kind)
+        if got.kind == L.PLANE:
+            tn = np.asarray(t["normal"])
+            assert abs(abs(got.normal @ tn) - 1) < 1e-6
+            assert abs((got.point - np.asarray(t["point"])) @ tn) < 0.01
+        elif got.kind == L.SPHERE:
+            assert np.linalg.norm(got.center - t["center"]) < 0.01 and abs(got.radius - t["radius"]) < 0.01
+        elif got.kind == L.CYLINDER:
+            ta = np.asarray(t["axis"])
+            assert abs(abs(got.axis @ ta) - 1) < 1e-5 and abs(got.radius - t["radius"]) < 0.01
+            d = got.center - np.asarray(t["center"])
+            assert np.linalg.norm(d - ta * (d @ ta)) < 0.02
+        else:
+            ta = np.asarray(t["axis"])
+            assert abs(abs(got.axis @ ta) - 1) < 1e-4 and abs(got.opang - t["opang"]) < 2e-3
+            assert np.linalg.norm(got.apex - t["apex"]) < 0.1
+    assert seen == {L.PLANE, L.SPHERE, L.CYLINDER, L.CONE}
+    far = R.FittedSphere([1e4, 1e4, 1e4], 1.0, True)      # nothing within 3 eps: a clear error, not a NaN shape
+    with pytest.raises(R.RansacHipError):
+        R.refit_lsq(far, pc, cp)
+
+
 def test_largestconncomp_known_answers(golden):  # test/parameterspacebitmap.jl:1-55
     from test_oracle_golden import build_cc_case
     g = golden["largestconncomp"]
