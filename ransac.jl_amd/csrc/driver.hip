@@ -303,9 +303,9 @@ struct Driver {
                 uint32_t nd = 0;
                 bool gave_up = false;
                 int level = 1;
-                const bool ok = octree ? rhfit::sample_minimal_set_octree(en, oc, oP, c->n, en.count, drawN, &x, sd.data(), &nd,
+                const bool ok = octree ? rhfit::sample_minimal_set_octree<0>(en, oc, oP, c->n, en.count, drawN, &x, sd.data(), &nd,
                                                                           &gave_up, &level)
-                                       : rhfit::sample_minimal_set(en, c->n, en.count, drawN, &x, sd.data(), &nd, &gave_up);
+                                       : rhfit::sample_minimal_set<0>(en, c->n, en.count, drawN, &x, sd.data(), &nd, &gave_up);
                 rng->draws += nd;
                 if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
                 if (!ok) continue;

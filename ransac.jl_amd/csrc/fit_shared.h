@@ -11,7 +11,7 @@
 #include "ransac_hip.h"
 
 #if defined(__HIPCC__)
-#define RH_HD __host__ __device__ inline
+#define RH_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define RH_HD inline
 #endif
@@ -220,10 +220,12 @@ namespace rhfit {
 // samplepointcloud4! (src/fitting.jl:383-430) on the root cell, drawing from a per-set stream.
 // En provides test(i0) and select(rank) over the enabled bits.  Returns false for the
 // reference's (false, 0) / (false, 1) outcomes.  *ndraws counts rand() calls.
-template <class En>
-RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN, uint64_t *x, int64_t *sd,
+// DN > 0: compile-time drawN (loops unroll, the small arrays stay in registers on the device)
+template <int DN, class En>
+RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN_rt, uint64_t *x, int64_t *sd,
                               uint32_t *ndraws, bool *gave_up)
 {
+    const int drawN = DN > 0 ? DN : drawN_rt;
     if (n_enabled <= 0) return false;   // the reference would spin forever at fitting.jl:393
     int64_t r1 = set_stream_range(x, n);
     uint32_t nd = 1;
@@ -234,6 +236,7 @@ RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN, u
     *ndraws += nd;
     if (n_enabled < drawN) return false;
     sd[0] = r1;
+#pragma unroll
     for (int q = 1; q < drawN; q++) {
         int64_t pick = en.select(set_stream_range(x, n_enabled));
         ++*ndraws;
@@ -243,10 +246,12 @@ RH_HD bool sample_minimal_set(En &en, int64_t n, int64_t n_enabled, int drawN, u
         }
         sd[q] = pick;
     }
-    for (int a = 1; a < drawN; a++)   // allisdifferent: utilities.jl:285-295
-        for (int b = 0; b < a; b++)
-            if (sd[a] == sd[b]) return false;
-    return true;
+    bool distinct = true;   // allisdifferent: utilities.jl:285-295
+#pragma unroll
+    for (int a = 1; a < drawN; a++)
+#pragma unroll
+        for (int b = 0; b < a; b++) distinct = distinct && (sd[a] != sd[b]);
+    return distinct;
 }
 
 }  // namespace rhfit
@@ -298,10 +303,11 @@ struct OctView {
     }
 };
 
-template <class En>
+template <int DN, class En>
 RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P, int64_t n, int64_t n_enabled,
-                                     int drawN, uint64_t *x, int64_t *sd, uint32_t *ndraws, bool *gave_up, int *level_out)
+                                     int drawN_rt, uint64_t *x, int64_t *sd, uint32_t *ndraws, bool *gave_up, int *level_out)
 {
+    const int drawN = DN > 0 ? DN : drawN_rt;
     *level_out = 1;
     if (n_enabled <= 0) return false;
     int64_t r1 = set_stream_range(x, n);
@@ -330,6 +336,7 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
     const int64_t base = oc.rank(lo), ne = oc.rank(hi) - base;
     if (ne < drawN) return false;
     sd[0] = r1;
+#pragma unroll
     for (int q = 1; q < drawN; q++) {
         int64_t pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
         ++*ndraws;
@@ -339,10 +346,12 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
         }
         sd[q] = pick;
     }
+    bool distinct = true;
+#pragma unroll
     for (int a = 1; a < drawN; a++)
-        for (int b = 0; b < a; b++)
-            if (sd[a] == sd[b]) return false;
-    return true;
+#pragma unroll
+        for (int b = 0; b < a; b++) distinct = distinct && (sd[a] != sd[b]);
+    return distinct;
 }
 
 // level distribution update (src/octree.jl:198-205, x = 9/10) with the initialisation the docs

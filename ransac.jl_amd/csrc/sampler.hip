@@ -32,6 +32,7 @@ struct DevEnabled {
 
 constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the host sampler
 
+template <int DN>
 __global__ void __launch_bounds__(128)
 sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, DevEnabled en, int32_t n_enabled,
                   const rhfit::OctView oc, const double *__restrict__ Pwin, const rh_params prm, uint64_t seed,
@@ -45,21 +46,38 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
     const int32_t it = (int32_t)(t / prm.minsubsetN);
     const int32_t j = (int32_t)(t - (int64_t)it * prm.minsubsetN);
     uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
-    int64_t sd[RH_MAX_DRAWN];
+    constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
+    int64_t sd[CAP];
     uint32_t nd = 0;
     bool gave_up = false;
-    const int drawN = prm.drawN;
+    const int drawN = DN > 0 ? DN : prm.drawN;
     int level = 1;
     const bool ok = Pwin != nullptr
-                        ? rhfit::sample_minimal_set_octree(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled, drawN,
-                                                           &x, sd, &nd, &gave_up, &level)
-                        : rhfit::sample_minimal_set(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
-    atomicAdd(&draws_per_iter[it], (unsigned long long)nd);
+                        ? rhfit::sample_minimal_set_octree<DN>(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled,
+                                                               drawN, &x, sd, &nd, &gave_up, &level)
+                        : rhfit::sample_minimal_set<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+    // draws per iteration: one atomic per (wave, iteration) instead of one per set -- thousands of
+    // same-address atomics serialise in L2 and dominated the kernel
+    {
+        uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+        const int lane = threadIdx.x & 63;
+        while (todo != 0) {
+            const int leader = __builtin_ctzll(todo);
+            const int32_t it0 = __shfl(it, leader);
+            const uint64_t grp = __builtin_amdgcn_ballot_w64(it == it0) & todo;
+            unsigned v = (it == it0) ? nd : 0u;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == leader) atomicAdd(&draws_per_iter[it0], (unsigned long long)v);
+            todo &= ~grp;
+        }
+    }
     if (gave_up) atomicExch(gave_up_flag, 1);
     if (!ok) return;
-    double fp[3 * RH_MAX_DRAWN], fn[3 * RH_MAX_DRAWN];
+    double fp[3 * CAP], fn[3 * CAP];
+#pragma unroll
     for (int q = 0; q < drawN; q++) {
         const int64_t i0 = sd[q] - 1;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             fp[3 * q + k] = full[k * stride + i0];
             fn[3 * q + k] = full[(3 + k) * stride + i0];
@@ -109,8 +127,14 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     rhfit::OctView oc;
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
-    hipLaunchKernelGGL(sample_fit_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full, c->n_pad,
-                       c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up);
+    if (prm->drawN == 3)   // the reference's default: fully unrolled, no scratch
+        hipLaunchKernelGGL(sample_fit_kernel<3>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full,
+                           c->n_pad, c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
+                           d_gave_up);
+    else
+        hipLaunchKernelGGL(sample_fit_kernel<0>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full,
+                           c->n_pad, c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
+                           d_gave_up);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
