@@ -236,6 +236,9 @@ int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int
  * milliseconds of each kind's kernel (0 for kinds without candidates ~ an empty launch). */
 int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                              int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_kind_out /* [4] */);
+/* device time of the most recent rh_refit on this cloud: the full-cloud scan kernel and the
+ * compaction (popcount + scan + expansion), from HIP events on the cloud's stream */
+int rh_last_refit_ms(rh_cloud *c, float *ms_scan_out, float *ms_compact_out);
 int rh_timer_start(rh_cloud *c);
 int rh_timer_stop(rh_cloud *c, float *ms_out); /* synchronises the stream */
 int rh_cloud_sync(rh_cloud *c);

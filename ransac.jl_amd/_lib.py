@@ -90,6 +90,7 @@ SIGNATURES = {
     "rh_result_free": (None, [C.POINTER(Result)]),
     "rh_largestconncomp": (C.c_int, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int, _i64p, C.c_int64, _i64p]),
     "rh_bitmapparameters": (C.c_int, [_dp, _u8p, _i64p, C.c_int64, C.c_double, _i32p, _i32p, _dp, _dp, _u8p, _i64p]),
+    "rh_last_refit_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rh_timer_start": (C.c_int, [_vp]),
     "rh_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rh_cloud_sync": (C.c_int, [_vp]),

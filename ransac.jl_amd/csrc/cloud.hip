@@ -584,8 +584,11 @@ extern "C" int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p, 
     rh_prep P;
     rh_prep_host(*shape, &P);
     c->select_valid = false;   // block_sums / d_total are shared with the select directory
+    RH_HIP(hipEventRecord(c->evk[0], c->stream));
     RH_TRY(rhk_refit_mask(c, P, shape->kind, p->eps[shape->kind], p->cos_alpha[shape->kind]));
+    RH_HIP(hipEventRecord(c->evk[1], c->stream));
     RH_TRY(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
+    RH_HIP(hipEventRecord(c->evk[2], c->stream));
     int32_t total = 0;
     RH_HIP(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
@@ -598,6 +601,15 @@ extern "C" int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p, 
         RH_HIP(hipMemcpyAsync(idx_out, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         RH_HIP(hipStreamSynchronize(c->stream));
     }
+    return RH_OK;
+}
+
+extern "C" int rh_last_refit_ms(rh_cloud *c, float *ms_scan, float *ms_compact)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipEventSynchronize(c->evk[2]));
+    if (ms_scan) RH_HIP(hipEventElapsedTime(ms_scan, c->evk[0], c->evk[1]));
+    if (ms_compact) RH_HIP(hipEventElapsedTime(ms_compact, c->evk[1], c->evk[2]));
     return RH_OK;
 }
 

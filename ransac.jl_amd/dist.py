@@ -32,6 +32,10 @@ def score_batch_sharded(b, rank, world, local_score, counts_full, group=None):
     must fill out_view (= counts_full[lo:hi]) with the counts of candidates lo..hi-1."""
     lo, hi = shard_bounds(b, rank, world)
     counts_full.zero_()
+    if counts_full.is_cuda:
+        # the fill runs on torch's stream, the scoring on the library's: order them
+        import torch
+        torch.cuda.current_stream(counts_full.device).synchronize()
     if hi > lo:
         local_score(lo, hi, counts_full[lo:hi])
     return allreduce_counts(counts_full, group)
