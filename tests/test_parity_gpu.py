@@ -88,6 +88,56 @@ def test_score_counts_and_masks_all_kinds(small_scene):
     assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
 
 
+@pytest.mark.parametrize("eps,alpha_deg,seed", [(0.3, 5.0, 0), (0.01, 1.0, 1), (5.0, 60.0, 2), (40.0, 89.0, 3)])
+def test_score_fuzz_arbitrary_candidates(small_scene, eps, alpha_deg, seed):
+    """Candidates nowhere near a primitive, degenerate, non-unit, huge, tiny, NaN / inf: the box culling
+    may only ever skip pairs that cannot pass, so counts and masks still equal the oracle's bit for bit."""
+    pc, oc, truth = small_scene
+    pc.enable_all(); oc.enable_all()
+    rng = np.random.default_rng(1000 + seed)
+    a = math.radians(alpha_deg)
+    kinds = {k: {"ϵ": eps, "α": a} for k in ("plane", "sphere", "cylinder", "cone")}
+    cp = R.params_to_c(R.ransacparameters(**kinds))
+    b = 160
+    arr = (L.Shape * b)()
+    for i in range(b):
+        s = arr[i]
+        s.kind = i % 4
+        s.outwards = int(rng.integers(0, 2))
+        v = np.zeros(10)
+        v[0:3] = rng.uniform(-20, 120, 3)                       # point / centre / axis / apex
+        d = rng.normal(size=3)
+        scale = [1.0, 1.0, 1e-3, 7.5, 1e3][int(rng.integers(0, 5))]   # non-unit directions must not break the bounds
+        if s.kind == L.PLANE:
+            v[3:6] = d / np.linalg.norm(d) * scale
+        elif s.kind == L.SPHERE:
+            v[3] = [0.01, 1.0, 10.0, 60.0, 500.0, -3.0][int(rng.integers(0, 6))]
+        elif s.kind == L.CYLINDER:
+            v[0:3] = d / np.linalg.norm(d) * scale
+            v[3:6] = rng.uniform(-20, 120, 3)
+            v[6] = [0.01, 1.0, 8.0, 80.0, -1.0][int(rng.integers(0, 5))]
+        else:
+            v[3:6] = d / np.linalg.norm(d) * scale
+            v[6] = rng.uniform(0.01, 3.1)
+        if i % 37 == 36:
+            v[int(rng.integers(0, 7))] = [float("nan"), float("inf"), -float("inf"), 1e300][int(rng.integers(0, 4))]
+        if i % 41 == 40:
+            v[3:6] = 0.0                                          # zero normal / axis
+        for j in range(10):
+            s.v[j] = float(v[j])
+        R.lib().rh_shape_finalize(C.byref(s))
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc_shapes(arr, b), to_orc_params(cp), want_masks=True)
+    assert np.array_equal(counts, ocounts)
+    assert np.array_equal(masks, omasks)
+    assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
+    # points that touch a group's bounding-box corner exactly: put a plane exactly eps off a point
+    p0 = pc.vertices[pc.subsets[0][0] - 1]
+    edge = R.FittedPlane(p0 + np.array([0, 0, eps]), [0, 0, 1.0])
+    c1 = R.score_batch(pc, [edge], cp)
+    assert np.array_equal(c1, oc.score_batch(to_orc_shapes(shape_array([edge]), 1), to_orc_params(cp)))
+
+
 def test_scorecandidate_mirror_returns_reference_tuple(small_scene):
     pc, oc, truth = small_scene
     params = R.ransacparameters()
