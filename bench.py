@@ -199,6 +199,19 @@ def main():
                     "kernel would issue x 4 cycles / (1024 SIMDs x 2.4 GHz x time): > 1 means the culled kernel "
                     "skipped that share of the per-point tests (RH_SCORE_PATH=brute measures the un-culled kernel)",
         }
+        # the host-buffer form of the same step (rh_score_batch: H2D of the shapes, D2H of the counts, one sync)
+        hcounts = np.zeros(hi - lo, dtype=np.int32)
+        harr = (L.Shape * (hi - lo)).from_buffer_copy(bytes(arr)[C.sizeof(L.Shape) * lo:C.sizeof(L.Shape) * hi])
+        for _ in range(2):
+            L.check(lib.rh_score_batch(pc._h, harr, hi - lo, C.byref(cp), hcounts.ctypes.data_as(C.POINTER(C.c_int32)), None))
+        t0 = time.perf_counter()
+        for _ in range(10):
+            L.check(lib.rh_score_batch(pc._h, harr, hi - lo, C.byref(cp), hcounts.ctypes.data_as(C.POINTER(C.c_int32)), None))
+        t_host = (time.perf_counter() - t0) / 10
+        out["pcie_inclusive"] = {"ms_per_step": 1e3 * t_host, "candidates_per_sec": (hi - lo) / t_host,
+                                 "note": "rh_score_batch with host buffers (never `value`)"}
+        if not np.array_equal(hcounts, counts_h[lo:hi]):
+            raise SystemExit("PARITY FAILURE: rh_score_batch and rh_score_batch_dev disagree")
         out["per_kind"] = per_kind
         out["score_path"] = os.environ.get("RH_SCORE_PATH", "groups (culled)")
         out["event_ms_per_step"] = ev_ms.value / args.steps
