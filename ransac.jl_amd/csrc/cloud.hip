@@ -138,6 +138,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
+    (void)hipFree(c->gone_words); (void)hipFree(c->dis_gb);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
     (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk);
@@ -298,6 +299,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     c->ngroups = (s + 63) / 64;
     c->ng_pad = ((c->ngroups + RH_G2_TG - 1) / RH_G2_TG) * RH_G2_TG + RH_G2_TG;
     CK(dev_alloc(&c->gb, 7 * c->ng_pad));
+    CK(dev_alloc(&c->dis_gb, 7 * c->ng_pad));
+    CKH(hipMemsetAsync(c->dis_gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     CKH(hipMemsetAsync(c->gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     {
         const char *e = getenv("RH_SCORE_PATH");   // "brute" / "groups" force a path (tests, A/B runs)
@@ -308,8 +311,9 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->enabled, c->nwords));
     CK(dev_alloc(&c->sub_enabled, c->swords));
     CK(dev_alloc(&c->d_ndis, 1));
+    CK(dev_alloc(&c->gone_words, c->swords));
     CK(dev_alloc(&c->refit_mask, c->nwords));
-    CK(dev_alloc(&c->block_sums, c->nblocks + 2));
+    CK(dev_alloc(&c->block_sums, std::max<int64_t>(c->nblocks, (c->swords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK) + 2));
     CK(dev_alloc(&c->word_prefix, c->nwords + 1));
     CK(dev_alloc(&c->idx_out, n));
     CK(dev_alloc(&c->d_total, 1));

@@ -25,6 +25,8 @@
 // order, and levelscore never influences a result.  The driver therefore samples from the
 // enabled set directly and keeps no octree.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -115,6 +117,8 @@ struct Stored {
 // device-resident store of prepared candidates, one growable array per kind
 struct DeviceStore {
     rh_prep *prep[4] = { nullptr, nullptr, nullptr, nullptr };
+    rh_prep *spare[4] = { nullptr, nullptr, nullptr, nullptr };   // compaction target, same capacity
+    int64_t spare_cap[4] = { 0, 0, 0, 0 };
     int64_t cap[4] = { 0, 0, 0, 0 };
     int32_t n[4] = { 0, 0, 0, 0 };
     int32_t *iota = nullptr;      // 0..iota_cap-1
@@ -129,7 +133,7 @@ struct DeviceStore {
 int store_free(rh_cloud *c, DeviceStore &st)
 {
     (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 4; k++) (void)hipFree(st.prep[k]);
+    for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); }
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
     (void)hipFree(st.d_shapes);
     return RH_OK;
@@ -195,11 +199,13 @@ struct Driver {
     int64_t cc[4] = { 0, 0, 0, 0 };         // countcandidates (1-based like the reference)
     int64_t best = -1;                      // index into store of the running first maximum
     double t_score = 0, t_extract = 0, t_sample = 0;
+    double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
     int64_t iterations = 0;
     bool terminated = false;
 
     // level-weighted octree sampling (octree_sampling = 1)
     bool octree = false;
+    bool host_sampling = true;               // false: sampling runs on the device, no host bit mirrors needed
     int od = 1;                              // octree depth
     double oP[32], oS[32];                   // level distribution / summed scores per level
     std::vector<uint64_t> men;               // host mirror: enabled bits in Morton order
@@ -249,10 +255,12 @@ struct Driver {
             RUN(rh_octree_ensure(c, xyz, p->octree_max_depth));
             od = c->oct_depth;
             for (int i = 0; i < od; i++) { oP[i] = 1.0 / od; oS[i] = 0.0; }
-            men.assign((size_t)c->nwords, 0);
-            for (int64_t i = 0; i < c->n; i++)
-                if (en.test(i)) { const int32_t mp = c->h_oct_pos[(size_t)i]; men[(size_t)(mp >> 6)] |= 1ULL << (mp & 63); }
-            rebuild_mprefix();
+            if (host_sampling) {
+                men.assign((size_t)c->nwords, 0);
+                for (int64_t i = 0; i < c->n; i++)
+                    if (en.test(i)) { const int32_t mp = c->h_oct_pos[(size_t)i]; men[(size_t)(mp >> 6)] |= 1ULL << (mp & 63); }
+                rebuild_mprefix();
+            }
         }
         return RH_OK;
     }
@@ -462,8 +470,11 @@ struct Driver {
         RUNH(hipStreamSynchronize(c->stream));
         extracted.back().score_E = scr;
         extracted.back().iteration = k;
-        en.clear(ex.inpoints, total);
-        if (octree) {
+        double tq = now_s();
+        tp[0] += tq - t0;
+        if (host_sampling) en.clear(ex.inpoints, total);
+        else en.count -= total;   // refit only returns enabled points
+        if (octree && host_sampling) {
             for (int32_t q = 0; q < total; q++) {
                 const int32_t mp = c->h_oct_pos[(size_t)(ex.inpoints[q] - 1)];
                 men[(size_t)(mp >> 6)] &= ~(1ULL << (mp & 63));
@@ -473,12 +484,13 @@ struct Driver {
         const int64_t ndis_old = c->n_dis;
         c->n_dis = ndis_new;
 
-        // deleteat!(scoredshapes, best.index): iterations.jl:136
-        store.erase(store.begin() + best);
+        // deleteat!(scoredshapes, best.index): iterations.jl:136 -- dropped in the compaction pass below
+        const size_t extracted_pos = (size_t)best;
+        tp[1] += now_s() - tq; tq = now_s();
         // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
         std::vector<char> dead_slot[4];
-        for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 1);   // unreferenced slots are dead
-        for (const Stored &r : store) dead_slot[r.shape.kind][(size_t)r.slot] = 0;
+        for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 0);   // every slot is referenced by `store`
+        dead_slot[store[extracted_pos].shape.kind][(size_t)store[extracted_pos].slot] = 1;
         int64_t maxn = 0;
         for (int q = 0; q < 4; q++) maxn = std::max<int64_t>(maxn, st.n[q]);
         RUN(store_reserve_aux(c, st, maxn));
@@ -490,14 +502,15 @@ struct Driver {
             if (cnt <= 0) continue;
             RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)st.n[q], c->stream));
             RUNH(hipMemcpyAsync(st.d_nk + 4 + q, &st.n[q], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            RUN(rhk_score_kind(c, q, c->dis + first, c->dis_stride, cnt, nullptr, st.prep[q], st.iota, st.d_nk + 4 + q,
-                               st.n[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+            RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota, st.d_nk + 4 + q, st.n[q], p->eps[q],
+                                   p->cos_alpha[q], st.counts));
             counts_h.resize((size_t)st.n[q]);
             RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)st.n[q], hipMemcpyDeviceToHost, c->stream));
             RUNH(hipStreamSynchronize(c->stream));
             for (int32_t sl = 0; sl < st.n[q]; sl++)
                 if (counts_h[(size_t)sl] > 0) dead_slot[q][(size_t)sl] = 1;
         }
+        tp[2] += now_s() - tq; tq = now_s();
         // drop dead candidates on the host (order preserved), compact the device store
         std::vector<int32_t> remap[4];
         for (int q = 0; q < 4; q++) {
@@ -511,23 +524,29 @@ struct Driver {
             const int32_t alive = (int32_t)idx_h.size();
             if (alive != st.n[q]) {
                 if (alive > 0) {
-                    rh_prep *np = nullptr;
-                    RUNH(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)st.cap[q]));
-                    hipError_t e1 = hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream);
-                    int rc2 = e1 == hipSuccess ? rhk_gather_prep(c, st.prep[q], st.d_idx, alive, np) : RH_E_NODEVICE;
-                    hipError_t e2 = hipStreamSynchronize(c->stream);
-                    (void)hipFree(st.prep[q]);
-                    st.prep[q] = np;
-                    if (rc2 != RH_OK || e2 != hipSuccess) { rh_set_error("candidate store compaction failed"); return RH_E_NODEVICE; }
+                    if (st.spare_cap[q] < st.cap[q]) {
+                        RUNH(hipStreamSynchronize(c->stream));
+                        (void)hipFree(st.spare[q]);
+                        st.spare[q] = nullptr;
+                        st.spare_cap[q] = 0;
+                        RUNH(hipMalloc((void **)&st.spare[q], sizeof(rh_prep) * (size_t)st.cap[q]));
+                        st.spare_cap[q] = st.cap[q];
+                    }
+                    RUNH(hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream));
+                    RUN(rhk_gather_prep(c, st.prep[q], st.d_idx, alive, st.spare[q]));
+                    RUNH(hipStreamSynchronize(c->stream));   // idx_h is reused for the next kind
+                    std::swap(st.prep[q], st.spare[q]);
+                    std::swap(st.cap[q], st.spare_cap[q]);
                 }
                 st.n[q] = alive;
             }
         }
+        tp[3] += now_s() - tq; tq = now_s();
         size_t wpos = 0;
         for (size_t i = 0; i < store.size(); i++) {
             const int q = store[i].shape.kind;
             const int32_t ns = remap[q][(size_t)store[i].slot];
-            if (ns < 0) continue;
+            if (ns < 0 || i == extracted_pos) continue;
             store[wpos] = store[i];
             store[wpos].slot = ns;
             wpos++;
@@ -537,6 +556,7 @@ struct Driver {
         best = -1;
         for (size_t i = 0; i < store.size(); i++)
             if (best < 0 || store[i].E > store[(size_t)best].E) best = (int64_t)i;
+        tp[4] += now_s() - tq;
         t_extract += now_s() - t0;
         *did = true;
         return RH_OK;
@@ -718,12 +738,13 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     RH_HIP(hipSetDevice(c->device));
     const double t_start = now_s();
 
-    Driver d;
-    d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
-    RH_TRY(d.init());
     bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;
     for (int t = 0; t < p->n_shape_types; t++)
         if (p->shape_types[t] == RH_CONE) device_sampler = false;   // the cone fit needs libm acos/cos/sin: host
+    Driver d;
+    d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
+    d.host_sampling = !device_sampler;
+    RH_TRY(d.init());
     RH_TRY(device_sampler ? d.run_streams_device() : d.run_sequential());
 
     out->iterations = d.iterations;
@@ -739,5 +760,8 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     out->seconds_score = d.t_score;
     out->seconds_extract = d.t_extract;
     out->seconds_host = d.t_sample;
+    if (getenv("RH_DRIVER_PROF"))
+        fprintf(stderr, "[rh_ransac] extract: refit+invalidate %.4f erase %.4f liveness %.4f store-compact %.4f host-compact %.4f s\n",
+                d.tp[0], d.tp[1], d.tp[2], d.tp[3], d.tp[4]);
     return RH_OK;
 }

@@ -695,13 +695,12 @@ __global__ void andnot_kernel(uint64_t *__restrict__ enabled, const uint64_t *__
     if (w < nwords) enabled[w] &= ~mask[w];
 }
 
-// sub_enabled bit j = enabled[sub_idx0[j]]; optionally append the points whose bit went 1 -> 0
-// (or, with reset, every disabled point) to the disabled-subset-1 list used by the liveness pass.
+// sub_enabled bit j = enabled[sub_idx0[j]]; gone[w] = the bits that went 1 -> 0 (or, with reset, every
+// disabled bit): the points the liveness pass has to look at.  They are appended to `dis` in internal
+// (Morton) order by append_gone_kernel, so consecutive 64-point groups of `dis` are spatially compact.
 __global__ void __launch_bounds__(256)
 rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ sub_idx0, int64_t s,
-                           uint64_t *__restrict__ sub_enabled, const double *__restrict__ sub, int64_t sub_stride,
-                           double *__restrict__ dis, int64_t dis_stride, int32_t *__restrict__ ndis, int append,
-                           int reset)
+                           uint64_t *__restrict__ sub_enabled, uint64_t *__restrict__ gone_out, int reset)
 {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -715,18 +714,57 @@ rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *
     const uint64_t valid = valid_mask(w << 6, s);
     if (valid == 0) return;
     const uint64_t oldw = reset ? valid : sub_enabled[w];
-    if (lane == 0) sub_enabled[w] = neww;
-    if (!append) return;
-    const uint64_t gone = oldw & ~neww & valid;
-    if (gone == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(ndis, __popcll(gone));
-    base = __shfl(base, 0);
-    if ((gone >> lane) & 1ULL) {
-        const int64_t pos = base + __popcll(gone & ((1ULL << lane) - 1ULL));
-#pragma unroll
-        for (int k = 0; k < 6; k++) dis[k * dis_stride + pos] = sub[k * sub_stride + j];
+    if (lane == 0) {
+        sub_enabled[w] = neww;
+        gone_out[w] = oldw & ~neww & valid;
     }
+}
+
+// block b copies the points of gone words [b*1024, (b+1)*1024) to dis[base + prefix ...], in order
+__global__ void __launch_bounds__(256)
+append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int32_t *__restrict__ block_prefix,
+                   const double *__restrict__ sub, int64_t sub_stride, double *__restrict__ dis, int64_t dis_stride,
+                   const int32_t *__restrict__ base_ptr)
+{
+    __shared__ int32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wbase = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
+    uint64_t m[4];
+    int tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t w = wbase + threadIdx.x * 4 + k;
+        m[k] = w < swords ? gone[w] : 0ULL;
+        tsum += __popcll(m[k]);
+    }
+    int inc = tsum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wave; k++) woff += wsum[k];
+    int64_t run = (int64_t)*base_ptr + block_prefix[blockIdx.x] + woff + inc - tsum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t w = wbase + threadIdx.x * 4 + k;
+        uint64_t bits = m[k];
+        while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const int64_t j = (w << 6) + b;
+#pragma unroll
+            for (int q = 0; q < 6; q++) dis[q * dis_stride + run] = sub[q * sub_stride + j];
+            run++;
+        }
+    }
+}
+
+__global__ void bump_counter_kernel(int32_t *__restrict__ counter, const int32_t *__restrict__ delta, int reset)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *counter = (reset ? 0 : *counter) + *delta;
 }
 
 __global__ void select_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ word_prefix,
@@ -963,14 +1001,22 @@ int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask)
 
 int rhk_rebuild_sub_enabled(rh_cloud *c, bool append, bool reset)
 {
-    if (reset) {
-        RH_HIP(hipMemsetAsync(c->d_ndis, 0, sizeof(int32_t), c->stream));
-    }
+    if (reset) RH_HIP(hipMemsetAsync(c->d_ndis, 0, sizeof(int32_t), c->stream));
     if (c->s == 0) return RH_OK;
     hipLaunchKernelGGL(rebuild_sub_enabled_kernel, dim3(cdiv(c->s, 256)), dim3(256), 0, c->stream, c->enabled,
-                       c->sub_idx0, c->s, c->sub_enabled, c->sub, c->s_pad, c->dis, c->dis_stride, c->d_ndis,
-                       append ? 1 : 0, reset ? 1 : 0);
+                       c->sub_idx0, c->s, c->sub_enabled, c->gone_words, reset ? 1 : 0);
     RH_HIP(hipGetLastError());
+    if (!append) return RH_OK;
+    // ordered compaction of the gone bits: popcount per 1024 words, scan, copy the points
+    const int64_t nb = (c->swords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
+    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, c->gone_words, c->swords,
+                       c->block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, c->d_total);
+    hipLaunchKernelGGL(append_gone_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, c->gone_words, c->swords,
+                       c->block_sums, c->sub, c->s_pad, c->dis, c->dis_stride, c->d_ndis);
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, c->stream, c->d_ndis, c->d_total, 0);
+    RH_HIP(hipGetLastError());
+    c->select_valid = false;   // block_sums / d_total were clobbered
     return RH_OK;
 }
 
@@ -1045,12 +1091,20 @@ int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords
     return RH_OK;
 }
 
+struct GroupSet {   // a point set in 64-point groups with boxes: subset 1, or a segment of `dis`
+    const double *pts;
+    int64_t stride, s;
+    const double *gb;
+    int64_t gstride, ngroups, mask_stride;
+    double coord_mag;
+};
+
 template <int KIND>
-static int launch_score_groups(rh_cloud *c, const uint64_t *en, const rh_prep *prep, const int32_t *orig,
-                               const int32_t *nk, int32_t nk_bound, double eps, double cosa, int32_t *counts,
-                               uint64_t *masks)
+static int launch_score_groups(rh_cloud *c, const GroupSet &G, const uint64_t *en, const rh_prep *prep,
+                               const int32_t *orig, const int32_t *nk, int32_t nk_bound, double eps, double cosa,
+                               int32_t *counts, uint64_t *masks)
 {
-    const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
+    const int64_t ntiles = (G.ngroups + RH_G2_TG - 1) / RH_G2_TG;
     const int nchunks = cdiv(nk_bound, 64);
     if (ntiles == 0 || nchunks == 0) return RH_OK;
     static int env_blocks = -1;
@@ -1069,8 +1123,9 @@ static int launch_score_groups(rh_cloud *c, const uint64_t *en, const rh_prep *p
     static int nt = -1;
     if (nt < 0) { const char *e = getenv("RH_G2_NT"); nt = e ? atoi(e) : 256; }
 #define RH_G2_LAUNCH(M, NT)                                                                                          \
-    hipLaunchKernelGGL((score_groups_kernel<KIND, M, NT>), grid, dim3(NT), 0, c->stream, c->sub, c->s_pad, c->s, en, \
-                       c->gb, c->ng_pad, c->ngroups, prep, orig, nk, eps, cosa, c->coord_mag, counts, masks, c->swords, dbg)
+    hipLaunchKernelGGL((score_groups_kernel<KIND, M, NT>), grid, dim3(NT), 0, c->stream, G.pts, G.stride, G.s, en,  \
+                       G.gb, G.gstride, G.ngroups, prep, orig, nk, eps, cosa, G.coord_mag, counts, masks,          \
+                       G.mask_stride, dbg)
     if (masks) RH_G2_LAUNCH(true, 256);
     else if (nt == 1024) RH_G2_LAUNCH(false, 1024);
     else if (nt == 512) RH_G2_LAUNCH(false, 512);
@@ -1080,18 +1135,42 @@ static int launch_score_groups(rh_cloud *c, const uint64_t *en, const rh_prep *p
     return RH_OK;
 }
 
+static int score_groups_dispatch(rh_cloud *c, const GroupSet &G, int kind, const uint64_t *en, const rh_prep *d_prep,
+                                 const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
+                                 int32_t *d_counts, uint64_t *d_masks_int)
+{
+    switch (kind) {
+    case RH_PLANE: return launch_score_groups<RH_PLANE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_SPHERE: return launch_score_groups<RH_SPHERE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_CYLINDER: return launch_score_groups<RH_CYLINDER>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    case RH_CONE: return launch_score_groups<RH_CONE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+    }
+    rh_set_error("unknown shape kind %d", kind);
+    return RH_E_INVALID;
+}
+
 int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_prep *d_prep, const int32_t *d_orig,
                           const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
                           uint64_t *d_masks_int)
 {
-    switch (kind) {
-    case RH_PLANE: return launch_score_groups<RH_PLANE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_SPHERE: return launch_score_groups<RH_SPHERE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_CYLINDER: return launch_score_groups<RH_CYLINDER>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_CONE: return launch_score_groups<RH_CONE>(c, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    }
-    rh_set_error("unknown shape kind %d", kind);
-    return RH_E_INVALID;
+    GroupSet G = { c->sub, c->s_pad, c->s, c->gb, c->ng_pad, c->ngroups, c->swords, c->coord_mag };
+    return score_groups_dispatch(c, G, kind, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+}
+
+// liveness pass: candidates against dis[first, first + cnt) (counts only); boxes are rebuilt for the segment
+int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
+                       const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts)
+{
+    if (cnt <= 0 || nk_bound <= 0) return RH_OK;
+    if (cnt < 512 || nk_bound < 256)   // tiny: the brute-force kernel has less overhead
+        return rhk_score_kind(c, kind, c->dis + first, c->dis_stride, cnt, nullptr, d_prep, d_orig, d_nk, nk_bound, eps,
+                              cosa, d_counts, nullptr, 0);
+    const int64_t ng = (cnt + 63) / 64;
+    hipLaunchKernelGGL(group_bounds_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, c->stream, c->dis + first, c->dis_stride, cnt,
+                       ng, c->dis_gb, c->ng_pad);
+    RH_HIP(hipGetLastError());
+    GroupSet G = { c->dis + first, c->dis_stride, cnt, c->dis_gb, c->ng_pad, ng, 0, c->coord_mag };
+    return score_groups_dispatch(c, G, kind, nullptr, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, nullptr);
 }
 
 int rhk_group_bounds(rh_cloud *c)

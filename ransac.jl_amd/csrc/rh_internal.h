@@ -75,6 +75,8 @@ struct rh_cloud {
     int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
     double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
     bool use_groups = false;           // culled scoring path available (s large enough)
+    uint64_t *gone_words = nullptr;    // [swords] subset bits that were just disabled
+    double *dis_gb = nullptr;          // boxes of the dis segment in use (7 x ng_pad)
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
 
@@ -134,6 +136,8 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
 int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_or_null, const rh_prep *d_prep,
                           const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
                           int32_t *d_counts, uint64_t *d_masks_int_or_null);
+int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
+                       const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts);
 int rhk_group_bounds(rh_cloud *c);
 int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out);
 int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa);
