@@ -166,3 +166,17 @@ def test_device_calls_fail_loudly_without_gpu():
     assert e.value.code == L.RH_E_NODEVICE
     with pytest.raises(R.RansacHipError):
         R.largestconncomp(np.ones((4, 4), dtype=bool))
+
+
+def test_c_example_builds_and_fails_loudly_without_gpu():
+    """examples/score_demo.c uses the ABI from plain C (no Python, no torch)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "score_demo")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "score_demo.c"), "-L", os.path.join(ROOT, "ransac.jl_amd"),
+                           "-lransac_hip", "-lm", "-Wl,-rpath,$ORIGIN/../ransac.jl_amd", "-o", exe])
+    n = C.c_int()
+    if R.lib().rh_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present: the gpu-marked test runs the example")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "no ROCm-capable device" in r.stderr + r.stdout or "no HIP device" in r.stderr

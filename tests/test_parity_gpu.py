@@ -232,6 +232,18 @@ def test_ragged_sizes(n, s):
         assert np.array_equal(ex.inpoints, oc.refit(orc.Shape.from_buffer_copy(bytes(c.to_c())), to_orc_params(cp)))
 
 
+def test_c_example_runs(score_path):
+    """The plain-C example (examples/score_demo.c) through the same library, as a child process."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "score_demo")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "score_demo.c"),
+                           "-L", os.path.join(root, "ransac.jl_amd"), "-lransac_hip", "-lm",
+                           "-Wl,-rpath,$ORIGIN/../ransac.jl_amd", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "score_demo ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_empty_cloud_and_empty_subset():
     cp = R.params_to_c(R.ransacparameters())
     pc0 = R.RANSACCloud(np.zeros((0, 3)), np.zeros((0, 3)), [np.zeros(0, dtype=np.int64)])
