@@ -855,6 +855,10 @@ int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, cons
     const int ctiles = cdiv(nk_bound, RH_SC_CT);
     const int64_t ntiles = (s + RH_SC_TILE - 1) / RH_SC_TILE;
     if (ctiles == 0 || ntiles == 0) return RH_OK;
+    if (ctiles > 65535) {   // grid.y limit: 4M candidates of one kind per launch
+        rh_set_error("batch of %d candidates is too large for one launch (max %d per kind)", nk_bound, 65535 * RH_SC_CT);
+        return RH_E_INVALID;
+    }
     // Blocks that
     // share a candidate tile differ in blockIdx.x, so consecutive ids (dealt round-robin over the
     // XCDs) stream different point tiles against the same SGPR-resident candidates.
