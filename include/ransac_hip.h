@@ -53,7 +53,8 @@ enum { RH_PLANE = 0, RH_SPHERE = 1, RH_CYLINDER = 2, RH_CONE = 3 };
  *   RH_CONE     FittedCone     (src/shapes/cone.jl:11-19)     v[0..2]=apex   v[3..5]=axis   v[6]=opang
  *                              v[7]=cos(-opang/2), v[8]=sin(-opang/2): computed by the HOST
  *                              (the reference evaluates them in rodrigues, src/utilities.jl:21-22);
- *                              rh_shape_finalize fills them with the C libm.
+ *                              rh_shape_finalize fills them with fdlibm-algorithm kernels (det_math.h: the
+ *                              same bits on host and device, <= 1 ulp from any libm).
  * `outwards` is the Bool field of sphere/cylinder/cone; ignored for planes. */
 typedef struct {
     int32_t kind;

@@ -15,6 +15,12 @@
 #include "ransac_oracle.h"
 
 #include <math.h>
+
+/* acos / cos / sin of the cone code: the fdlibm-algorithm kernels shared with the product
+ * (ransac.jl_amd/csrc/det_math.h; the same algorithms Julia's own Base.acos/sin/cos port), so that a cone
+ * fitted by the oracle, by the product's host code and by the product's device code has identical bits.
+ * tests/test_abi.py checks them against the platform libm (<= 1 ulp). */
+#include "../ransac.jl_amd/csrc/det_math.h"
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -80,8 +86,8 @@ void orc_shape_finalize(orc_shape *s)
     if (s->kind == ORC_CONE) {
         /* rodriguesrad(rot_ax, -cone.opang/2): cone.jl:76; cos/sin at utilities.jl:21-22 */
         double th = -s->v[6] / 2;
-        s->v[7] = cos(th);
-        s->v[8] = sin(th);
+        s->v[7] = rh_cos(th);
+        s->v[8] = rh_sin(th);
     }
 }
 
@@ -869,7 +875,7 @@ int orc_fit3pointcone(const double *p, const double *n, orc_shape *out)
     v3 dirv = vnormalize(vsub(midp, ap));
     if (vdot(ax, dirv) < 0) ax = vscale(ax, -1.0);
     double angles[3];
-    for (int i = 0; i < 3; i++) angles[i] = acos(clamp1(vdot(vnormalize(vsub(V(p + 3 * i), ap)), ax)));
+    for (int i = 0; i < 3; i++) angles[i] = rh_acos(clamp1(vdot(vnormalize(vsub(V(p + 3 * i), ap)), ax)));
     double opangle = 2 * ((angles[0] + angles[1]) + angles[2]) / 3;
     memset(out, 0, sizeof *out);
     out->kind = ORC_CONE;

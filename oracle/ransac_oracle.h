@@ -45,7 +45,8 @@ enum { ORC_PLANE = 0, ORC_SPHERE = 1, ORC_CYLINDER = 2, ORC_CONE = 3 };
  *   CONE     (cone.jl:11-19)      v[0..2]=apex   v[3..5]=axis   v[6]=opang
  *                                 v[7]=cos(-opang/2) v[8]=sin(-opang/2) outwards
  * v[7], v[8] are host-computed (the reference evaluates cos/sin inside
- * rodrigues, utilities.jl:21-22, with the host libm). orc_shape_finalize fills them. */
+ * rodrigues, utilities.jl:21-22). orc_shape_finalize fills them with the fdlibm-algorithm kernels of
+ * det_math.h (what Julia's Base.sin/cos port; <= 1 ulp from any libm). */
 typedef struct {
     int32_t kind;
     int32_t outwards;

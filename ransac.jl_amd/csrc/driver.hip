@@ -739,8 +739,7 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     const double t_start = now_s();
 
     bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;
-    for (int t = 0; t < p->n_shape_types; t++)
-        if (p->shape_types[t] == RH_CONE) device_sampler = false;   // the cone fit needs libm acos/cos/sin: host
+    if (getenv("RH_HOST_SAMPLER")) device_sampler = false;   // A/B and tests: the same streams drawn on the host
     Driver d;
     d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
     d.host_sampling = !device_sampler;

@@ -14,179 +14,6 @@ using namespace rhfit;
 
 constexpr double kPi = 3.14159265358979323846;
 
-// ---- LinearAlgebra stand-ins for cone.jl:44,48,50 ----
-// singular values via one-sided Jacobi on the columns (rows x cols, rows >= cols)
-void jacobi_svals(double *M, int rows, int cols, double *sv)
-{
-    for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-        for (int p = 0; p + 1 < cols; p++)
-            for (int q = p + 1; q < cols; q++) {
-                double a = 0, b = 0, g = 0;
-                for (int i = 0; i < rows; i++) {
-                    a += M[i * cols + p] * M[i * cols + p];
-                    b += M[i * cols + q] * M[i * cols + q];
-                    g += M[i * cols + p] * M[i * cols + q];
-                }
-                if (g == 0.0 || fabs(g) <= 1e-300 + 2.2e-16 * sqrt(a * b)) continue;
-                rotated = true;
-                const double zeta = (b - a) / (2 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                const double cs = 1 / sqrt(1 + t * t), sn = cs * t;
-                for (int i = 0; i < rows; i++) {
-                    const double mp = M[i * cols + p], mq = M[i * cols + q];
-                    M[i * cols + p] = cs * mp - sn * mq;
-                    M[i * cols + q] = sn * mp + cs * mq;
-                }
-            }
-        if (!rotated) break;
-    }
-    for (int j = 0; j < cols; j++) {
-        double a = 0;
-        for (int i = 0; i < rows; i++) a += M[i * cols + j] * M[i * cols + j];
-        sv[j] = sqrt(a);
-    }
-}
-
-int matrix_rank(const double *A, int m, int n)   // rank(A): count(svdvals .> min(m,n)*eps*max)
-{
-    double M[16], sv[4];
-    int rows, cols;
-    if (m >= n) {
-        rows = m; cols = n;
-        for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[i * cols + j] = A[i * n + j];
-    } else {
-        rows = n; cols = m;
-        for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[j * cols + i] = A[i * n + j];
-    }
-    jacobi_svals(M, rows, cols, sv);
-    double smax = 0;
-    for (int j = 0; j < cols; j++) smax = sv[j] > smax ? sv[j] : smax;
-    const double tol = (double)(m < n ? m : n) * 2.220446049250313e-16 * smax;
-    int r = 0;
-    for (int j = 0; j < cols; j++) r += sv[j] > tol;
-    return r;
-}
-
-bool lu_solve3(const double A0[9], const double b0[3], double x[3])   // A \ b, partial pivoting
-{
-    double A[9], b[3];
-    memcpy(A, A0, sizeof A);
-    memcpy(b, b0, sizeof b);
-    for (int k = 0; k < 3; k++) {
-        int piv = k;
-        double best = fabs(A[k * 3 + k]);
-        for (int i = k + 1; i < 3; i++)
-            if (fabs(A[i * 3 + k]) > best) { best = fabs(A[i * 3 + k]); piv = i; }
-        if (best == 0.0) return false;
-        if (piv != k) {
-            for (int j = 0; j < 3; j++) { const double t = A[k * 3 + j]; A[k * 3 + j] = A[piv * 3 + j]; A[piv * 3 + j] = t; }
-            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
-        }
-        for (int i = k + 1; i < 3; i++) {
-            const double l = A[i * 3 + k] / A[k * 3 + k];
-            A[i * 3 + k] = l;
-            for (int j = k + 1; j < 3; j++) A[i * 3 + j] -= l * A[k * 3 + j];
-            b[i] -= l * b[k];
-        }
-    }
-    for (int i = 2; i >= 0; i--) {
-        double acc = b[i];
-        for (int j = i + 1; j < 3; j++) acc -= A[i * 3 + j] * x[j];
-        x[i] = acc / A[i * 3 + i];
-    }
-    return true;
-}
-
-// ---- cone.jl:68-85 (host twin of the device test, used by validatecone) ----
-void project2cone(const rh_shape &cone, const Vec &p, double *dist, Vec *cn)
-{
-    const Vec apex(cone.v), axis(cone.v + 3);
-    const Vec to_point = apex - p;
-    const Vec to_pointn = normalize(to_point);
-    const Vec rot_ax = normalize(cross(axis, to_pointn));
-    const Vec comp_n = normalize(cross(axis, rot_ax));
-    const Vec v = normalize(rot_ax);   // rodriguesrad re-normalizes (utilities.jl:62)
-    const double c = cone.v[7], s = cone.v[8];
-    const double e[3] = { v.x, v.y, v.z };
-    double R[3][3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-            const double nn = e[i] * e[j];
-            R[i][j] = nn + c * ((i == j ? 1.0 : 0.0) - nn);
-        }
-    R[0][1] -= s * e[2]; R[0][2] += s * e[1];   // pluscrossprod!: utilities.jl:32-43
-    R[1][0] += s * e[2]; R[1][2] -= s * e[0];
-    R[2][0] -= s * e[1]; R[2][1] += s * e[0];
-    const Vec rc((R[0][0] * comp_n.x + R[0][1] * comp_n.y) + R[0][2] * comp_n.z,
-                 (R[1][0] * comp_n.x + R[1][1] * comp_n.y) + R[1][2] * comp_n.z,
-                 (R[2][0] * comp_n.x + R[2][1] * comp_n.y) + R[2][2] * comp_n.z);
-    *cn = normalize(rc);
-    *dist = dot(-*cn, -to_point);
-}
-
-inline double clamp_unit(double x) { return x < -1 ? -1 : (x > 1 ? 1 : x); }
-
-// ---- cone.jl:39-61 ----
-bool fit3pointcone(const double *p, const double *n, rh_shape *cone)
-{
-    double r[9], rv[12], ds[3], ap[3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = n[3 * i + j];
-    if (matrix_rank(r, 3, 3) != 3) return false;
-    for (int i = 0; i < 3; i++) ds[i] = dot(Vec(p + 3 * i), Vec(n + 3 * i));
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) rv[i * 4 + j] = r[i * 3 + j];
-        rv[i * 4 + 3] = -1 * ds[i];
-    }
-    if (matrix_rank(rv, 3, 4) != 3) return false;
-    if (!lu_solve3(r, ds, ap)) return false;
-    const Vec apex(ap);
-    Vec a3[3];
-    for (int i = 0; i < 3; i++) {
-        const Vec d = Vec(p + 3 * i) - apex;
-        a3[i] = apex + d / norm(d);
-    }
-    Vec ax = normalize(cross(a3[1] - a3[0], a3[2] - a3[0]));
-    const Vec midp = ((a3[0] + a3[1]) + a3[2]) / 3;
-    const Vec dirv = normalize(midp - apex);
-    if (dot(ax, dirv) < 0) ax = -1.0 * ax;
-    double ang[3];
-    for (int i = 0; i < 3; i++) ang[i] = acos(clamp_unit(dot(normalize(Vec(p + 3 * i) - apex), ax)));
-    memset(cone, 0, sizeof *cone);
-    cone->kind = RH_CONE;
-    cone->outwards = 1;
-    apex.store(cone->v);
-    ax.store(cone->v + 3);
-    cone->v[6] = 2 * ((ang[0] + ang[1]) + ang[2]) / 3;
-    rh_shape_finalize(cone);
-    return true;
-}
-
-// ---- cone.jl:87-115, 123-128 ----
-bool fit_cone(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
-{
-    if (lp > 16) return false;
-    rh_shape cone;
-    if (!fit3pointcone(p, n, &cone)) return false;
-    double dist[16];
-    Vec cn[16];
-    for (int i = 0; i < lp; i++) project2cone(cone, Vec(p + 3 * i), &dist[i], &cn[i]);
-    for (int i = 0; i < lp; i++)
-        if (dist[i] > prm.eps[RH_CONE]) return false;   // no abs in the reference (cone.jl:93)
-    if (cone.v[6] < prm.minconeopang) return false;
-    const double thr = prm.cos_alpha[RH_CONE];
-    bool same = true, opposite = true;
-    for (int i = 0; i < lp; i++) {
-        const double dotp = dot(cn[i], Vec(n + 3 * i));
-        same = same && (dotp > thr);
-        opposite = opposite && (dotp < -thr);
-    }
-    if (!same && !opposite) return false;
-    *out = cone;
-    out->outwards = same ? 1 : 0;
-    return true;
-}
-
 inline double julia_min(double x, double y) { return x != x ? x : (y != y ? y : (y < x ? y : x)); }
 inline double julia_max(double x, double y) { return x != x ? x : (y != y ? y : (x < y ? y : x)); }
 
@@ -237,11 +64,7 @@ extern "C" void rh_default_params(rh_params *p)
 
 extern "C" void rh_shape_finalize(rh_shape *s)
 {
-    if (s->kind == RH_CONE) {
-        const double th = -s->v[6] / 2;   // rodriguesrad(rot_ax, -cone.opang/2): cone.jl:76
-        s->v[7] = cos(th);
-        s->v[8] = sin(th);
-    }
+    if (s->kind == RH_CONE) rhfit::cone_finalize(s);   // deterministic cos / sin (det_math.h)
 }
 
 extern "C" int rh_fit(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm, rh_shape *out,

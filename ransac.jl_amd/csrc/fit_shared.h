@@ -1,13 +1,14 @@
-// fit_shared.h -- minimal-set fits for plane / sphere / cylinder and the per-set random stream,
-// compiled for BOTH host and device (hipcc, -ffp-contract=off): only + - * / sqrt fabs and
-// comparisons are used, so the two sides produce bit-identical candidates.  The cone fit needs
-// acos/cos/sin (libm) and LAPACK-like rank / solve: it stays host-only in fit.cpp.
+// fit_shared.h -- minimal-set fits for plane / sphere / cylinder / cone and the per-set random
+// streams, compiled for BOTH host and device (hipcc, -ffp-contract=off): only + - * / sqrt fabs and
+// comparisons are used (the cone's acos / cos / sin come from det_math.h, built from the same
+// operations), so the two sides produce bit-identical candidates.
 // Paths in comments are under /root/reference/src.
 #pragma once
 
 #include <math.h>
 #include <stdint.h>
 
+#include "det_math.h"
 #include "ransac_hip.h"
 
 #if defined(__HIPCC__)
@@ -184,6 +185,189 @@ RH_HD bool fit_cylinder(const double *p, const double *n, int lp, const rh_param
     axis.store(out->v);
     center.store(out->v + 3);
     out->v[6] = radius;
+    return true;
+}
+
+
+// cos(-opang/2), sin(-opang/2) of a cone (rodriguesrad(rot_ax, -cone.opang/2): cone.jl:76,
+// utilities.jl:21-22) with the deterministic det_math.h kernels: same bits on host and device
+RH_HD void cone_finalize(rh_shape *s)
+{
+    const double th = -s->v[6] / 2;
+    s->v[7] = rh_cos(th);
+    s->v[8] = rh_sin(th);
+}
+
+// ---- LinearAlgebra stand-ins for cone.jl:44,48,50 ----
+// singular values via one-sided Jacobi on the columns (rows x cols, rows >= cols)
+RH_HD void jacobi_svals(double *M, int rows, int cols, double *sv)
+{
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p + 1 < cols; p++)
+            for (int q = p + 1; q < cols; q++) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < rows; i++) {
+                    a += M[i * cols + p] * M[i * cols + p];
+                    b += M[i * cols + q] * M[i * cols + q];
+                    g += M[i * cols + p] * M[i * cols + q];
+                }
+                if (g == 0.0 || fabs(g) <= 1e-300 + 2.2e-16 * sqrt(a * b)) continue;
+                rotated = true;
+                const double zeta = (b - a) / (2 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                const double cs = 1 / sqrt(1 + t * t), sn = cs * t;
+                for (int i = 0; i < rows; i++) {
+                    const double mp = M[i * cols + p], mq = M[i * cols + q];
+                    M[i * cols + p] = cs * mp - sn * mq;
+                    M[i * cols + q] = sn * mp + cs * mq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < cols; j++) {
+        double a = 0;
+        for (int i = 0; i < rows; i++) a += M[i * cols + j] * M[i * cols + j];
+        sv[j] = sqrt(a);
+    }
+}
+
+RH_HD int matrix_rank(const double *A, int m, int n)   // rank(A): count(svdvals .> min(m,n)*eps*max)
+{
+    double M[16], sv[4];
+    int rows, cols;
+    if (m >= n) {
+        rows = m; cols = n;
+        for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[i * cols + j] = A[i * n + j];
+    } else {
+        rows = n; cols = m;
+        for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[j * cols + i] = A[i * n + j];
+    }
+    jacobi_svals(M, rows, cols, sv);
+    double smax = 0;
+    for (int j = 0; j < cols; j++) smax = sv[j] > smax ? sv[j] : smax;
+    const double tol = (double)(m < n ? m : n) * 2.220446049250313e-16 * smax;
+    int r = 0;
+    for (int j = 0; j < cols; j++) r += sv[j] > tol;
+    return r;
+}
+
+RH_HD bool lu_solve3(const double A0[9], const double b0[3], double x[3])   // A \ b, partial pivoting
+{
+    double A[9], b[3];
+    for (int i = 0; i < 9; i++) A[i] = A0[i];
+    for (int i = 0; i < 3; i++) b[i] = b0[i];
+    for (int k = 0; k < 3; k++) {
+        int piv = k;
+        double best = fabs(A[k * 3 + k]);
+        for (int i = k + 1; i < 3; i++)
+            if (fabs(A[i * 3 + k]) > best) { best = fabs(A[i * 3 + k]); piv = i; }
+        if (best == 0.0) return false;
+        if (piv != k) {
+            for (int j = 0; j < 3; j++) { const double t = A[k * 3 + j]; A[k * 3 + j] = A[piv * 3 + j]; A[piv * 3 + j] = t; }
+            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < 3; i++) {
+            const double l = A[i * 3 + k] / A[k * 3 + k];
+            A[i * 3 + k] = l;
+            for (int j = k + 1; j < 3; j++) A[i * 3 + j] -= l * A[k * 3 + j];
+            b[i] -= l * b[k];
+        }
+    }
+    for (int i = 2; i >= 0; i--) {
+        double acc = b[i];
+        for (int j = i + 1; j < 3; j++) acc -= A[i * 3 + j] * x[j];
+        x[i] = acc / A[i * 3 + i];
+    }
+    return true;
+}
+
+// ---- cone.jl:68-85 (host twin of the device test, used by validatecone) ----
+RH_HD void project2cone(const rh_shape &cone, const Vec &p, double *dist, Vec *cn)
+{
+    const Vec apex(cone.v), axis(cone.v + 3);
+    const Vec to_point = apex - p;
+    const Vec to_pointn = normalize(to_point);
+    const Vec rot_ax = normalize(cross(axis, to_pointn));
+    const Vec comp_n = normalize(cross(axis, rot_ax));
+    const Vec v = normalize(rot_ax);   // rodriguesrad re-normalizes (utilities.jl:62)
+    const double c = cone.v[7], s = cone.v[8];
+    const double e[3] = { v.x, v.y, v.z };
+    double R[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const double nn = e[i] * e[j];
+            R[i][j] = nn + c * ((i == j ? 1.0 : 0.0) - nn);
+        }
+    R[0][1] -= s * e[2]; R[0][2] += s * e[1];   // pluscrossprod!: utilities.jl:32-43
+    R[1][0] += s * e[2]; R[1][2] -= s * e[0];
+    R[2][0] -= s * e[1]; R[2][1] += s * e[0];
+    const Vec rc((R[0][0] * comp_n.x + R[0][1] * comp_n.y) + R[0][2] * comp_n.z,
+                 (R[1][0] * comp_n.x + R[1][1] * comp_n.y) + R[1][2] * comp_n.z,
+                 (R[2][0] * comp_n.x + R[2][1] * comp_n.y) + R[2][2] * comp_n.z);
+    *cn = normalize(rc);
+    *dist = dot(-*cn, -to_point);
+}
+
+RH_HD double clamp_unit(double x) { return x < -1 ? -1 : (x > 1 ? 1 : x); }
+
+// ---- cone.jl:39-61 ----
+RH_HD bool fit3pointcone(const double *p, const double *n, rh_shape *cone)
+{
+    double r[9], rv[12], ds[3], ap[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = n[3 * i + j];
+    if (matrix_rank(r, 3, 3) != 3) return false;
+    for (int i = 0; i < 3; i++) ds[i] = dot(Vec(p + 3 * i), Vec(n + 3 * i));
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) rv[i * 4 + j] = r[i * 3 + j];
+        rv[i * 4 + 3] = -1 * ds[i];
+    }
+    if (matrix_rank(rv, 3, 4) != 3) return false;
+    if (!lu_solve3(r, ds, ap)) return false;
+    const Vec apex(ap);
+    Vec a3[3];
+    for (int i = 0; i < 3; i++) {
+        const Vec d = Vec(p + 3 * i) - apex;
+        a3[i] = apex + d / norm(d);
+    }
+    Vec ax = normalize(cross(a3[1] - a3[0], a3[2] - a3[0]));
+    const Vec midp = ((a3[0] + a3[1]) + a3[2]) / 3;
+    const Vec dirv = normalize(midp - apex);
+    if (dot(ax, dirv) < 0) ax = -1.0 * ax;
+    double ang[3];
+    for (int i = 0; i < 3; i++) ang[i] = rh_acos(clamp_unit(dot(normalize(Vec(p + 3 * i) - apex), ax)));
+    for (int i = 0; i < 10; i++) cone->v[i] = 0.0;
+    cone->kind = RH_CONE;
+    cone->outwards = 1;
+    apex.store(cone->v);
+    ax.store(cone->v + 3);
+    cone->v[6] = 2 * ((ang[0] + ang[1]) + ang[2]) / 3;
+    cone_finalize(cone);
+    return true;
+}
+
+// ---- cone.jl:87-115, 123-128 ----
+RH_HD bool fit_cone(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+{
+    if (lp > 16) return false;
+    rh_shape cone;
+    if (!fit3pointcone(p, n, &cone)) return false;
+    double dist[16];
+    Vec cn[16];
+    for (int i = 0; i < lp; i++) project2cone(cone, Vec(p + 3 * i), &dist[i], &cn[i]);
+    for (int i = 0; i < lp; i++)
+        if (dist[i] > prm.eps[RH_CONE]) return false;   // no abs in the reference (cone.jl:93)
+    if (cone.v[6] < prm.minconeopang) return false;
+    const double thr = prm.cos_alpha[RH_CONE];
+    bool same = true, opposite = true;
+    for (int i = 0; i < lp; i++) {
+        const double dotp = dot(cn[i], Vec(n + 3 * i));
+        same = same && (dotp > thr);
+        opposite = opposite && (dotp < -thr);
+    }
+    if (!same && !opposite) return false;
+    *out = cone;
+    out->outwards = same ? 1 : 0;
     return true;
 }
 

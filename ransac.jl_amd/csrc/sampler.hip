@@ -93,7 +93,8 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
         case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
         case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
         case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
-        default: break;   // cones are fitted on the host (libm): the driver never sends them here
+        case RH_CONE: fitted = rhfit::fit_cone(fp, fn, drawN, prm, &s); break;
+        default: break;
         }
         if (!fitted) continue;
         const int32_t pos = atomicAdd(out_count, 1);

@@ -180,3 +180,24 @@ def test_c_example_builds_and_fails_loudly_without_gpu():
         pytest.skip("a GPU is present: the gpu-marked test runs the example")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode != 0 and "no ROCm-capable device" in r.stderr + r.stdout or "no HIP device" in r.stderr
+
+
+def test_deterministic_trig_is_within_one_ulp_of_libm():
+    """det_math.h (fdlibm-algorithm acos / sin / cos shared by host, device and oracle): <= 1 ulp from libm."""
+    rng = np.random.default_rng(9)
+    sh = orc.Shape()
+    sh.kind = orc.CONE
+    worst = 0
+    for op in list(rng.uniform(0, 2 * math.pi, 2000)) + [0.0, 1e-9, math.pi / 2, math.pi, 3.0, 6.0, 50.0]:
+        sh.v[6] = float(op)
+        orc.lib().orc_shape_finalize(C.byref(sh))
+        ps = L.Shape.from_buffer_copy(bytes(sh))
+        ps.v[7] = ps.v[8] = 0.0
+        R.lib().rh_shape_finalize(C.byref(ps))
+        assert (ps.v[7], ps.v[8]) == (sh.v[7], sh.v[8])          # product == oracle, bit for bit
+        for got, ref in ((sh.v[7], math.cos(-op / 2)), (sh.v[8], math.sin(-op / 2))):
+            if got == ref:
+                continue
+            ulp = abs(int(np.float64(got).view(np.int64)) - int(np.float64(ref).view(np.int64)))
+            worst = max(worst, ulp)
+    assert worst <= 1

@@ -345,14 +345,17 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
     assert_same_run(pc, oc, got, exp, stats)
 
 
-@pytest.mark.parametrize("prims,kinds,seed", [
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11),   # device sampler + speculation
-    (["plane", "sphere", "cylinder", "cone"], "all", 12),                             # cone present: host sampler
-    (["plane", "plane"], "p", 13),
+@pytest.mark.parametrize("prims,kinds,seed,host", [
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, False),   # device sampler + speculation
+    (["plane", "sphere", "cylinder", "cone"], "all", 12, False),                             # cones on the device as well
+    (["plane", "sphere", "cylinder", "cone"], "all", 12, True),                              # host twin of the sampler
+    (["plane", "plane"], "p", 13, False),
 ])
-def test_ransac_per_set_streams(prims, kinds, seed):
+def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
     """sampling_streams = 1: sampling + fitting on the device, iterations speculated in windows;
     must equal the oracle's strictly sequential loop over the same per-set streams."""
+    if host:
+        monkeypatch.setenv("RH_HOST_SAMPLER", "1")
     xyz, nrm, truth = synth.make_cloud(30_000, prims, 0.1, seed=60 + seed)
     subs = synth.make_subsets(30_000, 2, seed=seed)
     types = {"psc": [R.FittedPlane, R.FittedSphere, R.FittedCylinder], "p": [R.FittedPlane],
@@ -368,14 +371,17 @@ def test_ransac_per_set_streams(prims, kinds, seed):
     assert len(got0) >= 2
 
 
-@pytest.mark.parametrize("prims,kinds,seed", [
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder", "plane", "sphere"], "psc", 21),   # device sampler
-    (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22),                                        # host sampler
+@pytest.mark.parametrize("prims,kinds,seed,host", [
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder", "plane", "sphere"], "psc", 21, False),
+    (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22, False),     # cones fitted on the device too
+    (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22, True),      # same streams drawn on the host
 ])
-def test_ransac_octree_sampling(prims, kinds, seed):
+def test_ransac_octree_sampling(prims, kinds, seed, host, monkeypatch):
     """octree_sampling = 1 (fixed behaviour, docs/src/ransac.md:73-96): level-weighted cells of a
     linear octree, level distribution updated from the scores -- device windows vs the oracle's
     sequential loop, identical shapes / index sets / draw counts."""
+    if host:
+        monkeypatch.setenv("RH_HOST_SAMPLER", "1")
     xyz, nrm, truth = synth.make_cloud(40_000, prims, 0.25, seed=80 + seed)
     subs = synth.make_subsets(40_000, 4, seed=seed)
     types = {"psc": [R.FittedPlane, R.FittedSphere, R.FittedCylinder],
