@@ -44,13 +44,34 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000, help="cloud size (default: BASELINE cfg3)")
+    ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
+    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
     return ap.parse_args()
+
+
+def pmc_traffic(kernel_key, enabled):
+    """HBM bytes per launch of one kernel from the committed PMC passes (profiles/rN/pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, KB per dispatch).  gfx950's
+    FETCH_SIZE counts half the bytes of a coalesced stream (MI355X_MICROARCH.md; calibrated on the refit
+    scan in profiles/r1/README.md), hence 2 x FETCH + WRITE.  None when no pass exists for this workload."""
+    if not enabled:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    rows = json.load(open(files[-1]))
+    rd = [r["mean_KB"] for r in rows if r["counter"] == "FETCH_SIZE" and kernel_key in r["kernel"]]
+    wr = [r["mean_KB"] for r in rows if r["counter"] == "WRITE_SIZE" and kernel_key in r["kernel"]]
+    if not rd or not wr:
+        return None
+    return (2.0 * rd[0] + wr[0]) * 1024.0
 
 
 def shapes_to_c(R, L, cands):
@@ -95,15 +116,23 @@ def main():
     lib = R.lib()
 
     # ---- workload: BASELINE cfg3 (cfg4 when sharded) -----------------------------------
-    n = args.points
     prim = ["plane"] * 16 + ["sphere"] * 12 + ["cylinder"] * 12
+    types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+    wseed, wname = 3, "cfg3: 10M-point 40-primitive cloud, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
+    n_default = 10_000_000
+    if args.workload == "cfg5":
+        prim = prim + ["cone"] * 8
+        types = types + [R.FittedCone]
+        wseed, wname = 5, "cfg5: 50M-point 48-primitive cloud with cones, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
+        n_default = 50_000_000
+    n = args.points or n_default
     t0 = time.time()
-    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=3)
-    subs = synth.make_subsets(n, 32, seed=3)
+    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=wseed)
+    subs = synth.make_subsets(n, 32, seed=wseed)
     S = subs[0].size
     pc = R.RANSACCloud(xyz, nrm, subs, device=local_rank)
     t_setup = time.time() - t0
-    params = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder])
+    params = R.ransacparameters(types)
     cp = R.params_to_c(params, score_mode=L.SCORE_F64)   # Int64 score wraps at this size
 
     b_global = B_PER_GPU * world
@@ -151,10 +180,10 @@ def main():
         "metric": "candidates_scored_per_sec", "value": value, "unit": "candidates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "cfg3: 10M-point 40-primitive cloud, 30% outliers, r=32 subsets, "
-                               "B=4096 candidates/GPU/step" if n == 10_000_000 else "custom",
+        "config": {"workload": wname if n == n_default else "custom (%s primitives)" % args.workload,
                    "points": n, "subset_points": int(S), "candidates_per_step": b_global,
-                   "kinds": "plane/sphere/cylinder (cycled over the 40 ground-truth primitives, 1% jitter)",
+                   "kinds": "%s (cycled over the %d ground-truth primitives, 1%% jitter)"
+                            % ("/".join(sorted(set(prim), key=KINDS.index)), len(prim)),
                    "score_mode": "f64", "parallelism": "candidate-sharded x%d, int32 sum all-reduce" % world},
         "tests_per_sec": value * S,
     }
@@ -163,36 +192,51 @@ def main():
         # ---- per-kind kernel time (HIP events) and rooflines -----------------------------
         per_kind = {}
         reps = 10
-        acc = [0.0] * 4
-        msk = (C.c_float * 4)()
-        for _ in range(reps):   # the same launches as the timed steps, bracketed by events per kind
+        acc = [0.0] * 5
+        msk = (C.c_float * 5)()
+        for _ in range(reps):   # [4]: the launch of the timed steps (all kinds, one kernel); [0..3]: one launch per kind
             L.check(lib.rh_score_batch_dev_timed(pc._h, batch.slice_ptr(lo), hi - lo, C.byref(cp),
                                                  C.c_void_p(counts.data_ptr() + 4 * lo), None, msk))
-            for k in range(4):
+            for k in range(5):
                 acc[k] += msk[k]
         for ki, k in enumerate(KINDS):
             nk = sum(1 for c in cands[lo:hi] if c[0] == k)
             if nk:
-                per_kind[k] = {"candidates": nk, "ms_per_launch": acc[ki] / reps}
-        dom = max(per_kind, key=lambda k: per_kind[k]["ms_per_launch"])
-        d = per_kind[dom]
-        tests = d["candidates"] * S
-        sec = d["ms_per_launch"] * 1e-3
-        alg_bytes = tests * SCORE_BYTES_PER_TEST + d["candidates"] * (64 + 4)
+                per_kind[k] = {"candidates": nk, "ms_separate_launch": acc[ki] / reps}
+        merged = os.environ.get("RH_SCORE_MERGED", "1") != "0" and os.environ.get("RH_SCORE_PATH", "groups") == "groups"
+        if merged:
+            kname = "score_groups_all_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
+            sec = acc[4] / reps * 1e-3
+            kinds_in = list(per_kind)
+            pmc_key = "score_groups_all_kernel<false>"
+        else:   # per-kind launches: the dominant one
+            dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
+            kname = "score kernel <%s>" % dom
+            sec = per_kind[dom]["ms_separate_launch"] * 1e-3
+            kinds_in = [dom]
+            pmc_key = "score_groups_kernel<%d," % KINDS.index(dom)
+        ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
+        tests = ncand * S
+        # the committed PMC passes were taken on the default workload and batch split
+        pmc_ok = args.workload == "cfg3" and n == n_default and world == 1 and "RH_SCORE_PATH" not in os.environ
+        alg_bytes = tests * SCORE_BYTES_PER_TEST + ncand * (64 + 4)
         out["roofline"] = {
-            "kernel": "score_groups_kernel<%s>" % dom, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel": kname, "bound": "hbm", "achieved": alg_bytes / sec / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(pmc_key, pmc_ok),
+            "ms_per_launch": sec * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "EFFECTIVE rate on algorithmic bytes = 48.25 B x (candidate, point) tests (SURVEY.md 8d). The "
                     "kernel never streams those bytes: points are staged once per tile and re-used across the "
                     "candidate batch, and box tests on Morton-ordered 64-point groups reject most (candidate, "
-                    "group) pairs, so frac > 1 by design; measured HBM traffic is in profiles/ (PMC)",
+                    "group) pairs, so frac > 1 by design; `traffic` = HBM bytes per launch from the committed PMC "
+                    "passes (profiles/rN/pmc_hbm_traffic.json, 2 x FETCH_SIZE + WRITE_SIZE)",
         }
-        issue = VALU_F64_PER_TEST[dom] * tests / 64 * 4          # SIMD cycles at 4 cycles per wave64 f64 op
+        flops = sum(FLOPS_PER_TEST[k] * per_kind[k]["candidates"] * S for k in kinds_in)
+        issue = sum(VALU_F64_PER_TEST[k] * per_kind[k]["candidates"] * S for k in kinds_in) / 64 * 4   # SIMD cycles
         out["roofline_valu"] = {
-            "kernel": "score_groups_kernel<%s>" % dom, "bound": "fp64_valu",
-            "achieved": FLOPS_PER_TEST[dom] * tests / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": FLOPS_PER_TEST[dom] * tests / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "kernel": kname, "bound": "fp64_valu",
+            "achieved": flops / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_issue_frac": issue / (1024 * 2.4e9 * sec),
             "note": "EFFECTIVE: reference flops/test x ALGORITHMIC tests / time (no FMA allowed: bit-exact parity "
                     "caps real work at half the FMA peak). valu_issue_frac = f64 vector instructions the brute-force "
@@ -234,11 +278,11 @@ def main():
         rbytes = n * REFIT_BYTES_PER_POINT
         out["roofline_refit"] = {"kernel": "refit_mask_kernel<plane>", "bound": "hbm", "achieved": rbytes / t_scan / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rbytes / t_scan / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": None, "ms_per_launch": 1e3 * t_scan,
+                                 "traffic": pmc_traffic("refit_mask_kernel<0>", pmc_ok), "ms_per_launch": 1e3 * t_scan,
                                  "algorithmic_bytes_per_launch": rbytes,
                                  "compaction_ms": sum(comp_ms) / len(comp_ms), "rh_refit_host_wall_ms": 1e3 * t_refit,
                                  "inliers": int(nout.value),
-                                 "note": "the HBM-bound kernel of the path: one pass over the 10M-point cloud "
+                                 "note": "the HBM-bound kernel of the path: one pass over the whole cloud "
                                          "(48.125 B/point); HIP events on the library's stream; host wall adds the "
                                          "compaction, two syncs and the D2H of the index list"}
 
@@ -263,7 +307,7 @@ def main():
 
         # ---- end to end: shapes / s of the whole ransac() loop on the same cloud ----------
         if not args.no_e2e:
-            e2e = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
+            e2e = R.ransacparameters(types,
                                      iteration={"minsubsetN": 4096, "itermax": args.e2e_iters, "τ": 900, "prob_det": 0.9})
             ecp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
             pc.enable_all()

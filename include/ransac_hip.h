@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 101
+#define RH_VERSION 102
 
 enum {
     RH_OK = 0,
@@ -232,11 +232,12 @@ int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int
                         uint8_t *bitmap_or_null, int64_t *idxmap_or_null);
 
 /* ---- measurement plumbing (bench.py): HIP events on the cloud's stream ---- */
-/* rh_score_batch_dev with a HIP event recorded on the cloud's stream before each of the four
- * per-kind score launches and after the last; waits for the batch and returns the elapsed
- * milliseconds of each kind's kernel (0 for kinds without candidates ~ an empty launch). */
+/* rh_score_batch_dev twice, bracketed by HIP events on the cloud's stream: first the way
+ * rh_score_batch_dev runs it (one kernel for all kinds) -> ms_out[4]; then one launch per kind
+ * with an event before each and after the last -> ms_out[0..3] (0 for kinds without candidates
+ * ~ an empty launch).  Waits for the batch. */
 int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
-                             int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_kind_out /* [4] */);
+                             int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_out /* [5] */);
 /* device time of the most recent rh_refit on this cloud: the full-cloud scan kernel and the
  * compaction (popcount + scan + expansion), from HIP events on the cloud's stream */
 int rh_last_refit_ms(rh_cloud *c, float *ms_scan_out, float *ms_compact_out);

@@ -133,7 +133,7 @@ static void cloud_free(rh_cloud *c)
     if (!c) return;
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->full); (void)hipFree(c->sub); (void)hipFree(c->dis);
+    (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
@@ -292,6 +292,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipEventCreate(&c->ev1));
     for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
     CK(dev_alloc(&c->full, 6 * c->n_pad));
+    CK(dev_alloc(&c->rec, 8 * std::max<int64_t>(n, 1)));
     CK(dev_alloc(&c->sub, 6 * c->s_pad));
     CK(dev_alloc(&c->dis, 6 * c->dis_stride));
     CK(dev_alloc(&c->sub_idx0, s));
@@ -329,6 +330,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
         CKH(hipMemcpyAsync(t_xyz, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         CKH(hipMemcpyAsync(t_nrm, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
+        CK(rhk_pack_records(c, t_xyz, t_nrm, n, c->rec));
         if (s > 0) {
             // internal order of subset 1 = Morton order of its points: 64 consecutive points are
             // spatially compact, which is what the culled score kernel's per-group boxes need
@@ -475,6 +477,33 @@ static int score_kind_subset(rh_cloud *c, int k, const rh_params *p, const rh_pr
                           p->eps[k], p->cos_alpha[k], d_counts, d_masks_int, c->swords);
 }
 
+// all four kind bins (bin k at prep/orig + off[k], its size in d_nk[k]) against subset 1
+static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_prep, const int32_t *d_orig,
+                             const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], int32_t total_bound,
+                             int32_t *d_counts, uint64_t *d_masks_int, float *ms_kind)
+{
+    static int merged = -1;
+    if (merged < 0) { const char *e = getenv("RH_SCORE_MERGED"); merged = e ? atoi(e) : 1; }
+    if (c->use_groups && merged && !ms_kind) {
+        const uint64_t *en[4];
+        const rh_prep *pr[4];
+        const int32_t *og[4], *nk[4];
+        for (int k = 0; k < 4; k++) {
+            en[k] = enabled_for_kind(c, k, p);
+            pr[k] = d_prep + off[k];
+            og[k] = d_orig + off[k];
+            nk[k] = d_nk + k;
+        }
+        return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int);
+    }
+    for (int k = 0; k < 4; k++) {
+        if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
+        if (nk_bound[k] == 0) continue;
+        RH_TRY(score_kind_subset(c, k, p, d_prep + off[k], d_orig + off[k], d_nk + k, nk_bound[k], d_counts, d_masks_int));
+    }
+    return RH_OK;
+}
+
 extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, int32_t *counts_out,
                               uint64_t *masks_out)
 {
@@ -518,11 +547,8 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         d_masks_int = c->d_masks_int;
         RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
-    for (int k = 0; k < 4; k++) {
-        if (nk[k] == 0) continue;
-        RH_TRY(score_kind_subset(c, k, p, c->d_prep + off[k], c->d_orig + off[k], c->d_nk + k, nk[k], c->d_counts,
-                                 d_masks_int));
-    }
+    const int64_t off64[4] = { off[0], off[1], off[2], off[3] };
+    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off64, c->d_nk, nk, b, c->d_counts, d_masks_int, nullptr));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     RH_HIP(hipMemcpyAsync(counts_out, c->d_counts, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
     if (d_masks)
@@ -538,7 +564,7 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     RH_TRY(enter(c));
     RH_TRY(rh_validate_params(p));
     if (b < 0 || (b > 0 && (!d_shapes || !d_counts))) { rh_set_error("rh_score_batch_dev: bad arguments"); return RH_E_INVALID; }
-    if (ms_kind) for (int k = 0; k < 4; k++) ms_kind[k] = 0.f;
+    if (ms_kind) for (int k = 0; k < 5; k++) ms_kind[k] = 0.f;
     if (b == 0) return RH_OK;
     RH_TRY(rh_ensure_batch(c, b));
     RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
@@ -549,11 +575,19 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
         d_masks_int = c->d_masks_int;
         RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
-    for (int k = 0; k < 4; k++) {
-        if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
-        RH_TRY(score_kind_subset(c, k, p, c->d_prep + (int64_t)k * c->batch_cap, c->d_orig + (int64_t)k * c->batch_cap,
-                                 c->d_nk + k, b, d_counts, d_masks_int));
+    const int64_t off[4] = { 0, c->batch_cap, 2 * (int64_t)c->batch_cap, 3 * (int64_t)c->batch_cap };
+    const int32_t bound[4] = { b, b, b, b };
+    if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
+        ms_kind[4] = 0.f;
+        RH_HIP(hipEventRecord(c->evk[0], c->stream));
+        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, c->d_nk, bound, b, d_counts, d_masks_int, nullptr));
+        RH_HIP(hipEventRecord(c->evk[1], c->stream));
+        RH_HIP(hipEventSynchronize(c->evk[1]));
+        RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
+        RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
+        if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
+    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, c->d_nk, bound, b, d_counts, d_masks_int, ms_kind));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     if (ms_kind) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));

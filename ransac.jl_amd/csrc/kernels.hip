@@ -369,29 +369,117 @@ __device__ __forceinline__ void sprefetch_wait(rh_u32x16 &lo, rh_u32x8 &hi, rh_p
     for (int i = 0; i < 4; i++) { cv.u[0] = hi[2 * i]; cv.u[1] = hi[2 * i + 1]; out.f[8 + i] = cv.d; }
 }
 
-template <int KIND, bool MASK, int NT>
-__global__ void __launch_bounds__(NT)
-score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
-                    const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
-                    int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
-                    const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
-                    int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+
+// ---- stage 2a / 2b: band prefilter + pair queue (sphere, cylinder, cone) ----------------------
+// Of the points of a surviving (candidate, group) pair only ~10-30 % lie inside the candidate's
+// distance band, so running the exact test on the whole group wastes most lanes.  Stage 2a
+// evaluates a cheap CONSERVATIVE form of the distance half of the test on every lane
+// (squared distances against a band widened by `slack`, no sqrt / divide / normalisation) and
+// pushes the passing (candidate, point) pairs on a per-wave LDS ring; stage 2b pops 64 pairs at a
+// time and runs the exact test with one pair per lane (candidate record per lane), so its lanes are
+// dense.  A pair the exact test would accept always passes 2a: 2a uses the same leading operations
+// (sphere, cylinder) or a closed form of the same distance (cone) and its band is wider by >= 10^5 x
+// the rounding error; NaN (disabled points are staged as NaN) fails both.
+struct rh_pre { double a, b, c, d, e; };
+
+template <int KIND>
+__device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, double slack)
 {
+    rh_pre o = { -1.0, __builtin_inf(), 0.0, 0.0, 0.0 };
+    if (KIND == RH_SPHERE || KIND == RH_CYLINDER) {
+        const double R = KIND == RH_SPHERE ? P.f[3] : P.f[6];
+        const double hi = (R + eps) + slack, lo = (R - eps) - slack;
+        double hi2 = hi > 0.0 ? hi * hi * (1.0 + 1e-9) : 0.0;
+        if (!(hi == hi)) hi2 = __builtin_inf();
+        o.a = lo > 0.0 ? lo * lo * (1.0 - 1e-9) : -1.0;   // NaN -> -1: everything passes the lower bound
+        o.b = hi2;
+        return o;
+    }
+    // cone: with t = p - apex, h = t . a^ (a^ = unit axis), rho^2 = |t|^2 - h^2 the reference's distance is
+    // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = the record's cos / sin of -opang/2): |dist| < eps  <=>
+    // rho in (k h - e, k h + e), k = -s / c, e = eps sqrt(c^2 + s^2) / c     (c > 0)
+    const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7];
+    const double an = sqrt((ax * ax + ay * ay) + az * az), cs = sqrt(c * c + sn * sn);
+    const bool ok = (c > 1e-6 * cs) & (an > 0.0) & (an < __builtin_inf());
+    const double ia = 1.0 / an;
+    o.a = ok ? ax * ia : 0.0; o.b = ok ? ay * ia : 0.0; o.c = ok ? az * ia : 0.0;
+    o.d = ok ? -sn / c : 0.0;
+    const double e = (eps * cs / c) * (1.0 + 1e-9) + slack * (1.0 + fabs(sn / c));
+    o.e = (ok & (e == e)) ? e : __builtin_inf();              // inf: every (non-NaN) point goes to the exact test
+    return o;
+}
+
+__device__ __forceinline__ double rl_f64(double v, int l)
+{
+    union { double d; uint32_t u[2]; } cv;
+    cv.d = v;
+    cv.u[0] = __builtin_amdgcn_readlane(cv.u[0], l);
+    cv.u[1] = __builtin_amdgcn_readlane(cv.u[1], l);
+    return cv.d;
+}
+
+// wave mask of the points that may pass the distance half of the exact test
+template <int KIND>
+__device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_pre &Q, double px, double py, double pz)
+{
+    if (KIND == RH_SPHERE) {
+        const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
+        const double n2 = (dx * dx + dy * dy) + dz * dz;
+        return WB(n2 >= Q.a) & WB(n2 <= Q.b);
+    }
+    if (KIND == RH_CYLINDER) {
+        const double ax = P.f[0], ay = P.f[1], az = P.f[2];
+        const double cx = P.f[3], cy = P.f[4], cz = P.f[5];
+        const double tx = px - cx, ty = py - cy, tz = pz - cz;
+        const double sd = (ax * tx + ay * ty) + az * tz;
+        const double qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
+        const double n2 = (qx * qx + qy * qy) + qz * qz;
+        return WB(n2 >= Q.a) & WB(n2 <= Q.b);
+    }
+    const double tx = px - P.f[0], ty = py - P.f[1], tz = pz - P.f[2];
+    const double tt = (tx * tx + ty * ty) + tz * tz;
+    const double h = (tx * Q.a + ty * Q.b) + tz * Q.c;
+    const double rho2 = tt - h * h;
+    const double u = Q.d * h;
+    const double lo = u - Q.e, hi = u + Q.e;
+    const double s2 = 1e-9 * tt + 1e-300;
+    const double hi2 = hi * hi * (1.0 + 1e-9) + s2, lo2 = lo * lo * (1.0 - 1e-9) - s2;
+    // next to the axis the reference's frame is ill-conditioned: hand those points to the exact test
+    const uint64_t near_axis = WB(rho2 <= 1e-10 * tt);
+    return near_axis | (WB(hi > 0.0) & WB(rho2 <= hi2) & (WB(lo <= 0.0) | WB(rho2 >= lo2)));
+}
+
+// LDS of one block of the culled score kernel (declared once per kernel, shared by the per-kind bodies)
+struct G2Shared {
     // points of the tile as three 16-byte planes (x,y) (z,nx) (ny,nz): one ds_read_b128 each per test.
     // Disabled / out-of-range points are staged with x = NaN: every distance test is then false, so
     // the inner loop needs no enabled word.
-    __shared__ rh_f64x2 lp[3][RH_G2_TILE];
-    __shared__ double lb[7][RH_G2_TG];
-    __shared__ uint64_t len[RH_G2_TG];
-    __shared__ int next_chunk;
+    rh_f64x2 lp[3][RH_G2_TILE];
+    double lb[7][RH_G2_TG];
+    uint64_t len[RH_G2_TG];
+    uint16_t pq[4][128];     // per-wave ring of (candidate-in-chunk << 8 | point-in-tile)
+    int32_t pcnt[4][64];     // per-wave inlier counts of the current chunk
+    int next_chunk;
+};
 
-    const int nk = *nk_ptr;
-    const int nchunks = (nk + 63) >> 6;
-    const int cpb = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int chunk_lo = (int)blockIdx.y * cpb;
-    const int chunk_hi = min(nchunks, chunk_lo + cpb);
-    if (chunk_lo >= chunk_hi) return;
+template <int KIND, bool MASK, int NT>
+__device__ __forceinline__ void
+score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const double *__restrict__ pts, int64_t stride, int64_t s,
+                  const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
+                  int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
+                  const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
+                  int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+{
+    static_assert(NT == 256, "four waves per block: one tile of RH_G2_TG groups, G2Shared::pq / pcnt rows");
+    auto &lp = sh.lp;
+    auto &lb = sh.lb;
+    auto &len = sh.len;
+    auto &pq = sh.pq;
+    auto &pcnt = sh.pcnt;
+    int &next_chunk = sh.next_chunk;
+    constexpr bool QUEUED = !MASK && KIND != RH_PLANE;     // plane: the exact test is as cheap as a prefilter
 
+    const int nk = *nk_ptr;     // chunk_lo < chunk_hi <= ceil(nk / 64): 64-candidate chunks of this block
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t g0 = (int64_t)blockIdx.x * RH_G2_TG;
     const int64_t p0 = g0 * 64;
@@ -435,6 +523,7 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
 
         // ---- stage 1: lane = candidate, one box test per group of the tile
         unsigned surv = 0;
+        rh_pre Ql = { 0.0, 0.0, 0.0, 0.0, 0.0 };
         if (ci < nk) {
             const rh_prep Pl = prep[ci];
             const double slack = box_slack(Pl, coord_mag);
@@ -446,13 +535,71 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
                 surv |= skip ? 0u : (1u << g);
             }
             if (dbg == 2) surv = (1u << RH_G2_TG) - 1u;
+            if (QUEUED) Ql = pre_make<KIND>(Pl, eps, slack);
         }
         if (dbg == 1) surv = 0;
 
-        // ---- stage 2: lane = point, exact test for the surviving (candidate, group) pairs
         uint64_t todo = WB(surv != 0);
         int acc = 0;
-        if (todo != 0) {
+        if constexpr (QUEUED) {
+            // ---- stage 2a: lane = point, band prefilter; passing pairs go on the wave's ring
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            int qh = 0, qn = 0;                       // ring head / fill (wave-uniform)
+            pcnt[wv][lane] = 0;
+            // ---- stage 2b: lane = queued pair, exact test, one LDS add per inlier
+            auto drain = [&](int k) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool act = lane < k;
+                const unsigned e = act ? pq[wv][(qh + lane) & 127] : 0u;
+                const int l2 = (int)(e >> 8), i2 = (int)(e & 255u);
+                const rh_prep Pv = prep[cbase + l2];
+                const rh_f64x2 a = lp[0][i2], b = lp[1][i2], c = lp[2][i2];
+                const uint64_t r = test_point<KIND>(Pv, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
+                if (act && ((r >> lane) & 1ULL)) atomicAdd(&pcnt[wv][l2], 1);
+            };
+            if (todo != 0) {
+                int l = __builtin_ctzll(todo);
+                rh_u32x16 nlo;
+                rh_u32x8 nhi;
+                rh_prep P;
+                sprefetch_issue(&prep[cbase + l], nlo, nhi);
+                sprefetch_wait(nlo, nhi, P);
+                for (;;) {
+                    todo &= todo - 1;
+                    const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
+                    sprefetch_issue(&prep[cbase + ln], nlo, nhi);
+                    unsigned rem = __builtin_amdgcn_readlane(surv, l);
+                    rh_pre Q;
+                    Q.a = rl_f64(Ql.a, l); Q.b = rl_f64(Ql.b, l);
+                    if (KIND == RH_CONE) { Q.c = rl_f64(Ql.c, l); Q.d = rl_f64(Ql.d, l); Q.e = rl_f64(Ql.e, l); }
+                    while (rem != 0) {
+                        const int g = __builtin_ctz(rem);
+                        rem &= rem - 1;
+                        const int i = (g << 6) + lane;
+                        const rh_f64x2 a = lp[0][i];
+                        const double z = lp[1][i].x;
+                        const uint64_t m = pre_test<KIND>(P, Q, a.x, a.y, z);
+                        if (m != 0) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                            if ((m >> lane) & 1ULL) pq[wv][(qh + qn + rank) & 127] = (uint16_t)((l << 8) | i);
+                            qn += __popcll(m);
+                            if (qn >= 64) { drain(64); qh = (qh + 64) & 127; qn -= 64; }
+                        }
+                    }
+                    sprefetch_wait(nlo, nhi, P);
+                    if (todo == 0) break;
+                    l = ln;
+                }
+                if (qn > 0) drain(qn);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                acc = pcnt[wv][lane];
+            }
+        } else if (todo != 0) {
+            // ---- stage 2: lane = point, exact test for the surviving (candidate, group) pairs
             int l = __builtin_ctzll(todo);
             rh_u32x16 nlo;
             rh_u32x8 nhi;
@@ -484,6 +631,69 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
         }
         if (acc != 0) atomicAdd(&counts[orig[ci]], acc);
     }
+}
+
+template <int KIND, bool MASK, int NT>
+__global__ void __launch_bounds__(NT)
+score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
+                    const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
+                    int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
+                    const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
+                    int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+{
+    __shared__ G2Shared sh;
+    const int nchunks = (*nk_ptr + 63) >> 6;
+    const int cpb = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int chunk_lo = (int)blockIdx.y * cpb, chunk_hi = min(nchunks, chunk_lo + cpb);
+    if (chunk_lo >= chunk_hi) return;
+    score_groups_body<KIND, MASK, NT>(sh, chunk_lo, chunk_hi, pts, stride, s, enabled_words, gb, gstride, ngroups, prep,
+                                      orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg);
+}
+
+// All four kinds in ONE launch.  The 64-candidate chunks of the four kind bins are laid end to end,
+// the expensive kinds first (cone, cylinder, sphere, plane), and cut into gridDim.y equal rows; a
+// block runs the per-kind body on each segment of its row (almost always one).  The per-launch
+// floor (tile staging, box tests, tail) is paid once and the cheap kinds fill the tail.
+struct G2KindArgs {
+    const rh_prep *prep;
+    const int32_t *orig, *nk;
+    const uint64_t *en;
+    double eps, cosa;
+};
+struct G2AllArgs { G2KindArgs k[4]; };
+
+template <bool MASK>
+__global__ void __launch_bounds__(256)
+score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const double *__restrict__ gb,
+                        int64_t gstride, int64_t ngroups, const G2AllArgs A, double coord_mag,
+                        int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+{
+    __shared__ G2Shared sh;
+    int nch[4], total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
+    const int cpb = (total + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int lo = (int)blockIdx.y * cpb, hi = min(total, lo + cpb);
+    if (lo >= hi) return;
+    int base = 0;
+    bool ran = false;
+#define RH_G2_BODY(K)                                                                                                  \
+    {                                                                                                                  \
+        const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
+        if (slo < shi) {                                                                                               \
+            if (ran) __syncthreads();   /* the previous segment's waves are done with the tile in LDS */              \
+            score_groups_body<K, MASK, 256>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,             \
+                                            A.k[K].prep, A.k[K].orig, A.k[K].nk, A.k[K].eps, A.k[K].cosa, coord_mag,   \
+                                            counts, masks, mask_stride, dbg);                                         \
+            ran = true;                                                                                                \
+        }                                                                                                              \
+        base += nch[K];                                                                                                \
+    }
+    RH_G2_BODY(RH_CONE)
+    RH_G2_BODY(RH_CYLINDER)
+    RH_G2_BODY(RH_SPHERE)
+    RH_G2_BODY(RH_PLANE)
+#undef RH_G2_BODY
 }
 
 // one wave per 64-point group: axis-aligned box of its valid points
@@ -803,6 +1013,20 @@ __global__ void transpose_kernel(const double *__restrict__ xyz, const double *_
     dst[5 * stride + j] = nrm[3 * i + 2];
 }
 
+// 64-byte point records for the sampler's random gathers (one HBM line per point instead of six)
+__global__ void pack_records_kernel(const double *__restrict__ xyz, const double *__restrict__ nrm, int64_t n,
+                                    rh_f64x2 *__restrict__ rec)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    rh_f64x2 a, b, c, d;
+    a.x = xyz[3 * j]; a.y = xyz[3 * j + 1];
+    b.x = xyz[3 * j + 2]; b.y = nrm[3 * j];
+    c.x = nrm[3 * j + 1]; c.y = nrm[3 * j + 2];
+    d.x = 0.0; d.y = 0.0;
+    rec[4 * j] = a; rec[4 * j + 1] = b; rec[4 * j + 2] = c; rec[4 * j + 3] = d;
+}
+
 // men[pos[i]] = enabled[i] for every point: one thread per Morton position
 __global__ void oct_gather_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ perm,
                                           int64_t n, uint64_t *__restrict__ men)
@@ -920,6 +1144,14 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_xyz, const double *d_nrm, int
     if (count == 0) return RH_OK;
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, d_xyz, d_nrm, d_gather,
                        count, dst, dst_stride);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec)
+{
+    if (n == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_records_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_xyz, d_nrm, n, (rh_f64x2 *)d_rec);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1124,15 +1356,11 @@ static int launch_score_groups(rh_cloud *c, const GroupSet &G, const uint64_t *e
     if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
     if (rows < 1) rows = 1;
     dim3 grid((unsigned)ntiles, (unsigned)rows);
-    static int nt = -1;
-    if (nt < 0) { const char *e = getenv("RH_G2_NT"); nt = e ? atoi(e) : 256; }
 #define RH_G2_LAUNCH(M, NT)                                                                                          \
     hipLaunchKernelGGL((score_groups_kernel<KIND, M, NT>), grid, dim3(NT), 0, c->stream, G.pts, G.stride, G.s, en,  \
                        G.gb, G.gstride, G.ngroups, prep, orig, nk, eps, cosa, G.coord_mag, counts, masks,          \
                        G.mask_stride, dbg)
     if (masks) RH_G2_LAUNCH(true, 256);
-    else if (nt == 1024) RH_G2_LAUNCH(false, 1024);
-    else if (nt == 512) RH_G2_LAUNCH(false, 512);
     else RH_G2_LAUNCH(false, 256);
 #undef RH_G2_LAUNCH
     RH_HIP(hipGetLastError());
@@ -1159,6 +1387,36 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_pr
 {
     GroupSet G = { c->sub, c->s_pad, c->s, c->gb, c->ng_pad, c->ngroups, c->swords, c->coord_mag };
     return score_groups_dispatch(c, G, kind, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
+}
+
+// all kinds against subset 1 in one launch; nk_total_bound >= the number of candidates over all kinds
+int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
+                         const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
+                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int)
+{
+    const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
+    const int nchunks = cdiv(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
+    if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
+    static int env_blocks = -1, dbg = -1, env_cpb = -1;
+    if (env_blocks < 0) { const char *e = getenv("RH_G2_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
+    if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
+    const int min_cpb = env_cpb > 0 ? env_cpb : 8;
+    int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
+    if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
+    if (rows < 1) rows = 1;
+    if (rows > 65535) rows = 65535;
+    G2AllArgs A;
+    for (int k = 0; k < 4; k++) A.k[k] = { prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
+    dim3 grid((unsigned)ntiles, (unsigned)rows);
+    if (d_masks_int)
+        hipLaunchKernelGGL((score_groups_all_kernel<true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
+                           c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
+    else
+        hipLaunchKernelGGL((score_groups_all_kernel<false>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
+                           c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
 }
 
 // liveness pass: candidates against dis[first, first + cnt) (counts only); boxes are rebuilt for the segment

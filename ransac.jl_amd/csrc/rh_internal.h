@@ -64,6 +64,7 @@ struct rh_cloud {
 
     // HBM layout: six SoA planes of n_pad (resp. s_pad) doubles: x y z nx ny nz
     double *full = nullptr;            // full cloud, original order
+    double *rec = nullptr;             // the same points as 64-byte records (x y z nx ny nz 0 0): one line per random gather
     double *sub = nullptr;             // subset 1, subset order
     double *dis = nullptr;             // disabled subset-1 points (append-only), capacity s_pad + tile
     int64_t dis_stride = 0;
@@ -123,6 +124,7 @@ struct rh_cloud {
 // ---- kernel launchers (kernels.hip) -----------------------------------------
 int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_nrm, int64_t n,
                       const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
+int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap);
@@ -136,6 +138,9 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
 int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_or_null, const rh_prep *d_prep,
                           const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
                           int32_t *d_counts, uint64_t *d_masks_int_or_null);
+int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
+                         const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
+                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
 int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts);
 int rhk_group_bounds(rh_cloud *c);

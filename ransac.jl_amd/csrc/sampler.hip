@@ -34,7 +34,7 @@ constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the ho
 
 template <int DN>
 __global__ void __launch_bounds__(128)
-sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, DevEnabled en, int32_t n_enabled,
+sample_fit_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int32_t n_enabled,
                   const rhfit::OctView oc, const double *__restrict__ Pwin, const rh_params prm, uint64_t seed,
                   int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out,
                   int32_t cap, int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
@@ -77,11 +77,11 @@ sample_fit_kernel(const double *__restrict__ full, int64_t stride, int64_t n, De
 #pragma unroll
     for (int q = 0; q < drawN; q++) {
         const int64_t i0 = sd[q] - 1;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            fp[3 * q + k] = full[k * stride + i0];
-            fn[3 * q + k] = full[(3 + k) * stride + i0];
-        }
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 *r = (const f64x2 *)(rec + 8 * i0);   // one 64-byte record per point
+        const f64x2 a = r[0], b = r[1], c = r[2];
+        fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
+        fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
     }
     for (int ti = 0; ti < prm.n_shape_types; ti++) {
         rh_shape s;
@@ -129,12 +129,12 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     if (prm->drawN == 3)   // the reference's default: fully unrolled, no scratch
-        hipLaunchKernelGGL(sample_fit_kernel<3>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full,
-                           c->n_pad, c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
+        hipLaunchKernelGGL(sample_fit_kernel<3>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->rec,
+                           c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
                            d_gave_up);
     else
-        hipLaunchKernelGGL(sample_fit_kernel<0>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->full,
-                           c->n_pad, c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
+        hipLaunchKernelGGL(sample_fit_kernel<0>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->rec,
+                           c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
                            d_gave_up);
     RH_HIP(hipGetLastError());
     return RH_OK;
