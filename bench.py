@@ -320,7 +320,7 @@ def main():
             t_e2e = time.perf_counter() - t0
             last_it = max([g.iteration for g in got], default=0)
             out["end_to_end"] = {"metric": "shapes_per_sec", "value": len(got) / t_e2e, "shapes": len(got), "seconds": t_e2e,
-                                 "iterations": st["iterations"], "minimal_sets": st["iterations"] * 4096,
+                                 "seconds_rh_ransac": st["seconds"], "iterations": st["iterations"], "minimal_sets": st["iterations"] * 4096,
                                  "minimal_sets_per_sec": st["iterations"] * 4096 / t_e2e,
                                  "candidates_scored": st["candidates_scored"], "last_extraction_iteration": last_it,
                                  "breakdown_s": {"sample_fit": st["seconds_host"], "score": st["seconds_score"],
@@ -341,7 +341,7 @@ def main():
             goto_, _, sto = R.ransac(pc, ocp, seed=1234, return_stats=True)
             t_oct = time.perf_counter() - t0
             out["end_to_end_octree"] = {
-                "metric": "shapes_per_sec", "value": len(goto_) / t_oct, "shapes": len(goto_), "seconds": t_oct,
+                "metric": "shapes_per_sec", "value": len(goto_) / t_oct, "shapes": len(goto_), "seconds": t_oct, "seconds_rh_ransac": sto["seconds"],
                 "iterations": sto["iterations"], "candidates_scored": sto["candidates_scored"],
                 "last_extraction_iteration": max([g.iteration for g in goto_], default=0),
                 "breakdown_s": {"sample_fit": sto["seconds_host"], "score": sto["seconds_score"], "extract": sto["seconds_extract"]},

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 102
+#define RH_VERSION 103
 
 enum {
     RH_OK = 0,
@@ -196,7 +196,7 @@ int64_t rh_rng_range(rh_rng *r, int64_t n);
 typedef struct {
     rh_shape shape;
     int64_t n_inpoints;
-    int64_t *inpoints;       /* ascending, 1-based; owned by the result */
+    int64_t *inpoints;       /* ascending, 1-based; points into the result's arena (rh_result_free) */
     double score_E;
     int64_t iteration;
 } rh_extracted;              /* ExtractedShape, src/fitting.jl:81-84 */
@@ -211,6 +211,7 @@ typedef struct {
     double seconds_score;    /* device time in score launches + count read-back */
     double seconds_extract;  /* refit + invalidate + candidate liveness */
     double seconds_host;     /* sampling + fit + bookkeeping */
+    void *arena;             /* internal: the pinned host block that holds every inpoints list */
 } rh_result;
 
 /* xyz_aos / nrm_aos: the same host arrays given to rh_cloud_create (read for the

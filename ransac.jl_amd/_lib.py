@@ -43,7 +43,8 @@ class Extracted(C.Structure):
 class Result(C.Structure):
     _fields_ = [("shapes", C.POINTER(Extracted)), ("n_shapes", C.c_int64), ("iterations", C.c_int64),
                 ("candidates_scored", C.c_int64), ("scored_left", C.c_int64), ("seconds", C.c_double),
-                ("seconds_score", C.c_double), ("seconds_extract", C.c_double), ("seconds_host", C.c_double)]
+                ("seconds_score", C.c_double), ("seconds_extract", C.c_double), ("seconds_host", C.c_double),
+                ("arena", C.c_void_p)]
 
 
 class RansacHipError(RuntimeError):

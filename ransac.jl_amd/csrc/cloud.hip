@@ -133,7 +133,7 @@ static void cloud_free(rh_cloud *c)
     if (!c) return;
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->sub); (void)hipFree(c->dis);
+    (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
@@ -293,6 +293,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
     CK(dev_alloc(&c->full, 6 * c->n_pad));
     CK(dev_alloc(&c->rec, 8 * std::max<int64_t>(n, 1)));
+    CK(dev_alloc(&c->sel_list, c->nwords * 64 + 64));
     CK(dev_alloc(&c->sub, 6 * c->s_pad));
     CK(dev_alloc(&c->dis, 6 * c->dis_stride));
     CK(dev_alloc(&c->sub_idx0, s));

@@ -31,6 +31,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "fit_shared.h"
@@ -171,10 +172,54 @@ int store_reserve_aux(rh_cloud *c, DeviceStore &st, int64_t need)
 
 }  // namespace
 
+// ---- result arenas ---------------------------------------------------------------------------
+// The index lists of a run (<= 8 bytes x the points enabled at its start) land in ONE pinned host
+// block: the D2H copies are asynchronous at PCIe rate and nothing is copied a second time
+// (pageable destinations cost ~0.25 ms per extracted shape at 10M points).  Pinning is slow, so
+// blocks are recycled through a small process-wide pool: rh_result_free hands the block back.
+namespace {
+struct ArenaBlock { void *p; size_t cap; bool in_use; };
+std::mutex g_arena_mu;
+std::vector<ArenaBlock> g_arenas;
+
+void *arena_acquire(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    int bestfit = -1;
+    for (size_t i = 0; i < g_arenas.size(); i++)
+        if (!g_arenas[i].in_use && g_arenas[i].cap >= bytes && (bestfit < 0 || g_arenas[i].cap < g_arenas[(size_t)bestfit].cap))
+            bestfit = (int)i;
+    if (bestfit >= 0) { g_arenas[(size_t)bestfit].in_use = true; return g_arenas[(size_t)bestfit].p; }
+    for (size_t i = 0; i < g_arenas.size();) {   // too small to be useful again: give the pages back
+        if (!g_arenas[i].in_use) { (void)hipHostFree(g_arenas[i].p); g_arenas.erase(g_arenas.begin() + (long)i); }
+        else i++;
+    }
+    void *p = nullptr;
+    const size_t cap = std::max<size_t>(bytes, 1 << 20);
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    g_arenas.push_back({ p, cap, true });
+    return p;
+}
+
+void arena_release(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    int nfree = 0;
+    for (ArenaBlock &b : g_arenas) nfree += !b.in_use;
+    for (size_t i = 0; i < g_arenas.size(); i++) {
+        if (g_arenas[i].p != p) continue;
+        if (nfree >= 2) { (void)hipHostFree(p); g_arenas.erase(g_arenas.begin() + (long)i); }
+        else g_arenas[i].in_use = false;
+        return;
+    }
+}
+}  // namespace
+
 extern "C" void rh_result_free(rh_result *r)
 {
     if (!r) return;
-    for (int64_t i = 0; i < r->n_shapes; i++) free(r->shapes[i].inpoints);
+    arena_release(r->arena);
     free(r->shapes);
     memset(r, 0, sizeof *r);
 }
@@ -219,17 +264,34 @@ struct Driver {
     std::vector<double> fp, fn;
 
     // device sampler buffers
-    rh_cand_entry *d_entries = nullptr;
-    int32_t entries_cap = 0;
-    int32_t *d_count = nullptr, *d_gave_up = nullptr;
-    unsigned long long *d_draws = nullptr;
-    int32_t draws_cap = 0;
+    // a sampled window in flight: device list + status, pinned landing zones, completion event
+    struct Window {
+        rh_cand_entry *d_entries = nullptr, *h_entries = nullptr;   // h_entries: pinned, head of the list
+        int32_t entries_cap = 0;
+        char *d_status = nullptr, *h_status = nullptr;              // int32 count, int32 gave_up, u64 draws[W]
+        int32_t *d_counts = nullptr, *h_counts = nullptr;           // inlier counts per list entry (h: pinned head)
+        bool scored = false;                                        // the counts were computed with the window
+        hipEvent_t ev = nullptr;
+        int64_t k = 0;
+        int32_t W = 0;
+        bool pending = false;
+    };
+    Window win[2];
+    static constexpr int32_t ENTRIES_HEAD = 512;
+
+    int64_t *arena = nullptr;           // pinned block for the extracted index lists (result arenas, above)
+    int64_t arena_used = 0, arena_cap = 0;
 
     ~Driver()
     {
-        for (rh_extracted &e : extracted) free(e.inpoints);
+        if (arena && c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in it
+        arena_release(arena);   // null once the result owns it
         store_free(c, st);
-        (void)hipFree(d_entries); (void)hipFree(d_count); (void)hipFree(d_gave_up); (void)hipFree(d_draws);
+        for (Window &w : win) {
+            (void)hipFree(w.d_entries); (void)hipFree(w.d_status); (void)hipFree(w.d_counts);
+            (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
+            if (w.ev) (void)hipEventDestroy(w.ev);
+        }
     }
 
     int init()
@@ -242,6 +304,10 @@ struct Driver {
         en.w.assign((size_t)c->nwords, 0);
         if (c->nwords > 0) RUN(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
         en.recount();
+        arena_cap = std::max<int64_t>(en.count, 1);   // a point is extracted at most once
+        arena = (int64_t *)arena_acquire(sizeof(int64_t) * (size_t)arena_cap);
+        if (!arena) { rh_set_error("rh_ransac: cannot pin %lld bytes for the index lists", (long long)(8 * arena_cap)); return RH_E_NOMEM; }
+        arena_used = 0;
         // the disabled list must describe the cloud as it is now (points disabled before the call)
         RUN(rhk_rebuild_sub_enabled(c, true, true));
         int32_t ndis = 0;
@@ -388,15 +454,24 @@ struct Driver {
         RUN(rh_ensure_batch(c, ncand));
         RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)ncand, c->stream));
         RUN(rhk_prep_sorted(c, st.d_shapes, ncand, c->d_prep));
-        for (int q = 0; q < 4; q++) {
-            if (nk[q] == 0) continue;
-            const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
-            if (c->use_groups)
-                RUN(rhk_score_kind_groups(c, q, enw, c->d_prep + off[q], st.d_idx + off[q], st.d_nk + q, nk[q], p->eps[q],
-                                          p->cos_alpha[q], st.counts, nullptr));
-            else
+        if (c->use_groups) {   // all kinds in one launch
+            const uint64_t *enw[4];
+            const rh_prep *pr[4];
+            const int32_t *og[4], *nkp[4];
+            for (int q = 0; q < 4; q++) {
+                enw[q] = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
+                pr[q] = c->d_prep + off[q];
+                og[q] = st.d_idx + off[q];
+                nkp[q] = st.d_nk + q;
+            }
+            RUN(rhk_score_all_groups(c, enw, pr, og, nkp, ncand, p->eps, p->cos_alpha, st.counts, nullptr));
+        } else {
+            for (int q = 0; q < 4; q++) {
+                if (nk[q] == 0) continue;
+                const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
                 RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, c->d_prep + off[q], st.d_idx + off[q], st.d_nk + q,
                                    nk[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
+            }
         }
         RUNH(hipMemcpyAsync(counts.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
         RUNH(hipStreamSynchronize(c->stream));
@@ -462,12 +537,13 @@ struct Driver {
         memset(&ex, 0, sizeof ex);
         ex.shape = bestshape;
         ex.n_inpoints = total;
-        ex.inpoints = (int64_t *)malloc(sizeof(int64_t) * (size_t)std::max<int32_t>(total, 1));
-        if (!ex.inpoints) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
-        extracted.push_back(ex);   // owned from here on
-        if (total > 0)
+        if (arena_used + total > arena_cap) { rh_set_error("rh_ransac: index arena overflow"); return RH_E_INTERNAL; }
+        ex.inpoints = arena + arena_used;
+        arena_used += total;
+        extracted.push_back(ex);
+        if (total > 0)   // pinned destination: asynchronous; idx_out is only rewritten by later work on this stream
             RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
-        RUNH(hipStreamSynchronize(c->stream));
+        if (host_sampling) RUNH(hipStreamSynchronize(c->stream));   // the host mirrors need the list now
         extracted.back().score_E = scr;
         extracted.back().iteration = k;
         double tq = now_s();
@@ -605,24 +681,35 @@ struct Driver {
     {
         const int64_t sets_budget = 1 << 20;
         const int64_t Kmax = std::max<int64_t>(1, std::min<int64_t>(128, sets_budget / std::max(1, p->minsubsetN)));
-        int64_t K = Kmax;        // window length in use; adapted to how often windows get cut short
-        int64_t Kcur = octree ? 1 : Kmax;
-        RUNH(hipMalloc((void **)&d_count, sizeof(int32_t)));
-        RUNH(hipMalloc((void **)&d_gave_up, sizeof(int32_t)));
-        draws_cap = (int32_t)K;
-        RUNH(hipMalloc((void **)&d_draws, sizeof(unsigned long long) * (size_t)draws_cap));
-        entries_cap = 1 << 16;
-        RUNH(hipMalloc((void **)&d_entries, sizeof(rh_cand_entry) * (size_t)entries_cap));
+        const int64_t K = Kmax;  // longest window
+        int64_t Kcur = octree ? 1 : Kmax;   // window length in use; adapted to how often windows get cut short
+        const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)K + 63) / 64 * 64;
+        for (Window &w : win) {
+            RUNH(hipMalloc((void **)&w.d_status, status_bytes));
+            RUNH(hipHostMalloc((void **)&w.h_status, status_bytes));
+            RUNH(hipHostMalloc((void **)&w.h_entries, sizeof(rh_cand_entry) * (size_t)ENTRIES_HEAD));
+            w.entries_cap = 1 << 16;
+            RUNH(hipMalloc((void **)&w.d_entries, sizeof(rh_cand_entry) * (size_t)w.entries_cap));
+            RUNH(hipMalloc((void **)&w.d_counts, sizeof(int32_t) * (size_t)w.entries_cap));
+            RUNH(hipHostMalloc((void **)&w.h_counts, sizeof(int32_t) * (size_t)ENTRIES_HEAD));
+            RUNH(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+        }
+        // With the culled score kernel (it takes its candidate counts from device memory) the window's
+        // candidates are scored on the device right after they are fitted, in the same stream: the
+        // host gets list + counts in one wait instead of a second round trip per window.
+        const bool fused_score = c->use_groups && !getenv("RH_NO_FUSED_SCORE");
+        int32_t cnt_est = 64;
+        // Without the octree a window's draws depend only on (seed, k, j) and the enabled bits, so the
+        // NEXT window is put on the stream before the host waits for this one: it is valid unless this
+        // one ends in an extraction (then it is dropped and drawn again).  The GPU samples window
+        // w + 1 while the host replays window w.
+        const bool pipeline = !octree && !getenv("RH_NO_PIPELINE");
         std::vector<rh_cand_entry> entries;
-        std::vector<unsigned long long> draws((size_t)K);
         std::vector<rh_shape> cands;
-        std::vector<int32_t> counts, levels;
+        std::vector<int32_t> counts, levels, wcounts, order;
+        std::vector<int64_t> slots;
         const int T = p->n_shape_types;
-        int64_t k = 1;
-        while (k <= p->itermax) {
-            if (en.count < p->tau) break;
-            const int32_t W = (int32_t)std::min<int64_t>(Kcur, p->itermax - k + 1);
-            const double t0 = now_s();
+        auto issue = [&](Window &w, int64_t k0, int32_t W) -> int {
             const double *d_P = nullptr;
             if (octree) {
                 // the level distribution of every iteration of the window, assuming no candidate is
@@ -644,42 +731,103 @@ struct Driver {
                 RUNH(hipMemcpyAsync(c->oct_P, Pwin.data(), sizeof(double) * Pwin.size(), hipMemcpyHostToDevice, c->stream));
                 d_P = c->oct_P;
             }
-            int32_t cnt = 0, gave_up = 0;
-            for (;;) {
-                RUN(rhk_sample_fit(c, p, rng->s[0], k, W, (int32_t)en.count, d_P, d_entries, entries_cap, d_count, d_draws, d_gave_up));
-                RUNH(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
-                RUNH(hipMemcpyAsync(&gave_up, d_gave_up, sizeof gave_up, hipMemcpyDeviceToHost, c->stream));
-                RUNH(hipMemcpyAsync(draws.data(), d_draws, sizeof(unsigned long long) * (size_t)W, hipMemcpyDeviceToHost, c->stream));
-                RUNH(hipStreamSynchronize(c->stream));
-                if (cnt <= entries_cap) break;
-                (void)hipFree(d_entries);   // the list overflowed: grow it and draw the window again
-                d_entries = nullptr;
-                entries_cap = cnt + cnt / 4;
-                RUNH(hipMalloc((void **)&d_entries, sizeof(rh_cand_entry) * (size_t)entries_cap));
+            RUN(rhk_sample_fit(c, p, rng->s[0], k0, W, (int32_t)en.count, d_P, w.d_entries, w.entries_cap, w.d_status));
+            w.scored = false;
+            if (fused_score) {
+                RUN(rh_ensure_batch(c, w.entries_cap));
+                // launch sizes from the previous windows' list lengths; any length is handled (the
+                // kernels read the true count), a longer list only gets fewer blocks per candidate
+                const int32_t bound = std::min<int32_t>(w.entries_cap, std::max<int32_t>(4 * cnt_est, 1024));
+                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts));
+                const uint64_t *enw[4];
+                const rh_prep *pr[4];
+                const int32_t *og[4], *nkp[4];
+                for (int q = 0; q < 4; q++) {
+                    enw[q] = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
+                    pr[q] = c->d_prep + (int64_t)q * c->batch_cap;
+                    og[q] = c->d_orig + (int64_t)q * c->batch_cap;
+                    nkp[q] = c->d_nk + q;
+                }
+                RUN(rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr));
+                RUNH(hipMemcpyAsync(w.h_counts, w.d_counts, sizeof(int32_t) * (size_t)ENTRIES_HEAD, hipMemcpyDeviceToHost, c->stream));
+                w.scored = true;
             }
+            RUNH(hipMemcpyAsync(w.h_status, w.d_status, 8 + sizeof(unsigned long long) * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+            RUNH(hipMemcpyAsync(w.h_entries, w.d_entries, sizeof(rh_cand_entry) * (size_t)ENTRIES_HEAD, hipMemcpyDeviceToHost, c->stream));
+            RUNH(hipEventRecord(w.ev, c->stream));
+            w.k = k0; w.W = W; w.pending = true;
+            return RH_OK;
+        };
+        int cur = 0;
+        int64_t k = 1;
+        while (k <= p->itermax) {
+            if (en.count < p->tau) break;
+            Window &A = win[cur], &B = win[1 - cur];
+            const double t0 = now_s();
+            if (!(A.pending && A.k == k)) RUN(issue(A, k, (int32_t)std::min<int64_t>(Kcur, p->itermax - k + 1)));
+            const int32_t W = A.W;
+            B.pending = false;
+            if (pipeline && k + W <= p->itermax) RUN(issue(B, k + W, (int32_t)std::min<int64_t>(Kcur, p->itermax - (k + W) + 1)));
+            RUNH(hipEventSynchronize(A.ev));
+            A.pending = false;
+            int32_t cnt = ((const int32_t *)A.h_status)[0];
+            const int32_t gave_up = ((const int32_t *)A.h_status)[1];
+            const unsigned long long *draws = (const unsigned long long *)(A.h_status + 8);
             if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
-            entries.resize((size_t)cnt);
-            if (cnt > 0) {
-                RUNH(hipMemcpyAsync(entries.data(), d_entries, sizeof(rh_cand_entry) * (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+            if (cnt > A.entries_cap) {   // the list overflowed: grow it and draw the window again
                 RUNH(hipStreamSynchronize(c->stream));
-                std::sort(entries.begin(), entries.end(),
-                          [](const rh_cand_entry &a, const rh_cand_entry &b) { return a.slot < b.slot; });
+                B.pending = false;
+                (void)hipFree(A.d_entries);
+                A.d_entries = nullptr;
+                A.entries_cap = cnt + cnt / 4;
+                RUNH(hipMalloc((void **)&A.d_entries, sizeof(rh_cand_entry) * (size_t)A.entries_cap));
+                (void)hipFree(A.d_counts);
+                A.d_counts = nullptr;
+                RUNH(hipMalloc((void **)&A.d_counts, sizeof(int32_t) * (size_t)A.entries_cap));
+                t_sample += now_s() - t0;
+                continue;
+            }
+            cnt_est = cnt;
+            entries.resize((size_t)cnt);
+            wcounts.resize((size_t)cnt);
+            if (cnt > 0) {
+                const int32_t head = std::min(cnt, ENTRIES_HEAD);
+                memcpy(entries.data(), A.h_entries, sizeof(rh_cand_entry) * (size_t)head);
+                if (A.scored) memcpy(wcounts.data(), A.h_counts, sizeof(int32_t) * (size_t)head);
+                if (cnt > head) {
+                    RUNH(hipMemcpyAsync(entries.data() + head, A.d_entries + head, sizeof(rh_cand_entry) * (size_t)(cnt - head),
+                                        hipMemcpyDeviceToHost, c->stream));
+                    if (A.scored)
+                        RUNH(hipMemcpyAsync(wcounts.data() + head, A.d_counts + head, sizeof(int32_t) * (size_t)(cnt - head),
+                                            hipMemcpyDeviceToHost, c->stream));
+                    RUNH(hipStreamSynchronize(c->stream));
+                }
+                // candidate order of the reference = slot order; the counts travel with their entries
+                order.resize((size_t)cnt);
+                for (int32_t i = 0; i < cnt; i++) order[(size_t)i] = i;
+                std::sort(order.begin(), order.end(),
+                          [&](int32_t a, int32_t b) { return entries[(size_t)a].slot < entries[(size_t)b].slot; });
             }
             t_sample += now_s() - t0;
             if (octree && cnt > 0) {
                 // candidates after the first candidate-bearing iteration were drawn from a stale level
-                // distribution: drop them before scoring (they are re-drawn in the next window)
+                // distribution: drop them (they are re-drawn in the next window)
                 const int64_t per_it = (int64_t)p->minsubsetN * T;
-                const int64_t first_it = entries[0].slot / per_it;
+                const int64_t first_it = entries[(size_t)order[0]].slot / per_it;
                 int32_t keep = 0;
-                while (keep < cnt && entries[(size_t)keep].slot / per_it == first_it) keep++;
+                while (keep < cnt && entries[(size_t)order[(size_t)keep]].slot / per_it == first_it) keep++;
                 cnt = keep;
-                entries.resize((size_t)cnt);
             }
             cands.resize((size_t)cnt);
             levels.resize((size_t)cnt);
-            for (int32_t i = 0; i < cnt; i++) { cands[(size_t)i] = entries[(size_t)i].shape; levels[(size_t)i] = entries[(size_t)i].level; }
-            RUN(score(cands.data(), cnt, counts));
+            slots.resize((size_t)cnt);
+            counts.resize((size_t)cnt);
+            for (int32_t i = 0; i < cnt; i++) {
+                const rh_cand_entry &e = entries[(size_t)order[(size_t)i]];
+                cands[(size_t)i] = e.shape; levels[(size_t)i] = e.level; slots[(size_t)i] = e.slot;
+                if (A.scored) counts[(size_t)i] = wcounts[(size_t)order[(size_t)i]];
+            }
+            if (!A.scored) RUN(score(cands.data(), cnt, counts));
             // replay the window in iteration order
             int32_t pos = 0;
             bool stop = false, did = false;
@@ -689,8 +837,8 @@ struct Driver {
                 if (en.count < p->tau) { stop = true; break; }   // iterations.jl:75 (only after an extraction)
                 const int64_t slot_end = (int64_t)(it + 1) * p->minsubsetN * T;
                 int32_t e = pos;
-                while (e < cnt && entries[(size_t)e].slot < slot_end) e++;
-                rng->draws += (int64_t)draws[(size_t)it];
+                while (e < cnt && slots[(size_t)e] < slot_end) e++;
+                rng->draws += (int64_t)draws[it];
                 RUN(finish_iteration(kk, cands.data() + pos, levels.data() + pos, e - pos, counts.data() + pos, &did, &stop));
                 const bool cut = octree && e > pos;   // new scores change the level distribution
                 pos = e;
@@ -698,11 +846,15 @@ struct Driver {
             }
             k += it;
             if (stop) break;
+            // the speculated window stands only if this one ran to its end without touching the enabled bits
+            if (B.pending && !did && it == W && B.k == k) cur = 1 - cur;
+            else B.pending = false;
             // a window cut short wasted its tail: halve; a window used to the end: double
-            if (it < W) Kcur = std::max<int64_t>(1, std::min<int64_t>(Kcur, it) / 2 + (it > 1 ? 0 : 0));
+            if (it < W) Kcur = std::max<int64_t>(1, std::min<int64_t>(Kcur, it) / 2);
             else Kcur = std::min<int64_t>(K, Kcur * 2);
-            if (Kcur < 1) Kcur = 1;
         }
+        // nothing of a dropped window may still be in flight when the buffers go away
+        RUNH(hipStreamSynchronize(c->stream));
         return RH_OK;
     }
 };
@@ -745,6 +897,7 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     d.host_sampling = !device_sampler;
     RH_TRY(d.init());
     RH_TRY(device_sampler ? d.run_streams_device() : d.run_sequential());
+    RH_HIP(hipStreamSynchronize(c->stream));   // the index lists have landed in the arena
 
     out->iterations = d.iterations;
     out->candidates_scored = d.cc[2];
@@ -753,7 +906,9 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     out->shapes = (rh_extracted *)malloc(sizeof(rh_extracted) * std::max<size_t>(d.extracted.size(), 1));
     if (!out->shapes) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
     for (size_t i = 0; i < d.extracted.size(); i++) out->shapes[i] = d.extracted[i];
-    d.extracted.clear();   // ownership of the index lists moved to the result
+    d.extracted.clear();
+    out->arena = d.arena;   // ownership of the index lists moved to the result
+    d.arena = nullptr;
     c->select_valid = false;
     out->seconds = now_s() - t_start;
     out->seconds_score = d.t_score;

@@ -192,6 +192,36 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
     orig[(int64_t)kind * cap + slot] = i;
 }
 
+// the sampler's candidate list (count on the device): bin by kind like prep_binned_kernel, zero the counts
+__global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
+                                    int32_t cap_entries, rh_prep *__restrict__ prep, int32_t *__restrict__ orig,
+                                    int32_t *__restrict__ nk, int64_t cap, int32_t *__restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int b = min(*count_ptr, cap_entries);
+    rh_shape s;
+    int kind = -1;
+    if (i < b) {
+        s = entries[i].shape;
+        counts[i] = 0;
+        if (s.kind >= 0 && s.kind <= 3) kind = s.kind;
+    }
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t m = WB(kind == k);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&nk[k], __popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+    }
+    if (kind < 0) return;
+    prep_one(s, prep[(int64_t)kind * cap + slot]);
+    orig[(int64_t)kind * cap + slot] = i;
+}
+
 // ------------------------------------------------------------- score ------
 // grid.x = point splits, grid.y = candidate tiles of RH_SC_CT.  A wave owns
 // RH_SC_WAVE_PTS contiguous points per tile (PPT x 64, PPT points per lane in
@@ -930,13 +960,16 @@ rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *
     }
 }
 
-// block b copies the points of gone words [b*1024, (b+1)*1024) to dis[base + prefix ...], in order
+// block b copies the points of gone words [b*1024, (b+1)*1024) to dis[base + prefix ...], in order:
+// block-wide exclusive scan of the word popcounts, then one wave per word with one lane per bit
 __global__ void __launch_bounds__(256)
 append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int32_t *__restrict__ block_prefix,
                    const double *__restrict__ sub, int64_t sub_stride, double *__restrict__ dis, int64_t dis_stride,
                    const int32_t *__restrict__ base_ptr)
 {
     __shared__ int32_t wsum[4];
+    __shared__ uint64_t lm[RH_WORDS_PER_BLOCK];
+    __shared__ int32_t lpre[RH_WORDS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
     uint64_t m[4];
@@ -956,18 +989,23 @@ append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int3
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < wave; k++) woff += wsum[k];
-    int64_t run = (int64_t)*base_ptr + block_prefix[blockIdx.x] + woff + inc - tsum;
+    int run = woff + inc - tsum;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int64_t w = wbase + threadIdx.x * 4 + k;
-        uint64_t bits = m[k];
-        while (bits) {
-            const int b = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const int64_t j = (w << 6) + b;
+        lm[threadIdx.x * 4 + k] = m[k];
+        lpre[threadIdx.x * 4 + k] = run;
+        run += __popcll(m[k]);
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)*base_ptr + block_prefix[blockIdx.x];
+    for (int wl = wave; wl < RH_WORDS_PER_BLOCK; wl += 4) {
+        const uint64_t bits = lm[wl];
+        if (bits == 0) continue;
+        if ((bits >> lane) & 1ULL) {
+            const int64_t j = ((wbase + wl) << 6) + lane;
+            const int64_t dst = base + lpre[wl] + __popcll(bits & ((1ULL << lane) - 1ULL));
 #pragma unroll
-            for (int q = 0; q < 6; q++) dis[q * dis_stride + run] = sub[q * sub_stride + j];
-            run++;
+            for (int q = 0; q < 6; q++) dis[q * dis_stride + dst] = sub[q * sub_stride + j];
         }
     }
 }
@@ -1164,6 +1202,18 @@ int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_
     return RH_OK;
 }
 
+// prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
+int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
+                     int32_t launch_bound, int32_t *d_counts)
+{
+    RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    if (launch_bound <= 0) return RH_OK;
+    hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
+                       cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap)
 {
@@ -1256,6 +1306,20 @@ int rhk_rebuild_sub_enabled(rh_cloud *c, bool append, bool reset)
     return RH_OK;
 }
 
+// one thread per bit: the set bits of word w land at word_prefix[w] + (rank inside the word);
+// a wave owns one word, so the writes of a dense mask are coalesced
+static __global__ void __launch_bounds__(256)
+expand_dense_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ word_prefix,
+                    int32_t *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = g >> 6;
+    if (w >= nwords) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t m = mask[w];
+    if ((m >> lane) & 1ULL) out[word_prefix[w] + __popcll(m & ((1ULL << lane) - 1ULL))] = (int32_t)g;
+}
+
 int rhk_build_select(rh_cloud *c)
 {
     if (c->nwords == 0) { c->select_valid = true; return RH_OK; }
@@ -1264,6 +1328,8 @@ int rhk_build_select(rh_cloud *c)
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
     hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
                        c->block_sums, (int64_t *)nullptr, (int64_t)0, c->word_prefix);
+    hipLaunchKernelGGL(expand_dense_kernel, dim3((unsigned)cdiv(c->nwords * 64, 256)), dim3(256), 0, c->stream, c->enabled,
+                       c->nwords, c->word_prefix, c->sel_list);
     RH_HIP(hipGetLastError());
     c->select_valid = true;
     return RH_OK;

@@ -64,6 +64,10 @@ struct rh_cloud {
 
     // HBM layout: six SoA planes of n_pad (resp. s_pad) doubles: x y z nx ny nz
     double *full = nullptr;            // full cloud, original order
+    double *set_ws = nullptr;          // sampler -> fitter hand-over: gathered minimal sets, [drawN * 6][sets]
+    int32_t *set_level = nullptr;      // per set: octree level it was drawn from, 0 = no set
+    int64_t set_ws_sets = 0, set_ws_doubles = 0;
+    int32_t *sel_list = nullptr;       // sel_list[r] = 0-based index of the (r+1)-th enabled point (valid with select_valid)
     double *rec = nullptr;             // the same points as 64-byte records (x y z nx ny nz 0 0): one line per random gather
     double *sub = nullptr;             // subset 1, subset order
     double *dis = nullptr;             // disabled subset-1 points (append-only), capacity s_pad + tile
@@ -126,6 +130,9 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_
                       const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
+struct rh_cand_entry;
+int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
+                     int32_t launch_bound, int32_t *d_counts);
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap);
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
@@ -169,8 +176,7 @@ struct rh_cand_entry {
 };
 // d_P: null (root-cell sampling) or n_iters x oct_depth level distributions
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   const double *d_P, rh_cand_entry *d_out, int32_t cap, int32_t *d_count,
-                   unsigned long long *d_draws, int32_t *d_gave_up);
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status);
 int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth);   // cloud.hip
 int rhk_oct_sync_enabled(rh_cloud *c);                                  // men = permuted enabled; prefix
 int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask);             // clear the bits of an original-order mask

@@ -1,9 +1,10 @@
 // sampler.hip -- device-side minimal-set sampling + fitting (sampling_streams = 1).
 // One thread per (iteration, minimal set): draws the set from its own splitmix64 stream
-// (fit_shared.h), gathers the points, runs the plane / sphere / cylinder fits in the order of
-// iteration.shape_types (forcefitshapes!, src/fitting.jl:165-173) and appends every fitted
-// candidate, tagged with its slot = ((iteration, set), shape type), to a compact list.  The host
-// sorts the list by slot, which restores the reference's candidate order exactly.
+// (fit_shared.h) and gathers the points (sample_sets_kernel); a second kernel runs the plane /
+// sphere / cylinder / cone fits in the order of iteration.shape_types (forcefitshapes!,
+// src/fitting.jl:165-173) and appends every fitted candidate, tagged with its slot =
+// ((iteration, set), shape type), to a compact list.  The host sorts the list by slot, which
+// restores the reference's candidate order exactly.
 #include "fit_shared.h"
 #include "rh_internal.h"
 
@@ -15,42 +16,37 @@ struct DevEnabled {
     int64_t nwords;
     int32_t total;
     __device__ bool test(int64_t i0) const { return (w[i0 >> 6] >> (i0 & 63)) & 1ULL; }
-    __device__ int64_t select(int64_t r) const
-    {
-        if (r < 1 || r > total) return 0;
-        int64_t lo = 0, hi = nwords;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (prefix[mid] < r) lo = mid; else hi = mid;
-        }
-        uint64_t m = w[lo];
-        const int rem = (int)(r - prefix[lo]);
-        for (int t = 1; t < rem; t++) m &= m - 1;
-        return (lo << 6) + __ffsll((unsigned long long)m);
-    }
+    // r-th enabled point (1-based), 0 when out of range: one read of the select list the cloud
+    // rebuilds whenever the enabled bits change (a binary search over the word prefixes costs ~17
+    // dependent L2 reads per draw and bounded the kernel by latency)
+    const int32_t *sel;
+    __device__ int64_t select(int64_t r) const { return (r < 1 || r > total) ? 0 : (int64_t)sel[r - 1] + 1; }
 };
 
 constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the host sampler
 
+// Two kernels.  sample_sets_kernel is latency-bound (dependent random reads of enabled words, then
+// the point gathers) and needs few registers, so it runs at full occupancy; it hands the gathered
+// sets over in a coalesced [component][set] workspace.  fit_sets_kernel is the arithmetic (up to
+// ~400 VGPRs with the cone fit's two 3x3 SVDs inlined) and reads that workspace with unit stride.
 template <int DN>
-__global__ void __launch_bounds__(128)
-sample_fit_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int32_t n_enabled,
-                  const rhfit::OctView oc, const double *__restrict__ Pwin, const rh_params prm, uint64_t seed,
-                  int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out,
-                  int32_t cap, int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
-                  int32_t *__restrict__ gave_up_flag)
+__global__ void __launch_bounds__(256)
+sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int32_t n_enabled,
+                   const rhfit::OctView oc, const double *__restrict__ Pwin, int32_t drawN_rt, int32_t minsubsetN,
+                   uint64_t seed, int64_t k0, int32_t n_iters, double *__restrict__ ws, int32_t *__restrict__ set_level,
+                   unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)n_iters * prm.minsubsetN;
+    const int64_t total = (int64_t)n_iters * minsubsetN;
     if (t >= total) return;
-    const int32_t it = (int32_t)(t / prm.minsubsetN);
-    const int32_t j = (int32_t)(t - (int64_t)it * prm.minsubsetN);
+    const int32_t it = (int32_t)(t / minsubsetN);
+    const int32_t j = (int32_t)(t - (int64_t)it * minsubsetN);
     uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
     constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
     int64_t sd[CAP];
     uint32_t nd = 0;
     bool gave_up = false;
-    const int drawN = DN > 0 ? DN : prm.drawN;
+    const int drawN = DN > 0 ? DN : drawN_rt;
     int level = 1;
     const bool ok = Pwin != nullptr
                         ? rhfit::sample_minimal_set_octree<DN>(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled,
@@ -72,16 +68,39 @@ sample_fit_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int3
         }
     }
     if (gave_up) atomicExch(gave_up_flag, 1);
+    set_level[t] = ok ? level : 0;
     if (!ok) return;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < drawN; q++) {
+        const f64x2 *r = (const f64x2 *)(rec + 8 * (sd[q] - 1));   // one 64-byte record per point
+        const f64x2 a = r[0], b = r[1], c = r[2];
+        double *w = ws + (int64_t)(6 * q) * total + t;
+        w[0] = a.x; w[total] = a.y; w[2 * total] = b.x;
+        w[3 * total] = b.y; w[4 * total] = c.x; w[5 * total] = c.y;
+    }
+}
+
+template <int DN, bool CONE>
+__global__ void __launch_bounds__(128)
+fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_level, int64_t total, const rh_params prm,
+                rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int level = set_level[t];
+    if (level == 0) return;
+    constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
+    const int drawN = DN > 0 ? DN : prm.drawN;
     double fp[3 * CAP], fn[3 * CAP];
 #pragma unroll
     for (int q = 0; q < drawN; q++) {
-        const int64_t i0 = sd[q] - 1;
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-        const f64x2 *r = (const f64x2 *)(rec + 8 * i0);   // one 64-byte record per point
-        const f64x2 a = r[0], b = r[1], c = r[2];
-        fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
-        fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
+        const double *w = ws + (int64_t)(6 * q) * total + t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            fp[3 * q + k] = w[k * total];
+            fn[3 * q + k] = w[(3 + k) * total];
+        }
     }
     for (int ti = 0; ti < prm.n_shape_types; ti++) {
         rh_shape s;
@@ -93,7 +112,7 @@ sample_fit_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int3
         case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
         case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
         case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
-        case RH_CONE: fitted = rhfit::fit_cone(fp, fn, drawN, prm, &s); break;
+        case RH_CONE: if (CONE) fitted = rhfit::fit_cone(fp, fn, drawN, prm, &s); break;
         default: break;
         }
         if (!fitted) continue;
@@ -110,14 +129,15 @@ sample_fit_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int3
 }  // namespace
 
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   const double *d_P, rh_cand_entry *d_out, int32_t cap, int32_t *d_count, unsigned long long *d_draws,
-                   int32_t *d_gave_up)
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status)
 {
+    // status block: int32 count, int32 gave_up, u64 draws[n_iters]
+    int32_t *d_count = (int32_t *)d_status, *d_gave_up = d_count + 1;
+    unsigned long long *d_draws = (unsigned long long *)((char *)d_status + 8);
     if (prm->drawN > RH_MAX_DRAWN) { rh_set_error("device sampler supports drawN <= %d", RH_MAX_DRAWN); return RH_E_INVALID; }
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
-    RH_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
-    RH_HIP(hipMemsetAsync(d_gave_up, 0, sizeof(int32_t), c->stream));
-    RH_HIP(hipMemsetAsync(d_draws, 0, sizeof(unsigned long long) * (size_t)n_iters, c->stream));
+    // (the block is a multiple of 64 bytes: one aligned fill)
+    RH_HIP(hipMemsetAsync(d_status, 0, (size_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 64), c->stream));
     const int64_t total = (int64_t)n_iters * prm->minsubsetN;
     if (total == 0) return RH_OK;
     DevEnabled en;
@@ -125,17 +145,42 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     en.prefix = c->word_prefix;
     en.nwords = c->nwords;
     en.total = n_enabled;
+    en.sel = c->sel_list;
     rhfit::OctView oc;
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
-    if (prm->drawN == 3)   // the reference's default: fully unrolled, no scratch
-        hipLaunchKernelGGL(sample_fit_kernel<3>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->rec,
-                           c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
-                           d_gave_up);
-    else
-        hipLaunchKernelGGL(sample_fit_kernel<0>, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, c->stream, c->rec,
-                           c->n, en, n_enabled, oc, d_P, *prm, seed, k0, n_iters, d_out, cap, d_count, d_draws,
-                           d_gave_up);
+    // hand-over workspace (grown on demand; a window of 128 x 4096 sets of 3 points is 75 MB)
+    const int64_t need = total * 6 * prm->drawN;
+    if (c->set_ws_doubles < need) {
+        (void)hipFree(c->set_ws);
+        c->set_ws = nullptr; c->set_ws_doubles = 0;
+        RH_HIP(hipMalloc((void **)&c->set_ws, sizeof(double) * (size_t)need));
+        c->set_ws_doubles = need;
+    }
+    if (c->set_ws_sets < total) {
+        (void)hipFree(c->set_level);
+        c->set_level = nullptr; c->set_ws_sets = 0;
+        RH_HIP(hipMalloc((void **)&c->set_level, sizeof(int32_t) * (size_t)total));
+        c->set_ws_sets = total;
+    }
+    bool cone = false;
+    for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
+    const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
+#define RH_SAMPLE(DN)                                                                                                  \
+    hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
+                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up)
+#define RH_FIT(DN, CONE)                                                                                               \
+    hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
+                       d_out, cap, d_count)
+    if (prm->drawN == 3) {   // the reference's default: fully unrolled, no scratch
+        RH_SAMPLE(3);
+        if (cone) RH_FIT(3, true); else RH_FIT(3, false);
+    } else {
+        RH_SAMPLE(0);
+        if (cone) RH_FIT(0, true); else RH_FIT(0, false);
+    }
+#undef RH_SAMPLE
+#undef RH_FIT
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
