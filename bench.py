@@ -140,12 +140,17 @@ def main():
     arr = shapes_to_c(R, L, cands)
     batch = rdist.DeviceBatch(pc, arr, b_global)
     counts = torch.zeros(b_global, dtype=torch.int32, device="cuda")
-    local = rdist.gpu_local_score(pc, batch, cp)
+    # N > 1: the cloud shares torch's stream, so fill -> score -> all-reduce are ordered on the device
+    # and a step has no host synchronisation (RH_BENCH_SPLIT_STREAMS=1: the library's own stream + two waits)
+    same_stream = world > 1 and not os.environ.get("RH_BENCH_SPLIT_STREAMS")
+    if same_stream:
+        pc.set_stream(torch.cuda.current_stream().cuda_stream)
+    local = rdist.gpu_local_score(pc, batch, cp, wait=not same_stream)
     lo, hi = rdist.shard_bounds(b_global, rank, world)
 
     def step():
         if world > 1:
-            rdist.score_batch_sharded(b_global, rank, world, local, counts)
+            rdist.score_batch_sharded(b_global, rank, world, local, counts, same_stream=same_stream)
         else:   # no collective, no host sync inside the timed region
             L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp),
                                            C.c_void_p(counts.data_ptr()), None))

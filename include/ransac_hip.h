@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 103
+#define RH_VERSION 104
 
 enum {
     RH_OK = 0,
@@ -242,6 +242,12 @@ int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, c
 /* device time of the most recent rh_refit on this cloud: the full-cloud scan kernel and the
  * compaction (popcount + scan + expansion), from HIP events on the cloud's stream */
 int rh_last_refit_ms(rh_cloud *c, float *ms_scan_out, float *ms_compact_out);
+/* Stream the cloud's kernels and copies are enqueued on.  By default a cloud owns a non-blocking
+ * stream.  use_external = 1: use the caller's hipStream_t (0 = the null stream) from now on, so the
+ * caller can order its own work (a fill before, an RCCL collective after) against a
+ * rh_score_batch_dev WITHOUT host synchronisation; use_external = 0: back to the own stream.
+ * Waits for the work already enqueued on the previous stream.  The caller keeps the stream alive. */
+int rh_cloud_set_stream(rh_cloud *c, void *hip_stream, int use_external);
 int rh_timer_start(rh_cloud *c);
 int rh_timer_stop(rh_cloud *c, float *ms_out); /* synchronises the stream */
 int rh_cloud_sync(rh_cloud *c);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rh_cloud_count_enabled": (C.c_int, [_vp, _i64p]),
     "rh_score_batch": (C.c_int, [_vp, _sp, C.c_int32, _pp, _i32p, _u64p]),
     "rh_score_batch_dev": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp]),
+    "rh_cloud_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "rh_score_batch_dev_timed": (C.c_int, [_vp, _vp, C.c_int32, _pp, _vp, _vp, C.POINTER(C.c_float)]),
     "rh_refit": (C.c_int, [_vp, _sp, _pp, _i64p, C.c_int64, _i64p]),
     "rh_refit_lsq": (C.c_int, [_vp, _sp, _pp, C.c_int32, _sp, _i64p, _dp, _i32p]),
@@ -104,6 +105,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libransac_hip.so needs) and loads it by file name: if the system copy
+    under /opt/rocm is mapped first, a later `import torch` maps a SECOND runtime that finds no device
+    ("no ROCm-capable device is detected").  When torch is installed but not imported yet, map its copy
+    first so both sides bind to the same one (RH_SYSTEM_HIP=1 skips this)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("RH_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def lib():
     """The loaded library.  Raises if libransac_hip.so is missing (run `python -c 'import
     __graft_entry__ as g; g.build()'` or `python ransac.jl_amd/build.py`)."""
@@ -113,6 +135,7 @@ def lib():
             raise RuntimeError(
                 "%s is missing: the HIP extension has not been built and this package has no CPU "
                 "fallback (build it with ransac.jl_amd/build.py)" % SO_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

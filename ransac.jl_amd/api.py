@@ -328,6 +328,11 @@ class RANSACCloud:
     def enable_all(self):
         check(lib().rh_cloud_enable_all(self._h))
 
+    def set_stream(self, hip_stream):
+        """Enqueue this cloud's work on the caller's HIP stream (an int handle, e.g.
+        torch.cuda.current_stream().cuda_stream; None = back to the cloud's own stream)."""
+        check(lib().rh_cloud_set_stream(self._h, C.c_void_p(hip_stream or 0), 0 if hip_stream is None else 1))
+
     def count_enabled(self):
         out = C.c_int64()
         check(lib().rh_cloud_count_enabled(self._h, C.byref(out)))

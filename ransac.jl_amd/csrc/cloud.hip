@@ -148,7 +148,7 @@ static void cloud_free(rh_cloud *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 5; k++)
         if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -287,7 +287,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     };
 #define CK(x) do { rc = (x); if (rc != RH_OK) return fail(rc); } while (0)
 #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); return fail(RH_E_NODEVICE); } } while (0)
-    CKH(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CKH(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     CKH(hipEventCreate(&c->ev0));
     CKH(hipEventCreate(&c->ev1));
     for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
@@ -712,6 +713,14 @@ extern "C" int rh_timer_stop(rh_cloud *c, float *ms_out)
     float ms = 0.f;
     RH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (ms_out) *ms_out = ms;
+    return RH_OK;
+}
+
+extern "C" int rh_cloud_set_stream(rh_cloud *c, void *hip_stream, int use_external)
+{
+    RH_TRY(enter(c));
+    RH_HIP(hipStreamSynchronize(c->stream));   // nothing of this cloud may still be in flight on the old stream
+    c->stream = use_external ? (hipStream_t)hip_stream : c->own_stream;
     return RH_OK;
 }
 

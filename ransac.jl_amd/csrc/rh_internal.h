@@ -54,7 +54,8 @@ constexpr int64_t RH_G2_MIN_POINTS = 8192;               // below this the brute
 // ---- the cloud --------------------------------------------------------------
 struct rh_cloud {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every launch / copy of this cloud goes to
+    hipStream_t own_stream = nullptr;  // created with the cloud; `stream` is this or the caller's (rh_cloud_set_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // per-kind launch brackets
     int64_t n = 0, s = 0;

@@ -27,12 +27,15 @@ def allreduce_counts(counts_full, group=None):
     return counts_full
 
 
-def score_batch_sharded(b, rank, world, local_score, counts_full, group=None):
-    """counts_full: zeroed int32 tensor [b] on the rank's device.  local_score(lo, hi, out_view)
-    must fill out_view (= counts_full[lo:hi]) with the counts of candidates lo..hi-1."""
+def score_batch_sharded(b, rank, world, local_score, counts_full, group=None, same_stream=False):
+    """counts_full: int32 tensor [b] on the rank's device.  local_score(lo, hi, out_view) must fill
+    out_view (= counts_full[lo:hi]) with the counts of candidates lo..hi-1.
+    same_stream: the cloud was put on torch's current stream (RANSACCloud.set_stream) and local_score
+    does not wait -- fill, scoring and collective are then ordered by the stream alone, with no host
+    synchronisation inside a step."""
     lo, hi = shard_bounds(b, rank, world)
     counts_full.zero_()
-    if counts_full.is_cuda:
+    if counts_full.is_cuda and not same_stream:
         # the fill runs on torch's stream, the scoring on the library's: order them
         import torch
         torch.cuda.current_stream(counts_full.device).synchronize()
@@ -60,12 +63,14 @@ class DeviceBatch:
             self.d_shapes = None
 
 
-def gpu_local_score(pc, batch, cparams):
+def gpu_local_score(pc, batch, cparams, wait=True):
     """local_score callback: scores candidates lo..hi-1 of `batch` on pc's device, writing
-    straight into the torch tensor view (device pointer), then waits for the stream."""
+    straight into the torch tensor view (device pointer); wait=True waits for the cloud's stream
+    (needed unless the cloud shares torch's stream, see score_batch_sharded)."""
     def fn(lo, hi, out_view):
         assert out_view.is_cuda and out_view.dtype.itemsize == 4 and out_view.is_contiguous()
         check(lib().rh_score_batch_dev(pc._h, batch.slice_ptr(lo), hi - lo, C.byref(cparams),
                                        C.c_void_p(out_view.data_ptr()), None))
-        check(lib().rh_cloud_sync(pc._h))
+        if wait:
+            check(lib().rh_cloud_sync(pc._h))
     return fn

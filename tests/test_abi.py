@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libransac_hip.so does not export %s" % s
         assert s in L.SIGNATURES, "python binding has no signature for %s" % s
     assert sorted(L.SIGNATURES) == syms
-    assert lib.rh_version() == 103
+    assert lib.rh_version() == 104
 
 
 def test_struct_layouts_match_oracle():

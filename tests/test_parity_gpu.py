@@ -512,3 +512,29 @@ def test_full_size_properties_cfg2():
         assert R.refit(cand, pc, cp).inpoints.size == 0
     assert pc.count_enabled() == n - int(seen.sum())
     assert np.array_equal(pc.isenabled, ~seen)
+
+
+def test_score_on_callers_stream_matches():
+    """rh_cloud_set_stream: the cloud's work goes to a torch stream; a fill before and a read after are
+    ordered by that stream alone (what dist.score_batch_sharded(same_stream=True) relies on)."""
+    import torch
+    from ransac_jl_amd import dist as rdist
+    xyz, nrm, truth = synth.make_cloud(200_000, ["plane", "sphere", "cylinder", "cone"], 0.2, seed=77)
+    subs = synth.make_subsets(200_000, 4, seed=77)
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder, R.FittedCone]))
+    shapes = make_candidates(truth, 300, seed=3)
+    want = R.score_batch(pc, shapes, cp)
+    arr = (L.Shape * len(shapes))(*[s.to_c() for s in shapes])
+    batch = rdist.DeviceBatch(pc, arr, len(shapes))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        pc.set_stream(st.cuda_stream)
+        counts = torch.full((len(shapes),), -7, dtype=torch.int32, device="cuda")
+        fn = rdist.gpu_local_score(pc, batch, cp, wait=False)
+        for _ in range(3):
+            rdist.score_batch_sharded(len(shapes), 0, 1, fn, counts, same_stream=True)
+        got = counts.cpu().numpy()      # stream-ordered copy on `st`
+    pc.set_stream(None)
+    batch.free()
+    assert np.array_equal(got, np.asarray(want))
