@@ -308,6 +308,20 @@ def main():
                                    "sample": "first %d candidates of the same batch on the same subset (S=%d), "
                                              "%.1f s; counts checked equal to the GPU's" % (nb, S, t_cpu),
                                    "host_cpus": os.cpu_count()}
+            # steelman: the same passes spread over the host cores this GPU's share allows (OpenMP over candidates)
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            nb_mt = min(b_global, 192 * nthr)
+            oarr_mt = (orc.Shape * nb_mt)()
+            C.memmove(oarr_mt, arr, C.sizeof(L.Shape) * nb_mt)
+            t0 = time.perf_counter()
+            mt_counts = oc.score_batch_mt(oarr_mt, op, nthr)
+            t_mt = time.perf_counter() - t0
+            if not np.array_equal(mt_counts, counts_h[:nb_mt]):
+                raise SystemExit("PARITY FAILURE: GPU counts differ from the oracle on the multi-thread sample")
+            out["cpu_baseline_all_cores"] = {"value": nb_mt / t_mt, "unit": "candidates/s", "cores": nthr, "kind": "port",
+                                             "sample": "first %d candidates of the same batch, OpenMP over candidates "
+                                                       "(the reference itself is single-threaded), %.1f s; counts "
+                                                       "checked equal to the GPU's" % (nb_mt, t_mt)}
             del oc
 
         # ---- end to end: shapes / s of the whole ransac() loop on the same cloud ----------

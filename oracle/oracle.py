@@ -128,6 +128,7 @@ def lib():
         "orc_cloud_count_enabled": (C.c_int64, [C.c_void_p]),
         "orc_scorecandidate": (C.c_int64, [C.c_void_p, sp, pp, i64p, u64p]),
         "orc_score_batch": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p]),
+        "orc_score_batch_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, C.c_int32]),
         "orc_refit": (C.c_int64, [C.c_void_p, sp, pp, i64p, C.c_int64]),
         "orc_invalidate": (None, [C.c_void_p, i64p, C.c_int64]),
         "orc_refit_lsq": (C.c_int, [C.c_void_p, sp, pp, C.c_int, sp, i64p, dp, i32p]),
@@ -261,6 +262,14 @@ class Cloud:
                               counts.ctypes.data_as(C.POINTER(C.c_int32)),
                               masks.ctypes.data_as(C.POINTER(C.c_uint64)) if want_masks else None)
         return (counts[:b], masks[:b, :w]) if want_masks else counts[:b]
+
+    def score_batch_mt(self, shapes, params, nthreads):
+        """Counts only, candidates spread over `nthreads` host threads (OpenMP)."""
+        b = len(shapes)
+        arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
+        counts = np.zeros(max(1, b), dtype=np.int32)
+        lib().orc_score_batch_mt(self.h, arr, b, C.byref(params), counts.ctypes.data_as(C.POINTER(C.c_int32)), nthreads)
+        return counts[:b]
 
     def refit(self, shape, params):
         out = np.zeros(max(1, self.n), dtype=np.int64)

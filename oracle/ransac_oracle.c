@@ -378,6 +378,17 @@ void orc_score_batch(const orc_cloud *c, const orc_shape *s, int32_t b, const or
         counts[i] = (int32_t)orc_scorecandidate(c, &s[i], p, NULL, masks ? masks + (size_t)i * w : NULL);
 }
 
+/* Steelman of the CPU side for bench.py: the same per-candidate passes spread over host threads (the
+ * reference has no threading at all; candidates are independent, fitting.jl:182-186). */
+void orc_score_batch_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                        int32_t *counts, int32_t nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (int32_t i = 0; i < b; i++)
+        counts[i] = (int32_t)orc_scorecandidate(c, &s[i], p, NULL, NULL);
+}
+
 /* refit: plane.jl:137-143, sphere.jl:179-190, cylinder.jl:228-234, cone.jl:176-182 */
 int64_t orc_refit(const orc_cloud *c, const orc_shape *s, const orc_params *p, int64_t *idx_out, int64_t cap)
 {

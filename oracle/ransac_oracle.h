@@ -121,6 +121,8 @@ int64_t orc_scorecandidate(const orc_cloud *c, const orc_shape *s, const orc_par
 /* batched: counts[b] */
 void orc_score_batch(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
                      int32_t *counts, uint64_t *masks /* b x ceil(s/64) or NULL */);
+void orc_score_batch_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                        int32_t *counts, int32_t nthreads);   /* OpenMP over candidates (bench steelman) */
 /* refit (plane.jl:137-143 etc.): ascending 1-based indices; returns count */
 int64_t orc_refit(const orc_cloud *c, const orc_shape *s, const orc_params *p,
                   int64_t *idx_out, int64_t cap);

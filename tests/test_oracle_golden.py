@@ -1,6 +1,7 @@
 """Pins the CPU oracle against the reference's own known-answer tests
 (tests/golden/reference_known_answers.json, transcribed from
 /root/reference/test/*.jl -- SURVEY.md 8c)."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -144,3 +145,21 @@ def test_largestconncomp(golden, case):  # test/parameterspacebitmap.jl:1-55
         lin = orc.largestconncomp(bm, conn8=conn8)
         exp = g[case][key]
         assert cc_indices(bm, idx, lin) == exp["idx"] * exp["repeat"]
+
+
+def test_multithreaded_score_batch_equals_sequential():
+    """bench.py's all-cores steelman (OpenMP over candidates) returns the sequential oracle's counts."""
+    from ransac_jl_amd import synth
+    xyz, nrm, truth = synth.make_cloud(20_000, ["plane", "sphere", "cylinder", "cone"], 0.2, seed=5)
+    subs = synth.make_subsets(20_000, 4, seed=5)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    p = orc.default_params()
+    cands = synth.jittered_candidates(truth, 64, seed=1)
+    arr = (orc.Shape * len(cands))()
+    kmap = {"plane": 0, "sphere": 1, "cylinder": 2, "cone": 3}
+    for i, (name, outw, v) in enumerate(cands):
+        arr[i].kind, arr[i].outwards = kmap[name], int(outw)
+        for j, x in enumerate(v):
+            arr[i].v[j] = float(x)
+        orc.lib().orc_shape_finalize(C.byref(arr[i]))
+    assert np.array_equal(oc.score_batch(arr, p), oc.score_batch_mt(arr, p, 4))

@@ -350,11 +350,16 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
     (["plane", "sphere", "cylinder", "cone"], "all", 12, False),                             # cones on the device as well
     (["plane", "sphere", "cylinder", "cone"], "all", 12, True),                              # host twin of the sampler
     (["plane", "plane"], "p", 13, False),
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_PIPELINE"),      # one window at a time
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SCORE"),   # scores through the host
 ])
 def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
-    """sampling_streams = 1: sampling + fitting on the device, iterations speculated in windows;
-    must equal the oracle's strictly sequential loop over the same per-set streams."""
-    if host:
+    """sampling_streams = 1: sampling + fitting + scoring on the device, iterations speculated in
+    pipelined windows; must equal the oracle's strictly sequential loop over the same per-set streams
+    (also with each pipeline stage switched off)."""
+    if isinstance(host, str):
+        monkeypatch.setenv(host, "1")
+    elif host:
         monkeypatch.setenv("RH_HOST_SAMPLER", "1")
     xyz, nrm, truth = synth.make_cloud(30_000, prims, 0.1, seed=60 + seed)
     subs = synth.make_subsets(30_000, 2, seed=seed)
