@@ -327,23 +327,28 @@ __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, double cy,
         return fabs(d) > (ext + eps) + slack;
     }
     if (KIND == RH_SPHERE) {
-        // |p - o| lies between the min and max distance from o to the box
+        // |p - o| lies between the min and max distance from o to the box; compared as squares (no sqrt:
+        // the thresholds carry `slack`, 10^6 x the rounding of the squares)
         const double ax = fabs(cx - P.f[0]), ay = fabs(cy - P.f[1]), az = fabs(cz - P.f[2]);
         const double nx = fmax(ax - hx, 0.0), ny = fmax(ay - hy, 0.0), nz = fmax(az - hz, 0.0);
         const double fx = ax + hx, fy = ay + hy, fz = az + hz;
-        const double dmin = sqrt((nx * nx + ny * ny) + nz * nz), dmax = sqrt((fx * fx + fy * fy) + fz * fz);
-        return (dmin > (P.f[3] + eps) + slack) | (dmax < (P.f[3] - eps) - slack);
+        const double dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+        const double A = (P.f[3] + eps) + slack, B = (P.f[3] - eps) - slack;
+        const double A2 = A > 0.0 ? A * A : (A <= 0.0 ? 0.0 : A);   // A <= 0: any positive distance is outside; NaN stays NaN
+        return (dmin2 > A2) | ((B > 0.0) & (dmax2 < B * B));
     }
     if (KIND == RH_CYLINDER) {
-        // q(p) = (I - a a')(p - c0) is linear: |q(p) - q(c)| <= max(1, |1 - |a|^2|) * |p - c|
+        // q(p) = (I - a a')(p - c0) is linear: |q(p) - q(c)| <= max(1, |1 - |a|^2|) * |p - c|; squares as above
         const double ax = P.f[0], ay = P.f[1], az = P.f[2];
         const double tx = cx - P.f[3], ty = cy - P.f[4], tz = cz - P.f[5];
         const double sd = (ax * tx + ay * ty) + az * tz;
         const double qx = (cx - ax * sd) - P.f[3], qy = (cy - ay * sd) - P.f[4], qz = (cz - az * sd) - P.f[5];
-        const double rho = sqrt((qx * qx + qy * qy) + qz * qz);
+        const double rho2 = (qx * qx + qy * qy) + qz * qz;
         const double a2 = (ax * ax + ay * ay) + az * az;
         const double lip = fmax(1.0, fabs(1.0 - a2)) * hr;
-        return (rho - lip > (P.f[6] + eps) + slack) | (rho + lip < (P.f[6] - eps) - slack);
+        const double X = ((P.f[6] + eps) + slack) + lip, Y = ((P.f[6] - eps) - slack) - lip;
+        const double X2 = X > 0.0 ? X * X : (X <= 0.0 ? 0.0 : X);
+        return (rho2 > X2) | ((Y > 0.0) & (rho2 < Y * Y));
     }
     // cone: dist(p) = cos(w/2) rho(p) +- sin(w/2) h(p) (rho, h = radial / axial coordinate of p - apex;
     // the axis only enters through normalized cross products) is 1-Lipschitz in p
