@@ -334,8 +334,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
         CK(rhk_pack_records(c, t_xyz, t_nrm, n, c->rec));
         if (s > 0) {
-            // internal order of subset 1 = Morton order of its points: 64 consecutive points are
-            // spatially compact, which is what the culled score kernel's per-group boxes need
+            // internal order of subset 1: 64 consecutive points are spatially compact, which is what the
+            // culled score kernel's per-group boxes need (k-d leaves, below)
             h_idx = new (std::nothrow) int32_t[2 * (size_t)s];
             if (!h_idx) { rh_set_error("out of host memory"); return fail(RH_E_NOMEM); }
             double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 }, mag = 0;
@@ -352,23 +352,72 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
                 first = false;
             }
             c->coord_mag = mag;
-            std::vector<std::pair<uint64_t, int32_t>> keys((size_t)s);
-            for (int64_t j = 0; j < s; j++) {
-                const double *pp = xyz + 3 * (subset1[j] - 1);
-                uint64_t code = 0;
-                for (int k = 0; k < 3; k++) {
-                    const double ext = hi[k] - lo[k];
-                    double t = ext > 0 ? (pp[k] - lo[k]) / ext : 0.0;
-                    if (!(t >= 0)) t = 0;
-                    if (t > 1) t = 1;
-                    code |= spread21((uint64_t)(t * 2097151.0)) << k;
+            // Internal order = leaves of a balanced k-d tree, 64 points each (median split along the widest
+            // axis of the node's box, the left child always a multiple of 64 so that only the LAST group
+            // is partial).  Against Morton order the groups' boxes are ~30 % smaller in radius and
+            // 16-26 % fewer (candidate, group) pairs survive the box tests (cfg3).  RH_SUB_ORDER=morton
+            // keeps the Morton order (A/B).
+            std::vector<int32_t> order((size_t)s);
+            for (int64_t j = 0; j < s; j++) order[(size_t)j] = (int32_t)j;
+            const char *ord_env = getenv("RH_SUB_ORDER");
+            if (ord_env && ord_env[0] == 'm') {
+                std::vector<std::pair<uint64_t, int32_t>> keys((size_t)s);
+                for (int64_t j = 0; j < s; j++) {
+                    const double *pp = xyz + 3 * (subset1[j] - 1);
+                    uint64_t code = 0;
+                    for (int k = 0; k < 3; k++) {
+                        const double ext = hi[k] - lo[k];
+                        double t = ext > 0 ? (pp[k] - lo[k]) / ext : 0.0;
+                        if (!(t >= 0)) t = 0;
+                        if (t > 1) t = 1;
+                        code |= spread21((uint64_t)(t * 2097151.0)) << k;
+                    }
+                    keys[(size_t)j] = std::make_pair(code, (int32_t)j);
                 }
-                keys[(size_t)j] = std::make_pair(code, (int32_t)j);
+                std::sort(keys.begin(), keys.end());
+                for (int64_t i = 0; i < s; i++) order[(size_t)i] = keys[(size_t)i].second;
+            } else {
+                struct Node { int64_t lo, hi; };
+                std::vector<Node> stack;
+                stack.push_back({ 0, s });
+                auto key = [&](int32_t j, int ax) {   // NaN sorts last; the order only has to be total
+                    const double v = xyz[3 * (subset1[j] - 1) + ax];
+                    return v == v ? v : HUGE_VAL;
+                };
+                while (!stack.empty()) {
+                    const Node nd = stack.back();
+                    stack.pop_back();
+                    const int64_t cnt = nd.hi - nd.lo;
+                    if (cnt <= 64) continue;
+                    double blo[3] = { HUGE_VAL, HUGE_VAL, HUGE_VAL }, bhi[3] = { -HUGE_VAL, -HUGE_VAL, -HUGE_VAL };
+                    for (int64_t i = nd.lo; i < nd.hi; i++) {
+                        const double *pp = xyz + 3 * (subset1[order[(size_t)i]] - 1);
+                        for (int k = 0; k < 3; k++) {
+                            const double v = pp[k];
+                            if (!(v == v) || v - v != 0) continue;
+                            if (v < blo[k]) blo[k] = v;
+                            if (v > bhi[k]) bhi[k] = v;
+                        }
+                    }
+                    int ax = 0;
+                    double best = -1;
+                    for (int k = 0; k < 3; k++) {
+                        const double e = bhi[k] - blo[k];
+                        if (e > best) { best = e; ax = k; }
+                    }
+                    const int64_t nl = ((cnt / 64 + 1) / 2) * 64;
+                    std::nth_element(order.begin() + nd.lo, order.begin() + nd.lo + nl, order.begin() + nd.hi,
+                                     [&](int32_t a, int32_t b) {
+                                         const double ka = key(a, ax), kb = key(b, ax);
+                                         return ka < kb || (ka == kb && a < b);
+                                     });
+                    stack.push_back({ nd.lo + nl, nd.hi });
+                    stack.push_back({ nd.lo, nd.lo + nl });
+                }
             }
-            std::sort(keys.begin(), keys.end());
             int32_t *h_perm = h_idx + s;
             for (int64_t i = 0; i < s; i++) {
-                h_perm[i] = keys[(size_t)i].second;
+                h_perm[i] = order[(size_t)i];
                 h_idx[i] = (int32_t)(subset1[h_perm[i]] - 1);
             }
             CKH(hipMemcpyAsync(c->sub_idx0, h_idx, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
