@@ -301,7 +301,7 @@ score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
 }
 
 // ------------------------------------------------- culled score (groups) ----
-// Subset 1 is stored in Morton order; every 64 consecutive points form a group with an
+// Subset 1 is stored in k-d leaf order (cloud.hip); every 64 consecutive points form a group with an
 // axis-aligned box (centre c, half extents h, radius hr = |h|).  A block stages a tile of
 // RH_G2_TG groups in LDS.  Per 64-candidate chunk a wave runs
 //   stage 1 (lane = candidate): one conservative box test per (candidate, group) -> survivor bits;
@@ -767,7 +767,7 @@ group_bounds_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, i
     }
 }
 
-// masks in internal (Morton) order -> subset order; `out` must be zeroed
+// masks in internal (k-d leaf) order -> subset order; `out` must be zeroed
 __global__ void unpermute_masks_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ perm, int64_t swords,
                                        int64_t total_words, uint64_t *__restrict__ out)
 {
@@ -942,7 +942,7 @@ __global__ void andnot_kernel(uint64_t *__restrict__ enabled, const uint64_t *__
 
 // sub_enabled bit j = enabled[sub_idx0[j]]; gone[w] = the bits that went 1 -> 0 (or, with reset, every
 // disabled bit): the points the liveness pass has to look at.  They are appended to `dis` in internal
-// (Morton) order by append_gone_kernel, so consecutive 64-point groups of `dis` are spatially compact.
+// (k-d leaf) order by append_gone_kernel, so consecutive 64-point groups of `dis` are spatially compact.
 __global__ void __launch_bounds__(256)
 rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ sub_idx0, int64_t s,
                            uint64_t *__restrict__ sub_enabled, uint64_t *__restrict__ gone_out, int reset)

@@ -76,7 +76,7 @@ struct rh_cloud {
     int32_t *sub_idx0 = nullptr;       // [s] 0-based original index of subset position j
     uint64_t *enabled = nullptr;       // [nwords]  pc.isenabled chunks
     uint64_t *sub_enabled = nullptr;   // [swords]  enabled bits gathered into subset order
-    int32_t *sub_perm = nullptr;       // [s] internal (Morton) position -> subset position j
+    int32_t *sub_perm = nullptr;       // [s] internal (k-d leaf order) position -> subset position j
     double *gb = nullptr;              // 7 planes x ng_pad: box centre cx cy cz, half extents hx hy hz, radius hr
     int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
     double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
@@ -142,7 +142,7 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
                    const uint64_t *enabled_words_or_null, const rh_prep *d_prep, const int32_t *d_orig,
                    const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
                    uint64_t *d_masks_or_null, int64_t mask_stride);
-// culled path over c->sub (Morton order + per-group boxes); masks (optional) are in INTERNAL order
+// culled path over c->sub (k-d leaf order + per-group boxes); masks (optional) are in INTERNAL order
 int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_or_null, const rh_prep *d_prep,
                           const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
                           int32_t *d_counts, uint64_t *d_masks_int_or_null);
