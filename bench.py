@@ -74,6 +74,18 @@ def pmc_traffic(kernel_key, enabled):
     return (2.0 * rd[0] + wr[0]) * 1024.0
 
 
+def pmc_sq(kernel_key, counter, enabled):
+    """Per-launch SQ counter (summed over the chip) from the committed pass profiles/rN/pmc_sq_counters.json."""
+    if not enabled:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_sq_counters.json")))
+    if not files:
+        return None
+    v = [r["mean"] for r in json.load(open(files[-1])) if r["counter"] == counter and kernel_key in r["kernel"]]
+    return v[0] if v else None
+
+
 def shapes_to_c(R, L, cands):
     arr = (L.Shape * max(1, len(cands)))()
     kmap = {"plane": L.PLANE, "sphere": L.SPHERE, "cylinder": L.CYLINDER, "cone": L.CONE}
@@ -243,10 +255,15 @@ def main():
             "achieved": flops / sec / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flops / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_issue_frac": issue / (1024 * 2.4e9 * sec),
+            "valu_issue_frac_measured": (lambda n_: None if n_ is None else n_ * 4 / (1024 * 2.4e9 * sec))(
+                pmc_sq(pmc_key, "SQ_INSTS_VALU", pmc_ok)),
             "note": "EFFECTIVE: reference flops/test x ALGORITHMIC tests / time (no FMA allowed: bit-exact parity "
                     "caps real work at half the FMA peak). valu_issue_frac = f64 vector instructions the brute-force "
                     "kernel would issue x 4 cycles / (1024 SIMDs x 2.4 GHz x time): > 1 means the culled kernel "
-                    "skipped that share of the per-point tests (RH_SCORE_PATH=brute measures the un-culled kernel)",
+                    "skipped that share of the per-point tests (RH_SCORE_PATH=brute measures the un-culled kernel). "
+                    "valu_issue_frac_measured = SQ_INSTS_VALU of this kernel (committed PMC pass, profiles/rN/"
+                    "pmc_sq_counters.json) x 4 cycles / (1024 SIMDs x 2.4 GHz x the live launch time): the share of "
+                    "vector-ALU issue slots the kernel really fills",
         }
         # the host-buffer form of the same step (rh_score_batch: H2D of the shapes, D2H of the counts, one sync)
         hcounts = np.zeros(hi - lo, dtype=np.int32)
