@@ -543,3 +543,30 @@ def test_score_on_callers_stream_matches():
     pc.set_stream(None)
     batch.free()
     assert np.array_equal(got, np.asarray(want))
+
+
+def test_non_finite_and_duplicate_points_match_oracle():
+    """NaN / inf coordinates and normals and heavy duplication in subset 1: the k-d leaf order, the
+    group boxes and the band prefilter must leave every count equal to the oracle's (NaN never passes)."""
+    rng = np.random.default_rng(5)
+    xyz, nrm, truth = synth.make_cloud(40_000, ["plane", "sphere", "cylinder", "cone"], 0.2, seed=91)
+    xyz = xyz.copy(); nrm = nrm.copy()
+    bad = rng.choice(40_000, size=400, replace=False)
+    xyz[bad[:100], rng.integers(0, 3, 100)] = np.nan
+    xyz[bad[100:200], rng.integers(0, 3, 100)] = np.inf
+    xyz[bad[200:250], rng.integers(0, 3, 50)] = -np.inf
+    nrm[bad[250:350], rng.integers(0, 3, 100)] = np.nan
+    nrm[bad[350:400]] = 0.0
+    xyz[5000:9000] = xyz[4999]          # 4000 copies of one point: zero-extent k-d nodes
+    nrm[5000:9000] = nrm[4999]
+    subs = synth.make_subsets(40_000, 2, seed=9)
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder, R.FittedCone]))
+    shapes = make_candidates(truth, 200, seed=2)
+    got, gmask = R.score_batch(pc, shapes, cp, want_masks=True)
+    arr = (L.Shape * len(shapes))(*[s.to_c() for s in shapes])
+    exp, emask = oc.score_batch(to_orc_shapes(arr, len(shapes)), to_orc_params(cp), want_masks=True)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(gmask, emask)
+    assert got.max() > 100
