@@ -160,14 +160,24 @@ def main():
     local = rdist.gpu_local_score(pc, batch, cp, wait=not same_stream)
     lo, hi = rdist.shard_bounds(b_global, rank, world)
 
+    # N > 1: two batches in flight -- batch i's all-reduce overlaps batch i + 1's score launch
+    # (RH_BENCH_NO_OVERLAP=1: one batch at a time)
+    scorer = None
+    if world > 1 and not os.environ.get("RH_BENCH_NO_OVERLAP"):
+        scorer = rdist.ShardedScorer(b_global, rank, world, local, "cuda", same_stream=same_stream)
+
     def step():
-        if world > 1:
+        if scorer is not None:
+            scorer.submit()
+        elif world > 1:
             rdist.score_batch_sharded(b_global, rank, world, local, counts, same_stream=same_stream)
         else:   # no collective, no host sync inside the timed region
             L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp),
                                            C.c_void_p(counts.data_ptr()), None))
 
     def fence():
+        if scorer is not None:
+            scorer.drain()      # every batch's collective has been waited for before the clock stops
         L.check(lib.rh_cloud_sync(pc._h))
         torch.cuda.synchronize()
         if world > 1:
@@ -191,7 +201,7 @@ def main():
         dt = float(tmax.item())
     ms_per_step = 1e3 * dt / args.steps
     value = b_global * args.steps / dt
-    counts_h = counts.cpu().numpy()
+    counts_h = (scorer.result(scorer.k - 1) if scorer is not None else counts).cpu().numpy()
 
     out = {
         "metric": "candidates_scored_per_sec", "value": value, "unit": "candidates/s", "n_gpus": world,

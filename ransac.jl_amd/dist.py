@@ -44,6 +44,55 @@ def score_batch_sharded(b, rank, world, local_score, counts_full, group=None, sa
     return allreduce_counts(counts_full, group)
 
 
+class ShardedScorer:
+    """score_batch_sharded as a two-deep software pipeline: batch i's all-reduce (asynchronous, on the
+    collective's own stream) runs while batch i + 1 is being scored.  The collective is tiny (4*B bytes)
+    but latency-bound over xGMI, so hiding it is what keeps weak scaling flat.  submit() enqueues one
+    batch and returns its ticket; result(ticket) waits for that batch's collective and returns the
+    int32[B] tensor (valid until `depth` more batches have been submitted); drain() waits for all."""
+
+    def __init__(self, b, rank, world, local_score, device, group=None, same_stream=False, depth=2):
+        import torch
+        self.b, self.rank, self.world, self.local_score = b, rank, world, local_score
+        self.group, self.same_stream, self.depth = group, same_stream, depth
+        self.bufs = [torch.zeros(max(1, b), dtype=torch.int32, device=device)[:b] for _ in range(depth)]
+        self.works = [None] * depth
+        self.k = 0
+        self.lo, self.hi = shard_bounds(b, rank, world)
+
+    def submit(self):
+        import torch
+        import torch.distributed as dist
+        i = self.k % self.depth
+        if self.works[i] is not None:       # the buffer's previous collective (two batches ago)
+            self.works[i].wait()
+            self.works[i] = None
+        buf = self.bufs[i]
+        buf.zero_()
+        if buf.is_cuda and not self.same_stream:
+            torch.cuda.current_stream(buf.device).synchronize()
+        if self.hi > self.lo:
+            self.local_score(self.lo, self.hi, buf[self.lo:self.hi])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            self.works[i] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.k += 1
+        return self.k - 1
+
+    def result(self, ticket):
+        assert self.k - self.depth <= ticket < self.k, "that batch's buffer has been reused"
+        i = ticket % self.depth
+        if self.works[i] is not None:
+            self.works[i].wait()
+            self.works[i] = None
+        return self.bufs[i]
+
+    def drain(self):
+        for i in range(self.depth):
+            if self.works[i] is not None:
+                self.works[i].wait()
+                self.works[i] = None
+
+
 class DeviceBatch:
     """A candidate batch resident in HBM next to a cloud, for the *_dev entry points."""
 

@@ -56,6 +56,13 @@ def _worker(rank, world, port, b, q):
         rdist.score_batch_sharded(b, rank, world, local, counts)
     full = oc.score_batch(shapes, p)
     ok = bool(np.array_equal(counts.numpy(), full)) and int(full.sum()) > 0
+    # the two-deep pipeline bench.py uses at N > 1: same counts from every in-flight batch
+    sc = rdist.ShardedScorer(b, rank, world, local, "cpu")
+    tickets = [sc.submit() for _ in range(2)]
+    ok = ok and all(np.array_equal(sc.result(t).numpy(), full) for t in tickets)
+    t3 = sc.submit()
+    sc.drain()
+    ok = ok and bool(np.array_equal(sc.result(t3).numpy(), full))
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
