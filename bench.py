@@ -156,7 +156,11 @@ def main():
     # and a step has no host synchronisation (RH_BENCH_SPLIT_STREAMS=1: the library's own stream + two waits)
     same_stream = world > 1 and not os.environ.get("RH_BENCH_SPLIT_STREAMS")
     if same_stream:
-        pc.set_stream(torch.cuda.current_stream().cuda_stream)
+        # an explicit (non-default) stream: the legacy null stream would serialise against the
+        # collective's stream and undo the overlap
+        compute_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(compute_stream)
+        pc.set_stream(compute_stream.cuda_stream)
     local = rdist.gpu_local_score(pc, batch, cp, wait=not same_stream)
     lo, hi = rdist.shard_bounds(b_global, rank, world)
 
