@@ -12,7 +12,8 @@ N x 4096 batch and one RCCL int32 sum all-reduce per step gives every rank every
 One JSON line on rank 0.  Extra objects: `roofline` (dominant score kernel, HIP events on the
 library's stream), `roofline_valu` (FP64 vector-ALU view of the same kernel -- the batched
 score is ALU-bound), `roofline_refit` (the HBM-bound full-cloud scan),
-`cpu_baseline` (the oracle, 1 thread, bounded sample), `end_to_end` (rh_ransac on the same cloud).
+`cpu_baseline` (the oracle, 1 thread, bounded sample; `cpu_baseline_all_cores`: OpenMP steelman),
+`end_to_end` (rh_ransac on the same cloud), `cfg5` (the 50M-point / cones config, child process).
 """
 import argparse
 import ctypes as C
@@ -47,6 +48,7 @@ def parse():
     ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the 50M-point / cones leg (a child process at N = 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
@@ -419,6 +421,26 @@ def main():
                     "sample": "the oracle's ransac() on the first %d iterations of the same run; extracted shapes, "
                               "index sets and draw counts checked identical to rh_ransac's" % nit}
         out["setup_seconds"] = t_setup
+        # ---- BASELINE cfg5 (50M points, cones in the batch) on this one GPU: a child process, same script
+        if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
+            import subprocess
+            pc = None   # noqa: F841 -- the parent's cloud stays resident (2 GB); the child needs ~12 GB
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--no-cpu", "--no-e2e",
+                                    "--no-cfg5", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+                c5 = json.loads(r.stdout.strip().splitlines()[-1])
+                out["cfg5"] = {"config": c5["config"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
+                               "tests_per_sec": c5["tests_per_sec"], "per_kind": c5["per_kind"],
+                               "score_kernel_ms": c5["roofline"]["ms_per_launch"],
+                               "roofline_refit": {k: c5["roofline_refit"][k] for k in
+                                                  ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
+                                                   "algorithmic_bytes_per_launch", "inliers")},
+                               "setup_seconds": c5["setup_seconds"],
+                               "note": "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 5 (child process): one replica of "
+                                       "the 50M-point cloud on this GPU, S = 1 562 500, cones in the batch; the refit scan "
+                                       "streams 2.4 GB"}
+            except Exception as e:   # the headline line must not depend on this leg
+                out["cfg5"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     batch.free()
     if world > 1:
