@@ -570,3 +570,39 @@ def test_non_finite_and_duplicate_points_match_oracle():
     assert np.array_equal(got, exp)
     assert np.array_equal(gmask, emask)
     assert got.max() > 100
+
+
+def test_results_own_their_index_lists_until_freed():
+    """Two rh_ransac results alive at once: each owns its own pinned arena (the pool hands a block out
+    once), freeing in either order is fine, and a later run re-uses a returned block."""
+    c = synth.config("cfg1")
+    subs = synth.make_subsets(50000, c["r"], c["seed"])
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere]), sampling_streams=1)
+    lib = R.lib()
+
+    def run(seed):
+        pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
+        rng = L.Rng()
+        lib.rh_rng_seed(C.byref(rng), seed)
+        res = L.Result()
+        L.check(lib.rh_ransac(pc._h, pc.vertices.ctypes.data_as(C.POINTER(C.c_double)),
+                              pc.normals.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cp), C.byref(rng), C.byref(res)))
+        lists = [np.ctypeslib.as_array(res.shapes[i].inpoints, shape=(res.shapes[i].n_inpoints,)) for i in range(res.n_shapes)]
+        return pc, res, lists
+
+    pc1, r1, l1 = run(1)
+    snap = [a.copy() for a in l1]
+    pc2, r2, l2 = run(1)
+    assert r1.arena and r2.arena and r1.arena != r2.arena
+    assert r1.n_shapes == r2.n_shapes == 2
+    for a, b, s0 in zip(l1, l2, snap):
+        assert np.array_equal(a, s0) and np.array_equal(a, b)       # the second run did not touch the first result
+        assert np.all(np.diff(a) > 0) and a[0] >= 1 and a[-1] <= 50000
+    first = r1.arena
+    lib.rh_result_free(C.byref(r1))
+    assert not r1.arena and r1.n_shapes == 0
+    pc3, r3, l3 = run(1)
+    assert r3.arena == first                                        # recycled block
+    assert all(np.array_equal(a, b) for a, b in zip(l2, l3))
+    lib.rh_result_free(C.byref(r3))
+    lib.rh_result_free(C.byref(r2))
