@@ -132,7 +132,7 @@ int rh_cloud_count_enabled(rh_cloud *c, int64_t *out);  /* count(pc.isenabled): 
 
 /* Replaces scorecandidates! (src/fitting.jl:181-190) = B x scorecandidate
  * (plane.jl:61-71, sphere.jl:118-134, cylinder.jl:172-183, cone.jl:155-167) with one
- * batched launch per shape kind.  counts_out[b] = number of compatible (and, except
+ * batched launch for all candidates of all kinds.  counts_out[b] = number of compatible (and, except
  * for spheres in reference mode, enabled) points of subset 1.  masks_out (optional):
  * b rows of ceil(s/64) words; bit j of row i = subset position j is an inpoint of
  * candidate i, so inpoints = subsets[1][mask] in subset order. */

@@ -363,7 +363,7 @@ def _shape_array(cands):
 
 
 def score_batch(pc, candidates, params, want_masks=False):
-    """One launch per shape kind for the whole batch (replaces the loop of scorecandidates!,
+    """One launch for the whole batch, all shape kinds (replaces the loop of scorecandidates!,
     fitting.jl:181-190).  Returns counts[b] (and masks[b, ceil(S/64)] over subset positions)."""
     b = len(candidates)
     arr = candidates if isinstance(candidates, C.Array) else _shape_array(candidates)

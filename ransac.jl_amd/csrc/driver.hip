@@ -1,11 +1,14 @@
 // driver.hip -- rh_ransac: the reference's ransac() loop (src/iterations.jl:35-162) with the
 // data-parallel steps on the GPU.
 //
-// Host: RNG, minimal-set sampling (samplepointcloud4!, src/fitting.jl:383-430), fits, score
-// statistics, best-candidate bookkeeping.  Device: batched scoring of every candidate an
-// iteration produced (one launch per shape kind instead of src/fitting.jl:181-190's sequential
-// loop -- legal because nothing inside an iteration reads a score before iterations.jl:99 is
-// done), the full-cloud refit scan, enabled-bit maintenance and candidate liveness.
+// Host: score statistics, best-candidate bookkeeping, the replay of speculated iterations in order;
+// with sampling_streams = 0 (the reference's single sequential stream, or an injected one) also RNG,
+// minimal-set sampling (samplepointcloud4!, src/fitting.jl:383-430) and fits.  Device: sampling and
+// fitting of whole windows of iterations (sampling_streams = 1, sampler.hip), batched scoring of
+// every candidate a window / iteration produced (one launch instead of src/fitting.jl:181-190's
+// sequential loop -- legal because nothing inside an iteration reads a score before
+// iterations.jl:99 is done), the full-cloud refit scan, enabled-bit maintenance and candidate
+// liveness.
 //
 // Candidate store.  The reference keeps every scored candidate with its inlier index list and
 // deletes, at each extraction, every candidate that owns a now-disabled point
@@ -443,7 +446,7 @@ struct Driver {
     }
 
     // scorecandidates! (fitting.jl:181-190) for a batch: counts in candidate order.  One launch
-    // per shape kind -- nothing reads a score before the loop ends (iterations.jl:99).
+    // (per kind on the brute-force path) -- nothing reads a score before the loop ends (iterations.jl:99).
     int score(const rh_shape *cands, int32_t ncand, std::vector<int32_t> &counts)
     {
         counts.assign((size_t)ncand, 0);
