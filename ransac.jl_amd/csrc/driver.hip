@@ -689,6 +689,7 @@ struct Driver {
         const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)K + 63) / 64 * 64;
         for (Window &w : win) {
             RUNH(hipMalloc((void **)&w.d_status, status_bytes));
+            RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));   // kept zero by pack_window_kernel from here on
             RUNH(hipHostMalloc((void **)&w.h_status, status_bytes));
             RUNH(hipHostMalloc((void **)&w.h_entries, sizeof(rh_cand_entry) * (size_t)ENTRIES_HEAD));
             w.entries_cap = 1 << 16;
@@ -734,14 +735,15 @@ struct Driver {
                 RUNH(hipMemcpyAsync(c->oct_P, Pwin.data(), sizeof(double) * Pwin.size(), hipMemcpyHostToDevice, c->stream));
                 d_P = c->oct_P;
             }
-            RUN(rhk_sample_fit(c, p, rng->s[0], k0, W, (int32_t)en.count, d_P, w.d_entries, w.entries_cap, w.d_status));
+            RUN(rhk_sample_fit(c, p, rng->s[0], k0, W, (int32_t)en.count, d_P, w.d_entries, w.entries_cap, w.d_status, 1,
+                               fused_score ? c->d_nk : nullptr));
             w.scored = false;
             if (fused_score) {
                 RUN(rh_ensure_batch(c, w.entries_cap));
                 // launch sizes from the previous windows' list lengths; any length is handled (the
                 // kernels read the true count), a longer list only gets fewer blocks per candidate
                 const int32_t bound = std::min<int32_t>(w.entries_cap, std::max<int32_t>(4 * cnt_est, 1024));
-                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts));
+                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts, 1));
                 const uint64_t *enw[4];
                 const rh_prep *pr[4];
                 const int32_t *og[4], *nkp[4];
@@ -752,11 +754,11 @@ struct Driver {
                     nkp[q] = c->d_nk + q;
                 }
                 RUN(rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr));
-                RUNH(hipMemcpyAsync(w.h_counts, w.d_counts, sizeof(int32_t) * (size_t)ENTRIES_HEAD, hipMemcpyDeviceToHost, c->stream));
                 w.scored = true;
             }
-            RUNH(hipMemcpyAsync(w.h_status, w.d_status, 8 + sizeof(unsigned long long) * (size_t)W, hipMemcpyDeviceToHost, c->stream));
-            RUNH(hipMemcpyAsync(w.h_entries, w.d_entries, sizeof(rh_cand_entry) * (size_t)ENTRIES_HEAD, hipMemcpyDeviceToHost, c->stream));
+            // status + head of the list (+ counts) land in pinned host memory through one small kernel
+            RUN(rhk_pack_window(c, w.d_status, W, w.d_entries, w.scored ? w.d_counts : nullptr, ENTRIES_HEAD, w.h_status,
+                                w.h_entries, w.h_counts));
             RUNH(hipEventRecord(w.ev, c->stream));
             w.k = k0; w.W = W; w.pending = true;
             return RH_OK;

@@ -1209,9 +1209,9 @@ int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_
 
 // prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts)
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero)
 {
-    RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    if (!nk_is_zero) RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
     if (launch_bound <= 0) return RH_OK;
     hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
                        cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts);

@@ -133,7 +133,7 @@ int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int6
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
 struct rh_cand_entry;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts);
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero);
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap);
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
@@ -177,7 +177,11 @@ struct rh_cand_entry {
 };
 // d_P: null (root-cell sampling) or n_iters x oct_depth level distributions
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status);
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status, int status_is_zero,
+                   int32_t *d_nk_zero);
+// status block, head of the list and of its counts -> pinned host memory; zeroes the status block
+int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
+                    int32_t head_cap, void *h_status, void *h_entries, int32_t *h_counts);
 int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth);   // cloud.hip
 int rhk_oct_sync_enabled(rh_cloud *c);                                  // men = permuted enabled; prefix
 int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask);             // clear the bits of an original-order mask

@@ -84,9 +84,10 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
 template <int DN, bool CONE>
 __global__ void __launch_bounds__(128)
 fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_level, int64_t total, const rh_params prm,
-                rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count)
+                rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count, int32_t *__restrict__ nk_zero)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;   // the kind bins prep_entries_kernel fills next
     if (t >= total) return;
     const int level = set_level[t];
     if (level == 0) return;
@@ -126,18 +127,50 @@ fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_l
     }
 }
 
+// End of a window's chain: one block copies the status block, the head of the candidate list and the
+// head of its counts straight into pinned host memory (three copy-engine transfers cost ~15 us per
+// window), then zeroes the status block for the buffer's next window.
+__global__ void __launch_bounds__(1024)
+pack_window_kernel(uint64_t *__restrict__ status, int32_t status_words, const rh_cand_entry *__restrict__ entries,
+                   const int32_t *__restrict__ counts, int32_t head_cap, uint64_t *__restrict__ h_status,
+                   uint64_t *__restrict__ h_entries, int32_t *__restrict__ h_counts)
+{
+    const int tid = threadIdx.x;
+    const int32_t cnt = min(((const int32_t *)status)[0], head_cap);
+    for (int i = tid; i < status_words; i += 1024) h_status[i] = status[i];
+    constexpr int EW = (int)(sizeof(rh_cand_entry) / 8);
+    const uint64_t *src = (const uint64_t *)entries;
+    for (int i = tid; i < cnt * EW; i += 1024) h_entries[i] = src[i];
+    if (counts != nullptr)
+        for (int i = tid; i < cnt; i += 1024) h_counts[i] = counts[i];
+    __syncthreads();
+    for (int i = tid; i < status_words; i += 1024) status[i] = 0;
+}
+
 }  // namespace
 
+int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
+                    int32_t head_cap, void *h_status, void *h_entries, int32_t *h_counts)
+{
+    static_assert(sizeof(rh_cand_entry) % 8 == 0, "entries are copied as 64-bit words");
+    const int32_t words = (int32_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 8);
+    hipLaunchKernelGGL(pack_window_kernel, dim3(1), dim3(1024), 0, c->stream, (uint64_t *)d_status, words, d_entries, d_counts,
+                       head_cap, (uint64_t *)h_status, (uint64_t *)h_entries, h_counts);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
-                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status)
+                   const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status, int status_is_zero,
+                   int32_t *d_nk_zero)
 {
     // status block: int32 count, int32 gave_up, u64 draws[n_iters]
     int32_t *d_count = (int32_t *)d_status, *d_gave_up = d_count + 1;
     unsigned long long *d_draws = (unsigned long long *)((char *)d_status + 8);
     if (prm->drawN > RH_MAX_DRAWN) { rh_set_error("device sampler supports drawN <= %d", RH_MAX_DRAWN); return RH_E_INVALID; }
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
-    // (the block is a multiple of 64 bytes: one aligned fill)
-    RH_HIP(hipMemsetAsync(d_status, 0, (size_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 64), c->stream));
+    // (the block is a multiple of 64 bytes: one aligned fill; the driver's windows keep it zero themselves)
+    if (!status_is_zero) RH_HIP(hipMemsetAsync(d_status, 0, (size_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 64), c->stream));
     const int64_t total = (int64_t)n_iters * prm->minsubsetN;
     if (total == 0) return RH_OK;
     DevEnabled en;
@@ -171,7 +204,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
                        prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
-                       d_out, cap, d_count)
+                       d_out, cap, d_count, d_nk_zero)
     if (prm->drawN == 3) {   // the reference's default: fully unrolled, no scratch
         RH_SAMPLE(3);
         if (cone) RH_FIT(3, true); else RH_FIT(3, false);
