@@ -427,6 +427,19 @@ def select_enabled(pc, ranks):
     return out[: r.size]
 
 
+class _ResultOwner:
+    """Keeps an rh_result (and with it the pinned block of index lists) alive; frees it on collection."""
+
+    def __init__(self, res):
+        self.res = res
+
+    def __del__(self):
+        try:
+            lib().rh_result_free(C.byref(self.res))
+        except Exception:   # interpreter shutdown
+            pass
+
+
 def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=None,
            score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0, octree_sampling=False,
            return_stats=False):
@@ -446,17 +459,25 @@ def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=Non
     res = L.Result()
     check(lib().rh_ransac(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
                           C.byref(rng), C.byref(res)))
+    # the index lists stay where rh_ransac put them (one pinned block per run): every `inpoints` is a
+    # zero-copy view whose base keeps the result alive; rh_result_free runs when the last view is gone
+    owner = _ResultOwner(res)
     extracted = []
     for i in range(res.n_shapes):
         e = res.shapes[i]
-        idx = np.ctypeslib.as_array(e.inpoints, shape=(max(1, e.n_inpoints),))[: e.n_inpoints].copy()
+        if e.n_inpoints > 0:
+            raw = (C.c_int64 * e.n_inpoints).from_address(C.addressof(e.inpoints.contents))
+            raw._owner = owner
+            idx = np.frombuffer(raw, dtype=np.int64)
+        else:
+            idx = np.zeros(0, dtype=np.int64)
         es = ExtractedShape(shape_from_c(e.shape), idx)
         es.score_E, es.iteration, es.c_shape = e.score_E, e.iteration, L.Shape.from_buffer_copy(bytes(e.shape))
         extracted.append(es)
     stats = {"iterations": res.iterations, "candidates_scored": res.candidates_scored,
              "scored_left": res.scored_left, "seconds": res.seconds, "seconds_score": res.seconds_score,
              "seconds_extract": res.seconds_extract, "seconds_host": res.seconds_host, "draws": rng.draws}
-    lib().rh_result_free(C.byref(res))
+    del owner
     seconds = stats["seconds"]
     return (extracted, seconds, stats) if return_stats else (extracted, seconds)
 

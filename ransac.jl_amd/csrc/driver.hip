@@ -282,12 +282,15 @@ struct Driver {
     Window win[2];
     static constexpr int32_t ENTRIES_HEAD = 512;
 
+    int32_t *h_scr = nullptr;           // pinned scratch: scalars read back, liveness counts, gather lists
+    int64_t h_scr_cap = 0;              // in int32
     int64_t *arena = nullptr;           // pinned block for the extracted index lists (result arenas, above)
     int64_t arena_used = 0, arena_cap = 0;
 
     ~Driver()
     {
-        if (arena && c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in it
+        if (c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in the pinned blocks
+        (void)hipHostFree(h_scr);
         arena_release(arena);   // null once the result owns it
         store_free(c, st);
         for (Window &w : win) {
@@ -295,6 +298,20 @@ struct Driver {
             (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
             if (w.ev) (void)hipEventDestroy(w.ev);
         }
+    }
+
+    // pinned scratch of at least `ints` int32 (contents are not preserved when it grows)
+    int ensure_scratch(int64_t ints)
+    {
+        if (ints <= h_scr_cap) return RH_OK;
+        RUNH(hipStreamSynchronize(c->stream));
+        (void)hipHostFree(h_scr);
+        h_scr = nullptr;
+        h_scr_cap = 0;
+        const int64_t cap = std::max<int64_t>(ints, 1 << 16);
+        RUNH(hipHostMalloc((void **)&h_scr, sizeof(int32_t) * (size_t)cap));
+        h_scr_cap = cap;
+        return RH_OK;
     }
 
     int init()
@@ -307,6 +324,7 @@ struct Driver {
         en.w.assign((size_t)c->nwords, 0);
         if (c->nwords > 0) RUN(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
         en.recount();
+        RUN(ensure_scratch(1 << 16));
         arena_cap = std::max<int64_t>(en.count, 1);   // a point is extracted at most once
         arena = (int64_t *)arena_acquire(sizeof(int64_t) * (size_t)arena_cap);
         if (!arena) { rh_set_error("rh_ransac: cannot pin %lld bytes for the index lists", (long long)(8 * arena_cap)); return RH_E_NOMEM; }
@@ -526,16 +544,15 @@ struct Driver {
         rh_prep_host(bestshape, &P);
         RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
         RUN(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
-        int32_t total = 0;
-        RUNH(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
         // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
+        RUN(rhk_fetch2_i32(c, c->d_total, h_scr));        // the list length, before the next compaction reuses d_total
         RUN(rhk_andnot_enabled(c, c->refit_mask));
         RUN(rhk_rebuild_sub_enabled(c, true, false));
         if (octree) RUN(rhk_oct_clear_mask(c, c->refit_mask));
         c->select_valid = false;
-        int32_t ndis_new = 0;
-        RUNH(hipMemcpyAsync(&ndis_new, c->d_ndis, sizeof ndis_new, hipMemcpyDeviceToHost, c->stream));
+        RUN(rhk_fetch2_i32(c, c->d_ndis, h_scr + 1));
         RUNH(hipStreamSynchronize(c->stream));
+        const int32_t total = h_scr[0], ndis_new = h_scr[1];
         rh_extracted ex;
         memset(&ex, 0, sizeof ex);
         ex.shape = bestshape;
@@ -570,37 +587,49 @@ struct Driver {
         std::vector<char> dead_slot[4];
         for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 0);   // every slot is referenced by `store`
         dead_slot[store[extracted_pos].shape.kind][(size_t)store[extracted_pos].slot] = 1;
-        int64_t maxn = 0;
-        for (int q = 0; q < 4; q++) maxn = std::max<int64_t>(maxn, st.n[q]);
-        RUN(store_reserve_aux(c, st, maxn));
-        for (int q = 0; q < 4; q++) {
-            if (st.n[q] == 0) continue;
-            const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
-            const int64_t first = all_disabled ? 0 : ndis_old;
-            const int64_t cnt = (int64_t)ndis_new - first;
-            if (cnt <= 0) continue;
-            RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)st.n[q], c->stream));
-            RUNH(hipMemcpyAsync(st.d_nk + 4 + q, &st.n[q], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-            RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota, st.d_nk + 4 + q, st.n[q], p->eps[q],
-                                   p->cos_alpha[q], st.counts));
-            counts_h.resize((size_t)st.n[q]);
-            RUNH(hipMemcpyAsync(counts_h.data(), st.counts, sizeof(int32_t) * (size_t)st.n[q], hipMemcpyDeviceToHost, c->stream));
-            RUNH(hipStreamSynchronize(c->stream));
-            for (int32_t sl = 0; sl < st.n[q]; sl++)
-                if (counts_h[(size_t)sl] > 0) dead_slot[q][(size_t)sl] = 1;
+        int64_t base[5] = { 0, 0, 0, 0, 0 };
+        for (int q = 0; q < 4; q++) base[q + 1] = base[q] + st.n[q];
+        const int64_t sum_n = base[4];
+        RUN(store_reserve_aux(c, st, sum_n));
+        RUN(ensure_scratch(32 + 2 * sum_n));
+        int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
+        bool any_live = false;
+        if (sum_n > 0) {
+            // every kind's pass goes to its own slice of st.counts (orig = iota + base: counts[base + slot]);
+            // one read-back and one wait for all of them
+            RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)sum_n, c->stream));
+            for (int q = 0; q < 4; q++) h_nk[q] = st.n[q];
+            RUNH(hipMemcpyAsync(st.d_nk + 4, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            for (int q = 0; q < 4; q++) {
+                if (st.n[q] == 0) continue;
+                const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                const int64_t first = all_disabled ? 0 : ndis_old;
+                const int64_t cnt = (int64_t)ndis_new - first;
+                if (cnt <= 0) continue;
+                RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota + base[q], st.d_nk + 4 + q, st.n[q], p->eps[q],
+                                       p->cos_alpha[q], st.counts));
+                any_live = true;
+            }
+            if (any_live) {
+                RUNH(hipMemcpyAsync(h_counts, st.counts, sizeof(int32_t) * (size_t)sum_n, hipMemcpyDeviceToHost, c->stream));
+                RUNH(hipStreamSynchronize(c->stream));
+                for (int q = 0; q < 4; q++)
+                    for (int32_t sl = 0; sl < st.n[q]; sl++)
+                        if (h_counts[base[q] + sl] > 0) dead_slot[q][(size_t)sl] = 1;
+            }
         }
         tp[2] += now_s() - tq; tq = now_s();
         // drop dead candidates on the host (order preserved), compact the device store
         std::vector<int32_t> remap[4];
         for (int q = 0; q < 4; q++) {
             remap[q].assign((size_t)st.n[q], -1);
-            idx_h.clear();
+            int32_t *lst = h_lists + base[q];      // pinned, one slice per kind: nothing waits between the kinds
+            int32_t alive = 0;
             for (int32_t sl = 0; sl < st.n[q]; sl++)
                 if (!dead_slot[q][(size_t)sl]) {
-                    remap[q][(size_t)sl] = (int32_t)idx_h.size();
-                    idx_h.push_back(sl);
+                    remap[q][(size_t)sl] = alive;
+                    lst[alive++] = sl;
                 }
-            const int32_t alive = (int32_t)idx_h.size();
             if (alive != st.n[q]) {
                 if (alive > 0) {
                     if (st.spare_cap[q] < st.cap[q]) {
@@ -611,15 +640,15 @@ struct Driver {
                         RUNH(hipMalloc((void **)&st.spare[q], sizeof(rh_prep) * (size_t)st.cap[q]));
                         st.spare_cap[q] = st.cap[q];
                     }
-                    RUNH(hipMemcpyAsync(st.d_idx, idx_h.data(), sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream));
-                    RUN(rhk_gather_prep(c, st.prep[q], st.d_idx, alive, st.spare[q]));
-                    RUNH(hipStreamSynchronize(c->stream));   // idx_h is reused for the next kind
+                    RUNH(hipMemcpyAsync(st.d_idx + base[q], lst, sizeof(int32_t) * (size_t)alive, hipMemcpyHostToDevice, c->stream));
+                    RUN(rhk_gather_prep(c, st.prep[q], st.d_idx + base[q], alive, st.spare[q]));
                     std::swap(st.prep[q], st.spare[q]);
                     std::swap(st.cap[q], st.spare_cap[q]);
                 }
                 st.n[q] = alive;
             }
         }
+        // (the lists stay in the scratch until the next extraction, which starts with a stream wait)
         tp[3] += now_s() - tq; tq = now_s();
         size_t wpos = 0;
         for (size_t i = 0; i < store.size(); i++) {

@@ -1191,6 +1191,19 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_xyz, const double *d_nrm, int
     return RH_OK;
 }
 
+// one int32 from device memory into (pinned) host memory, in stream order, without a copy-engine transfer
+__global__ void fetch_i32_kernel(const int32_t *__restrict__ src, int32_t *__restrict__ h_dst)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *h_dst = *src;
+}
+
+int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src, int32_t *h_pinned_dst)
+{
+    hipLaunchKernelGGL(fetch_i32_kernel, dim3(1), dim3(64), 0, c->stream, d_src, h_pinned_dst);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec)
 {
     if (n == 0) return RH_OK;

@@ -129,6 +129,7 @@ struct rh_cloud {
 // ---- kernel launchers (kernels.hip) -----------------------------------------
 int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_nrm, int64_t n,
                       const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
+int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src, int32_t *h_pinned_dst);   // *h = *d in stream order (pinned h)
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
 struct rh_cand_entry;
