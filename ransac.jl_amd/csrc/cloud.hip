@@ -143,7 +143,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->gone_words); (void)hipFree(c->dis_gb);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
-    (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk);
+    (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk); (void)hipFree(c->d_nk2);
     (void)hipFree(c->d_counts); (void)hipFree(c->d_masks); (void)hipFree(c->d_ranks);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -323,6 +323,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->idx_out, n));
     CK(dev_alloc(&c->d_total, 1));
     CK(dev_alloc(&c->d_nk, 4));
+    CK(dev_alloc(&c->d_nk2, 8));
     CKH(hipMemsetAsync(c->full, 0, sizeof(double) * 6 * (size_t)c->n_pad, c->stream));
     CKH(hipMemsetAsync(c->sub, 0, sizeof(double) * 6 * (size_t)c->s_pad, c->stream));
     CKH(hipMemsetAsync(c->dis, 0, sizeof(double) * 6 * (size_t)c->dis_stride, c->stream));
@@ -620,8 +621,15 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     if (ms_kind) for (int k = 0; k < 5; k++) ms_kind[k] = 0.f;
     if (b == 0) return RH_OK;
     RH_TRY(rh_ensure_batch(c, b));
-    RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
-    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, c->d_nk, c->batch_cap));
+    // bin sizes: two halves of d_nk2 used alternately; the prep kernel zeroes the counts and the other half,
+    // so a step is two launches and no memset
+    if (!c->nk2_ready) {
+        RH_HIP(hipMemsetAsync(c->d_nk2, 0, 8 * sizeof(int32_t), c->stream));
+        c->nk2_ready = true;
+    }
+    int32_t *nk_cur = c->d_nk2 + 4 * c->nk2_flip, *nk_next = c->d_nk2 + 4 * (1 - c->nk2_flip);
+    c->nk2_flip = 1 - c->nk2_flip;
+    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1));
     uint64_t *d_masks_int = nullptr;
     if (d_masks && c->swords > 0) {
         RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
@@ -633,14 +641,14 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
         ms_kind[4] = 0.f;
         RH_HIP(hipEventRecord(c->evk[0], c->stream));
-        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, c->d_nk, bound, b, d_counts, d_masks_int, nullptr));
+        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, nullptr));
         RH_HIP(hipEventRecord(c->evk[1], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[1]));
         RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
         RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
         if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
-    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, c->d_nk, bound, b, d_counts, d_masks_int, ms_kind));
+    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     if (ms_kind) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));

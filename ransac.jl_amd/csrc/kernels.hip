@@ -166,14 +166,19 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
 }
 
 // unknown kinds (device-resident batch): bin by kind, one atomic per (wave, kind)
+// counts_zero (optional): the batch's counts array, zeroed here; nk_other (optional): the OTHER half of a
+// double-buffered bin-size array, zeroed for the next batch -- a scoring step then needs no memset at all
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
-                                   int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap)
+                                   int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap,
+                                   int32_t *__restrict__ counts_zero, int32_t *__restrict__ nk_other)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     rh_shape s;
     int kind = -1;
+    if (i < 4 && nk_other != nullptr) nk_other[i] = 0;
     if (i < b) {
+        if (counts_zero != nullptr) counts_zero[i] = 0;
         s = shapes[i];
         if (s.kind >= 0 && s.kind <= 3) kind = s.kind;   // anything else: counts[i] stays 0
     }
@@ -1233,12 +1238,12 @@ int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t 
 }
 
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
-                    int32_t *d_nk, int64_t cap)
+                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero)
 {
-    RH_HIP(hipMemsetAsync(d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    if (!nk_is_zero) RH_HIP(hipMemsetAsync(d_nk, 0, 4 * sizeof(int32_t), c->stream));
     if (b == 0) return RH_OK;
     hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
-                       d_nk, cap);
+                       d_nk, cap, d_counts_to_zero, d_nk_other);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -113,6 +113,9 @@ struct rh_cloud {
     rh_prep *d_prep = nullptr;         // [4 * batch_cap], kind-major
     int32_t *d_orig = nullptr;         // [4 * batch_cap]
     int32_t *d_nk = nullptr;           // [4]
+    int32_t *d_nk2 = nullptr;          // [8] rh_score_batch_dev: two halves used alternately, each batch zeroes the other
+    int nk2_flip = 0;
+    bool nk2_ready = false;
     int32_t *d_counts = nullptr;       // [batch_cap]
     uint64_t *d_masks = nullptr;       // grown on demand
     int64_t masks_cap = 0;
@@ -136,7 +139,7 @@ struct rh_cand_entry;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
                      int32_t launch_bound, int32_t *d_counts, int nk_is_zero);
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
-                    int32_t *d_nk, int64_t cap);
+                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero);
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates
 int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s,
