@@ -76,7 +76,7 @@ kindof(::Type{<:FittedCylinder}) = RH_CYLINDER
 kindof(::Type{<:FittedCone}) = RH_CONE
 
 # nested NamedTuple (src/utilities.jl:332-399) -> rh_params; thresholds use Julia's cos / cosd
-function toC(p::NamedTuple; score_mode = 0, sphere_uses_enabled = 0)
+function toC(p::NamedTuple; score_mode = 0, sphere_uses_enabled = 0, sampling_streams = 0)
     get2(nt, k, d) = haskey(nt, k) ? getfield(nt, k) : d
     sh(name) = get2(p, name, (ϵ = 0.3, α = deg2rad(5)))
     order = (:plane, :sphere, :cylinder, :cone)                       # RH_* kind order
@@ -91,7 +91,7 @@ function toC(p::NamedTuple; score_mode = 0, sphere_uses_enabled = 0)
         get2(get2(p, :cone, NamedTuple()), :minconeopang, deg2rad(2)),
         it.prob_det, it.τ, it.itermax, it.drawN, it.minsubsetN,
         sym[it.extract_s], sym[it.terminate_s], length(st),
-        ntuple(i -> i <= length(st) ? st[i] : Cint(0), 8), score_mode, sphere_uses_enabled, 0, 0, 10)
+        ntuple(i -> i <= length(st) ? st[i] : Cint(0), 8), score_mode, sphere_uses_enabled, sampling_streams, 0, 10)
 end
 
 "Device-resident twin of a RANSACCloud; `pc` stays authoritative for fits and sampling."
@@ -112,8 +112,10 @@ mutable struct HIPCloud{P}
     end
 end
 
-# pc.isenabled::BitVector -> device (same chunk layout)
+# pc.isenabled::BitVector -> device (same chunk layout), and back
 push_enabled!(h::HIPCloud) = check(ccall((:rh_cloud_set_enabled, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{UInt64}, Int64), h.handle, h.pc.isenabled.chunks, length(h.pc.isenabled.chunks)))
+pull_enabled!(h::HIPCloud) = check(ccall((:rh_cloud_get_enabled, LIB), Cint,
     (Ptr{Cvoid}, Ptr{UInt64}, Int64), h.handle, h.pc.isenabled.chunks, length(h.pc.isenabled.chunks)))
 
 """
@@ -206,6 +208,72 @@ function ransac(h::HIPCloud, params; reset_rand = false)
         prob(it.τ, chooseS(countcandidates, it.terminate_s), pc.size, it.drawN) > it.prob_det && break
     end
     return extracted, trunc((time_ns() - start_time) / 1_000_000_000, digits = 2)
+end
+
+# ---- the whole loop on the device: rh_ransac (driver.hip) -------------------------------------
+# Mirrors of rh_rng / rh_extracted / rh_result (include/ransac_hip.h).  The index lists live in one
+# pinned block owned by the result; they are copied into Julia vectors here and the block goes back
+# to the library's pool with rh_result_free.
+mutable struct RhRng
+    s::NTuple{4,UInt64}
+    stream::Ptr{UInt64}
+    stream_len::Int64
+    stream_pos::Int64
+    draws::Int64
+end
+
+struct RhExtracted
+    shape::RhShape
+    n_inpoints::Int64
+    inpoints::Ptr{Int64}
+    score_E::Cdouble
+    iteration::Int64
+end
+
+mutable struct RhResult
+    shapes::Ptr{RhExtracted}
+    n_shapes::Int64
+    iterations::Int64
+    candidates_scored::Int64
+    scored_left::Int64
+    seconds::Cdouble
+    seconds_score::Cdouble
+    seconds_extract::Cdouble
+    seconds_host::Cdouble
+    arena::Ptr{Cvoid}
+end
+
+fromC(s::RhShape) =
+    s.kind == RH_PLANE    ? FittedPlane(SVector(s.v[1:3]...), SVector(s.v[4:6]...)) :
+    s.kind == RH_SPHERE   ? FittedSphere(SVector(s.v[1:3]...), s.v[4], s.outwards != 0) :
+    s.kind == RH_CYLINDER ? FittedCylinder(SVector(s.v[1:3]...), SVector(s.v[4:6]...), s.v[7], s.outwards != 0) :
+                            FittedCone(SVector(s.v[1:3]...), SVector(s.v[4:6]...), s.v[7], s.outwards != 0)
+
+"""
+`ransac_device(h, params; seed, sampling_streams)`: the whole `ransac` loop inside the library
+(sampling, fits, scoring, refit, invalidation, candidate liveness on the GPU; `sampling_streams = 1`
+draws every minimal set from its own counter-based stream so that whole windows of iterations run
+on the device).  Same return value as `ransac`.
+"""
+function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_streams::Integer = 1)
+    pc = h.pc
+    push_enabled!(h)
+    cp = Ref(toC(params; sampling_streams = sampling_streams))
+    rng = Ref(RhRng((0, 0, 0, 0), C_NULL, 0, 0, 0))
+    ccall((:rh_rng_seed, LIB), Cvoid, (Ptr{RhRng}, UInt64), rng, UInt64(seed))
+    res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL))
+    GC.@preserve pc check(ccall((:rh_ransac, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
+        h.handle, pointer(reinterpret(Cdouble, pc.vertices)), pointer(reinterpret(Cdouble, pc.normals)), cp, rng, res))
+    extracted = ExtractedShape[]
+    for i in 1:res[].n_shapes
+        e = unsafe_load(res[].shapes, i)
+        push!(extracted, ExtractedShape(fromC(e.shape), copy(unsafe_wrap(Array, e.inpoints, e.n_inpoints))))
+    end
+    secs = res[].seconds
+    ccall((:rh_result_free, LIB), Cvoid, (Ptr{RhResult},), res)
+    pull_enabled!(h)          # the cloud's isenabled now reflects the extractions
+    return extracted, secs
 end
 
 end # module
