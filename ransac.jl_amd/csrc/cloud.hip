@@ -258,6 +258,10 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
                          (long long)n);
             return RH_E_INVALID;
         }
+    if (n > 2000000000LL) {   // internal indices (subset gather, select list, octree permutation) are int32
+        rh_set_error("rh_cloud_create: %lld points exceed the 2e9 limit of one cloud", (long long)n);
+        return RH_E_INVALID;
+    }
     int ndev = 0;
     RH_TRY(rh_device_count(&ndev));
     if (ndev <= 0) { rh_set_error("no HIP device is visible; libransac_hip has no CPU fallback"); return RH_E_NODEVICE; }

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end parity: rh_ransac against the oracle's sequential ransac() over many
+(cloud, parameter, mode) combinations.  Not part of the test suite (minutes of oracle time);
+run on a GPU box:  python tools/fuzz_e2e.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ransac_jl_amd as R
+from ransac_jl_amd import _lib as L, synth
+from oracle import oracle as orc
+
+KINDS = {"plane": R.FittedPlane, "sphere": R.FittedSphere, "cylinder": R.FittedCylinder, "cone": R.FittedCone}
+
+
+def one(case, rng):
+    n = int(rng.choice([6_000, 20_000, 40_000, 90_000]))
+    names = list(rng.choice(list(KINDS), size=int(rng.integers(2, 7))))
+    out_frac = float(rng.choice([0.0, 0.1, 0.3]))
+    r = int(rng.choice([1, 2, 4]))
+    xyz, nrm, truth = synth.make_cloud(n, names, out_frac, seed=1000 + case)
+    subs = synth.make_subsets(n, r, seed=case)
+    types = [KINDS[k] for k in sorted(set(names), key=lambda k: rng.random())]
+    it = {"minsubsetN": int(rng.choice([15, 40, 120])), "τ": int(rng.choice([50, 300, 900])),
+          "itermax": int(rng.choice([30, 120, 400])), "prob_det": float(rng.choice([0.5, 0.8, 0.9])),
+          "drawN": int(rng.choice([3, 3, 3, 4]))}
+    params = R.ransacparameters(types, iteration=it)
+    streams = int(rng.integers(0, 2))
+    octree = bool(streams and rng.integers(0, 3) == 0)
+    kw = dict(score_mode=int(rng.choice([L.SCORE_F64, L.SCORE_INT64_WRAP])), sphere_uses_enabled=bool(rng.integers(0, 2)),
+              sampling_streams=streams, octree_sampling=octree)
+    env = None
+    if streams:
+        env = rng.choice([None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER"])
+    for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER"):
+        os.environ.pop(k, None)
+    if env:
+        os.environ[env] = "1"
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    cp = R.params_to_c(params, **kw)
+    seed = int(rng.integers(1, 10_000))
+    got, secs, st = R.ransac(pc, cp, seed=seed, return_stats=True)
+    exp = oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=seed)
+    ok = (exp["rc"] == 0 and st["iterations"] == exp["iterations"] and st["candidates_scored"] == exp["candidates_scored"]
+          and st["scored_left"] == exp["scored_left"] and st["draws"] == exp["draws"] and len(got) == len(exp["shapes"])
+          and all(bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
+                  and g.score_E == e["score_E"] and g.iteration == e["iteration"] for g, e in zip(got, exp["shapes"]))
+          and np.array_equal(pc.enabled_chunks(), oc.get_enabled()))
+    desc = "n=%d r=%d prims=%s types=%s it=%s %s env=%s seed=%d -> %d shapes, %d cands, %d its" % (
+        n, r, "".join(k[0] for k in names), "".join(R.strt(t)[0] if hasattr(R, "strt") and not isinstance(t, type) else t.__name__[6] for t in types),
+        it, {k: int(v) for k, v in kw.items()}, env, seed, len(got), st["candidates_scored"], st["iterations"])
+    return ok, desc
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    bad = 0
+    t0 = time.time()
+    for case in range(ncases):
+        ok, desc = one(case, rng)
+        print("%s case %2d  %s" % ("ok  " if ok else "FAIL", case, desc), flush=True)
+        bad += not ok
+    print("%d cases, %d failures, %.0f s" % (ncases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
