@@ -971,26 +971,23 @@ rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *
 }
 
 // block b copies the points of gone words [b*1024, (b+1)*1024) to dis[base + prefix ...], in order:
-// block-wide exclusive scan of the word popcounts, then one wave per word with one lane per bit
-__global__ void __launch_bounds__(256)
+// block-wide exclusive scan of the word popcounts (one word per thread), then one wave per word with one
+// lane per bit
+__global__ void __launch_bounds__(1024)
 append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int32_t *__restrict__ block_prefix,
                    const double *__restrict__ sub, int64_t sub_stride, double *__restrict__ dis, int64_t dis_stride,
                    const int32_t *__restrict__ base_ptr)
 {
-    __shared__ int32_t wsum[4];
+    static_assert(RH_WORDS_PER_BLOCK == 1024, "one word per thread");
+    __shared__ int32_t wsum[16];
     __shared__ uint64_t lm[RH_WORDS_PER_BLOCK];
     __shared__ int32_t lpre[RH_WORDS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wbase = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
-    uint64_t m[4];
-    int tsum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int64_t w = wbase + threadIdx.x * 4 + k;
-        m[k] = w < swords ? gone[w] : 0ULL;
-        tsum += __popcll(m[k]);
-    }
-    int inc = tsum;
+    const int64_t w = wbase + threadIdx.x;
+    const uint64_t m = w < swords ? gone[w] : 0ULL;
+    const int pc = __popcll(m);
+    int inc = pc;
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(inc, o);
         if (lane >= o) inc += t;
@@ -999,16 +996,11 @@ append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int3
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < wave; k++) woff += wsum[k];
-    int run = woff + inc - tsum;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        lm[threadIdx.x * 4 + k] = m[k];
-        lpre[threadIdx.x * 4 + k] = run;
-        run += __popcll(m[k]);
-    }
+    lm[threadIdx.x] = m;
+    lpre[threadIdx.x] = woff + inc - pc;
     __syncthreads();
     const int64_t base = (int64_t)*base_ptr + block_prefix[blockIdx.x];
-    for (int wl = wave; wl < RH_WORDS_PER_BLOCK; wl += 4) {
+    for (int wl = wave; wl < RH_WORDS_PER_BLOCK; wl += 16) {
         const uint64_t bits = lm[wl];
         if (bits == 0) continue;
         if ((bits >> lane) & 1ULL) {
@@ -1321,7 +1313,7 @@ int rhk_rebuild_sub_enabled(rh_cloud *c, bool append, bool reset)
     hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, c->gone_words, c->swords,
                        c->block_sums);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, c->d_total);
-    hipLaunchKernelGGL(append_gone_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, c->gone_words, c->swords,
+    hipLaunchKernelGGL(append_gone_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->gone_words, c->swords,
                        c->block_sums, c->sub, c->s_pad, c->dis, c->dis_stride, c->d_ndis);
     hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, c->stream, c->d_ndis, c->d_total, 0);
     RH_HIP(hipGetLastError());
