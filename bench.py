@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
+    ap.add_argument("--shard", choices=["candidates", "points"], default="candidates",
+                    help="N > 1 partitioning: candidates (each rank scores its 4096 of the N x 4096 batch on a replica "
+                         "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
+                         "on its 1/N slice of subset 1; the all-reduce is a true sum)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 50M-point / cones leg (a child process at N = 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
@@ -165,16 +169,28 @@ def main():
         pc.set_stream(compute_stream.cuda_stream)
     local = rdist.gpu_local_score(pc, batch, cp, wait=not same_stream)
     lo, hi = rdist.shard_bounds(b_global, rank, world)
+    points_mode = world > 1 and args.shard == "points"
+    tcloud = pc
+    if points_mode:   # a second cloud: just this rank's slice of subset 1; pc stays for the rank-0 diagnostics
+        sx, sn, ssub, _ = rdist.point_shard_subset(xyz, nrm, subs[0], None, rank, world)
+        pcs = R.RANSACCloud(sx, sn, [ssub], device=local_rank)
+        sbatch = rdist.DeviceBatch(pcs, arr, b_global)
+        if same_stream:
+            pcs.set_stream(compute_stream.cuda_stream)
+        local = rdist.gpu_local_score(pcs, sbatch, cp, wait=not same_stream)
+        tcloud = pcs
 
     # N > 1: two batches in flight -- batch i's all-reduce overlaps batch i + 1's score launch
     # (RH_BENCH_NO_OVERLAP=1: one batch at a time)
     scorer = None
     if world > 1 and not os.environ.get("RH_BENCH_NO_OVERLAP"):
-        scorer = rdist.ShardedScorer(b_global, rank, world, local, "cuda", same_stream=same_stream)
+        scorer = rdist.ShardedScorer(b_global, rank, world, local, "cuda", same_stream=same_stream, points=points_mode)
 
     def step():
         if scorer is not None:
             scorer.submit()
+        elif points_mode:
+            rdist.score_batch_point_sharded(lambda out: local(0, b_global, out), counts)
         elif world > 1:
             rdist.score_batch_sharded(b_global, rank, world, local, counts, same_stream=same_stream)
         else:   # no collective, no host sync inside the timed region
@@ -185,6 +201,7 @@ def main():
         if scorer is not None:
             scorer.drain()      # every batch's collective has been waited for before the clock stops
         L.check(lib.rh_cloud_sync(pc._h))
+        L.check(lib.rh_cloud_sync(tcloud._h))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -194,11 +211,11 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    L.check(lib.rh_timer_start(pc._h))
+    L.check(lib.rh_timer_start(tcloud._h))
     for _ in range(args.steps):
         step()
     ev_ms = C.c_float()
-    L.check(lib.rh_timer_stop(pc._h, C.byref(ev_ms)))
+    L.check(lib.rh_timer_stop(tcloud._h, C.byref(ev_ms)))
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -217,7 +234,10 @@ def main():
                    "points": n, "subset_points": int(S), "candidates_per_step": b_global,
                    "kinds": "%s (cycled over the %d ground-truth primitives, 1%% jitter)"
                             % ("/".join(sorted(set(prim), key=KINDS.index)), len(prim)),
-                   "score_mode": "f64", "parallelism": "candidate-sharded x%d, int32 sum all-reduce" % world},
+                   "score_mode": "f64",
+                   "parallelism": ("point-sharded x%d (1/%d of subset 1 per GPU, every GPU scores the whole batch), "
+                                   "int32 sum all-reduce" % (world, world)) if points_mode
+                   else "candidate-sharded x%d, int32 sum all-reduce" % world},
         "tests_per_sec": value * S,
     }
 
@@ -443,6 +463,8 @@ def main():
                 out["cfg5"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     batch.free()
+    if points_mode:
+        sbatch.free()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,14 +51,16 @@ class ShardedScorer:
     batch and returns its ticket; result(ticket) waits for that batch's collective and returns the
     int32[B] tensor (valid until `depth` more batches have been submitted); drain() waits for all."""
 
-    def __init__(self, b, rank, world, local_score, device, group=None, same_stream=False, depth=2):
+    def __init__(self, b, rank, world, local_score, device, group=None, same_stream=False, depth=2, points=False):
+        """points=True: the point-sharded partitioning -- local_score fills the WHOLE buffer with this
+        rank's partial counts and the all-reduce is a true sum (score_batch_point_sharded)."""
         import torch
         self.b, self.rank, self.world, self.local_score = b, rank, world, local_score
         self.group, self.same_stream, self.depth = group, same_stream, depth
         self.bufs = [torch.zeros(max(1, b), dtype=torch.int32, device=device)[:b] for _ in range(depth)]
         self.works = [None] * depth
         self.k = 0
-        self.lo, self.hi = shard_bounds(b, rank, world)
+        self.lo, self.hi = (0, b) if points else shard_bounds(b, rank, world)
 
     def submit(self):
         import torch
@@ -91,6 +93,53 @@ class ShardedScorer:
             if self.works[i] is not None:
                 self.works[i].wait()
                 self.works[i] = None
+
+
+# ---- the other partitioning: points sharded, every rank scores every candidate ----------------------
+#   Rank g holds a contiguous 1/G slice of subset 1 (scoring) and a contiguous 1/G slice
+# of the cloud in original order (refit).  The collective of the score step is then a TRUE reduction:
+# int32[B] partial inlier counts summed over ranks (bit-exact in any order); refit lists concatenate
+# in rank order and stay ascending.  Candidate sharding (above) is the default because subset 1 is
+# small (15 MB at cfg3) and a replica per GPU costs nothing; point sharding is what scales the
+# HBM-bound refit scan and the per-GPU state.
+def point_shard_subset(vertices, normals, subset1, enabled_bool, rank, world):
+    """This rank's slice of subset 1 as a self-contained (xyz, nrm, subset, enabled) quadruple: a cloud
+    of just those points, all of them subset 1, with their enabled bits gathered."""
+    lo, hi = shard_bounds(subset1.size, rank, world)
+    idx0 = subset1[lo:hi] - 1
+    xyz = np.ascontiguousarray(vertices[idx0])
+    nrm = np.ascontiguousarray(normals[idx0])
+    en = None if enabled_bool is None else np.ascontiguousarray(enabled_bool[idx0])
+    return xyz, nrm, np.arange(1, hi - lo + 1, dtype=np.int64), en
+
+
+def score_batch_point_sharded(local_score_all, counts_full, group=None):
+    """local_score_all(out) fills out (= counts_full, int32[B]) with this rank's PARTIAL counts of all B
+    candidates over its point slice; the sum all-reduce makes them the full counts on every rank."""
+    local_score_all(counts_full)
+    return allreduce_counts(counts_full, group)
+
+
+def refit_point_sharded(local_indices_1based, offset, device, group=None):
+    """local_indices_1based: ascending inlier indices within this rank's cloud slice (which starts at
+    original 0-based index `offset`).  Returns the ascending list over the whole cloud on every rank:
+    all-gather of the lengths, then of the zero-padded lists."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.as_tensor(np.asarray(local_indices_1based, dtype=np.int64) + int(offset), device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mine.cpu().numpy()
+    world = dist.get_world_size(group)
+    n_mine = torch.tensor([mine.numel()], dtype=torch.int64, device=device)
+    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lens, n_mine, group=group)
+    lens = [int(x.item()) for x in lens]
+    cap = max(max(lens), 1)
+    padded = torch.zeros(cap, dtype=torch.int64, device=device)
+    padded[: mine.numel()] = mine
+    parts = [torch.zeros(cap, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, lens)])
 
 
 class DeviceBatch:

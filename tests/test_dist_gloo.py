@@ -63,6 +63,29 @@ def _worker(rank, world, port, b, q):
     t3 = sc.submit()
     sc.drain()
     ok = ok and bool(np.array_equal(sc.result(t3).numpy(), full))
+    # point-sharded: every rank scores all candidates on its slice of subset 1, true sum reduction
+    def chunks(mask):
+        bits = np.zeros(((mask.size + 63) // 64) * 64, dtype=np.uint8)
+        bits[: mask.size] = mask
+        return np.packbits(bits, bitorder="little").view(np.uint64)
+
+    en = np.ones(6000, dtype=bool)
+    en[::7] = False
+    oc.set_enabled(chunks(en))
+    full_en = oc.score_batch(shapes, p)
+    pxyz, pnrm, psub, pen = rdist.point_shard_subset(xyz, nrm, subs[0], en, rank, world)
+    poc = orc.Cloud(pxyz, pnrm, psub)
+    poc.set_enabled(chunks(pen))
+    pc_counts = torch.zeros(b, dtype=torch.int32)
+    rdist.score_batch_point_sharded(lambda out: out.copy_(torch.from_numpy(poc.score_batch(shapes, p).astype(np.int32))), pc_counts)
+    ok = ok and bool(np.array_equal(pc_counts.numpy(), full_en))
+    # point-sharded refit: slices of the cloud in original order, lists concatenated in rank order
+    lo, hi = rdist.shard_bounds(6000, rank, world)
+    soc = orc.Cloud(xyz[lo:hi], nrm[lo:hi], np.arange(1, hi - lo + 1, dtype=np.int64))
+    soc.set_enabled(chunks(en[lo:hi]))
+    whole = oc.refit(shapes[0], p)
+    got = rdist.refit_point_sharded(soc.refit(shapes[0], p), lo, "cpu")
+    ok = ok and bool(np.array_equal(got, whole)) and whole.size > 0
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
