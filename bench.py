@@ -141,11 +141,12 @@ def main():
     if args.workload == "cfg5":
         prim = prim + ["cone"] * 8
         types = types + [R.FittedCone]
-        wseed, wname = 5, "cfg5: 50M-point 48-primitive cloud with cones, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
+        wseed, wname = 5, "cfg5: 50M-point 48-primitive cloud with cones, scanner-style density, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
         n_default = 50_000_000
     n = args.points or n_default
     t0 = time.time()
-    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=wseed)
+    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=wseed,
+                                       scanner=[synth.BOX / 2] * 3 if args.workload == "cfg5" else None)
     subs = synth.make_subsets(n, 32, seed=wseed)
     S = subs[0].size
     pc = R.RANSACCloud(xyz, nrm, subs, device=local_rank)
