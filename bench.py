@@ -345,6 +345,30 @@ def main():
                                          "(48.125 B/point); HIP events on the library's stream; host wall adds the "
                                          "compaction, two syncs and the D2H of the index list"}
 
+        # ---- what this box's HBM delivers to simple streaming kernels (torch ops as the probe) ------
+        try:
+            nbytes = 1 << 30
+            a_ = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").normal_()
+            b_ = torch.empty_like(a_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def _time(fn, reps=10):
+                fn(); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e-3 / reps
+            t_copy = _time(lambda: b_.copy_(a_))
+            t_read = _time(lambda: a_.sum())
+            out["hbm_measured"] = {"copy_GBs": 2 * nbytes / t_copy / 1e9, "read_GBs": nbytes / t_read / 1e9, "bytes": nbytes,
+                                   "note": "1-GiB float32 tensor on this box: b.copy_(a) counts read + write bytes, a.sum() "
+                                           "read bytes; the refit scan's achieved GB/s can be read against these as well as "
+                                           "against the 8 TB/s spec"}
+            del a_, b_
+        except Exception as e:   # a probe, never fatal
+            out["hbm_measured"] = {"error": repr(e)[:200]}
+
         # ---- cpu_baseline: the oracle (port of the reference's single-threaded path) ------
         if not args.no_cpu:
             from oracle import oracle as orc
