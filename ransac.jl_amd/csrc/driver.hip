@@ -280,7 +280,7 @@ struct Driver {
         bool pending = false;
     };
     Window win[2];
-    static constexpr int32_t ENTRIES_HEAD = 512;
+    static constexpr int32_t ENTRIES_HEAD = 4096;   // list entries that travel with the window (pack_window_kernel copies min(count, this))
 
     int32_t *h_scr = nullptr;           // pinned scratch: scalars read back, liveness counts, gather lists
     int64_t h_scr_cap = 0;              // in int32
