@@ -248,6 +248,8 @@ struct Driver {
     int64_t best = -1;                      // index into store of the running first maximum
     double t_score = 0, t_extract = 0, t_sample = 0;
     double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
+    double tw[4] = { 0, 0, 0, 0 };           // windows: enqueue, wait, host list handling, record()
+    int64_t nwin = 0;
     int64_t iterations = 0;
     bool terminated = false;
 
@@ -676,7 +678,9 @@ struct Driver {
                          bool *did_extract, bool *stop)
     {
         cc[2] += ncand;
+        const double tr0 = now_s();
         RUN(record(cands, levels, ncand, counts));
+        tw[3] += now_s() - tr0;
         cc[3] = k * p->minsubsetN;
         cc[1] = (int64_t)store.size();
         RUN(maybe_extract(k, did_extract));
@@ -802,7 +806,11 @@ struct Driver {
             const int32_t W = A.W;
             B.pending = false;
             if (pipeline && k + W <= p->itermax) RUN(issue(B, k + W, (int32_t)std::min<int64_t>(Kcur, p->itermax - (k + W) + 1)));
+            const double tw0 = now_s();
+            tw[0] += tw0 - t0;
             RUNH(hipEventSynchronize(A.ev));
+            tw[1] += now_s() - tw0;
+            nwin++;
             A.pending = false;
             int32_t cnt = ((const int32_t *)A.h_status)[0];
             const int32_t gave_up = ((const int32_t *)A.h_status)[1];
@@ -843,6 +851,7 @@ struct Driver {
                           [&](int32_t a, int32_t b) { return entries[(size_t)a].slot < entries[(size_t)b].slot; });
             }
             t_sample += now_s() - t0;
+            const double tw2 = now_s();
             if (octree && cnt > 0) {
                 // candidates after the first candidate-bearing iteration were drawn from a stale level
                 // distribution: drop them (they are re-drawn in the next window)
@@ -862,6 +871,7 @@ struct Driver {
                 if (A.scored) counts[(size_t)i] = wcounts[(size_t)order[(size_t)i]];
             }
             if (!A.scored) RUN(score(cands.data(), cnt, counts));
+            tw[2] += now_s() - tw2;
             // replay the window in iteration order
             int32_t pos = 0;
             bool stop = false, did = false;
@@ -948,8 +958,11 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     out->seconds_score = d.t_score;
     out->seconds_extract = d.t_extract;
     out->seconds_host = d.t_sample;
-    if (getenv("RH_DRIVER_PROF"))
+    if (getenv("RH_DRIVER_PROF")) {
+        fprintf(stderr, "[rh_ransac] %lld windows: enqueue %.4f wait %.4f lists %.4f record %.4f s; total %.4f\n", (long long)d.nwin,
+                d.tw[0], d.tw[1], d.tw[2], d.tw[3], out->seconds);
         fprintf(stderr, "[rh_ransac] extract: refit+invalidate %.4f erase %.4f liveness %.4f store-compact %.4f host-compact %.4f s\n",
                 d.tp[0], d.tp[1], d.tp[2], d.tp[3], d.tp[4]);
+    }
     return RH_OK;
 }
