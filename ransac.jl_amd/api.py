@@ -395,6 +395,72 @@ def scorecandidate(pc, candidate, subsetID, params):
     return estimatescore(s1.size, pc.size, int(counts[0]), cp.score_mode), inpoints
 
 
+class IterationCandidates:  # fitting.jl:94-131
+    """Struct of arrays of the scored candidates: shapes, scores (ConfidenceInterval), inpoints."""
+
+    def __init__(self):
+        self.shapes, self.scores, self.inpoints = [], [], []
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __repr__(self):
+        return "IterationCandidates: %d candidates" % len(self)
+
+
+def recordscore(ic, shape, score, inpoints):  # recordscore!: fitting.jl:114-119
+    ic.shapes.append(shape)
+    ic.scores.append(score)
+    ic.inpoints.append(inpoints)
+    return ic
+
+
+def deleteat(ic, arg):  # deleteat!(ic, arg): fitting.jl:126-131 (1-based index or ascending list of them)
+    idx = [arg] if isinstance(arg, (int, np.integer)) else list(arg)
+    for i in sorted(idx, reverse=True):
+        for a in (ic.shapes, ic.scores, ic.inpoints):
+            del a[i - 1]
+    return ic
+
+
+def findhighestscore(A):  # fitting.jl:140-158: first maximum of E (strict >), overlap flag
+    if len(A) == 0:
+        return {"index": 0, "overlap": False}
+    ind, highest = 1, E(A.scores[0])
+    for i, sc in enumerate(A.scores, start=1):
+        if E(sc) > highest:
+            highest, ind = E(sc), i
+    best = A.scores[ind - 1]
+    for i, sc in enumerate(A.scores, start=1):
+        if i != ind and (sc.min <= best.max and best.min <= sc.max):   # isoverlap: confidenceintervals.jl:29-36
+            return {"index": ind, "overlap": True}
+    return {"index": ind, "overlap": False}
+
+
+def scorecandidates(pc, iterationcandidates, candidates, subsetID, params, octree_levels=None):
+    """scorecandidates! (fitting.jl:181-190) with the sequential loop replaced by ONE batched launch; the
+    results are recorded in candidate order and the two input lists are emptied like the reference does.
+    (`levelscore` is not kept: it never influences a result)"""
+    if subsetID != 1:
+        raise ValueError("only subsetID == 1 is resident on the device (iterations.jl:95)")
+    if candidates:
+        cp = _cparams(params)
+        counts, masks = score_batch(pc, candidates, cp, want_masks=True)
+        s1 = pc.subsets[0]
+        for cand, cnt, m in zip(candidates, counts, masks):
+            bits = np.unpackbits(m.view(np.uint8), bitorder="little")[: s1.size].astype(bool)
+            recordscore(iterationcandidates, cand, estimatescore(s1.size, pc.size, int(cnt), cp.score_mode), s1[bits])
+    del candidates[:]
+    if octree_levels is not None:
+        del octree_levels[:]
+
+
+def removeinvalidshapes(pc, candidates):  # removeinvalidshapes!: fitting.jl:209-221
+    en = pc.isenabled
+    toremove = [i for i, ip in enumerate(candidates.inpoints, start=1) if ip.size and not en[ip - 1].all()]
+    deleteat(candidates, toremove)
+
+
 def refit(s, pc, params):
     """refit(s, pc, params) -> ExtractedShape (shapes/plane.jl:137-143 ...)."""
     out = np.zeros(max(1, pc.size), dtype=np.int64)

@@ -113,6 +113,20 @@ out["largestconncomp"] = {
     },
 }
 
+# test/utilitytests.jl:5-28 -- 30 rand points in [0,1)^d plus the two corners (-1,...) and (2,...): findAABB
+# must return exactly those corners.  (The reference draws the 30 points with rand(); any points inside
+# the unit cube pin the same property, so a fixed list stands in for them.)
+import random
+_r = random.Random(20260101)
+out["findAABB"] = {
+    "source": "test/utilitytests.jl:5-28",
+    "cases": [
+        {"dim": d, "points": [[_r.random() for _ in range(d)] for _ in range(30)] + [[-1.0] * d, [2.0] * d],
+         "expected_min": [-1.0] * d, "expected_max": [2.0] * d}
+        for d in (3, 2)
+    ],
+}
+
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_known_answers.json"), "w") as f:
     json.dump(out, f, indent=1)
 print("ok")

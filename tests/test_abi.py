@@ -203,3 +203,24 @@ def test_deterministic_trig_is_within_one_ulp_of_libm():
             ulp = abs(int(np.float64(got).view(np.int64)) - int(np.float64(ref).view(np.int64)))
             worst = max(worst, ulp)
     assert worst <= 1
+
+
+def test_iterationcandidates_bookkeeping():  # test/fitting.jl:1-18
+    ic = R.IterationCandidates()
+    fp = R.FittedPlane([0.5, 0.5, 0.5], [0, 0, 1.0])
+    sc = R.ConfidenceInterval(0, 1)
+    inds = np.array([1, 2, 3, 4, 5])
+    assert len(ic) == 0
+    R.recordscore(ic, fp, sc, inds)
+    assert len(ic) == 1
+    assert len(ic.shapes) == 1 and len(ic.scores) == 1 and len(ic.inpoints) == 1
+    R.deleteat(ic, 1)
+    assert len(ic) == 0
+    assert len(ic.shapes) == 0 and len(ic.scores) == 0 and len(ic.inpoints) == 0
+    # findhighestscore (fitting.jl:140-158): first maximum, strict >; overlap flag
+    assert R.findhighestscore(ic) == {"index": 0, "overlap": False}
+    for lo, hi in ((0, 1), (2, 4), (2, 4), (5, 6)):
+        R.recordscore(ic, fp, R.ConfidenceInterval(lo, hi), inds)
+    assert R.findhighestscore(ic) == {"index": 4, "overlap": False}
+    R.deleteat(ic, [1, 4])
+    assert R.findhighestscore(ic) == {"index": 1, "overlap": True}

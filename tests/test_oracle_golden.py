@@ -147,6 +147,16 @@ def test_largestconncomp(golden, case):  # test/parameterspacebitmap.jl:1-55
         assert cc_indices(bm, idx, lin) == exp["idx"] * exp["repeat"]
 
 
+def test_findAABB(golden):  # test/utilitytests.jl:5-28
+    for case in golden["findAABB"]["cases"]:
+        pts = np.ascontiguousarray(case["points"], dtype=np.float64)
+        d = case["dim"]
+        mn, mx = np.zeros(d), np.zeros(d)
+        dp = C.POINTER(C.c_double)
+        orc.lib().orc_findAABB(pts.ctypes.data_as(dp), pts.shape[0], d, mn.ctypes.data_as(dp), mx.ctypes.data_as(dp))
+        assert mn.tolist() == case["expected_min"] and mx.tolist() == case["expected_max"]
+
+
 def test_multithreaded_score_batch_equals_sequential():
     """bench.py's all-cores steelman (OpenMP over candidates) returns the sequential oracle's counts."""
     from ransac_jl_amd import synth

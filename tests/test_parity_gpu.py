@@ -606,3 +606,32 @@ def test_results_own_their_index_lists_until_freed():
     assert all(np.array_equal(a, b) for a, b in zip(l2, l3))
     lib.rh_result_free(C.byref(r3))
     lib.rh_result_free(C.byref(r2))
+
+
+def test_scorecandidates_and_removeinvalidshapes_mirror(small_scene):
+    """The reference's per-iteration bookkeeping on top of the batched launch: scorecandidates! records
+    (score, inpoints) per candidate in order and empties its inputs; after an extraction
+    removeinvalidshapes! drops exactly the candidates that own a disabled point (fitting.jl:181-221)."""
+    pc, oc, truth = small_scene
+    params = R.ransacparameters()
+    pc.enable_all()
+    cands = make_candidates(truth, 12, seed=4)
+    keep = list(cands)
+    levels = [1] * len(cands)
+    ic = R.IterationCandidates()
+    R.scorecandidates(pc, ic, cands, 1, params, levels)
+    assert cands == [] and levels == [] and len(ic) == len(keep)
+    for shp, sc, ip in zip(keep, ic.scores, ic.inpoints):
+        sc1, ip1 = R.scorecandidate(pc, shp, 1, params)
+        assert (sc.min, sc.max) == (sc1.min, sc1.max) and np.array_equal(ip, ip1)
+    best = R.findhighestscore(ic)["index"]
+    ex = R.refit(ic.shapes[best - 1], pc, params)
+    R.invalidate_indexes(pc, ex.inpoints)
+    en = pc.isenabled
+    expect = [i for i, ip in enumerate(ic.inpoints) if ip.size == 0 or en[ip - 1].all()]
+    shapes_before = list(ic.shapes)
+    R.deleteat(ic, best)
+    expect = [shapes_before[i] for i in expect if i != best - 1]
+    R.removeinvalidshapes(pc, ic)
+    assert ic.shapes == expect
+    pc.enable_all()
