@@ -3,7 +3,8 @@ cserteGT3/RANSAC.jl: FittedShape / RANSACCloud / ransac().  Import as `ransac_jl
 from . import _lib, synth
 from ._lib import (CONE, CYLINDER, PLANE, SPHERE, SCORE_F64, SCORE_INT64_WRAP, RansacHipError, lib)
 from .api import (DEFAULT_PARAMETERS, DEFAULT_SHAPE_DICT, ConfidenceInterval, E, ExtractedShape, FittedCone,
-                  IterationCandidates, deleteat, findhighestscore, recordscore, removeinvalidshapes, scorecandidates,
+                  IterationCandidates, deleteat, findhighestscore, forcefitshapes, push2candidatesandlevels, recordscore,
+                  removeinvalidshapes, scorecandidates, setfloattype,
                   FittedCylinder, FittedPlane, FittedShape, FittedSphere, RANSACCloud, bitmapparameters,
                   defaultcommonparameters, defaultiterationparameters, defaultparameters,
                   defaultshapeparameters, estimatescore, fit, invalidate_indexes, largestconncomp,

@@ -395,6 +395,37 @@ def scorecandidate(pc, candidate, subsetID, params):
     return estimatescore(s1.size, pc.size, int(counts[0]), cp.score_mode), inpoints
 
 
+def push2candidatesandlevels(candidates, candidate, levels, current_level):  # utilities.jl:473-481
+    """Push `candidate` (one shape or a list of shapes) and its octree level."""
+    if isinstance(candidate, (list, tuple)):
+        candidates.extend(candidate)
+        levels.extend([current_level] * len(candidate))
+    else:
+        candidates.append(candidate)
+        levels.append(current_level)
+
+
+def forcefitshapes(points, normals, parameters, candidates, level_array, octree_lev, pc):  # forcefitshapes!: fitting.jl:165-173
+    """Call `fit` for every type of iteration.shape_types, in that order, and append what fits."""
+    for T in parameters["iteration"]["shape_types"]:
+        fitted = fit(T, points, normals, pc, parameters)
+        if fitted is not None:
+            push2candidatesandlevels(candidates, fitted, level_array, octree_lev)
+
+
+def setfloattype(nt, T):  # utilities.jl:488-504
+    """Convert every real-but-not-integer value of a nested parameter dict to numpy type T."""
+    out = {}
+    for k, v in nt.items():
+        if isinstance(v, dict):
+            out[k] = setfloattype(v, T)
+        elif isinstance(v, (float, np.floating)) and not isinstance(v, bool):
+            out[k] = T(v)
+        else:
+            out[k] = v
+    return out
+
+
 class IterationCandidates:  # fitting.jl:94-131
     """Struct of arrays of the scored candidates: shapes, scores (ConfidenceInterval), inpoints."""
 

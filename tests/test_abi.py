@@ -224,3 +224,32 @@ def test_iterationcandidates_bookkeeping():  # test/fitting.jl:1-18
     assert R.findhighestscore(ic) == {"index": 4, "overlap": False}
     R.deleteat(ic, [1, 4])
     assert R.findhighestscore(ic) == {"index": 1, "overlap": True}
+
+
+def test_push2candidatesandlevels():  # test/utilitytests.jl:134-149
+    fp = R.FittedPlane([0.5, 0.5, 0.5], [0, 0, 1.0])
+    candidates, levels = [], []
+    R.push2candidatesandlevels(candidates, fp, levels, 3)
+    assert len(candidates) == 1 and len(levels) == 1
+    R.push2candidatesandlevels(candidates, [fp, fp], levels, 0)
+    assert len(candidates) == 3 and len(levels) == 3
+    assert levels == [3, 0, 0]
+
+
+def test_setfloattype():  # test/utilitytests.jl:151-189
+    nta = {"α": 1.0, "somepar": "key1", "intpar": 1}
+    ntb = {"α": 1, "otherpar": np.float32(0.145), "str": "str"}
+    nt = {"α": 9, "ϵ": 0.1, "γ": np.float32(0.01), "shapea": nta, "shapeb": ntb}
+    f32 = R.setfloattype(nt, np.float32)
+    assert f32["α"] == 9 and isinstance(f32["α"], int)
+    assert isinstance(f32["ϵ"], np.float32) and math.isclose(f32["ϵ"], np.float32(0.1))
+    assert isinstance(f32["γ"], np.float32) and math.isclose(f32["γ"], np.float32(0.01))
+    assert isinstance(f32["shapea"]["α"], np.float32) and f32["shapea"]["somepar"] == "key1" and f32["shapea"]["intpar"] == 1
+    assert f32["shapeb"]["α"] == 1 and isinstance(f32["shapeb"]["otherpar"], np.float32) and f32["shapeb"]["str"] == "str"
+    f64 = R.setfloattype(f32, np.float64)
+    rt = math.sqrt(np.finfo(np.float32).eps)
+    assert f64["α"] == 9 and isinstance(f64["ϵ"], np.float64) and math.isclose(f64["ϵ"], 0.1, rel_tol=rt)
+    assert isinstance(f64["γ"], np.float64) and math.isclose(f64["γ"], 0.01, rel_tol=rt)
+    assert isinstance(f64["shapea"]["α"], np.float64) and f64["shapea"]["intpar"] == 1
+    assert isinstance(f64["shapeb"]["otherpar"], np.float64) and math.isclose(f64["shapeb"]["otherpar"], 0.145, rel_tol=rt)
+    assert f64["shapeb"]["str"] == "str"
