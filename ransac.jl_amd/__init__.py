@@ -4,7 +4,7 @@ from . import _lib, synth
 from ._lib import (CONE, CYLINDER, PLANE, SPHERE, SCORE_F64, SCORE_INT64_WRAP, RansacHipError, lib)
 from .api import (DEFAULT_PARAMETERS, DEFAULT_SHAPE_DICT, ConfidenceInterval, E, ExtractedShape, FittedCone,
                   IterationCandidates, deleteat, findhighestscore, forcefitshapes, push2candidatesandlevels, recordscore,
-                  removeinvalidshapes, scorecandidates, setfloattype,
+                  removeinvalidshapes, scorecandidates, setfloattype, findAABB, smallestdistance,
                   FittedCylinder, FittedPlane, FittedShape, FittedSphere, RANSACCloud, bitmapparameters,
                   defaultcommonparameters, defaultiterationparameters, defaultparameters,
                   defaultshapeparameters, estimatescore, fit, invalidate_indexes, largestconncomp,

@@ -413,6 +413,19 @@ def forcefitshapes(points, normals, parameters, candidates, level_array, octree_
             push2candidatesandlevels(candidates, fitted, level_array, octree_lev)
 
 
+def findAABB(points):  # utilities.jl:125-136
+    """(min, max) corners of the axis-aligned box of the points (host helper; the device builds its own boxes)."""
+    a = _f64(points)
+    return a.min(axis=0), a.max(axis=0)
+
+
+def smallestdistance(points):  # utilities.jl:187-199 (exported, unused by ransac(): iterations.jl:57 is a comment)
+    a = _f64(points)
+    assert a.shape[0] > 1, "At least two point is needed for that."
+    d = np.linalg.norm(a[:, None, :] - a[None, :, :], axis=2)
+    return float(d[~np.eye(a.shape[0], dtype=bool)].min())
+
+
 def setfloattype(nt, T):  # utilities.jl:488-504
     """Convert every real-but-not-integer value of a nested parameter dict to numpy type T."""
     out = {}

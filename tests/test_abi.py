@@ -253,3 +253,13 @@ def test_setfloattype():  # test/utilitytests.jl:151-189
     assert isinstance(f64["shapea"]["α"], np.float64) and f64["shapea"]["intpar"] == 1
     assert isinstance(f64["shapeb"]["otherpar"], np.float64) and math.isclose(f64["shapeb"]["otherpar"], 0.145, rel_tol=rt)
     assert f64["shapeb"]["str"] == "str"
+
+
+def test_findAABB_and_smallestdistance():  # test/utilitytests.jl:5-40
+    rng = np.random.default_rng(0)
+    for d in (3, 2):
+        pts = np.vstack([rng.random((30, d)), -np.ones(d), 2 * np.ones(d)])
+        mn, mx = R.findAABB(pts)
+        assert mn.tolist() == [-1.0] * d and mx.tolist() == [2.0] * d
+    assert math.isclose(R.smallestdistance([[0.0, 0], [1.0, 1], [2.2, 2]]), math.sqrt(2))
+    assert math.isclose(R.smallestdistance([[0.0, 0, 0], [1.0, 1, 1], [2.2, 2, 2]]), math.sqrt(3))
