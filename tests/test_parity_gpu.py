@@ -635,3 +635,81 @@ def test_scorecandidates_and_removeinvalidshapes_mirror(small_scene):
     R.removeinvalidshapes(pc, ic)
     assert ic.shapes == expect
     pc.enable_all()
+
+
+def _ransac_via_call_sites(pc, params, seed):
+    """The reference's own loop (iterations.jl:35-162) written against the API mirrors, with ONLY the three
+    hot calls going to the device -- scorecandidates! (batched), refit, invalidate_indexes! -- plus the
+    k-th-enabled select; sampling, fits, score statistics and candidate bookkeeping stay on the host, as in
+    julia/RANSACHIP.jl's `ransac`.  Returns (extracted, iterations, draws)."""
+    lib = R.lib()
+    it = params["iteration"]
+    drawN, minsubsetN, tau, itermax, prob_det = it["drawN"], it["minsubsetN"], it["τ"], it["itermax"], it["prob_det"]
+    which = {"lengthC": 0, "allcand": 1, "nofminset": 2}
+    rng = L.Rng()
+    lib.rh_rng_seed(C.byref(rng), seed)
+    rnd = lambda n: lib.rh_rng_range(C.byref(rng), n)
+    candidates, levels, ic, extracted = [], [], R.IterationCandidates(), []
+    cc = [0, 0, 0]
+    en = pc.isenabled
+    iterations = 0
+    for k in range(1, itermax + 1):
+        if int(en.sum()) < tau:
+            break
+        for _ in range(minsubsetN):
+            # samplepointcloud4! (fitting.jl:383-430), root cell
+            first = rnd(pc.size)
+            while not en[first - 1]:
+                first = rnd(pc.size)
+            n_en = int(en.sum())
+            if n_en < drawN:
+                continue
+            sd = [first]
+            for _q in range(1, drawN):
+                pick = int(R.select_enabled(pc, [rnd(n_en)])[0])
+                if pick == first:
+                    pick = int(R.select_enabled(pc, [rnd(n_en)])[0])
+                sd.append(pick)
+            if len(set(sd)) != drawN:
+                continue
+            idx = np.asarray(sd) - 1
+            R.forcefitshapes(pc.vertices[idx], pc.normals[idx], params, candidates, levels, 1, pc)
+        cc[1] += len(candidates)
+        R.scorecandidates(pc, ic, candidates, 1, params, levels)
+        cc[2] = k * minsubsetN
+        cc[0] = len(ic)
+        if len(ic) > 0:
+            best = R.findhighestscore(ic)["index"]
+            scr = R.E(ic.scores[best - 1])
+            if R.prob(scr, cc[which[str(it["extract_s"]).lstrip(":")]], pc.size, drawN) > prob_det:
+                ex = R.refit(ic.shapes[best - 1], pc, params)
+                R.invalidate_indexes(pc, ex.inpoints)
+                en = pc.isenabled
+                extracted.append(ex)
+                R.deleteat(ic, best)
+                R.removeinvalidshapes(pc, ic)
+        iterations = k
+        if R.prob(tau, cc[which[str(it["terminate_s"]).lstrip(":")]], pc.size, drawN) > prob_det:
+            break
+    return extracted, iterations, rng.draws
+
+
+def test_reference_loop_with_three_call_sites_swapped():
+    """Drop-in at the call sites INTEGRATION.md names: the reference's loop on the host with
+    scorecandidates! / refit / invalidate_indexes! (and the enabled select) served by the library gives
+    exactly the oracle's run -- shapes, index sets, iteration count, RNG draws."""
+    xyz, nrm, truth = synth.make_cloud(9_000, ["plane", "sphere", "cylinder"], 0.1, seed=31)
+    subs = synth.make_subsets(9_000, 2, seed=31)
+    params = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
+                                iteration={"minsubsetN": 12, "itermax": 25, "τ": 200, "prob_det": 0.7})
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    got, iters, draws = _ransac_via_call_sites(pc, params, seed=5)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    exp = oc.ransac(to_orc_params(R.params_to_c(params)), seed=5)
+    assert exp["rc"] == 0 and len(exp["shapes"]) >= 2
+    assert iters == exp["iterations"] and draws == exp["draws"]
+    assert len(got) == len(exp["shapes"])
+    for g, e in zip(got, exp["shapes"]):
+        assert bytes(g.shape.to_c()) == bytes(e["shape"])
+        assert np.array_equal(g.inpoints, e["inpoints"])
+    assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
