@@ -27,10 +27,15 @@ namespace {
 __device__ __forceinline__ uint64_t test_plane(const rh_prep &P, double px, double py, double pz, double nx,
                                            double ny, double nz, double eps, double cosa)
 {
+    // The normal half first: a point whose normal is not within alpha of the plane's fails whatever its
+    // distance, and in most groups that is every point of the wave (outliers and other primitives' points),
+    // so the distance half is skipped with one scalar branch.  Same bits as evaluating both.
+    const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
+    const uint64_t mn = WB(dn > cosa);
+    if (mn == 0) return 0;
     const double vx = px - P.f[0], vy = py - P.f[1], vz = pz - P.f[2];
     const double d = (P.f[6] * vx + P.f[7] * vy) + P.f[8] * vz;
-    const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
-    return WB(dn > cosa) & WB(fabs(d) < eps);
+    return mn & WB(fabs(d) < eps);
 }
 
 // sphere: compatiblesSphere shapes/sphere.jl:144-172.  Inward case: normalize(o-p) = -normalize(p-o)
