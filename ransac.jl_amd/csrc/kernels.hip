@@ -45,10 +45,12 @@ __device__ __forceinline__ uint64_t test_sphere(const rh_prep &P, double px, dou
 {
     const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
     const double nr = sqrt((dx * dx + dy * dy) + dz * dz);
+    const uint64_t md = WB(fabs(nr - P.f[3]) < eps);
+    if (md == 0) return 0;     // no lane of the wave inside the band: the normal half cannot change that
     const double inv = 1.0 / nr;
     const double ux = inv * dx, uy = inv * dy, uz = inv * dz;
     const double dt = (ux * nx + uy * ny) + uz * nz;
-    return WB(P.f[4] * dt > cosa) & WB(fabs(nr - P.f[3]) < eps);
+    return WB(P.f[4] * dt > cosa) & md;
 }
 
 // cylinder: compatiblesCylinder shapes/cylinder.jl:194-221
@@ -62,11 +64,13 @@ __device__ __forceinline__ uint64_t test_cylinder(const rh_prep &P, double px, d
     // curr_norm = p - a*dot(a, p-c) - c
     const double qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
     const double nr = sqrt((qx * qx + qy * qy) + qz * qz);
+    // the reference nests the two tests (cylinder.jl:209-214); their conjunction is the same bit
+    const uint64_t md = WB(fabs(nr - P.f[6]) < eps);
+    if (md == 0) return 0;
     const double inv = 1.0 / nr;
     const double ux = inv * qx, uy = inv * qy, uz = inv * qz;
     const double dt = (ux * nx + uy * ny) + uz * nz;
-    // the reference nests the two tests (cylinder.jl:209-214); their conjunction is the same bit
-    return WB(fabs(nr - P.f[6]) < eps) & WB(P.f[7] * dt > cosa);
+    return md & WB(P.f[7] * dt > cosa);
 }
 
 // cone: compatiblesCone shapes/cone.jl:132-153, project2cone :68-85,
