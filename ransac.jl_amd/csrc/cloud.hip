@@ -578,14 +578,18 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         nk[shapes[i].kind]++;
     }
     RH_TRY(rh_ensure_batch(c, b));
-    const int64_t stage_bytes = (int64_t)b * (sizeof(rh_shape) + sizeof(int32_t)) + 64;
+    // pinned staging: sorted shapes | original positions | bin sizes | counts on the way back -- every small
+    // transfer of the call is asynchronous and the call waits once
+    const int64_t stage_bytes = (int64_t)b * (sizeof(rh_shape) + 2 * sizeof(int32_t)) + 128;
     RH_TRY(rh_ensure_pin(c, stage_bytes));
     rh_shape *h_sorted = (rh_shape *)c->h_pin;
     int32_t *h_orig = (int32_t *)((char *)c->h_pin + (size_t)b * sizeof(rh_shape));
+    int32_t *h_nk = h_orig + b;
+    int32_t *h_counts = h_nk + 16;
     int32_t off[4], fill[4];
     off[0] = 0;
     for (int k = 1; k < 4; k++) off[k] = off[k - 1] + nk[k - 1];
-    for (int k = 0; k < 4; k++) fill[k] = off[k];
+    for (int k = 0; k < 4; k++) { fill[k] = off[k]; h_nk[k] = nk[k]; }
     for (int32_t i = 0; i < b; i++) {   // stable counting sort by kind
         const int k = shapes[i].kind;
         h_sorted[fill[k]] = shapes[i];
@@ -594,9 +598,8 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     }
     RH_HIP(hipMemcpyAsync(c->d_shapes, h_sorted, sizeof(rh_shape) * (size_t)b, hipMemcpyHostToDevice, c->stream));
     RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
-    RH_HIP(hipMemcpyAsync(c->d_nk, nk, sizeof nk, hipMemcpyHostToDevice, c->stream));
-    RH_HIP(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
-    RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep));
+    RH_HIP(hipMemcpyAsync(c->d_nk, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts));   // zeroes d_counts as well
     uint64_t *d_masks = nullptr, *d_masks_int = nullptr;
     if (masks_out && c->swords > 0) {
         RH_TRY(rh_ensure_masks(c, (int64_t)b * c->swords));
@@ -608,11 +611,12 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     const int64_t off64[4] = { off[0], off[1], off[2], off[3] };
     RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off64, c->d_nk, nk, b, c->d_counts, d_masks_int, nullptr));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
-    RH_HIP(hipMemcpyAsync(counts_out, c->d_counts, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipMemcpyAsync(h_counts, c->d_counts, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
     if (d_masks)
         RH_HIP(hipMemcpyAsync(masks_out, d_masks, sizeof(uint64_t) * (size_t)b * (size_t)c->swords,
                               hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
+    memcpy(counts_out, h_counts, sizeof(int32_t) * (size_t)b);
     return RH_OK;
 }
 

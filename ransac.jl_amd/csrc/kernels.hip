@@ -168,10 +168,14 @@ __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
     }
 }
 
-__global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep)
+__global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
+                                   int32_t *__restrict__ counts_zero)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < b) prep_one(shapes[i], prep[i]);
+    if (i < b) {
+        prep_one(shapes[i], prep[i]);
+        if (counts_zero != nullptr) counts_zero[i] = 0;
+    }
 }
 
 // unknown kinds (device-resident batch): bin by kind, one atomic per (wave, kind)
@@ -1218,10 +1222,11 @@ int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int6
     return RH_OK;
 }
 
-int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep)
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep, int32_t *d_counts_to_zero)
 {
     if (b == 0) return RH_OK;
-    hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep);
+    hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep,
+                       d_counts_to_zero);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

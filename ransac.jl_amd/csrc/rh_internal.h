@@ -134,7 +134,8 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_
                       const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
 int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src, int32_t *h_pinned_dst);   // *h = *d in stream order (pinned h)
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
-int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep);
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep,
+                    int32_t *d_counts_to_zero = nullptr);
 struct rh_cand_entry;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
                      int32_t launch_bound, int32_t *d_counts, int nk_is_zero);
