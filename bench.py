@@ -388,7 +388,7 @@ def main():
                                    "host_cpus": os.cpu_count()}
             # steelman: the same passes spread over the host cores this GPU's share allows (OpenMP over candidates)
             nthr = max(1, min(16, os.cpu_count() or 1))
-            nb_mt = min(b_global, 192 * nthr)
+            nb_mt = min(b_global, 256 * nthr)   # 16 threads: the whole 4096-candidate batch is checked against the oracle
             oarr_mt = (orc.Shape * nb_mt)()
             C.memmove(oarr_mt, arr, C.sizeof(L.Shape) * nb_mt)
             t0 = time.perf_counter()
