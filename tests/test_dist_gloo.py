@@ -79,6 +79,12 @@ def _worker(rank, world, port, b, q):
     pc_counts = torch.zeros(b, dtype=torch.int32)
     rdist.score_batch_point_sharded(lambda out: out.copy_(torch.from_numpy(poc.score_batch(shapes, p).astype(np.int32))), pc_counts)
     ok = ok and bool(np.array_equal(pc_counts.numpy(), full_en))
+    # the same through the two-deep pipeline (points=True: every rank fills the whole buffer with partial counts)
+    psc = rdist.ShardedScorer(b, rank, world, lambda lo_, hi_, out: out.copy_(
+        torch.from_numpy(poc.score_batch(shapes[lo_:hi_], p).astype(np.int32))), "cpu", points=True)
+    pt = [psc.submit() for _ in range(3)]
+    psc.drain()
+    ok = ok and bool(np.array_equal(psc.result(pt[-1]).numpy(), full_en)) and bool(np.array_equal(psc.result(pt[-2]).numpy(), full_en))
     # point-sharded refit: slices of the cloud in original order, lists concatenated in rank order
     lo, hi = rdist.shard_bounds(6000, rank, world)
     soc = orc.Cloud(xyz[lo:hi], nrm[lo:hi], np.arange(1, hi - lo + 1, dtype=np.int64))
