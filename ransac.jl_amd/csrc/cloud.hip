@@ -135,7 +135,7 @@ static void cloud_free(rh_cloud *c)
     // a caller's stream (rh_cloud_set_stream) may be gone by now: wait for the device instead of the handle
     if (c->stream != c->own_stream) (void)hipDeviceSynchronize();
     else if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
+    (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);

@@ -1361,6 +1361,7 @@ int rhk_build_select(rh_cloud *c)
                        c->nwords, c->word_prefix, c->sel_list);
     RH_HIP(hipGetLastError());
     c->select_valid = true;
+    c->crec_valid = false;   // the rank order just changed
     return RH_OK;
 }
 

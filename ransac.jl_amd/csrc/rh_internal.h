@@ -68,6 +68,9 @@ struct rh_cloud {
     double *set_ws = nullptr;          // sampler -> fitter hand-over: gathered minimal sets, [drawN * 6][sets]
     int32_t *set_level = nullptr;      // per set: octree level it was drawn from, 0 = no set
     int64_t set_ws_sets = 0, set_ws_doubles = 0;
+    double *crec = nullptr;            // 64-byte records of the ENABLED points in rank order (long sampling windows)
+    int64_t crec_cap = 0;              // in records
+    bool crec_valid = false;           // cleared whenever the select list is rebuilt
     int32_t *sel_list = nullptr;       // sel_list[r] = 0-based index of the (r+1)-th enabled point (valid with select_valid)
     double *rec = nullptr;             // the same points as 64-byte records (x y z nx ny nz 0 0): one line per random gather
     double *sub = nullptr;             // subset 1, subset order

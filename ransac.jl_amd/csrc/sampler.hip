@@ -25,6 +25,57 @@ struct DevEnabled {
 
 constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the host sampler
 
+// samplepointcloud4! on the root cell in RANK space (see sample_sets_kernel): the first point is drawn by
+// rejection on rand(1:n) like the reference and converted to its rank with the per-word popcount prefix; the
+// others are ranks already.  Draw count and stream position equal rhfit::sample_minimal_set's.
+template <int DN>
+__device__ bool sample_ranks(const DevEnabled &en, int64_t n, int64_t n_enabled, int drawN_rt, uint64_t *x, int64_t *sd,
+                             uint32_t *ndraws, bool *gave_up)
+{
+    const int drawN = DN > 0 ? DN : drawN_rt;
+    if (n_enabled <= 0) return false;
+    int64_t r1 = rhfit::set_stream_range(x, n);
+    uint32_t nd = 1;
+    while (!en.test(r1 - 1)) {
+        r1 = rhfit::set_stream_range(x, n);
+        if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+    }
+    *ndraws += nd;
+    if (n_enabled < drawN) return false;
+    const int64_t i0 = r1 - 1;
+    sd[0] = (int64_t)en.prefix[i0 >> 6] + __popcll(en.w[i0 >> 6] & ((1ULL << (i0 & 63)) - 1ULL)) + 1;
+#pragma unroll
+    for (int q = 1; q < drawN; q++) {
+        int64_t pick = rhfit::set_stream_range(x, n_enabled);
+        ++*ndraws;
+        if (pick == sd[0]) {   // one redraw: fitting.jl:416-419
+            pick = rhfit::set_stream_range(x, n_enabled);
+            ++*ndraws;
+        }
+        sd[q] = pick;
+    }
+    bool distinct = true;
+#pragma unroll
+    for (int a = 1; a < drawN; a++)
+#pragma unroll
+        for (int b = 0; b < a; b++) distinct = distinct && (sd[a] != sd[b]);
+    return distinct;
+}
+
+// crec[r] = rec[sel[r]]: the enabled points' records in rank order
+__global__ void __launch_bounds__(256)
+compact_records_kernel(const double *__restrict__ rec, const int32_t *__restrict__ sel, int64_t n_enabled,
+                       double *__restrict__ crec)
+{
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_enabled) return;
+    const f64x2 *s = (const f64x2 *)(rec + 8 * (int64_t)sel[r]);
+    f64x2 *d = (f64x2 *)(crec + 8 * r);
+    const f64x2 a = s[0], b = s[1], c = s[2];
+    d[0] = a; d[1] = b; d[2] = c;
+}
+
 // Two kernels.  sample_sets_kernel is latency-bound (dependent random reads of enabled words, then
 // the point gathers) and needs few registers, so it runs at full occupancy; it hands the gathered
 // sets over in a coalesced [component][set] workspace.  fit_sets_kernel is the arithmetic (up to
@@ -34,7 +85,8 @@ __global__ void __launch_bounds__(256)
 sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int32_t n_enabled,
                    const rhfit::OctView oc, const double *__restrict__ Pwin, int32_t drawN_rt, int32_t minsubsetN,
                    uint64_t seed, int64_t k0, int32_t n_iters, double *__restrict__ ws, int32_t *__restrict__ set_level,
-                   unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag)
+                   unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag,
+                   const double *__restrict__ crec)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)n_iters * minsubsetN;
@@ -48,10 +100,16 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
     bool gave_up = false;
     const int drawN = DN > 0 ? DN : drawN_rt;
     int level = 1;
+    // crec != null (root-cell sampling, long windows): sd[] holds RANKS among the enabled points and the
+    // points come from the rank-ordered compact records -- one 64-byte line per point instead of a select-list
+    // line plus a record line.  rank <-> index is a bijection on the enabled points, so "same point" and
+    // "all different" mean the same on ranks (fitting.jl:416-428).
     const bool ok = Pwin != nullptr
                         ? rhfit::sample_minimal_set_octree<DN>(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled,
                                                                drawN, &x, sd, &nd, &gave_up, &level)
-                        : rhfit::sample_minimal_set<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+                        : (crec != nullptr ? sample_ranks<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up)
+                                           : rhfit::sample_minimal_set<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up));
+    const double *src = crec != nullptr ? crec : rec;
     // draws per iteration: one atomic per (wave, iteration) instead of one per set -- thousands of
     // same-address atomics serialise in L2 and dominated the kernel
     {
@@ -73,7 +131,7 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
     typedef double f64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < drawN; q++) {
-        const f64x2 *r = (const f64x2 *)(rec + 8 * (sd[q] - 1));   // one 64-byte record per point
+        const f64x2 *r = (const f64x2 *)(src + 8 * (sd[q] - 1));   // one 64-byte record per point
         const f64x2 a = r[0], b = r[1], c = r[2];
         double *w = ws + (int64_t)(6 * q) * total + t;
         w[0] = a.x; w[total] = a.y; w[2 * total] = b.x;
@@ -198,10 +256,28 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
     bool cone = false;
     for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
+    // long root-cell windows sample from rank-ordered compact records (rebuilt with the select list)
+    static int no_crec = -1;
+    if (no_crec < 0) no_crec = getenv("RH_NO_CREC") ? 1 : 0;
+    const double *crec = nullptr;
+    if (d_P == nullptr && n_iters >= 32 && n_enabled > 0 && !no_crec) {
+        if (!c->crec_valid) {
+            if (c->crec_cap < n_enabled) {
+                (void)hipFree(c->crec);
+                c->crec = nullptr; c->crec_cap = 0;
+                RH_HIP(hipMalloc((void **)&c->crec, sizeof(double) * 8 * (size_t)n_enabled));
+                c->crec_cap = n_enabled;
+            }
+            hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)(((int64_t)n_enabled + 255) / 256)), dim3(256), 0, c->stream,
+                               c->rec, c->sel_list, (int64_t)n_enabled, c->crec);
+            c->crec_valid = true;
+        }
+        crec = c->crec;
+    }
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
 #define RH_SAMPLE(DN)                                                                                                  \
     hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
-                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up)
+                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
                        d_out, cap, d_count, d_nk_zero)
