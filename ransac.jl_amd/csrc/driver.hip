@@ -715,8 +715,8 @@ struct Driver {
     // kk + 1 -- bit-identical to the sequential loop.
     int run_streams_device()
     {
-        const int64_t sets_budget = 1 << 20;
-        const int64_t Kmax = std::max<int64_t>(1, std::min<int64_t>(128, sets_budget / std::max(1, p->minsubsetN)));
+        const int64_t sets_budget = 1 << 21;   // minimal sets per window: 512 iterations at minsubsetN = 4096
+        const int64_t Kmax = std::max<int64_t>(1, std::min<int64_t>(512, sets_budget / std::max(1, p->minsubsetN)));
         const int64_t K = Kmax;  // longest window
         int64_t Kcur = octree ? 1 : Kmax;   // window length in use; adapted to how often windows get cut short
         const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)K + 63) / 64 * 64;

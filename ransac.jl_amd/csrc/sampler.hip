@@ -34,12 +34,28 @@ __device__ bool sample_ranks(const DevEnabled &en, int64_t n, int64_t n_enabled,
 {
     const int drawN = DN > 0 ? DN : drawN_rt;
     if (n_enabled <= 0) return false;
-    int64_t r1 = rhfit::set_stream_range(x, n);
-    uint32_t nd = 1;
-    while (!en.test(r1 - 1)) {
-        r1 = rhfit::set_stream_range(x, n);
-        if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+    // rand(1:n) until enabled (fitting.jl:391-394).  The stream advances by a constant per draw, so draw k is a
+    // pure function of (x0, k): four draws are tested per round (four independent loads instead of a chain of
+    // dependent ones); the accepted index and the number of draws consumed are those of the one-at-a-time loop.
+    const uint64_t G = 0x9E3779B97F4A7C15ULL, x0 = *x;
+    uint32_t nd = 0;
+    int64_t r1 = 0;
+    for (;;) {
+        int64_t r[4];
+        bool e[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            r[i] = 1 + (int64_t)rhfit::mulhi64(rhfit::mix64(x0 + (uint64_t)(nd + 1 + i) * G), (uint64_t)n);
+            e[i] = en.test(r[i] - 1);
+        }
+        int hit = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; i--) hit = e[i] ? i : hit;
+        if (hit >= 0) { nd += (uint32_t)hit + 1; r1 = r[hit]; break; }
+        nd += 4;
+        if (nd > (1u << 24)) { *gave_up = true; *x = x0 + (uint64_t)nd * G; *ndraws += nd; return false; }
     }
+    *x = x0 + (uint64_t)nd * G;
     *ndraws += nd;
     if (n_enabled < drawN) return false;
     const int64_t i0 = r1 - 1;
@@ -205,6 +221,77 @@ pack_window_kernel(uint64_t *__restrict__ status, int32_t status_words, const rh
     for (int i = tid; i < status_words; i += 1024) status[i] = 0;
 }
 
+// Root-cell windows without cones, sampled in rank space: ONE kernel.  With the compact records every point
+// is a single 64-byte line from a set that fits the memory-side cache, so the hand-over workspace of the
+// two-kernel form (144 B written + read per set) costs more than the lower occupancy of a kernel that also
+// carries the plane / sphere / cylinder fits (~160 VGPRs, 3 waves per SIMD).
+template <int DN>
+__global__ void __launch_bounds__(128)
+sample_fit_ranks_kernel(const double *__restrict__ crec, int64_t n, DevEnabled en, int32_t n_enabled, const rh_params prm,
+                        uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out, int32_t cap,
+                        int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
+                        int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;
+    const int64_t total = (int64_t)n_iters * prm.minsubsetN;
+    if (t >= total) return;
+    const int32_t it = (int32_t)(t / prm.minsubsetN);
+    const int32_t j = (int32_t)(t - (int64_t)it * prm.minsubsetN);
+    uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
+    constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
+    int64_t sd[CAP];
+    uint32_t nd = 0;
+    bool gave_up = false;
+    const int drawN = DN > 0 ? DN : prm.drawN;
+    const bool ok = sample_ranks<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+    {
+        uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+        const int lane = threadIdx.x & 63;
+        while (todo != 0) {
+            const int leader = __builtin_ctzll(todo);
+            const int32_t it0 = __shfl(it, leader);
+            const uint64_t grp = __builtin_amdgcn_ballot_w64(it == it0) & todo;
+            unsigned v = (it == it0) ? nd : 0u;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == leader) atomicAdd(&draws_per_iter[it0], (unsigned long long)v);
+            todo &= ~grp;
+        }
+    }
+    if (gave_up) atomicExch(gave_up_flag, 1);
+    if (!ok) return;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    double fp[3 * CAP], fn[3 * CAP];
+#pragma unroll
+    for (int q = 0; q < drawN; q++) {
+        const f64x2 *r = (const f64x2 *)(crec + 8 * (sd[q] - 1));
+        const f64x2 a = r[0], b = r[1], c = r[2];
+        fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
+        fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
+    }
+    for (int ti = 0; ti < prm.n_shape_types; ti++) {
+        rh_shape s;
+        for (int q = 0; q < 10; q++) s.v[q] = 0.0;
+        s.kind = -1;
+        s.outwards = 0;
+        bool fitted = false;
+        switch (prm.shape_types[ti]) {
+        case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
+        case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
+        case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
+        default: break;   // cones take the two-kernel path
+        }
+        if (!fitted) continue;
+        const int32_t pos = atomicAdd(out_count, 1);
+        if (pos < cap) {
+            out[pos].slot = (int64_t)t * prm.n_shape_types + ti;
+            out[pos].level = 1;
+            out[pos].pad = 0;
+            out[pos].shape = s;
+        }
+    }
+}
+
 }  // namespace
 
 int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
@@ -256,6 +343,8 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
     bool cone = false;
     for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
+    static int no_fused = -1;
+    if (no_fused < 0) no_fused = getenv("RH_NO_FUSED_SAMPLER") ? 1 : 0;
     // long root-cell windows sample from rank-ordered compact records (rebuilt with the select list)
     static int no_crec = -1;
     if (no_crec < 0) no_crec = getenv("RH_NO_CREC") ? 1 : 0;
@@ -275,6 +364,17 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
         crec = c->crec;
     }
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
+    if (crec != nullptr && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
+        const dim3 gk((unsigned)((total + 127) / 128));
+        if (prm->drawN == 3)
+            hipLaunchKernelGGL(sample_fit_ranks_kernel<3>, gk, dim3(128), 0, c->stream, crec, c->n, en, n_enabled, *prm, seed, k0,
+                               n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+        else
+            hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->n, en, n_enabled, *prm, seed, k0,
+                               n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+        RH_HIP(hipGetLastError());
+        return RH_OK;
+    }
 #define RH_SAMPLE(DN)                                                                                                  \
     hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
                        prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec)
