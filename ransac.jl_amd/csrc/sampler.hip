@@ -343,11 +343,9 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
     bool cone = false;
     for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
-    static int no_fused = -1;
-    if (no_fused < 0) no_fused = getenv("RH_NO_FUSED_SAMPLER") ? 1 : 0;
+    const bool no_fused = getenv("RH_NO_FUSED_SAMPLER") != nullptr;   // read per call: the tests flip it
     // long root-cell windows sample from rank-ordered compact records (rebuilt with the select list)
-    static int no_crec = -1;
-    if (no_crec < 0) no_crec = getenv("RH_NO_CREC") ? 1 : 0;
+    const bool no_crec = getenv("RH_NO_CREC") != nullptr;
     const double *crec = nullptr;
     if (d_P == nullptr && n_iters >= 32 && n_enabled > 0 && !no_crec) {
         if (!c->crec_valid) {

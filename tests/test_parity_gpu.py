@@ -352,6 +352,8 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
     (["plane", "plane"], "p", 13, False),
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_PIPELINE"),      # one window at a time
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SCORE"),   # scores through the host
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SAMPLER"),  # sample + fit as two kernels
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_CREC"),           # index-space sampling
 ])
 def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
     """sampling_streams = 1: sampling + fitting + scoring on the device, iterations speculated in
