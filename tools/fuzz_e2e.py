@@ -30,8 +30,8 @@ def one(case, rng):
               sampling_streams=streams, octree_sampling=octree)
     env = None
     if streams:
-        env = rng.choice([None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER"])
-    for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER"):
+        env = rng.choice([None, None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER"])
+    for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER"):
         os.environ.pop(k, None)
     if env:
         os.environ[env] = "1"
