@@ -43,8 +43,8 @@ KINDS = ["plane", "sphere", "cylinder", "cone"]
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
@@ -245,7 +245,7 @@ def main():
     if rank == 0:
         # ---- per-kind kernel time (HIP events) and rooflines -----------------------------
         per_kind = {}
-        reps = 10
+        reps = 30
         acc = [0.0] * 5
         msk = (C.c_float * 5)()
         for _ in range(reps):   # [4]: the launch of the timed steps (all kinds, one kernel); [0..3]: one launch per kind
@@ -472,7 +472,7 @@ def main():
             pc = None   # noqa: F841 -- the parent's cloud stays resident (2 GB); the child needs ~12 GB
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--no-cpu", "--no-e2e",
-                                    "--no-cfg5", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+                                    "--no-cfg5", "--steps", "60", "--warmup", "10"], capture_output=True, text=True, timeout=600)
                 c5 = json.loads(r.stdout.strip().splitlines()[-1])
                 out["cfg5"] = {"config": c5["config"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
                                "tests_per_sec": c5["tests_per_sec"], "per_kind": c5["per_kind"],
@@ -481,7 +481,7 @@ def main():
                                                   ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
                                                    "algorithmic_bytes_per_launch", "inliers")},
                                "setup_seconds": c5["setup_seconds"],
-                               "note": "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 5 (child process): one replica of "
+                               "note": "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 60 --warmup 10 (child process): one replica of "
                                        "the 50M-point cloud on this GPU, S = 1 562 500, cones in the batch; the refit scan "
                                        "streams 2.4 GB"}
             except Exception as e:   # the headline line must not depend on this leg
