@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-ms", type=float, default=40.0,
+                    help="before the W warm-up steps, repeat the step for about this many ms so that the GPU has settled at "
+                         "its clocks (a 20-step timed region lasts 4 ms, less than the clock ramp); 0 disables it")
     ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
@@ -208,6 +211,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.prewarm_ms > 0:   # untimed, before the warm-up steps: bring the clocks up (reported as config.prewarm_ms)
+        for _ in range(int(args.prewarm_ms * 5)):   # ~0.2 ms per step; a fixed count, so every rank does the same
+            step()
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -235,7 +242,7 @@ def main():
                    "points": n, "subset_points": int(S), "candidates_per_step": b_global,
                    "kinds": "%s (cycled over the %d ground-truth primitives, 1%% jitter)"
                             % ("/".join(sorted(set(prim), key=KINDS.index)), len(prim)),
-                   "score_mode": "f64",
+                   "score_mode": "f64", "prewarm_ms": args.prewarm_ms,
                    "parallelism": ("point-sharded x%d (1/%d of subset 1 per GPU, every GPU scores the whole batch), "
                                    "int32 sum all-reduce" % (world, world)) if points_mode
                    else "candidate-sharded x%d, int32 sum all-reduce" % world},
