@@ -49,8 +49,9 @@ def parse():
                     help="before the W warm-up steps, repeat the step for about this many ms so that the GPU has settled at "
                          "its clocks (a 20-step timed region lasts 4 ms, less than the clock ramp); 0 disables it")
     ap.add_argument("--points", type=int, default=None, help="cloud size (default: the workload's)")
-    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
-                    help="cfg3 = the config the metric is quoted on (default); cfg5 = 50M points with cones")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg3",
+                    help="cfg3 = the config the metric is quoted on (default); cfg2 = 1M points, 6 primitives; "
+                         "cfg5 = 50M points with cones")
     ap.add_argument("--shard", choices=["candidates", "points"], default="candidates",
                     help="N > 1 partitioning: candidates (each rank scores its 4096 of the N x 4096 batch on a replica "
                          "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
@@ -141,6 +142,11 @@ def main():
     types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
     wseed, wname = 3, "cfg3: 10M-point 40-primitive cloud, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
     n_default = 10_000_000
+    outlier_frac = 0.30
+    if args.workload == "cfg2":
+        prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder"]
+        wseed, wname = 2, "cfg2: 1M-point 6-primitive cloud, no outliers, r=32 subsets, B=4096 candidates/GPU/step"
+        n_default, outlier_frac = 1_000_000, 0.0
     if args.workload == "cfg5":
         prim = prim + ["cone"] * 8
         types = types + [R.FittedCone]
@@ -148,7 +154,7 @@ def main():
         n_default = 50_000_000
     n = args.points or n_default
     t0 = time.time()
-    xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=wseed,
+    xyz, nrm, truth = synth.make_cloud(n, prim, outlier_frac, seed=wseed,
                                        scanner=[synth.BOX / 2] * 3 if args.workload == "cfg5" else None)
     subs = synth.make_subsets(n, 32, seed=wseed)
     S = subs[0].size

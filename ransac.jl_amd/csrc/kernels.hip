@@ -1446,7 +1446,9 @@ static int launch_score_groups(rh_cloud *c, const GroupSet &G, const uint64_t *e
     if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
     static int env_cpb = -1;
     if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
-    const int min_cpb = env_cpb > 0 ? env_cpb : 8;     // at least this many 64-candidate chunks per block (measured best)
+    // 64-candidate chunks per block: 8 for large subsets (measured best at >= 1000 tiles), down to 2 for small ones,
+    // where the grid would otherwise be a few hundred blocks
+    const int min_cpb = env_cpb > 0 ? env_cpb : (int)std::min<int64_t>(8, std::max<int64_t>(2, ntiles / 150));
     int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
     if (rows < 1) rows = 1;
     if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
@@ -1497,7 +1499,7 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     if (env_blocks < 0) { const char *e = getenv("RH_G2_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
     if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
     if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
-    const int min_cpb = env_cpb > 0 ? env_cpb : 8;
+    const int min_cpb = env_cpb > 0 ? env_cpb : (int)std::min<int64_t>(8, std::max<int64_t>(2, ntiles / 150));   // see launch_score_groups
     int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
     if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
     if (rows < 1) rows = 1;
