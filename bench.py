@@ -13,7 +13,7 @@ One JSON line on rank 0.  Extra objects: `roofline` (dominant score kernel, HIP 
 library's stream), `roofline_valu` (FP64 vector-ALU view of the same kernel -- the batched
 score is ALU-bound), `roofline_refit` (the HBM-bound full-cloud scan),
 `cpu_baseline` (the oracle, 1 thread, bounded sample; `cpu_baseline_all_cores`: OpenMP steelman),
-`end_to_end` (rh_ransac on the same cloud), `cfg5` (the 50M-point / cones config, child process).
+`end_to_end` (rh_ransac on the same cloud), `cfg2` / `cfg5` (BASELINE configs[1] and [4] on this GPU, child processes).
 """
 import argparse
 import ctypes as C
@@ -57,6 +57,7 @@ def parse():
                          "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
                          "on its 1/N slice of subset 1; the all-reduce is a true sum)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 50M-point / cones leg (a child process at N = 1)")
+    ap.add_argument("--no-cfg2", action="store_true", help="skip the 1M-point / 6-primitive leg (a child process at N = 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
@@ -487,26 +488,30 @@ def main():
                     "sample": "the oracle's ransac() on the first %d iterations of the same run; extracted shapes, "
                               "index sets and draw counts checked identical to rh_ransac's" % nit}
         out["setup_seconds"] = t_setup
-        # ---- BASELINE cfg5 (50M points, cones in the batch) on this one GPU: a child process, same script
-        if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
+        # ---- the other single-GPU BASELINE configs on this GPU: child processes of the same script
+        def child_leg(name, extra, note):
             import subprocess
-            pc = None   # noqa: F841 -- the parent's cloud stays resident (2 GB); the child needs ~12 GB
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--no-cpu", "--no-e2e",
-                                    "--no-cfg5", "--steps", "60", "--warmup", "10"], capture_output=True, text=True, timeout=600)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu", "--no-e2e",
+                                    "--no-cfg5", "--no-cfg2"] + extra, capture_output=True, text=True, timeout=600)
                 c5 = json.loads(r.stdout.strip().splitlines()[-1])
-                out["cfg5"] = {"config": c5["config"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
-                               "tests_per_sec": c5["tests_per_sec"], "per_kind": c5["per_kind"],
-                               "score_kernel_ms": c5["roofline"]["ms_per_launch"],
-                               "roofline_refit": {k: c5["roofline_refit"][k] for k in
-                                                  ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
-                                                   "algorithmic_bytes_per_launch", "inliers")},
-                               "setup_seconds": c5["setup_seconds"],
-                               "note": "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 60 --warmup 10 (child process): one replica of "
-                                       "the 50M-point cloud on this GPU, S = 1 562 500, cones in the batch; the refit scan "
-                                       "streams 2.4 GB"}
-            except Exception as e:   # the headline line must not depend on this leg
-                out["cfg5"] = {"error": repr(e)[:300]}
+                return {"config": c5["config"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
+                        "tests_per_sec": c5["tests_per_sec"], "per_kind": c5["per_kind"],
+                        "score_kernel_ms": c5["roofline"]["ms_per_launch"],
+                        "roofline_refit": {k: c5["roofline_refit"][k] for k in
+                                           ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
+                                            "algorithmic_bytes_per_launch", "inliers")},
+                        "setup_seconds": c5["setup_seconds"], "note": note}
+            except Exception as e:   # the headline line must not depend on these legs
+                return {"error": repr(e)[:300]}
+        if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg2:
+            out["cfg2"] = child_leg("cfg2", [], "python bench.py --workload cfg2 --no-cpu --no-e2e (child process): BASELINE configs[1], "
+                                    "1M points = 2 planes + 2 spheres + 2 cylinders without outliers, S = 31 250, B = 4096")
+        if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
+            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10"],
+                                    "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 60 --warmup 10 (child process): one "
+                                    "replica of the 50M-point cloud on this GPU, S = 1 562 500, cones in the batch; the refit scan "
+                                    "streams 2.4 GB")
         print(json.dumps(out))
     batch.free()
     if points_mode:
