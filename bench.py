@@ -129,8 +129,12 @@ def main():
     if os.environ.get("RH_BENCH_SHARE_GPU0"):   # rehearsal of the N > 1 flow on a one-GPU box (use with gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RH_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, pipelined scorer, all-reduce) with
+    # one rank -- the RCCL rehearsal a one-GPU box allows
+    multi = world > 1 or bool(os.environ.get("RH_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("RH_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -171,7 +175,7 @@ def main():
     counts = torch.zeros(b_global, dtype=torch.int32, device="cuda")
     # N > 1: the cloud shares torch's stream, so fill -> score -> all-reduce are ordered on the device
     # and a step has no host synchronisation (RH_BENCH_SPLIT_STREAMS=1: the library's own stream + two waits)
-    same_stream = world > 1 and not os.environ.get("RH_BENCH_SPLIT_STREAMS")
+    same_stream = multi and not os.environ.get("RH_BENCH_SPLIT_STREAMS")
     if same_stream:
         # an explicit (non-default) stream: the legacy null stream would serialise against the
         # collective's stream and undo the overlap
@@ -180,7 +184,7 @@ def main():
         pc.set_stream(compute_stream.cuda_stream)
     local = rdist.gpu_local_score(pc, batch, cp, wait=not same_stream)
     lo, hi = rdist.shard_bounds(b_global, rank, world)
-    points_mode = world > 1 and args.shard == "points"
+    points_mode = multi and args.shard == "points"
     tcloud = pc
     if points_mode:   # a second cloud: just this rank's slice of subset 1; pc stays for the rank-0 diagnostics
         sx, sn, ssub, _ = rdist.point_shard_subset(xyz, nrm, subs[0], None, rank, world)
@@ -194,7 +198,7 @@ def main():
     # N > 1: two batches in flight -- batch i's all-reduce overlaps batch i + 1's score launch
     # (RH_BENCH_NO_OVERLAP=1: one batch at a time)
     scorer = None
-    if world > 1 and not os.environ.get("RH_BENCH_NO_OVERLAP"):
+    if multi and not os.environ.get("RH_BENCH_NO_OVERLAP"):
         scorer = rdist.ShardedScorer(b_global, rank, world, local, "cuda", same_stream=same_stream, points=points_mode)
 
     def step():
@@ -202,7 +206,7 @@ def main():
             scorer.submit()
         elif points_mode:
             rdist.score_batch_point_sharded(lambda out: local(0, b_global, out), counts)
-        elif world > 1:
+        elif multi:
             rdist.score_batch_sharded(b_global, rank, world, local, counts, same_stream=same_stream)
         else:   # no collective, no host sync inside the timed region
             L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp),
@@ -214,7 +218,7 @@ def main():
         L.check(lib.rh_cloud_sync(pc._h))
         L.check(lib.rh_cloud_sync(tcloud._h))
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +237,7 @@ def main():
     L.check(lib.rh_timer_stop(tcloud._h, C.byref(ev_ms)))
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -295,7 +299,7 @@ def main():
             "ms_per_launch": sec * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "EFFECTIVE rate on algorithmic bytes = 48.25 B x (candidate, point) tests (SURVEY.md 8d). The "
                     "kernel never streams those bytes: points are staged once per tile and re-used across the "
-                    "candidate batch, and box tests on Morton-ordered 64-point groups reject most (candidate, "
+                    "candidate batch, and box tests on the 64-point k-d leaves of subset 1 reject most (candidate, "
                     "group) pairs, so frac > 1 by design; `traffic` = HBM bytes per launch from the committed PMC "
                     "passes (profiles/rN/pmc_hbm_traffic.json, 2 x FETCH_SIZE + WRITE_SIZE)",
         }
@@ -516,7 +520,7 @@ def main():
     batch.free()
     if points_mode:
         sbatch.free()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
