@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=["groups", "brute"], autouse=True)
 def score_path(request):
-    """Every test runs against both scoring kernels: the culled one (Morton groups + box tests)
+    """Every test runs against both scoring kernels: the culled one (k-d leaf groups + box tests)
     and the brute-force one.  The path is chosen when a cloud is created."""
     import os
     old = os.environ.get("RH_SCORE_PATH")
@@ -490,10 +490,11 @@ def test_largestconncomp_random_bitmaps(shape, density, seed):
         assert np.array_equal(got, orc.largestconncomp(bm, conn8=conn8))
 
 
-def test_full_size_properties_cfg2():
-    """BASELINE configs[1] at full size (1M points, r = 32, B = 4096): size-independent
-    properties, plus an oracle spot check on a slice of the batch."""
-    c = synth.config("cfg2")
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_size_properties(cfg):
+    """BASELINE configs[1] and configs[2] at full size (1M / 10M points, r = 32, B = 4096):
+    size-independent properties, plus an oracle spot check on a slice of the batch."""
+    c = synth.config(cfg)
     n = c["xyz"].shape[0]
     subs = synth.make_subsets(n, c["r"], c["seed"])
     pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
@@ -501,7 +502,7 @@ def test_full_size_properties_cfg2():
     cands = make_candidates(c["truth"], 4096, seed=8)
     arr = shape_array(cands)
     counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
-    pop = np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1)
+    pop = np.bitwise_count(masks).sum(axis=1, dtype=np.int64)
     assert np.array_equal(pop, counts)                    # checksum of checksums
     assert np.array_equal(R.score_batch(pc, arr, cp), counts)   # idempotent, both instantiations
     assert counts.max() <= subs[0].size and counts.sum() > 4096 * 100
@@ -519,6 +520,32 @@ def test_full_size_properties_cfg2():
         assert R.refit(cand, pc, cp).inpoints.size == 0
     assert pc.count_enabled() == n - int(seen.sum())
     assert np.array_equal(pc.isenabled, ~seen)
+
+
+def test_full_size_ransac_cfg3_replays_through_the_abi():
+    """BASELINE configs[2] at full size, end to end: every shape rh_ransac extracted is replayed with
+    the single-shot ABI calls on a second cloud (refit on the enabled set as it stood, then invalidate);
+    the index lists must agree bit for bit, be ascending and pairwise disjoint."""
+    c = synth.config("cfg3")
+    n = c["xyz"].shape[0]
+    subs = synth.make_subsets(n, c["r"], c["seed"])
+    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
+    params = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
+                                iteration={"minsubsetN": 4096, "itermax": 2048})
+    got, _, stats = R.ransac(pc, params, seed=7, score_mode=L.SCORE_F64, sampling_streams=1, return_stats=True)
+    assert len(got) >= 40 and stats["iterations"] == 2048
+    replay = R.RANSACCloud(c["xyz"], c["nrm"], subs)
+    cp = R.params_to_c(params, score_mode=L.SCORE_F64)
+    seen = np.zeros(n, dtype=bool)
+    for g in got:
+        ex = R.refit(g.c_shape, replay, cp)
+        assert np.array_equal(ex.inpoints, g.inpoints)
+        assert np.all(np.diff(g.inpoints) > 0) and not seen[g.inpoints - 1].any()
+        seen[g.inpoints - 1] = True
+        R.invalidate_indexes(replay, ex.inpoints)
+    assert np.array_equal(pc.isenabled, ~seen) and np.array_equal(replay.isenabled, ~seen)
+    # the 40 ground-truth primitives carry 175 000 points each; every one must have been found
+    assert sorted(len(g.inpoints) for g in got)[-40] > 150_000
 
 
 def test_score_on_callers_stream_matches():
