@@ -140,7 +140,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
-    (void)hipFree(c->gone_words); (void)hipFree(c->dis_gb);
+    (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
     (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk); (void)hipFree(c->d_nk2);
@@ -150,6 +150,10 @@ static void cloud_free(rh_cloud *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 5; k++)
         if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
+    if (c->ev_list) (void)hipEventDestroy(c->ev_list);
+    if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -164,8 +168,9 @@ static int set_all_enabled(rh_cloud *c)
             RH_HIP(hipStreamSynchronize(c->stream));
         }
     }
-    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
+    RH_TRY(rhk_rebuild_sub_enabled(c, true));
     c->select_valid = false;
+    c->en_sums_valid = false;
     c->n_dis = 0;
     return RH_OK;
 }
@@ -298,6 +303,10 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipEventCreate(&c->ev0));
     CKH(hipEventCreate(&c->ev1));
     for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
+    CKH(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    CKH(hipEventCreateWithFlags(&c->ev_list, hipEventDisableTiming));
+    CKH(hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+    CKH(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
     CK(dev_alloc(&c->full, 6 * c->n_pad));
     CK(dev_alloc(&c->rec, 8 * std::max<int64_t>(n, 1)));
     CK(dev_alloc(&c->sel_list, c->nwords * 64 + 64));
@@ -320,9 +329,9 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->enabled, c->nwords));
     CK(dev_alloc(&c->sub_enabled, c->swords));
     CK(dev_alloc(&c->d_ndis, 1));
-    CK(dev_alloc(&c->gone_words, c->swords));
     CK(dev_alloc(&c->refit_mask, c->nwords));
     CK(dev_alloc(&c->block_sums, std::max<int64_t>(c->nblocks, (c->swords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK) + 2));
+    CK(dev_alloc(&c->en_block_sums, c->nblocks + 2));
     CK(dev_alloc(&c->word_prefix, c->nwords + 1));
     CK(dev_alloc(&c->idx_out, n));
     CK(dev_alloc(&c->d_total, 1));
@@ -481,9 +490,10 @@ extern "C" int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t
         }
         RH_HIP(hipStreamSynchronize(c->stream));
     }
-    RH_TRY(rhk_rebuild_sub_enabled(c, true, true));
+    RH_TRY(rhk_rebuild_sub_enabled(c, true));
     RH_HIP(hipStreamSynchronize(c->stream));
     c->select_valid = false;
+    c->en_sums_valid = false;
     return RH_OK;
 }
 
@@ -736,7 +746,7 @@ extern "C" int rh_invalidate(rh_cloud *c, const int64_t *idx, int64_t n)
         }
     RH_HIP(hipMemcpyAsync(c->idx_out, idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     RH_TRY(rhk_invalidate_idx(c, c->idx_out, n));
-    RH_TRY(rhk_rebuild_sub_enabled(c, true, false));
+    RH_TRY(rhk_rebuild_sub_enabled(c, false));
     RH_HIP(hipStreamSynchronize(c->stream));
     c->select_valid = false;
     return RH_OK;

@@ -112,6 +112,8 @@ struct EnabledMirror {
     }
 };
 
+constexpr int64_t LIVE_MAX = 4096;   // stores up to this size take the one-wait extraction path
+
 struct Stored {
     rh_shape shape;
     double E;
@@ -128,6 +130,7 @@ struct DeviceStore {
     int32_t *iota = nullptr;      // 0..iota_cap-1
     int64_t iota_cap = 0;
     int32_t *counts = nullptr;    // liveness / score counts, iota_cap entries
+    int32_t *live = nullptr;      // LIVE_MAX liveness flags of the one-wait extraction path, zero between uses
     int32_t *d_idx = nullptr;     // gather lists
     int32_t *d_nk = nullptr;      // one int per launch slot (8)
     rh_shape *d_shapes = nullptr;
@@ -139,7 +142,7 @@ int store_free(rh_cloud *c, DeviceStore &st)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); }
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
-    (void)hipFree(st.d_shapes);
+    (void)hipFree(st.d_shapes); (void)hipFree(st.live);
     return RH_OK;
 }
 
@@ -263,6 +266,7 @@ struct Driver {
     std::vector<double> Pwin;
 
     // scratch
+    std::vector<rh_prep> prep_h[4];
     std::vector<rh_shape> sorted;
     std::vector<int32_t> orig, counts_h, idx_h;
     std::vector<int64_t> sd;
@@ -288,10 +292,12 @@ struct Driver {
     int64_t h_scr_cap = 0;              // in int32
     int64_t *arena = nullptr;           // pinned block for the extracted index lists (result arenas, above)
     int64_t arena_used = 0, arena_cap = 0;
+    bool list_copy_pending = false;     // a list is (or may still be) on its way from idx_out to the arena
 
     ~Driver()
     {
         if (c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in the pinned blocks
+        if (c) (void)hipStreamSynchronize(c->copy_stream);
         (void)hipHostFree(h_scr);
         arena_release(arena);   // null once the result owns it
         store_free(c, st);
@@ -332,13 +338,15 @@ struct Driver {
         if (!arena) { rh_set_error("rh_ransac: cannot pin %lld bytes for the index lists", (long long)(8 * arena_cap)); return RH_E_NOMEM; }
         arena_used = 0;
         // the disabled list must describe the cloud as it is now (points disabled before the call)
-        RUN(rhk_rebuild_sub_enabled(c, true, true));
+        RUN(rhk_rebuild_sub_enabled(c, true));
         int32_t ndis = 0;
         RUNH(hipMemcpyAsync(&ndis, c->d_ndis, sizeof ndis, hipMemcpyDeviceToHost, c->stream));
         RUNH(hipStreamSynchronize(c->stream));
         c->n_dis = ndis;
         c->select_valid = false;
         RUNH(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
+        RUNH(hipMalloc((void **)&st.live, sizeof(int32_t) * (size_t)LIVE_MAX));
+        RUNH(hipMemsetAsync(st.live, 0, sizeof(int32_t) * (size_t)LIVE_MAX, c->stream));
         octree = p->octree_sampling != 0;
         if (octree) {
             RUN(rh_octree_ensure(c, xyz, p->octree_max_depth));
@@ -506,12 +514,21 @@ struct Driver {
     int record(const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts)
     {
         if (ncand == 0) return RH_OK;
-        int32_t nk[4], off[4];
-        RUN(upload_sorted(cands, ncand, nk, off));
+        // the prepared records are made here (rh_prep_host is the host twin of the device's prep_one) and go
+        // straight behind the store of their kind: one small copy per kind present, no launch
+        int32_t nk[4] = { 0, 0, 0, 0 };
+        for (int q = 0; q < 4; q++) prep_h[q].clear();
+        for (int32_t i = 0; i < ncand; i++) {
+            const int q = cands[i].kind;
+            prep_h[q].emplace_back();
+            rh_prep_host(cands[i], &prep_h[q].back());
+            nk[q]++;
+        }
         for (int q = 0; q < 4; q++) {
             if (nk[q] == 0) continue;
             RUN(store_reserve(c, st, q, (int64_t)st.n[q] + nk[q]));
-            RUN(rhk_prep_sorted(c, st.d_shapes + off[q], nk[q], st.prep[q] + st.n[q]));
+            RUNH(hipMemcpyAsync(st.prep[q] + st.n[q], prep_h[q].data(), sizeof(rh_prep) * (size_t)nk[q], hipMemcpyHostToDevice,
+                                c->stream));
         }
         int32_t slot_next[4] = { st.n[0], st.n[1], st.n[2], st.n[3] };
         for (int32_t i = 0; i < ncand; i++) {   // slots follow candidate order within a kind (stable sort)
@@ -542,18 +559,50 @@ struct Driver {
         const double t0 = now_s();
         // refit: full-cloud scan + ascending compaction (plane.jl:137-143 ...)
         const rh_shape bestshape = store[(size_t)best].shape;
+        const size_t extracted_pos = (size_t)best;   // deleteat!(scoredshapes, best.index): iterations.jl:136
         rh_prep P;
         rh_prep_host(bestshape, &P);
+        int64_t base[5] = { 0, 0, 0, 0, 0 };
+        for (int q = 0; q < 4; q++) base[q + 1] = base[q] + st.n[q];
+        const int64_t sum_n = base[4];
+        // A small store (the usual case: root-cell sampling keeps a few hundred candidates) is checked for
+        // liveness in the same stream, before the host has seen the list lengths: ONE wait per extraction.
+        const bool fast = sum_n <= LIVE_MAX && !getenv("RH_NO_FAST_EXTRACT");
+        RUN(store_reserve_aux(c, st, sum_n));
+        RUN(ensure_scratch(32 + 2 * sum_n));   // (may wait for the stream: before anything lands in the scratch)
+        int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
+        const int64_t ndis_old = c->n_dis;
         RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
-        RUN(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
-        // invalidate_indexes! (fitting.jl:197-202) as enabled &= ~mask; then subset bits + disabled list
-        RUN(rhk_fetch2_i32(c, c->d_total, h_scr));        // the list length, before the next compaction reuses d_total
-        RUN(rhk_andnot_enabled(c, c->refit_mask));
-        RUN(rhk_rebuild_sub_enabled(c, true, false));
-        if (octree) RUN(rhk_oct_clear_mask(c, c->refit_mask));
-        c->select_valid = false;
-        RUN(rhk_fetch2_i32(c, c->d_ndis, h_scr + 1));
-        RUNH(hipStreamSynchronize(c->stream));
+        if (list_copy_pending) {   // the previous list must have left idx_out before it is written again
+            RUNH(hipStreamWaitEvent(c->stream, c->ev_copied, 0));
+            list_copy_pending = false;
+        }
+        // ... with invalidate_indexes! (fitting.jl:197-202) folded into the compaction as enabled &= ~mask;
+        // then subset bits + disabled list
+        RUN(rhk_compact_refit_apply(c));
+        RUNH(hipEventRecord(c->ev_list, c->stream));
+        RUN(rhk_rebuild_sub_enabled(c, false));
+        if (fast) {
+            rh_live_args A;
+            int64_t lo = c->s;
+            for (int q = 0; q < 4; q++) {
+                const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                A.prep[q] = st.prep[q];
+                A.nk[q] = st.n[q];
+                A.base[q] = (int32_t)base[q];
+                A.first[q] = all_disabled ? 0 : ndis_old;
+                A.eps[q] = p->eps[q];
+                A.cosa[q] = p->cos_alpha[q];
+                if (st.n[q] > 0) lo = std::min(lo, A.first[q]);
+            }
+            if (sum_n > 0) RUN(rhk_liveness_small(c, lo, A, st.live));
+            RUN(rhk_pack_live(c, st.live, (int32_t)sum_n, h_counts, h_scr));
+        } else {
+            RUN(rhk_fetch2_i32(c, c->d_total, c->d_ndis, h_scr));
+        }
+        RUNH(hipEventRecord(c->ev_sync, c->stream));
+        if (octree) RUN(rhk_oct_clear_mask(c, c->refit_mask));   // (its prefix pass reuses d_total: after the read-back)
+        RUNH(hipEventSynchronize(c->ev_sync));
         const int32_t total = h_scr[0], ndis_new = h_scr[1];
         rh_extracted ex;
         memset(&ex, 0, sizeof ex);
@@ -563,9 +612,15 @@ struct Driver {
         ex.inpoints = arena + arena_used;
         arena_used += total;
         extracted.push_back(ex);
-        if (total > 0)   // pinned destination: asynchronous; idx_out is only rewritten by later work on this stream
-            RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
-        if (host_sampling) RUNH(hipStreamSynchronize(c->stream));   // the host mirrors need the list now
+        if (total > 0) {
+            // pinned destination, on the copy stream: the 8 bytes per inlier cross PCIe while the compute stream
+            // goes on with the next window; the next extraction waits for ev_copied before it rewrites idx_out
+            RUNH(hipStreamWaitEvent(c->copy_stream, c->ev_list, 0));
+            RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->copy_stream));
+            RUNH(hipEventRecord(c->ev_copied, c->copy_stream));
+            list_copy_pending = true;
+        }
+        if (host_sampling) RUNH(hipStreamSynchronize(c->copy_stream));   // the host mirrors need the list now
         extracted.back().score_E = scr;
         extracted.back().iteration = k;
         double tq = now_s();
@@ -579,26 +634,21 @@ struct Driver {
             }
             rebuild_mprefix();
         }
-        const int64_t ndis_old = c->n_dis;
         c->n_dis = ndis_new;
 
-        // deleteat!(scoredshapes, best.index): iterations.jl:136 -- dropped in the compaction pass below
-        const size_t extracted_pos = (size_t)best;
         tp[1] += now_s() - tq; tq = now_s();
         // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
         std::vector<char> dead_slot[4];
         for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 0);   // every slot is referenced by `store`
         dead_slot[store[extracted_pos].shape.kind][(size_t)store[extracted_pos].slot] = 1;
-        int64_t base[5] = { 0, 0, 0, 0, 0 };
-        for (int q = 0; q < 4; q++) base[q + 1] = base[q] + st.n[q];
-        const int64_t sum_n = base[4];
-        RUN(store_reserve_aux(c, st, sum_n));
-        RUN(ensure_scratch(32 + 2 * sum_n));
-        int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
-        bool any_live = false;
-        if (sum_n > 0) {
+        if (fast) {
+            for (int q = 0; q < 4; q++)
+                for (int32_t sl = 0; sl < st.n[q]; sl++)
+                    if (h_counts[base[q] + sl] != 0) dead_slot[q][(size_t)sl] = 1;
+        } else if (sum_n > 0) {
             // every kind's pass goes to its own slice of st.counts (orig = iota + base: counts[base + slot]);
             // one read-back and one wait for all of them
+            bool any_live = false;
             RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)sum_n, c->stream));
             for (int q = 0; q < 4; q++) h_nk[q] = st.n[q];
             RUNH(hipMemcpyAsync(st.d_nk + 4, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -802,10 +852,22 @@ struct Driver {
             if (en.count < p->tau) break;
             Window &A = win[cur], &B = win[1 - cur];
             const double t0 = now_s();
-            if (!(A.pending && A.k == k)) RUN(issue(A, k, (int32_t)std::min<int64_t>(Kcur, p->itermax - k + 1)));
+            // Is iteration k certain to extract?  prob() grows with the candidate counters and the best score can
+            // only rise, so "the stored best already passes with the counters as they are now" decides it before
+            // anything of this window is known.  Then everything behind iteration k would be thrown away: the
+            // window is one iteration long and nothing is speculated behind it (the refit scan would queue
+            // behind that work).
+            bool certain = false;
+            if (!store.empty()) {
+                int64_t lb[4] = { 0, (int64_t)store.size(), cc[2], k * p->minsubsetN };
+                certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
+            }
+            if (!(A.pending && A.k == k))
+                RUN(issue(A, k, (int32_t)std::min<int64_t>(certain ? 1 : Kcur, p->itermax - k + 1)));
             const int32_t W = A.W;
             B.pending = false;
-            if (pipeline && k + W <= p->itermax) RUN(issue(B, k + W, (int32_t)std::min<int64_t>(Kcur, p->itermax - (k + W) + 1)));
+            if (pipeline && !certain && k + W <= p->itermax)
+                RUN(issue(B, k + W, (int32_t)std::min<int64_t>(Kcur, p->itermax - (k + W) + 1)));
             const double tw0 = now_s();
             tw[0] += tw0 - t0;
             RUNH(hipEventSynchronize(A.ev));
@@ -895,7 +957,7 @@ struct Driver {
             else B.pending = false;
             // a window cut short wasted its tail: halve; a window used to the end: double
             if (it < W) Kcur = std::max<int64_t>(1, std::min<int64_t>(Kcur, it) / 2);
-            else Kcur = std::min<int64_t>(K, Kcur * 2);
+            else if (!certain) Kcur = std::min<int64_t>(K, Kcur * 2);
         }
         // nothing of a dropped window may still be in flight when the buffers go away
         RUNH(hipStreamSynchronize(c->stream));
@@ -941,7 +1003,8 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     d.host_sampling = !device_sampler;
     RH_TRY(d.init());
     RH_TRY(device_sampler ? d.run_streams_device() : d.run_sequential());
-    RH_HIP(hipStreamSynchronize(c->stream));   // the index lists have landed in the arena
+    RH_HIP(hipStreamSynchronize(c->stream));
+    RH_HIP(hipStreamSynchronize(c->copy_stream));   // the index lists have landed in the arena
 
     out->iterations = d.iterations;
     out->candidates_scored = d.cc[2];

@@ -897,11 +897,16 @@ scan_block_sums_kernel(int32_t *__restrict__ block_sums, int64_t nb, int32_t *__
 // block b expands mask words [b*1024, (b+1)*1024): ascending 1-based indices.  Each thread owns
 // 4 consecutive words: block-wide exclusive scan of their popcounts, then every thread writes the
 // set bits of its own words (shape masks are sparse: a few bits per word).
+// With `andnot_words` the block also clears the mask's bits there (invalidate_indexes! as enabled &= ~mask)
+// and leaves the popcount of its updated words in andnot_sums[block]: the next select directory starts
+// from those instead of a pass of its own.
 __global__ void __launch_bounds__(256)
 expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ block_prefix,
-                   int64_t *__restrict__ idx_out, int64_t cap, int32_t *__restrict__ word_prefix_out)
+                   int64_t *__restrict__ idx_out, int64_t cap, int32_t *__restrict__ word_prefix_out,
+                   uint64_t *__restrict__ andnot_words, int32_t *__restrict__ andnot_sums)
 {
     __shared__ int32_t wsum[4];
+    __shared__ int32_t esum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
     uint64_t m[4];
@@ -913,6 +918,20 @@ expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int3
         pc[k] = __popcll(m[k]);
         tsum += pc[k];
     }
+    if (andnot_words != nullptr) {
+        int left = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t w = base + threadIdx.x * 4 + k;
+            if (w < nwords) {
+                const uint64_t e = andnot_words[w] & ~m[k];
+                if (m[k] != 0) andnot_words[w] = e;
+                left += __popcll(e);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) left += __shfl_down(left, off);
+        if (lane == 0) esum[wave] = left;
+    }
     int inc = tsum;
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(inc, o);
@@ -920,6 +939,7 @@ expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int3
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
+    if (andnot_words != nullptr && threadIdx.x == 0) andnot_sums[blockIdx.x] = esum[0] + esum[1] + esum[2] + esum[3];
     int woff = 0;
     for (int k = 0; k < wave; k++) woff += wsum[k];
     int64_t run = (int64_t)block_prefix[blockIdx.x] + woff + inc - tsum;
@@ -958,76 +978,146 @@ __global__ void andnot_kernel(uint64_t *__restrict__ enabled, const uint64_t *__
     if (w < nwords) enabled[w] &= ~mask[w];
 }
 
-// sub_enabled bit j = enabled[sub_idx0[j]]; gone[w] = the bits that went 1 -> 0 (or, with reset, every
-// disabled bit): the points the liveness pass has to look at.  They are appended to `dis` in internal
-// (k-d leaf) order by append_gone_kernel, so consecutive 64-point groups of `dis` are spatially compact.
+// One launch per change of the enabled bits: sub_enabled bit j = enabled[sub_idx0[j]], and the subset points
+// whose bit went 1 -> 0 (with `reset`: every disabled one) are appended to `dis`, the list the liveness
+// pass scores.  A wave regathers RH_SUBUPD_WPW consecutive words; a block reserves the range of its points
+// with ONE atomicAdd on the list length, so the ranges of different blocks follow each other in arbitrary
+// order (the liveness counts are sums over the points: only the culling boxes see the order), while the
+// points of a block stay in internal (k-d leaf) order, i.e. spatially compact.
+constexpr int RH_SUBUPD_WPW = 8;
+
 __global__ void __launch_bounds__(256)
-rebuild_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ sub_idx0, int64_t s,
-                           uint64_t *__restrict__ sub_enabled, uint64_t *__restrict__ gone_out, int reset)
+update_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ sub_idx0, int64_t s,
+                          int64_t swords, uint64_t *__restrict__ sub_enabled, int reset,
+                          const double *__restrict__ sub, int64_t sub_stride, double *__restrict__ dis,
+                          int64_t dis_stride, int32_t *__restrict__ ndis)
 {
+    __shared__ int32_t wtot[4];
+    __shared__ int32_t base_s;
+    __shared__ uint16_t lst[4][RH_SUBUPD_WPW * 64];   // per wave: positions (relative to its first word) of the gone points
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t w = j >> 6;
-    bool bit = false;
-    if (j < s) {
-        const int32_t i0 = sub_idx0[j];
-        bit = (enabled[i0 >> 6] >> (i0 & 63)) & 1ULL;
-    }
-    const uint64_t neww = __builtin_amdgcn_ballot_w64(bit);
-    const uint64_t valid = valid_mask(w << 6, s);
-    if (valid == 0) return;
-    const uint64_t oldw = reset ? valid : sub_enabled[w];
-    if (lane == 0) {
-        sub_enabled[w] = neww;
-        gone_out[w] = oldw & ~neww & valid;
-    }
-}
-
-// block b copies the points of gone words [b*1024, (b+1)*1024) to dis[base + prefix ...], in order:
-// block-wide exclusive scan of the word popcounts (one word per thread), then one wave per word with one
-// lane per bit
-__global__ void __launch_bounds__(1024)
-append_gone_kernel(const uint64_t *__restrict__ gone, int64_t swords, const int32_t *__restrict__ block_prefix,
-                   const double *__restrict__ sub, int64_t sub_stride, double *__restrict__ dis, int64_t dis_stride,
-                   const int32_t *__restrict__ base_ptr)
-{
-    static_assert(RH_WORDS_PER_BLOCK == 1024, "one word per thread");
-    __shared__ int32_t wsum[16];
-    __shared__ uint64_t lm[RH_WORDS_PER_BLOCK];
-    __shared__ int32_t lpre[RH_WORDS_PER_BLOCK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wbase = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
-    const int64_t w = wbase + threadIdx.x;
-    const uint64_t m = w < swords ? gone[w] : 0ULL;
-    const int pc = __popcll(m);
-    int inc = pc;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < wave; k++) woff += wsum[k];
-    lm[threadIdx.x] = m;
-    lpre[threadIdx.x] = woff + inc - pc;
-    __syncthreads();
-    const int64_t base = (int64_t)*base_ptr + block_prefix[blockIdx.x];
-    for (int wl = wave; wl < RH_WORDS_PER_BLOCK; wl += 16) {
-        const uint64_t bits = lm[wl];
-        if (bits == 0) continue;
-        if ((bits >> lane) & 1ULL) {
-            const int64_t j = ((wbase + wl) << 6) + lane;
-            const int64_t dst = base + lpre[wl] + __popcll(bits & ((1ULL << lane) - 1ULL));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w0 = ((int64_t)blockIdx.x * 4 + wave) * RH_SUBUPD_WPW;
+    // all the loads of the wave's words first (the two gathers are dependent; the words are not)
+    int32_t i0[RH_SUBUPD_WPW];
+    uint64_t ew[RH_SUBUPD_WPW];
 #pragma unroll
-            for (int q = 0; q < 6; q++) dis[q * dis_stride + dst] = sub[q * sub_stride + j];
-        }
+    for (int k = 0; k < RH_SUBUPD_WPW; k++) {
+        const int64_t j = ((w0 + k) << 6) + lane;
+        i0[k] = j < s ? sub_idx0[j] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < RH_SUBUPD_WPW; k++) ew[k] = i0[k] >= 0 ? enabled[i0[k] >> 6] : 0ULL;
+    const bool own = lane < RH_SUBUPD_WPW && w0 + lane < swords;   // lane k keeps word w0 + k
+    const uint64_t oldv = (own && !reset) ? sub_enabled[w0 + lane] : 0ULL;
+    uint64_t newv = 0;
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < RH_SUBUPD_WPW; k++) {
+        const bool bit = i0[k] >= 0 && ((ew[k] >> (i0[k] & 63)) & 1ULL);
+        const uint64_t neww = __builtin_amdgcn_ballot_w64(bit);
+        const uint64_t valid = w0 + k < swords ? valid_mask((w0 + k) << 6, s) : 0ULL;
+        const uint64_t oldw = reset ? valid : (uint64_t)__shfl((unsigned long long)oldv, k);
+        const uint64_t g = oldw & ~neww & valid;
+        if (lane == k) newv = neww;
+        if ((g >> lane) & 1ULL) lst[wave][tot + __popcll(g & ((1ULL << lane) - 1ULL))] = (uint16_t)(k * 64 + lane);
+        tot += __popcll(g);
+    }
+    if (own) sub_enabled[w0 + lane] = newv;
+    if (lane == 0) wtot[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        base_s = t > 0 ? atomicAdd(ndis, t) : 0;
+    }
+    __syncthreads();
+    int64_t run = base_s;
+    for (int k = 0; k < wave; k++) run += wtot[k];
+    for (int e = lane; e < tot; e += 64) {
+        const int64_t j = (w0 << 6) + lst[wave][e];
+        const int64_t dst = run + e;
+#pragma unroll
+        for (int q = 0; q < 6; q++) dis[q * dis_stride + dst] = sub[q * sub_stride + j];
     }
 }
 
-__global__ void bump_counter_kernel(int32_t *__restrict__ counter, const int32_t *__restrict__ delta, int reset)
+// ---- liveness of a SMALL candidate store after an extraction: removeinvalidshapes! (fitting.jl:209-221)
+// recomputed as "does the candidate contain one of the points that were just disabled".  All kinds in one
+// launch; the end of the disabled list is read from device memory (the host has not seen it yet), the grid
+// is sized for the longest list possible and the blocks beyond the end leave at once.  A wave keeps
+// RH_SC_WAVE_PTS points in registers and walks every stored candidate; flags[base[kind] + slot] = 1 marks
+// a dead one (the flags are all zero on entry, pack_live_kernel re-zeroes them).  grid.y splits the candidates
+// of every kind into rows of RH_LIVE_CH: the walk is a chain of dependent scalar loads, so it is kept short.
+constexpr int RH_LIVE_CH = 16;   // candidates of each kind per block row
+
+template <int KIND>
+__device__ __forceinline__ void live_kind(const rh_live_args &A, const double (&px)[RH_SC_PPT], const double (&py)[RH_SC_PPT],
+                                          const double (&pz)[RH_SC_PPT], const double (&qx)[RH_SC_PPT],
+                                          const double (&qy)[RH_SC_PPT], const double (&qz)[RH_SC_PPT], int64_t wbase,
+                                          int64_t nd, int lane, int32_t *__restrict__ flags)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *counter = (reset ? 0 : *counter) + *delta;
+    const int nk = A.nk[KIND];
+    if (nk == 0) return;
+    uint64_t vm[RH_SC_PPT];
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < RH_SC_PPT; p++) {
+        const int64_t gb = wbase + p * 64;   // bits of the points in [first, nd)
+        const int64_t skip = (int64_t)A.first[KIND] - gb;
+        vm[p] = valid_mask(gb, nd) & (skip <= 0 ? ~0ULL : (skip >= 64 ? 0ULL : ~((1ULL << skip) - 1ULL)));
+        any = any || vm[p] != 0;
+    }
+    if (!any) return;
+    const rh_prep *__restrict__ prep = A.prep[KIND];
+    const double eps = A.eps[KIND], cosa = A.cosa[KIND];
+    const int c_lo = blockIdx.y * RH_LIVE_CH, c_hi = min(nk, c_lo + RH_LIVE_CH);   // this block row's candidates
+    for (int c = c_lo; c < c_hi; c++) {
+        const rh_prep P = prep[c];
+        uint64_t hit = 0;
+#pragma unroll
+        for (int p = 0; p < RH_SC_PPT; p++)
+            hit |= test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & vm[p];
+        if (hit != 0 && lane == 0) flags[A.base[KIND] + c] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(RH_SC_THREADS)
+liveness_small_kernel(const double *__restrict__ dis, int64_t stride, const int32_t *__restrict__ ndis_ptr, int64_t lo,
+                      const rh_live_args A, int32_t *__restrict__ flags)
+{
+    const int64_t nd = *ndis_ptr;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wbase = lo + (int64_t)blockIdx.x * RH_SC_TILE + (int64_t)wave * RH_SC_WAVE_PTS;
+    if (wbase >= nd) return;
+    double px[RH_SC_PPT], py[RH_SC_PPT], pz[RH_SC_PPT], qx[RH_SC_PPT], qy[RH_SC_PPT], qz[RH_SC_PPT];
+#pragma unroll
+    for (int p = 0; p < RH_SC_PPT; p++) {   // (the list has a tile of slack behind its capacity)
+        const int64_t i = wbase + p * 64 + lane;
+        px[p] = dis[i]; py[p] = dis[stride + i]; pz[p] = dis[2 * stride + i];
+        qx[p] = dis[3 * stride + i]; qy[p] = dis[4 * stride + i]; qz[p] = dis[5 * stride + i];
+    }
+    live_kind<RH_PLANE>(A, px, py, pz, qx, qy, qz, wbase, nd, lane, flags);
+    live_kind<RH_SPHERE>(A, px, py, pz, qx, qy, qz, wbase, nd, lane, flags);
+    live_kind<RH_CYLINDER>(A, px, py, pz, qx, qy, qz, wbase, nd, lane, flags);
+    live_kind<RH_CONE>(A, px, py, pz, qx, qy, qz, wbase, nd, lane, flags);
+}
+
+// the extraction's read-back in one small kernel: liveness flags (re-zeroed behind the copy) and the two list
+// lengths, straight into pinned host memory
+__global__ void __launch_bounds__(256)
+pack_live_kernel(int32_t *__restrict__ flags, int32_t n_flags, int32_t *__restrict__ h_flags,
+                 const int32_t *__restrict__ d_total, const int32_t *__restrict__ d_ndis, int32_t *__restrict__ h_scalars)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_flags) {
+        h_flags[i] = flags[i];
+        flags[i] = 0;
+    }
+    if (i == 0) {
+        h_scalars[0] = *d_total;
+        h_scalars[1] = *d_ndis;
+    }
 }
 
 __global__ void select_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ word_prefix,
@@ -1201,15 +1291,40 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_xyz, const double *d_nrm, int
     return RH_OK;
 }
 
-// one int32 from device memory into (pinned) host memory, in stream order, without a copy-engine transfer
-__global__ void fetch_i32_kernel(const int32_t *__restrict__ src, int32_t *__restrict__ h_dst)
+// two int32 from device memory into (pinned) host memory, in stream order, without a copy-engine transfer
+__global__ void fetch_i32_kernel(const int32_t *__restrict__ src0, const int32_t *__restrict__ src1,
+                                 int32_t *__restrict__ h_dst)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *h_dst = *src;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        h_dst[0] = *src0;
+        h_dst[1] = *src1;
+    }
 }
 
-int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src, int32_t *h_pinned_dst)
+int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src0, const int32_t *d_src1, int32_t *h_pinned_dst)
 {
-    hipLaunchKernelGGL(fetch_i32_kernel, dim3(1), dim3(64), 0, c->stream, d_src, h_pinned_dst);
+    hipLaunchKernelGGL(fetch_i32_kernel, dim3(1), dim3(64), 0, c->stream, d_src0, d_src1, h_pinned_dst);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_liveness_small(rh_cloud *c, int64_t lo, const rh_live_args &A, int32_t *d_flags)
+{
+    const int64_t span = c->s - lo;   // the list never holds more than the subset
+    if (span <= 0) return RH_OK;
+    int nk_max = 0;
+    for (int q = 0; q < 4; q++) nk_max = std::max(nk_max, (int)A.nk[q]);
+    if (nk_max == 0) return RH_OK;
+    hipLaunchKernelGGL(liveness_small_kernel, dim3(cdiv(span, RH_SC_TILE), cdiv(nk_max, RH_LIVE_CH)), dim3(RH_SC_THREADS), 0,
+                       c->stream, c->dis, c->dis_stride, c->d_ndis, lo, A, d_flags);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_pack_live(rh_cloud *c, int32_t *d_flags, int32_t n_flags, int32_t *h_flags, int32_t *h_scalars)
+{
+    hipLaunchKernelGGL(pack_live_kernel, dim3(std::max(1, cdiv(n_flags, 256))), dim3(256), 0, c->stream, d_flags, n_flags,
+                       h_flags, c->d_total, c->d_ndis, h_scalars);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1298,9 +1413,29 @@ int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t 
     return rhk_compact_generic(c->stream, mask, nwords, c->block_sums, idx_out, cap, d_total);
 }
 
+// refit list + invalidate_indexes! in one compaction: idx_out = the set bits of refit_mask (ascending,
+// 1-based), enabled &= ~refit_mask, and the per-block popcounts of the updated enabled words are left for
+// the next select directory
+int rhk_compact_refit_apply(rh_cloud *c)
+{
+    c->select_valid = false;
+    c->en_sums_valid = false;
+    if (c->nblocks > 0)
+        hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->refit_mask, c->nwords,
+                           c->block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
+    if (c->nblocks > 0)
+        hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->refit_mask, c->nwords,
+                           c->block_sums, c->idx_out, c->n, (int32_t *)nullptr, c->enabled, c->en_block_sums);
+    RH_HIP(hipGetLastError());
+    c->en_sums_valid = c->nblocks > 0;
+    return RH_OK;
+}
+
 int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
 {
     if (n == 0) return RH_OK;
+    c->en_sums_valid = false;
     hipLaunchKernelGGL(invalidate_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_idx, n, c->n, c->enabled);
     RH_HIP(hipGetLastError());
     return RH_OK;
@@ -1309,29 +1444,22 @@ int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
 int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask)
 {
     if (c->nwords == 0) return RH_OK;
+    c->en_sums_valid = false;
     hipLaunchKernelGGL(andnot_kernel, dim3(cdiv(c->nwords, 256)), dim3(256), 0, c->stream, c->enabled, mask, c->nwords);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
 
-int rhk_rebuild_sub_enabled(rh_cloud *c, bool append, bool reset)
+// subset bits + the list of disabled subset points, after any change of the enabled bits (one launch;
+// `reset_list` rebuilds the list from every disabled point)
+int rhk_rebuild_sub_enabled(rh_cloud *c, bool reset_list)
 {
-    if (reset) RH_HIP(hipMemsetAsync(c->d_ndis, 0, sizeof(int32_t), c->stream));
+    if (reset_list) RH_HIP(hipMemsetAsync(c->d_ndis, 0, sizeof(int32_t), c->stream));
     if (c->s == 0) return RH_OK;
-    hipLaunchKernelGGL(rebuild_sub_enabled_kernel, dim3(cdiv(c->s, 256)), dim3(256), 0, c->stream, c->enabled,
-                       c->sub_idx0, c->s, c->sub_enabled, c->gone_words, reset ? 1 : 0);
+    hipLaunchKernelGGL(update_sub_enabled_kernel, dim3(cdiv(c->swords, 4 * RH_SUBUPD_WPW)), dim3(256), 0, c->stream,
+                       c->enabled, c->sub_idx0, c->s, c->swords, c->sub_enabled, reset_list ? 1 : 0, c->sub, c->s_pad,
+                       c->dis, c->dis_stride, c->d_ndis);
     RH_HIP(hipGetLastError());
-    if (!append) return RH_OK;
-    // ordered compaction of the gone bits: popcount per 1024 words, scan, copy the points
-    const int64_t nb = (c->swords + RH_WORDS_PER_BLOCK - 1) / RH_WORDS_PER_BLOCK;
-    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, c->gone_words, c->swords,
-                       c->block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, c->d_total);
-    hipLaunchKernelGGL(append_gone_kernel, dim3((unsigned)nb), dim3(1024), 0, c->stream, c->gone_words, c->swords,
-                       c->block_sums, c->sub, c->s_pad, c->dis, c->dis_stride, c->d_ndis);
-    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, c->stream, c->d_ndis, c->d_total, 0);
-    RH_HIP(hipGetLastError());
-    c->select_valid = false;   // block_sums / d_total were clobbered
     return RH_OK;
 }
 
@@ -1349,19 +1477,38 @@ expand_dense_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int
     if ((m >> lane) & 1ULL) out[word_prefix[w] + __popcll(m & ((1ULL << lane) - 1ULL))] = (int32_t)g;
 }
 
+// select directory of the enabled bits: word_prefix + d_total.  The per-block popcounts come from the
+// extraction that changed the bits when it left them (rhk_compact_refit_apply), else from a pass here.
 int rhk_build_select(rh_cloud *c)
 {
+    c->sel_valid = false;
+    c->crec_valid = false;   // the rank order changes with the bits
     if (c->nwords == 0) { c->select_valid = true; return RH_OK; }
-    hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
-                       c->block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
+    if (!c->en_sums_valid)
+        hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
+                           c->en_block_sums);
+    c->en_sums_valid = false;   // scanned in place
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->en_block_sums, c->nblocks, c->d_total);
     hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,
-                       c->block_sums, (int64_t *)nullptr, (int64_t)0, c->word_prefix);
-    hipLaunchKernelGGL(expand_dense_kernel, dim3((unsigned)cdiv(c->nwords * 64, 256)), dim3(256), 0, c->stream, c->enabled,
-                       c->nwords, c->word_prefix, c->sel_list);
+                       c->en_block_sums, (int64_t *)nullptr, (int64_t)0, c->word_prefix, (uint64_t *)nullptr,
+                       (int32_t *)nullptr);
     RH_HIP(hipGetLastError());
     c->select_valid = true;
-    c->crec_valid = false;   // the rank order just changed
+    return RH_OK;
+}
+
+// flat select list (sel_list[r] = index of the (r + 1)-th enabled point): what long sampling windows read
+// instead of searching the directory; 4 bytes per enabled point, so it is only built on demand
+int rhk_build_sel_list(rh_cloud *c)
+{
+    if (!c->select_valid) RH_TRY(rhk_build_select(c));
+    if (c->sel_valid) return RH_OK;
+    if (c->nwords > 0) {
+        hipLaunchKernelGGL(expand_dense_kernel, dim3((unsigned)cdiv(c->nwords * 64, 256)), dim3(256), 0, c->stream, c->enabled,
+                           c->nwords, c->word_prefix, c->sel_list);
+        RH_HIP(hipGetLastError());
+    }
+    c->sel_valid = true;
     return RH_OK;
 }
 
@@ -1418,7 +1565,7 @@ int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, ws_block_sums, nb, d_total);
     if (nb > 0)
         hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, mask, nwords, ws_block_sums,
-                           idx_out, cap, (int32_t *)nullptr);
+                           idx_out, cap, (int32_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1561,7 +1708,7 @@ int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t 
     hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, words, nwords, c->block_sums);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, nb, c->d_total);
     hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, words, nwords, c->block_sums,
-                       (int64_t *)nullptr, (int64_t)0, prefix_out);
+                       (int64_t *)nullptr, (int64_t)0, prefix_out, (uint64_t *)nullptr, (int32_t *)nullptr);
     RH_HIP(hipMemcpyAsync(prefix_out + nwords, c->d_total, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     RH_HIP(hipGetLastError());
     c->select_valid = false;

@@ -58,6 +58,9 @@ struct rh_cloud {
     hipStream_t own_stream = nullptr;  // created with the cloud; `stream` is this or the caller's (rh_cloud_set_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // per-kind launch brackets
+    hipStream_t copy_stream = nullptr; // rh_ransac: read-back of the extracted index lists, beside the compute stream
+    hipEvent_t ev_list = nullptr, ev_copied = nullptr;   // idx_out is complete / has been read back
+    hipEvent_t ev_sync = nullptr;      // rh_ransac: the host's one wait per extraction
     int64_t n = 0, s = 0;
     int64_t n_pad = 0, s_pad = 0;      // padded to RH_SC_TILE
     int64_t nwords = 0, swords = 0;    // ceil(n/64), ceil(s/64)
@@ -71,7 +74,8 @@ struct rh_cloud {
     double *crec = nullptr;            // 64-byte records of the ENABLED points in rank order (long sampling windows)
     int64_t crec_cap = 0;              // in records
     bool crec_valid = false;           // cleared whenever the select list is rebuilt
-    int32_t *sel_list = nullptr;       // sel_list[r] = 0-based index of the (r+1)-th enabled point (valid with select_valid)
+    int32_t *sel_list = nullptr;       // sel_list[r] = 0-based index of the (r+1)-th enabled point (valid with sel_valid)
+    bool sel_valid = false;            // built on demand by rhk_build_sel_list, dropped with the select directory
     double *rec = nullptr;             // the same points as 64-byte records (x y z nx ny nz 0 0): one line per random gather
     double *sub = nullptr;             // subset 1, subset order
     double *dis = nullptr;             // disabled subset-1 points (append-only), capacity s_pad + tile
@@ -84,7 +88,6 @@ struct rh_cloud {
     int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
     double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
     bool use_groups = false;           // culled scoring path available (s large enough)
-    uint64_t *gone_words = nullptr;    // [swords] subset bits that were just disabled
     double *dis_gb = nullptr;          // boxes of the dis segment in use (7 x ng_pad)
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
@@ -105,6 +108,8 @@ struct rh_cloud {
     // refit / select workspaces
     uint64_t *refit_mask = nullptr;    // [nwords]
     int32_t *block_sums = nullptr;     // [nblocks + 1]
+    int32_t *en_block_sums = nullptr;  // [nblocks + 1] popcounts of the enabled words per block (select directory)
+    bool en_sums_valid = false;        // left behind by rhk_compact_refit_apply for the next rhk_build_select
     int32_t *word_prefix = nullptr;    // [nwords + 1] exclusive prefix of popcount(enabled) (select)
     bool select_valid = false;
     int64_t *idx_out = nullptr;        // [n] compacted indices
@@ -132,10 +137,19 @@ struct rh_cloud {
     int64_t h_pin_cap = 0;
 };
 
+// liveness pass over a small store (rhk_liveness_small): per kind the prepared candidates, their number, where
+// their flags start, and the first entry of the disabled list they have to be tested against
+struct rh_live_args {
+    const rh_prep *prep[4];
+    int32_t nk[4], base[4];
+    int64_t first[4];
+    double eps[4], cosa[4];
+};
+
 // ---- kernel launchers (kernels.hip) -----------------------------------------
 int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_nrm, int64_t n,
                       const int32_t *d_gather_or_null, int64_t count, double *dst, int64_t dst_stride);
-int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src, int32_t *h_pinned_dst);   // *h = *d in stream order (pinned h)
+int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src0, const int32_t *d_src1, int32_t *h_pinned_dst);   // h[0..1] = *d0, *d1 in stream order (pinned h)
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep,
                     int32_t *d_counts_to_zero = nullptr);
@@ -166,7 +180,11 @@ int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t 
                      int32_t *d_total);
 int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n);
 int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask);
-int rhk_rebuild_sub_enabled(rh_cloud *c, bool append_newly_disabled, bool reset_list);
+int rhk_rebuild_sub_enabled(rh_cloud *c, bool reset_list);
+int rhk_compact_refit_apply(rh_cloud *c);
+int rhk_build_sel_list(rh_cloud *c);
+int rhk_liveness_small(rh_cloud *c, int64_t lo, const rh_live_args &A, int32_t *d_flags);   // flags must be zero on entry
+int rhk_pack_live(rh_cloud *c, int32_t *d_flags, int32_t n_flags, int32_t *h_flags, int32_t *h_scalars);
 int rhk_build_select(rh_cloud *c);
 int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out);
 int rhk_count_enabled(rh_cloud *c, int64_t *out);

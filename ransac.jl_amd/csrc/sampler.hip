@@ -16,11 +16,23 @@ struct DevEnabled {
     int64_t nwords;
     int32_t total;
     __device__ bool test(int64_t i0) const { return (w[i0 >> 6] >> (i0 & 63)) & 1ULL; }
-    // r-th enabled point (1-based), 0 when out of range: one read of the select list the cloud
-    // rebuilds whenever the enabled bits change (a binary search over the word prefixes costs ~17
-    // dependent L2 reads per draw and bounded the kernel by latency)
+    // r-th enabled point (1-based), 0 when out of range.  Long windows read the flat select list (one
+    // load; the cloud builds it on demand); short ones search the word prefixes (~17 dependent L2 reads
+    // per draw, which only bounds the kernel when there are millions of draws).
     const int32_t *sel;
-    __device__ int64_t select(int64_t r) const { return (r < 1 || r > total) ? 0 : (int64_t)sel[r - 1] + 1; }
+    __device__ int64_t select(int64_t r) const
+    {
+        if (r < 1 || r > total) return 0;
+        if (sel != nullptr) return (int64_t)sel[r - 1] + 1;
+        int64_t lo = 0, hi = nwords - 1;   // the last word whose exclusive prefix is <= r - 1 holds the point
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if ((int64_t)prefix[mid] <= r - 1) lo = mid; else hi = mid - 1;
+        }
+        uint64_t m = w[lo];
+        for (int64_t k = r - 1 - prefix[lo]; k > 0; k--) m &= m - 1;
+        return (lo << 6) + __builtin_ctzll(m) + 1;
+    }
 };
 
 constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the host sampler
@@ -318,15 +330,6 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     if (!status_is_zero) RH_HIP(hipMemsetAsync(d_status, 0, (size_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 64), c->stream));
     const int64_t total = (int64_t)n_iters * prm->minsubsetN;
     if (total == 0) return RH_OK;
-    DevEnabled en;
-    en.w = c->enabled;
-    en.prefix = c->word_prefix;
-    en.nwords = c->nwords;
-    en.total = n_enabled;
-    en.sel = c->sel_list;
-    rhfit::OctView oc;
-    oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
-    oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     // hand-over workspace (grown on demand; a window of 128 x 4096 sets of 3 points is 75 MB)
     const int64_t need = total * 6 * prm->drawN;
     if (c->set_ws_doubles < need) {
@@ -344,23 +347,40 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     bool cone = false;
     for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
     const bool no_fused = getenv("RH_NO_FUSED_SAMPLER") != nullptr;   // read per call: the tests flip it
-    // long root-cell windows sample from rank-ordered compact records (rebuilt with the select list)
+    // Windows with many root-cell sets pay for two structures that are rebuilt after every extraction: the
+    // flat select list (4 B per enabled point) and, from it, the rank-ordered compact records (64 B per
+    // enabled point).  Short windows -- the ones between extractions -- search the directory instead.
     const bool no_crec = getenv("RH_NO_CREC") != nullptr;
+    const char *ms = getenv("RH_LONG_WINDOW_SETS");
+    const int64_t long_sets = ms ? atoll(ms) : (int64_t)1 << 16;
+    const bool long_window = d_P == nullptr && n_enabled > 0 && total >= long_sets;
     const double *crec = nullptr;
-    if (d_P == nullptr && n_iters >= 32 && n_enabled > 0 && !no_crec) {
-        if (!c->crec_valid) {
-            if (c->crec_cap < n_enabled) {
-                (void)hipFree(c->crec);
-                c->crec = nullptr; c->crec_cap = 0;
-                RH_HIP(hipMalloc((void **)&c->crec, sizeof(double) * 8 * (size_t)n_enabled));
-                c->crec_cap = n_enabled;
+    if (long_window) {
+        RH_TRY(rhk_build_sel_list(c));
+        if (!no_crec) {
+            if (!c->crec_valid) {
+                if (c->crec_cap < n_enabled) {
+                    (void)hipFree(c->crec);
+                    c->crec = nullptr; c->crec_cap = 0;
+                    RH_HIP(hipMalloc((void **)&c->crec, sizeof(double) * 8 * (size_t)n_enabled));
+                    c->crec_cap = n_enabled;
+                }
+                hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)(((int64_t)n_enabled + 255) / 256)), dim3(256), 0,
+                                   c->stream, c->rec, c->sel_list, (int64_t)n_enabled, c->crec);
+                c->crec_valid = true;
             }
-            hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)(((int64_t)n_enabled + 255) / 256)), dim3(256), 0, c->stream,
-                               c->rec, c->sel_list, (int64_t)n_enabled, c->crec);
-            c->crec_valid = true;
+            crec = c->crec;
         }
-        crec = c->crec;
     }
+    DevEnabled en;
+    en.w = c->enabled;
+    en.prefix = c->word_prefix;
+    en.nwords = c->nwords;
+    en.total = n_enabled;
+    en.sel = c->sel_valid ? c->sel_list : nullptr;
+    rhfit::OctView oc;
+    oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
+    oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
     if (crec != nullptr && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));

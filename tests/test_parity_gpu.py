@@ -352,15 +352,21 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
     (["plane", "plane"], "p", 13, False),
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_PIPELINE"),      # one window at a time
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SCORE"),   # scores through the host
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SAMPLER"),  # sample + fit as two kernels
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_CREC"),           # index-space sampling
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FAST_EXTRACT"),  # liveness after the host saw the lengths
+    # windows this short search the select directory; RH_LONG_WINDOW_SETS=0 sends them down the long-window
+    # path (flat select list, rank-ordered compact records, sampling + fits in one kernel) and its variants
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS"),
+    (["plane", "sphere", "cylinder", "cone"], "all", 12, "RH_LONG_WINDOW_SETS"),
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_FUSED_SAMPLER"),  # sample + fit as two kernels
+    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_CREC"),           # index-space sampling
 ])
 def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
     """sampling_streams = 1: sampling + fitting + scoring on the device, iterations speculated in
     pipelined windows; must equal the oracle's strictly sequential loop over the same per-set streams
     (also with each pipeline stage switched off)."""
     if isinstance(host, str):
-        monkeypatch.setenv(host, "1")
+        for name in host.split(","):
+            monkeypatch.setenv(name, "0" if name == "RH_LONG_WINDOW_SETS" else "1")
     elif host:
         monkeypatch.setenv("RH_HOST_SAMPLER", "1")
     xyz, nrm, truth = synth.make_cloud(30_000, prims, 0.1, seed=60 + seed)

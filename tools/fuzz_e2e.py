@@ -30,11 +30,16 @@ def one(case, rng):
               sampling_streams=streams, octree_sampling=octree)
     env = None
     if streams:
-        env = rng.choice([None, None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER"])
-    for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER"):
+        env = rng.choice([None, None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_NO_FAST_EXTRACT"])
+    for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_LONG_WINDOW_SETS",
+              "RH_NO_FAST_EXTRACT"):
         os.environ.pop(k, None)
     if env:
         os.environ[env] = "1"
+    if streams and rng.integers(0, 2):   # half the cases take the long-window sampler path whatever their size
+        os.environ["RH_LONG_WINDOW_SETS"] = "0"
+    if rng.integers(0, 4) == 0:          # a quarter: liveness pass after the host has seen the list lengths
+        os.environ["RH_NO_FAST_EXTRACT"] = "1"
     pc = R.RANSACCloud(xyz, nrm, subs)
     oc = orc.Cloud(xyz, nrm, subs[0])
     cp = R.params_to_c(params, **kw)
