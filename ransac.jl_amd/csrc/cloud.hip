@@ -150,7 +150,6 @@ static void cloud_free(rh_cloud *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 5; k++)
         if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
-    if (c->ev_list) (void)hipEventDestroy(c->ev_list);
     if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -304,7 +303,6 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipEventCreate(&c->ev1));
     for (int k = 0; k < 5; k++) CKH(hipEventCreate(&c->evk[k]));
     CKH(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    CKH(hipEventCreateWithFlags(&c->ev_list, hipEventDisableTiming));
     CKH(hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
     CKH(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
     CK(dev_alloc(&c->full, 6 * c->n_pad));

@@ -117,7 +117,8 @@ constexpr int64_t LIVE_MAX = 4096;   // stores up to this size take the one-wait
 struct Stored {
     rh_shape shape;
     double E;
-    int32_t slot;   // index in the device store of its kind
+    int32_t slot;    // index in the device store of its kind
+    int32_t sigma;   // its count on subset 1
 };
 
 // device-resident store of prepared candidates, one growable array per kind
@@ -538,6 +539,7 @@ struct Driver {
             rec.shape = cands[i];
             rec.E = E;
             rec.slot = slot_next[cands[i].kind]++;
+            rec.sigma = counts[i];
             store.push_back(rec);
             if (octree) oS[levels[i] - 1] += E;   // pc.levelscore[level] += E(sc): fitting.jl:184
             // findhighestscore (fitting.jl:140-151) incrementally: first maximum, strict >
@@ -580,7 +582,6 @@ struct Driver {
         // ... with invalidate_indexes! (fitting.jl:197-202) folded into the compaction as enabled &= ~mask;
         // then subset bits + disabled list
         RUN(rhk_compact_refit_apply(c));
-        RUNH(hipEventRecord(c->ev_list, c->stream));
         RUN(rhk_rebuild_sub_enabled(c, false));
         if (fast) {
             rh_live_args A;
@@ -595,12 +596,17 @@ struct Driver {
                 A.cosa[q] = p->cos_alpha[q];
                 if (st.n[q] > 0) lo = std::min(lo, A.first[q]);
             }
-            if (sum_n > 0) RUN(rhk_liveness_small(c, lo, A, st.live));
+            // new entries of the list <= the candidate's own count on subset 1: the bits only went down since it
+            // was scored, and the refit scan applies the same per-point test
+            const int64_t span = (ndis_old - lo) + store[extracted_pos].sigma;
+            if (sum_n > 0) RUN(rhk_liveness_small(c, lo, std::min<int64_t>(c->s - lo, span), A, st.live));
             RUN(rhk_pack_live(c, st.live, (int32_t)sum_n, h_counts, h_scr));
         } else {
             RUN(rhk_fetch2_i32(c, c->d_total, c->d_ndis, h_scr));
         }
         RUNH(hipEventRecord(c->ev_sync, c->stream));
+        // the next window needs the select directory of the new bits: its two launches run while the host wakes up
+        if (!host_sampling && !octree) RUN(rhk_build_select(c));
         if (octree) RUN(rhk_oct_clear_mask(c, c->refit_mask));   // (its prefix pass reuses d_total: after the read-back)
         RUNH(hipEventSynchronize(c->ev_sync));
         const int32_t total = h_scr[0], ndis_new = h_scr[1];
@@ -615,7 +621,7 @@ struct Driver {
         if (total > 0) {
             // pinned destination, on the copy stream: the 8 bytes per inlier cross PCIe while the compute stream
             // goes on with the next window; the next extraction waits for ev_copied before it rewrites idx_out
-            RUNH(hipStreamWaitEvent(c->copy_stream, c->ev_list, 0));
+            // (idx_out is complete: the host has just waited for work that was queued behind the compaction)
             RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->copy_stream));
             RUNH(hipEventRecord(c->ev_copied, c->copy_stream));
             list_copy_pending = true;

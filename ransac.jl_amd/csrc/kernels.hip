@@ -1048,7 +1048,7 @@ update_sub_enabled_kernel(const uint64_t *__restrict__ enabled, const int32_t *_
 // RH_SC_WAVE_PTS points in registers and walks every stored candidate; flags[base[kind] + slot] = 1 marks
 // a dead one (the flags are all zero on entry, pack_live_kernel re-zeroes them).  grid.y splits the candidates
 // of every kind into rows of RH_LIVE_CH: the walk is a chain of dependent scalar loads, so it is kept short.
-constexpr int RH_LIVE_CH = 16;   // candidates of each kind per block row
+constexpr int RH_LIVE_CH = 4;   // candidates of each kind per block row
 
 template <int KIND>
 __device__ __forceinline__ void live_kind(const rh_live_args &A, const double (&px)[RH_SC_PPT], const double (&py)[RH_SC_PPT],
@@ -1308,9 +1308,9 @@ int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src0, const int32_t *d_src1, in
     return RH_OK;
 }
 
-int rhk_liveness_small(rh_cloud *c, int64_t lo, const rh_live_args &A, int32_t *d_flags)
+// `span`: an upper bound of the list entries behind `lo` (the true end is read on the device)
+int rhk_liveness_small(rh_cloud *c, int64_t lo, int64_t span, const rh_live_args &A, int32_t *d_flags)
 {
-    const int64_t span = c->s - lo;   // the list never holds more than the subset
     if (span <= 0) return RH_OK;
     int nk_max = 0;
     for (int q = 0; q < 4; q++) nk_max = std::max(nk_max, (int)A.nk[q]);

@@ -59,7 +59,7 @@ struct rh_cloud {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // per-kind launch brackets
     hipStream_t copy_stream = nullptr; // rh_ransac: read-back of the extracted index lists, beside the compute stream
-    hipEvent_t ev_list = nullptr, ev_copied = nullptr;   // idx_out is complete / has been read back
+    hipEvent_t ev_copied = nullptr;    // idx_out has been read back
     hipEvent_t ev_sync = nullptr;      // rh_ransac: the host's one wait per extraction
     int64_t n = 0, s = 0;
     int64_t n_pad = 0, s_pad = 0;      // padded to RH_SC_TILE
@@ -183,7 +183,7 @@ int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask);
 int rhk_rebuild_sub_enabled(rh_cloud *c, bool reset_list);
 int rhk_compact_refit_apply(rh_cloud *c);
 int rhk_build_sel_list(rh_cloud *c);
-int rhk_liveness_small(rh_cloud *c, int64_t lo, const rh_live_args &A, int32_t *d_flags);   // flags must be zero on entry
+int rhk_liveness_small(rh_cloud *c, int64_t lo, int64_t span, const rh_live_args &A, int32_t *d_flags);   // flags must be zero on entry
 int rhk_pack_live(rh_cloud *c, int32_t *d_flags, int32_t n_flags, int32_t *h_flags, int32_t *h_scalars);
 int rhk_build_select(rh_cloud *c);
 int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out);
