@@ -774,7 +774,9 @@ struct Driver {
         const int64_t sets_budget = 1 << 21;   // minimal sets per window: 512 iterations at minsubsetN = 4096
         const int64_t Kmax = std::max<int64_t>(1, std::min<int64_t>(512, sets_budget / std::max(1, p->minsubsetN)));
         const int64_t K = Kmax;  // longest window
-        int64_t Kcur = octree ? 1 : Kmax;   // window length in use; adapted to how often windows get cut short
+        // window length in use: slow start (an extraction within the first iterations would throw a long first
+        // window away), doubled by every window that is used to its end, halved by one that is cut short
+        int64_t Kcur = octree ? 1 : std::min<int64_t>(Kmax, 2);
         const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)K + 63) / 64 * 64;
         for (Window &w : win) {
             RUNH(hipMalloc((void **)&w.d_status, status_bytes));

@@ -357,7 +357,9 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     const double *crec = nullptr;
     if (long_window) {
         RH_TRY(rhk_build_sel_list(c));
-        if (!no_crec) {
+        // the compact records cost a gather of the whole enabled cloud: only for windows 8 x longer still
+        // (or when they exist already)
+        if (!no_crec && (c->crec_valid || total >= 8 * long_sets)) {
             if (!c->crec_valid) {
                 if (c->crec_cap < n_enabled) {
                     (void)hipFree(c->crec);
