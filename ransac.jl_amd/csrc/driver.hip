@@ -569,7 +569,14 @@ struct Driver {
         const int64_t sum_n = base[4];
         // A small store (the usual case: root-cell sampling keeps a few hundred candidates) is checked for
         // liveness in the same stream, before the host has seen the list lengths: ONE wait per extraction.
-        const bool fast = sum_n <= LIVE_MAX && !getenv("RH_NO_FAST_EXTRACT");
+        // (the in-stream pass is brute force over [first, end of the list) x the store: it is for small products --
+        // faithful-mode spheres, which are tested against every disabled point, outgrow it as the list fills)
+        int64_t live_work = 0;
+        for (int q = 0; q < 4; q++) {
+            const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+            live_work += (int64_t)st.n[q] * ((all_disabled ? c->n_dis : 0) + store[(size_t)best].sigma);
+        }
+        const bool fast = sum_n <= LIVE_MAX && live_work <= ((int64_t)1 << 24) && !getenv("RH_NO_FAST_EXTRACT");
         RUN(store_reserve_aux(c, st, sum_n));
         RUN(ensure_scratch(32 + 2 * sum_n));   // (may wait for the stream: before anything lands in the scratch)
         int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;

@@ -17,17 +17,35 @@ struct DevEnabled {
     int32_t total;
     __device__ bool test(int64_t i0) const { return (w[i0 >> 6] >> (i0 & 63)) & 1ULL; }
     // r-th enabled point (1-based), 0 when out of range.  Long windows read the flat select list (one
-    // load; the cloud builds it on demand); short ones search the word prefixes (~17 dependent L2 reads
-    // per draw, which only bounds the kernel when there are millions of draws).
+    // load; the cloud builds it on demand); short ones search the word prefixes.
     const int32_t *sel;
     __device__ int64_t select(int64_t r) const
     {
         if (r < 1 || r > total) return 0;
         if (sel != nullptr) return (int64_t)sel[r - 1] + 1;
-        int64_t lo = 0, hi = nwords - 1;   // the last word whose exclusive prefix is <= r - 1 holds the point
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) >> 1;
-            if ((int64_t)prefix[mid] <= r - 1) lo = mid; else hi = mid - 1;
+        // the last word whose exclusive prefix is <= r - 1 holds the point.  8-ary search: the seven pivots of a
+        // round are independent loads, so 156 250 words take 6 dependent rounds instead of 17
+        const int64_t t = r - 1;
+        int64_t lo = 0, hi = nwords - 1;
+        while (hi - lo >= 8) {
+            const int64_t step = (hi - lo + 8) >> 3;
+            int k = 0;   // prefix is non-decreasing: the pivots <= t are the first k
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                const int64_t pv = lo + i * step;
+                k += (pv <= hi && (int64_t)prefix[pv <= hi ? pv : hi] <= t) ? 1 : 0;
+            }
+            lo += k * step;
+            hi = hi < lo + step - 1 ? hi : lo + step - 1;
+        }
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                const int64_t pv = lo + i;
+                k += (pv <= hi && (int64_t)prefix[pv <= hi ? pv : hi] <= t) ? 1 : 0;
+            }
+            lo += k;
         }
         uint64_t m = w[lo];
         for (int64_t k = r - 1 - prefix[lo]; k > 0; k--) m &= m - 1;
@@ -42,7 +60,7 @@ constexpr int RH_MAX_DRAWN = 8;   // device path; larger minimal sets use the ho
 // others are ranks already.  Draw count and stream position equal rhfit::sample_minimal_set's.
 template <int DN>
 __device__ bool sample_ranks(const DevEnabled &en, int64_t n, int64_t n_enabled, int drawN_rt, uint64_t *x, int64_t *sd,
-                             uint32_t *ndraws, bool *gave_up)
+                             uint32_t *ndraws, bool *gave_up, int64_t *first_index = nullptr)
 {
     const int drawN = DN > 0 ? DN : drawN_rt;
     if (n_enabled <= 0) return false;
@@ -71,6 +89,7 @@ __device__ bool sample_ranks(const DevEnabled &en, int64_t n, int64_t n_enabled,
     *ndraws += nd;
     if (n_enabled < drawN) return false;
     const int64_t i0 = r1 - 1;
+    if (first_index != nullptr) *first_index = r1;
     sd[0] = (int64_t)en.prefix[i0 >> 6] + __popcll(en.w[i0 >> 6] & ((1ULL << (i0 & 63)) - 1ULL)) + 1;
 #pragma unroll
     for (int q = 1; q < drawN; q++) {
@@ -239,7 +258,8 @@ pack_window_kernel(uint64_t *__restrict__ status, int32_t status_words, const rh
 // carries the plane / sphere / cylinder fits (~160 VGPRs, 3 waves per SIMD).
 template <int DN>
 __global__ void __launch_bounds__(128)
-sample_fit_ranks_kernel(const double *__restrict__ crec, int64_t n, DevEnabled en, int32_t n_enabled, const rh_params prm,
+sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restrict__ rec, int64_t n, DevEnabled en,
+                        int32_t n_enabled, const rh_params prm,
                         uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out, int32_t cap,
                         int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
                         int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero)
@@ -256,7 +276,8 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, int64_t n, DevEnabled e
     uint32_t nd = 0;
     bool gave_up = false;
     const int drawN = DN > 0 ? DN : prm.drawN;
-    const bool ok = sample_ranks<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up);
+    int64_t first_index = 0;
+    const bool ok = sample_ranks<DN>(en, n, (int64_t)n_enabled, drawN, &x, sd, &nd, &gave_up, &first_index);
     {
         uint64_t todo = __builtin_amdgcn_ballot_w64(true);
         const int lane = threadIdx.x & 63;
@@ -274,9 +295,16 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, int64_t n, DevEnabled e
     if (!ok) return;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     double fp[3 * CAP], fn[3 * CAP];
+    // without the compact records (short windows) the ranks go back to indices through the select directory
+    if (crec == nullptr) {
+        sd[0] = first_index;
+#pragma unroll
+        for (int q = 1; q < drawN; q++) sd[q] = en.select(sd[q]);
+    }
+    const double *__restrict__ src = crec != nullptr ? crec : rec;
 #pragma unroll
     for (int q = 0; q < drawN; q++) {
-        const f64x2 *r = (const f64x2 *)(crec + 8 * (sd[q] - 1));
+        const f64x2 *r = (const f64x2 *)(src + 8 * (sd[q] - 1));
         const f64x2 a = r[0], b = r[1], c = r[2];
         fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
         fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
@@ -384,14 +412,14 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
-    if (crec != nullptr && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
+    if (d_P == nullptr && n_enabled > 0 && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));
         if (prm->drawN == 3)
-            hipLaunchKernelGGL(sample_fit_ranks_kernel<3>, gk, dim3(128), 0, c->stream, crec, c->n, en, n_enabled, *prm, seed, k0,
-                               n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+            hipLaunchKernelGGL(sample_fit_ranks_kernel<3>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
         else
-            hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->n, en, n_enabled, *prm, seed, k0,
-                               n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+            hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
         RH_HIP(hipGetLastError());
         return RH_OK;
     }
