@@ -426,10 +426,8 @@ def main():
                                      iteration={"minsubsetN": 4096, "itermax": args.e2e_iters, "τ": 900, "prob_det": 0.9})
             ecp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
             pc.enable_all()
-            ecp.itermax = 4
-            R.ransac(pc, ecp, seed=99)                      # warm-up (allocations, first launches)
-            pc.enable_all()
-            ecp.itermax = args.e2e_iters
+            R.ransac(pc, ecp, seed=99)                      # warm-up: a whole run (the cloud's one-time allocations:
+            pc.enable_all()                                 # select list, compact records, windows, pinned arena)
 
             def prewarm():   # the oracle legs above left the GPU idle for seconds: settle the clocks again
                 for _ in range(int(args.prewarm_ms * 5)):
@@ -450,7 +448,7 @@ def main():
                                  "largest_shapes": sorted((len(g.inpoints) for g in got), reverse=True)[:5],
                                  "note": "one rh_ransac call: minsubsetN=4096, itermax=%d, root-cell sampling like the "
                                          "reference, f64 score mode, per-set random streams (sampling + fits + scoring on "
-                                         "the device, iterations speculated in windows of 128)" % args.e2e_iters}
+                                         "the device, iterations speculated in pipelined windows of up to 512; after a warm-up run of the same length)" % args.e2e_iters}
             # fixed behaviour: level-weighted octree sampling (docs/src/ransac.md:73-96)
             ocp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1,
                                 octree_sampling=True)
