@@ -150,6 +150,9 @@ static void cloud_free(rh_cloud *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 5; k++)
         if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
+    c->stream = c->own_stream;   // (the deleter below waits on c->stream; everything has finished by now)
+    if (c->drv_cache != nullptr && c->drv_cache_free != nullptr) c->drv_cache_free(c, c->drv_cache);
+    c->drv_cache = nullptr;
     if (c->ev_copied) (void)hipEventDestroy(c->ev_copied);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }

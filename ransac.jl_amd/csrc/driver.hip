@@ -237,6 +237,48 @@ namespace {
 #define RUN(x) do { int rc_ = (x); if (rc_ != RH_OK) return rc_; } while (0)
 #define RUNH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); return RH_E_NODEVICE; } } while (0)
 
+// a sampled window in flight: device list + status, pinned landing zones, completion event
+struct Window {
+    rh_cand_entry *d_entries = nullptr, *h_entries = nullptr;   // h_entries: pinned, head of the list
+    int32_t entries_cap = 0;
+    char *d_status = nullptr, *h_status = nullptr;              // int32 count, int32 gave_up, u64 draws[W]
+    int32_t *d_counts = nullptr, *h_counts = nullptr;           // inlier counts per list entry (h: pinned head)
+    bool scored = false;                                        // the counts were computed with the window
+    hipEvent_t ev = nullptr;
+    int64_t k = 0;
+    int32_t W = 0;
+    bool pending = false;
+};
+
+void window_free(Window &w)
+{
+    (void)hipFree(w.d_entries); (void)hipFree(w.d_status); (void)hipFree(w.d_counts);
+    (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
+    if (w.ev) (void)hipEventDestroy(w.ev);
+    w = Window();
+}
+
+// What a run allocates and the next run on the same cloud can use again (two windows, the device store, the
+// pinned scratch: a dozen hipMalloc / hipHostMalloc / hipFree pairs, ~3 ms per call): parked on the cloud
+// between calls, freed with it.  Only a run that ended cleanly parks its buffers (the windows' status blocks and
+// the liveness flags are zero then).
+struct DriverCache {
+    Window win[2];
+    DeviceStore st;
+    int32_t *h_scr = nullptr;
+    int64_t h_scr_cap = 0;
+};
+
+void driver_cache_free(rh_cloud *c, void *p)
+{
+    DriverCache *dc = (DriverCache *)p;
+    if (!dc) return;
+    (void)hipHostFree(dc->h_scr);
+    store_free(c, dc->st);
+    for (Window &w : dc->win) window_free(w);
+    delete dc;
+}
+
 struct Driver {
     rh_cloud *c;
     const rh_params *p;
@@ -273,19 +315,6 @@ struct Driver {
     std::vector<int64_t> sd;
     std::vector<double> fp, fn;
 
-    // device sampler buffers
-    // a sampled window in flight: device list + status, pinned landing zones, completion event
-    struct Window {
-        rh_cand_entry *d_entries = nullptr, *h_entries = nullptr;   // h_entries: pinned, head of the list
-        int32_t entries_cap = 0;
-        char *d_status = nullptr, *h_status = nullptr;              // int32 count, int32 gave_up, u64 draws[W]
-        int32_t *d_counts = nullptr, *h_counts = nullptr;           // inlier counts per list entry (h: pinned head)
-        bool scored = false;                                        // the counts were computed with the window
-        hipEvent_t ev = nullptr;
-        int64_t k = 0;
-        int32_t W = 0;
-        bool pending = false;
-    };
     Window win[2];
     static constexpr int32_t ENTRIES_HEAD = 4096;   // list entries that travel with the window (pack_window_kernel copies min(count, this))
 
@@ -295,18 +324,25 @@ struct Driver {
     int64_t arena_used = 0, arena_cap = 0;
     bool list_copy_pending = false;     // a list is (or may still be) on its way from idx_out to the arena
 
+    bool clean = false;                 // set when the run ended without an error: its buffers may be parked
+
     ~Driver()
     {
         if (c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in the pinned blocks
         if (c) (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipHostFree(h_scr);
         arena_release(arena);   // null once the result owns it
-        store_free(c, st);
-        for (Window &w : win) {
-            (void)hipFree(w.d_entries); (void)hipFree(w.d_status); (void)hipFree(w.d_counts);
-            (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
-            if (w.ev) (void)hipEventDestroy(w.ev);
+        if (c && clean && c->drv_cache == nullptr && !getenv("RH_NO_DRIVER_CACHE")) {
+            DriverCache *dc = new DriverCache;
+            dc->win[0] = win[0]; dc->win[1] = win[1];
+            dc->st = st;
+            dc->h_scr = h_scr; dc->h_scr_cap = h_scr_cap;
+            c->drv_cache = dc;
+            c->drv_cache_free = driver_cache_free;
+            return;
         }
+        (void)hipHostFree(h_scr);
+        store_free(c, st);
+        for (Window &w : win) window_free(w);
     }
 
     // pinned scratch of at least `ints` int32 (contents are not preserved when it grows)
@@ -333,6 +369,16 @@ struct Driver {
         en.w.assign((size_t)c->nwords, 0);
         if (c->nwords > 0) RUN(rh_cloud_get_enabled(c, en.w.data(), c->nwords));
         en.recount();
+        if (c->drv_cache != nullptr) {   // the buffers the previous run on this cloud parked
+            DriverCache *dc = (DriverCache *)c->drv_cache;
+            c->drv_cache = nullptr;
+            win[0] = dc->win[0]; win[1] = dc->win[1];
+            st = dc->st;
+            h_scr = dc->h_scr; h_scr_cap = dc->h_scr_cap;
+            delete dc;
+            for (int q = 0; q < 4; q++) st.n[q] = 0;
+            for (Window &w : win) { w.pending = false; w.scored = false; }
+        }
         RUN(ensure_scratch(1 << 16));
         arena_cap = std::max<int64_t>(en.count, 1);   // a point is extracted at most once
         arena = (int64_t *)arena_acquire(sizeof(int64_t) * (size_t)arena_cap);
@@ -345,9 +391,11 @@ struct Driver {
         RUNH(hipStreamSynchronize(c->stream));
         c->n_dis = ndis;
         c->select_valid = false;
-        RUNH(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
-        RUNH(hipMalloc((void **)&st.live, sizeof(int32_t) * (size_t)LIVE_MAX));
-        RUNH(hipMemsetAsync(st.live, 0, sizeof(int32_t) * (size_t)LIVE_MAX, c->stream));
+        if (!st.d_nk) RUNH(hipMalloc((void **)&st.d_nk, sizeof(int32_t) * 8));
+        if (!st.live) {
+            RUNH(hipMalloc((void **)&st.live, sizeof(int32_t) * (size_t)LIVE_MAX));
+            RUNH(hipMemsetAsync(st.live, 0, sizeof(int32_t) * (size_t)LIVE_MAX, c->stream));
+        }
         octree = p->octree_sampling != 0;
         if (octree) {
             RUN(rh_octree_ensure(c, xyz, p->octree_max_depth));
@@ -784,8 +832,10 @@ struct Driver {
         // window length in use: slow start (an extraction within the first iterations would throw a long first
         // window away), doubled by every window that is used to its end, halved by one that is cut short
         int64_t Kcur = octree ? 1 : std::min<int64_t>(Kmax, 2);
-        const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)K + 63) / 64 * 64;
+        // (sized for the longest window whatever this run's parameters: the windows outlive the run on the cloud)
+        const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)512 + 63) / 64 * 64;
         for (Window &w : win) {
+            if (w.d_status != nullptr) continue;   // parked by the previous run
             RUNH(hipMalloc((void **)&w.d_status, status_bytes));
             RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));   // kept zero by pack_window_kernel from here on
             RUNH(hipHostMalloc((void **)&w.h_status, status_bytes));
@@ -1017,7 +1067,9 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
     d.host_sampling = !device_sampler;
     RH_TRY(d.init());
+    const double t_init = now_s() - t_start;
     RH_TRY(device_sampler ? d.run_streams_device() : d.run_sequential());
+    const double t_loop = now_s() - t_start - t_init;
     RH_HIP(hipStreamSynchronize(c->stream));
     RH_HIP(hipStreamSynchronize(c->copy_stream));   // the index lists have landed in the arena
 
@@ -1031,12 +1083,14 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     d.extracted.clear();
     out->arena = d.arena;   // ownership of the index lists moved to the result
     d.arena = nullptr;
+    d.clean = true;
     c->select_valid = false;
     out->seconds = now_s() - t_start;
     out->seconds_score = d.t_score;
     out->seconds_extract = d.t_extract;
     out->seconds_host = d.t_sample;
     if (getenv("RH_DRIVER_PROF")) {
+        fprintf(stderr, "[rh_ransac] init %.4f loop %.4f tail %.4f s\n", t_init, t_loop, out->seconds - t_init - t_loop);
         fprintf(stderr, "[rh_ransac] %lld windows: enqueue %.4f wait %.4f lists %.4f record %.4f s; total %.4f\n", (long long)d.nwin,
                 d.tw[0], d.tw[1], d.tw[2], d.tw[3], out->seconds);
         fprintf(stderr, "[rh_ransac] extract: refit+invalidate %.4f erase %.4f liveness %.4f store-compact %.4f host-compact %.4f s\n",

@@ -132,6 +132,10 @@ struct rh_cloud {
     int64_t *d_ranks = nullptr;        // select in/out
     int64_t ranks_cap = 0;
 
+    // rh_ransac's reusable buffers, parked here between calls (driver.hip owns the layout and the deleter)
+    void *drv_cache = nullptr;
+    void (*drv_cache_free)(rh_cloud *, void *) = nullptr;
+
     // pinned staging
     void *h_pin = nullptr;
     int64_t h_pin_cap = 0;

@@ -412,6 +412,40 @@ def test_ransac_octree_sampling(prims, kinds, seed, host, monkeypatch):
         R.ransac(pc2, R.params_to_c(params, octree_sampling=True), seed=seed)
 
 
+@pytest.mark.parametrize("cache", [True, False])
+def test_ransac_calls_in_a_row_on_one_cloud(cache, monkeypatch):
+    """rh_ransac parks its windows, device store and pinned scratch on the cloud for the next call
+    (RH_NO_DRIVER_CACHE=1: every call allocates its own).  Four runs in a row on one cloud, with different shape
+    types, window sizes and sampling modes, a continuation on the points the previous run left and a failing
+    call in between: every run equals the oracle's."""
+    if not cache:
+        monkeypatch.setenv("RH_NO_DRIVER_CACHE", "1")
+    prims = ["plane", "sphere", "cylinder", "plane", "cone", "sphere"]
+    xyz, nrm, truth = synth.make_cloud(36_000, prims, 0.15, seed=314)
+    subs = synth.make_subsets(36_000, 3, seed=15)
+    pc, oc = R.RANSACCloud(xyz, nrm, subs), orc.Cloud(xyz, nrm, subs[0])
+    kw = dict(score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
+    runs = [
+        ([R.FittedPlane, R.FittedSphere, R.FittedCylinder], {"minsubsetN": 60, "τ": 300, "itermax": 120, "prob_det": 0.6}, kw, 5, True),
+        ([R.FittedPlane, R.FittedCone, R.FittedCylinder, R.FittedSphere], {"minsubsetN": 25, "τ": 200, "itermax": 60, "prob_det": 0.5},
+         dict(kw, octree_sampling=True), 6, True),
+        ([R.FittedSphere, R.FittedPlane], {"minsubsetN": 200, "τ": 500, "itermax": 40, "prob_det": 0.7}, kw, 7, False),   # goes on
+        ([R.FittedPlane, R.FittedSphere, R.FittedCylinder], {"minsubsetN": 15, "τ": 900, "itermax": 30, "prob_det": 0.9}, {}, 8, True),
+    ]
+    for i, (types, it, kws, seed, reset) in enumerate(runs):
+        if reset:
+            pc.enable_all()
+            oc.enable_all()
+        cp = R.params_to_c(R.ransacparameters(types, iteration=it), **kws)
+        got, _, stats = R.ransac(pc, cp, seed=seed, return_stats=True)
+        exp = oc.ransac(to_orc_params(cp), seed=seed)
+        assert exp["rc"] == 0
+        assert_same_run(pc, oc, got, exp, stats)
+        if i == 1:
+            with pytest.raises(R.RansacHipError):   # an invalid call between two runs leaves the parked buffers alone
+                R.ransac(pc, R.params_to_c(R.ransacparameters(types, iteration=it), octree_sampling=True), seed=seed)
+
+
 def test_ransac_injected_stream_and_preexisting_disabled_points():
     xyz, nrm, truth = synth.make_cloud(12_000, ["plane", "sphere", "cylinder"], 0.1, seed=77)
     subs = synth.make_subsets(12_000, 2, seed=77)
