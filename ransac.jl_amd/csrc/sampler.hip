@@ -303,7 +303,40 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
     }
     const double *__restrict__ src = crec != nullptr ? crec : rec;
 #pragma unroll
-    for (int q = 0; q < drawN; q++) {
+    for (int q = 0; q < 2; q++) {
+        const f64x2 *r = (const f64x2 *)(src + 8 * (sd[q] - 1));
+        const f64x2 a = r[0], b = r[1], c = r[2];
+        fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
+        fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
+    }
+    // Can this set still give a candidate?  Decided on its first two points, before the others are fetched
+    // (a third of the random reads of a window of outliers):
+    //  - sphere / cylinder are built from points 1 and 2 and then checked against every point with the
+    //    conditions and-ed together, so fit(..., 2 points) = false implies fit(..., all points) = false --
+    //    the same code, the same bits;
+    //  - a plane needs every normal within alpha of +u or every one within alpha of -u for the unit normal u,
+    //    hence angle(n1, n2) <= 2 alpha: with t = cos alpha > 0 it cannot pass when
+    //    dot(n1^, n2^) < 2 t^2 - 1 (1e-9 below, far beyond the rounding of the dots).
+    if (drawN > 2) {
+        bool maybe = false;
+        rh_shape tmp;
+        for (int ti = 0; ti < prm.n_shape_types; ti++) {
+            switch (prm.shape_types[ti]) {
+            case RH_PLANE: {
+                const double tpl = prm.cos_alpha[RH_PLANE];
+                const double d12 = rhfit::dot(rhfit::normalize(rhfit::Vec(fn)), rhfit::normalize(rhfit::Vec(fn + 3)));
+                maybe = maybe || !(tpl > 0.0 && d12 < 2.0 * tpl * tpl - 1.0 - 1e-9);
+                break;
+            }
+            case RH_SPHERE: maybe = maybe || rhfit::fit_sphere(fp, fn, 2, prm, &tmp); break;
+            case RH_CYLINDER: maybe = maybe || rhfit::fit_cylinder(fp, fn, 2, prm, &tmp); break;
+            default: maybe = true; break;
+            }
+        }
+        if (!maybe) return;
+    }
+#pragma unroll
+    for (int q = 2; q < drawN; q++) {
         const f64x2 *r = (const f64x2 *)(src + 8 * (sd[q] - 1));
         const f64x2 a = r[0], b = r[1], c = r[2];
         fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
