@@ -763,20 +763,22 @@ struct Driver {
         }
         // (the lists stay in the scratch until the next extraction, which starts with a stream wait)
         tp[3] += now_s() - tq; tq = now_s();
+        // one pass: survivors move up (order kept), and the running maximum -- first maximum, strict > -- is
+        // recomputed over them on the way
         size_t wpos = 0;
+        best = -1;
+        double best_E = 0;
         for (size_t i = 0; i < store.size(); i++) {
             const int q = store[i].shape.kind;
             const int32_t ns = remap[q][(size_t)store[i].slot];
             if (ns < 0 || i == extracted_pos) continue;
-            store[wpos] = store[i];
+            if (wpos != i) store[wpos] = store[i];
             store[wpos].slot = ns;
+            const double E = store[wpos].E;
+            if (best < 0 || E > best_E) { best = (int64_t)wpos; best_E = E; }
             wpos++;
         }
         store.resize(wpos);
-        // the running maximum must be recomputed over the survivors
-        best = -1;
-        for (size_t i = 0; i < store.size(); i++)
-            if (best < 0 || store[i].E > store[(size_t)best].E) best = (int64_t)i;
         tp[4] += now_s() - tq;
         t_extract += now_s() - t0;
         *did = true;

@@ -1184,7 +1184,8 @@ __global__ void oct_gather_enabled_kernel(const uint64_t *__restrict__ enabled, 
     if ((threadIdx.x & 63) == 0 && (j >> 6) < (n + 63) / 64) men[j >> 6] = w;
 }
 
-// clear in `men` the Morton positions of the points set in an original-order mask
+// clear in `men` the Morton positions of the points set in an original-order mask (one lane per bit measured the
+// same 50 us at 10M points: the time goes into same-word atomics -- an extracted shape is compact in Morton order)
 __global__ void oct_clear_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ pos,
                                       uint64_t *__restrict__ men)
 {

@@ -263,3 +263,17 @@ def test_findAABB_and_smallestdistance():  # test/utilitytests.jl:5-40
         assert mn.tolist() == [-1.0] * d and mx.tolist() == [2.0] * d
     assert math.isclose(R.smallestdistance([[0.0, 0], [1.0, 1], [2.2, 2]]), math.sqrt(2))
     assert math.isclose(R.smallestdistance([[0.0, 0, 0], [1.0, 1, 1], [2.2, 2, 2]]), math.sqrt(3))
+
+
+def test_octview_searches_match_std(tmp_path):
+    """The linear octree's lower_bound / select (fit_shared.h, shared by the device sampler and its host twin)
+    against std::lower_bound and a plain list of the set bits."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "octview_search_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                           "-I", os.path.join(root, "ransac.jl_amd", "csrc"),
+                           os.path.join(root, "tests", "native", "octview_search_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert out.stdout.strip().endswith("0 bad")
