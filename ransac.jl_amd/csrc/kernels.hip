@@ -972,12 +972,6 @@ __global__ void invalidate_idx_kernel(const int64_t *__restrict__ idx, int64_t n
     atomicAnd((unsigned long long *)&enabled[i0 >> 6], ~(1ULL << (i0 & 63)));
 }
 
-__global__ void andnot_kernel(uint64_t *__restrict__ enabled, const uint64_t *__restrict__ mask, int64_t nwords)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nwords) enabled[w] &= ~mask[w];
-}
-
 // One launch per change of the enabled bits: sub_enabled bit j = enabled[sub_idx0[j]], and the subset points
 // whose bit went 1 -> 0 (with `reset`: every disabled one) are appended to `dis`, the list the liveness
 // pass scores.  A wave regathers RH_SUBUPD_WPW consecutive words; a block reserves the range of its points
@@ -1438,15 +1432,6 @@ int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
     if (n == 0) return RH_OK;
     c->en_sums_valid = false;
     hipLaunchKernelGGL(invalidate_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_idx, n, c->n, c->enabled);
-    RH_HIP(hipGetLastError());
-    return RH_OK;
-}
-
-int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask)
-{
-    if (c->nwords == 0) return RH_OK;
-    c->en_sums_valid = false;
-    hipLaunchKernelGGL(andnot_kernel, dim3(cdiv(c->nwords, 256)), dim3(256), 0, c->stream, c->enabled, mask, c->nwords);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -183,7 +183,6 @@ int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double c
 int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
                      int32_t *d_total);
 int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n);
-int rhk_andnot_enabled(rh_cloud *c, const uint64_t *mask);
 int rhk_rebuild_sub_enabled(rh_cloud *c, bool reset_list);
 int rhk_compact_refit_apply(rh_cloud *c);
 int rhk_build_sel_list(rh_cloud *c);
