@@ -260,6 +260,33 @@ def main():
         "tests_per_sec": value * S,
     }
 
+    # ---- N > 1, end to end: the ransac() loop is a one-GPU loop, so the node runs one scene per GPU ("replicas
+    # only"): every rank extracts the shapes of its own replica at the same time; shapes of all ranks / slowest rank
+    e2e_replicas = None
+    if world > 1 and not args.no_e2e:
+        rp = R.ransacparameters(types, iteration={"minsubsetN": 4096, "itermax": args.e2e_iters, "τ": 900, "prob_det": 0.9})
+        rcp = R.params_to_c(rp, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
+        pc.enable_all()
+        R.ransac(pc, rcp, seed=99)           # warm-up run (one-time allocations of the cloud)
+        pc.enable_all()
+        fence()
+        t0 = time.perf_counter()
+        rgot, _, _ = R.ransac(pc, rcp, seed=1234 + rank, return_stats=True)
+        torch.cuda.synchronize()
+        t_rep = time.perf_counter() - t0
+        agg = torch.tensor([t_rep, float(len(rgot))], dtype=torch.float64, device="cuda")
+        tmx = agg[:1].clone()
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        e2e_replicas = {"metric": "shapes_per_sec", "value": float(agg[1].item()) / float(tmx.item()), "n_gpus": world,
+                        "shapes": int(agg[1].item()), "seconds_slowest_rank": float(tmx.item()),
+                        "seconds_mean": float(agg[0].item()) / world, "scaling": "weak",
+                        "note": "replicas only: one rh_ransac call per rank on its own replica of the cloud (per-rank seeds), "
+                                "started together; the loop itself does not shard (DESIGN.md 7)"}
+        del rgot
+        pc.enable_all()
+        fence()
+
     if rank == 0:
         # ---- per-kind kernel time (HIP events) and rooflines -----------------------------
         per_kind = {}
@@ -489,6 +516,8 @@ def main():
                     "minimal_sets_per_sec": nit * 4096 / t_cpu, "shapes": len(eo["shapes"]),
                     "sample": "the oracle's ransac() on the first %d iterations of the same run; extracted shapes, "
                               "index sets and draw counts checked identical to rh_ransac's" % nit}
+        if e2e_replicas is not None:
+            out["end_to_end_replicas"] = e2e_replicas
         out["setup_seconds"] = t_setup
         # ---- the other single-GPU BASELINE configs on this GPU: child processes of the same script
         def child_leg(name, extra, note):
