@@ -415,6 +415,8 @@ def main():
             out["hbm_measured"] = {"error": repr(e)[:200]}
 
         # ---- cpu_baseline: the oracle (port of the reference's single-threaded path) ------
+        if world > 1:
+            args.no_cpu = True   # the CPU legs belong to the N = 1 line (the other ranks would sit in the barrier for them)
         if not args.no_cpu:
             from oracle import oracle as orc
             oc = orc.Cloud(xyz, nrm, subs[0])
