@@ -677,7 +677,9 @@ struct Driver {
             // pinned destination, on the copy stream: the 8 bytes per inlier cross PCIe while the compute stream
             // goes on with the next window; the next extraction waits for ev_copied before it rewrites idx_out
             // (idx_out is complete: the host has just waited for work that was queued behind the compaction)
+            const double tc0 = now_s();
             RUNH(hipMemcpyAsync(ex.inpoints, c->idx_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, c->copy_stream));
+            tp[5] += now_s() - tc0;
             RUNH(hipEventRecord(c->ev_copied, c->copy_stream));
             list_copy_pending = true;
         }
@@ -1095,8 +1097,8 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
         fprintf(stderr, "[rh_ransac] init %.4f loop %.4f tail %.4f s\n", t_init, t_loop, out->seconds - t_init - t_loop);
         fprintf(stderr, "[rh_ransac] %lld windows: enqueue %.4f wait %.4f lists %.4f record %.4f s; total %.4f\n", (long long)d.nwin,
                 d.tw[0], d.tw[1], d.tw[2], d.tw[3], out->seconds);
-        fprintf(stderr, "[rh_ransac] extract: refit+invalidate %.4f erase %.4f liveness %.4f store-compact %.4f host-compact %.4f s\n",
-                d.tp[0], d.tp[1], d.tp[2], d.tp[3], d.tp[4]);
+        fprintf(stderr, "[rh_ransac] extract: refit+invalidate %.4f (list copy call %.4f) erase %.4f liveness %.4f store-compact %.4f host-compact %.4f s\n",
+                d.tp[0], d.tp[5], d.tp[1], d.tp[2], d.tp[3], d.tp[4]);
     }
     return RH_OK;
 }

@@ -1,5 +1,6 @@
 """End-to-end rh_ransac on the cfg3 cloud only (the bench's end_to_end leg without the rest), for
-`rocprofv3 --kernel-trace --stats -- python tools/prof_e2e.py [itermax] [runs]` and RH_DRIVER_PROF=1."""
+`rocprofv3 --kernel-trace --stats -- python tools/prof_e2e.py [itermax] [runs] [root|octree] [cfg3|cfg5]` and
+RH_DRIVER_PROF=1."""
 import os
 import sys
 import time
@@ -12,11 +13,12 @@ from ransac_jl_amd import synth
 itermax = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 octree = len(sys.argv) > 3 and sys.argv[3] == "octree"
-c = synth.config("cfg3")
+cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
+c = synth.config(cfg)
 n = c["xyz"].shape[0]
 subs = synth.make_subsets(n, c["r"], c["seed"])
 pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
-types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder] + ([R.FittedCone] if cfg == "cfg5" else [])
 p = R.ransacparameters(types, iteration={"minsubsetN": 4096, "itermax": itermax, "τ": 900, "prob_det": 0.9})
 cp = R.params_to_c(p, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1, octree_sampling=octree)
 cp.itermax = 4
