@@ -1469,6 +1469,7 @@ int rhk_build_select(rh_cloud *c)
 {
     c->sel_valid = false;
     c->crec_valid = false;   // the rank order changes with the bits
+    c->very_long_windows = 0;
     if (c->nwords == 0) { c->select_valid = true; return RH_OK; }
     if (!c->en_sums_valid)
         hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->enabled, c->nwords,

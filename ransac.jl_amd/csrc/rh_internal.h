@@ -74,6 +74,7 @@ struct rh_cloud {
     double *crec = nullptr;            // 64-byte records of the ENABLED points in rank order (long sampling windows)
     int64_t crec_cap = 0;              // in records
     bool crec_valid = false;           // cleared whenever the select list is rebuilt
+    int very_long_windows = 0;         // windows of >= 2^19 sets sampled since the select directory was last built
     int32_t *sel_list = nullptr;       // sel_list[r] = 0-based index of the (r+1)-th enabled point (valid with sel_valid)
     bool sel_valid = false;            // built on demand by rhk_build_sel_list, dropped with the select directory
     double *rec = nullptr;             // the same points as 64-byte records (x y z nx ny nz 0 0): one line per random gather
