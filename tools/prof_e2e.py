@@ -19,6 +19,8 @@ n = c["xyz"].shape[0]
 subs = synth.make_subsets(n, c["r"], c["seed"])
 pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
 types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder] + ([R.FittedCone] if cfg == "cfg5" else [])
+if os.environ.get("RH_TYPES"):   # ablations: e.g. RH_TYPES=p or RH_TYPES=ps
+    types = [{"p": R.FittedPlane, "s": R.FittedSphere, "c": R.FittedCylinder, "k": R.FittedCone}[ch] for ch in os.environ["RH_TYPES"]]
 p = R.ransacparameters(types, iteration={"minsubsetN": 4096, "itermax": itermax, "τ": 900, "prob_det": 0.9})
 cp = R.params_to_c(p, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1, octree_sampling=octree)
 cp.itermax = 4
