@@ -170,6 +170,8 @@ def main():
 
     b_global = B_PER_GPU * world
     cands = synth.jittered_candidates(truth, b_global, seed=0)
+    if os.environ.get("RH_BENCH_SORT_CANDS"):   # experiment: the copies of one primitive next to each other
+        cands = [cands[i] for i in sorted(range(b_global), key=lambda i: i % len(truth))]
     arr = shapes_to_c(R, L, cands)
     batch = rdist.DeviceBatch(pc, arr, b_global)
     counts = torch.zeros(b_global, dtype=torch.int32, device="cuda")

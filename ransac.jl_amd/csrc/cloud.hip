@@ -601,7 +601,11 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     off[0] = 0;
     for (int k = 1; k < 4; k++) off[k] = off[k - 1] + nk[k - 1];
     for (int k = 0; k < 4; k++) { fill[k] = off[k]; h_nk[k] = nk[k]; }
-    for (int32_t i = 0; i < b; i++) {   // stable counting sort by kind
+    // counting sort by kind, walking the batch in the spread order (kernels.hip: neighbours in the batch, often
+    // hypotheses of the same primitive, go to different 64-candidate chunks)
+    const int64_t spread = getenv("RH_NO_SPREAD") ? 1 : rh_spread_multiplier(b);
+    for (int32_t t = 0; t < b; t++) {
+        const int32_t i = (int32_t)(((int64_t)t * spread) % b);
         const int k = shapes[i].kind;
         h_sorted[fill[k]] = shapes[i];
         h_orig[fill[k]] = i;

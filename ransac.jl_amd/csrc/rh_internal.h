@@ -218,6 +218,7 @@ int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask);             // clear 
 int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t *prefix_out);
 
 void rh_prep_host(const rh_shape &s, rh_prep *out);
+int32_t rh_spread_multiplier(int32_t b);   // t -> (t * m) mod b: a permutation of the batch that separates neighbours
 
 // ---- host helpers (cloud.hip) -----------------------------------------------
 int rh_ensure_batch(rh_cloud *c, int64_t b);

@@ -151,6 +151,24 @@ def test_scorecandidate_mirror_returns_reference_tuple(small_scene):
         R.scorecandidate(pc, cand, 2, params)
 
 
+def test_score_is_invariant_to_the_order_of_the_batch(small_scene, monkeypatch):
+    """The library spreads neighbouring candidates over different 64-candidate chunks (RH_NO_SPREAD=1: batch
+    order); counts and masks follow the caller's order whatever the internal one, host and device batches."""
+    pc, oc, truth = small_scene
+    cp = R.params_to_c(R.ransacparameters())
+    cands = make_candidates(truth, 700, seed=21)
+    order = np.random.default_rng(5).permutation(len(cands))
+    by_prim = sorted(range(len(cands)), key=lambda i: (cands[i].__class__.__name__, i % len(truth)))
+    ref_counts, ref_masks = R.score_batch(pc, shape_array(cands), cp, want_masks=True)
+    for perm in (order, np.asarray(by_prim)):
+        arr = shape_array([cands[i] for i in perm])
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        assert np.array_equal(counts, ref_counts[perm]) and np.array_equal(masks, ref_masks[perm])
+    monkeypatch.setenv("RH_NO_SPREAD", "1")
+    counts, _ = R.score_batch(pc, shape_array(cands), cp, want_masks=True)
+    assert np.array_equal(counts, ref_counts)
+
+
 def test_score_respects_enabled_bits_and_sphere_quirk(small_scene):
     pc, oc, truth = small_scene
     rng = np.random.default_rng(3)
