@@ -134,8 +134,6 @@ struct DeviceStore {
     int32_t *live = nullptr;      // LIVE_MAX liveness flags of the one-wait extraction path, zero between uses
     int32_t *d_idx = nullptr;     // gather lists
     int32_t *d_nk = nullptr;      // one int per launch slot (8)
-    rh_shape *d_shapes = nullptr;
-    int64_t shapes_cap = 0;
 };
 
 int store_free(rh_cloud *c, DeviceStore &st)
@@ -143,7 +141,7 @@ int store_free(rh_cloud *c, DeviceStore &st)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); }
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
-    (void)hipFree(st.d_shapes); (void)hipFree(st.live);
+    (void)hipFree(st.live);
     return RH_OK;
 }
 
@@ -310,8 +308,6 @@ struct Driver {
 
     // scratch
     std::vector<rh_prep> prep_h[4];
-    std::vector<rh_shape> sorted;
-    std::vector<int32_t> orig, counts_h, idx_h;
     std::vector<int64_t> sd;
     std::vector<double> fp, fn;
 
@@ -491,70 +487,15 @@ struct Driver {
         return RH_OK;
     }
 
-    // stable sort by kind + upload; fills off/nk
-    int upload_sorted(const rh_shape *cands, int32_t ncand, int32_t nk[4], int32_t off[4])
-    {
-        int32_t fill[4];
-        for (int q = 0; q < 4; q++) nk[q] = 0;
-        for (int32_t i = 0; i < ncand; i++) nk[cands[i].kind]++;
-        off[0] = 0;
-        for (int q = 1; q < 4; q++) off[q] = off[q - 1] + nk[q - 1];
-        for (int q = 0; q < 4; q++) fill[q] = off[q];
-        sorted.resize((size_t)ncand);
-        orig.resize((size_t)ncand);
-        for (int32_t i = 0; i < ncand; i++) {
-            const int q = cands[i].kind;
-            sorted[(size_t)fill[q]] = cands[i];
-            orig[(size_t)fill[q]] = i;
-            fill[q]++;
-        }
-        if (ncand > st.shapes_cap) {
-            RUNH(hipStreamSynchronize(c->stream));
-            (void)hipFree(st.d_shapes);
-            st.d_shapes = nullptr;
-            st.shapes_cap = std::max<int64_t>(ncand, 1024);
-            RUNH(hipMalloc((void **)&st.d_shapes, sizeof(rh_shape) * (size_t)st.shapes_cap));
-        }
-        RUN(store_reserve_aux(c, st, ncand));
-        RUNH(hipMemcpyAsync(st.d_shapes, sorted.data(), sizeof(rh_shape) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
-        RUNH(hipMemcpyAsync(st.d_idx, orig.data(), sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice, c->stream));
-        RUNH(hipMemcpyAsync(st.d_nk, nk, sizeof(int32_t) * 4, hipMemcpyHostToDevice, c->stream));
-        return RH_OK;
-    }
-
-    // scorecandidates! (fitting.jl:181-190) for a batch: counts in candidate order.  One launch
-    // (per kind on the brute-force path) -- nothing reads a score before the loop ends (iterations.jl:99).
+    // scorecandidates! (fitting.jl:181-190) for a batch: counts in candidate order -- the ABI's own batched call
+    // (one launch for all kinds; batches of a few candidates travel as one staged transfer).  Nothing reads a
+    // score before the loop ends (iterations.jl:99).
     int score(const rh_shape *cands, int32_t ncand, std::vector<int32_t> &counts)
     {
         counts.assign((size_t)ncand, 0);
         if (ncand == 0) return RH_OK;
         const double t0 = now_s();
-        int32_t nk[4], off[4];
-        RUN(upload_sorted(cands, ncand, nk, off));
-        RUN(rh_ensure_batch(c, ncand));
-        RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)ncand, c->stream));
-        RUN(rhk_prep_sorted(c, st.d_shapes, ncand, c->d_prep));
-        if (c->use_groups) {   // all kinds in one launch
-            const uint64_t *enw[4];
-            const rh_prep *pr[4];
-            const int32_t *og[4], *nkp[4];
-            for (int q = 0; q < 4; q++) {
-                enw[q] = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
-                pr[q] = c->d_prep + off[q];
-                og[q] = st.d_idx + off[q];
-                nkp[q] = st.d_nk + q;
-            }
-            RUN(rhk_score_all_groups(c, enw, pr, og, nkp, ncand, p->eps, p->cos_alpha, st.counts, nullptr));
-        } else {
-            for (int q = 0; q < 4; q++) {
-                if (nk[q] == 0) continue;
-                const uint64_t *enw = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
-                RUN(rhk_score_kind(c, q, c->sub, c->s_pad, c->s, enw, c->d_prep + off[q], st.d_idx + off[q], st.d_nk + q,
-                                   nk[q], p->eps[q], p->cos_alpha[q], st.counts, nullptr, 0));
-            }
-        }
-        RUNH(hipMemcpyAsync(counts.data(), st.counts, sizeof(int32_t) * (size_t)ncand, hipMemcpyDeviceToHost, c->stream));
-        RUNH(hipStreamSynchronize(c->stream));
+        RUN(rh_score_batch(c, cands, ncand, p, counts.data(), nullptr));
         t_score += now_s() - t0;
         return RH_OK;
     }

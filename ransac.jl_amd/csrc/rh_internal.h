@@ -137,6 +137,9 @@ struct rh_cloud {
     void *drv_cache = nullptr;
     void (*drv_cache_free)(rh_cloud *, void *) = nullptr;
 
+    // rh_score_batch with host buffers: device twin of the pinned staging block of a small batch (one upload)
+    void *d_stage = nullptr;
+
     // pinned staging
     void *h_pin = nullptr;
     int64_t h_pin_cap = 0;
