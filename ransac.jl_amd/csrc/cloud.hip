@@ -796,6 +796,17 @@ extern "C" int rh_select_enabled(rh_cloud *c, const int64_t *ranks, int32_t k, i
         c->ranks_cap = k;
     }
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
+    if (k <= 1024) {
+        // the per-sample call of the reference's loop (a couple of ranks): the kernel reads the ranks from the pinned
+        // block and writes the indices back into it -- one launch and one wait, no transfer operation
+        RH_TRY(rh_ensure_pin(c, 2 * (int64_t)sizeof(int64_t) * k));
+        int64_t *h_ranks = (int64_t *)c->h_pin, *h_out = h_ranks + k;
+        memcpy(h_ranks, ranks, sizeof(int64_t) * (size_t)k);
+        RH_TRY(rhk_select(c, h_ranks, k, h_out));
+        RH_HIP(hipStreamSynchronize(c->stream));
+        memcpy(idx_out, h_out, sizeof(int64_t) * (size_t)k);
+        return RH_OK;
+    }
     RH_HIP(hipMemcpyAsync(c->d_ranks, ranks, sizeof(int64_t) * (size_t)k, hipMemcpyHostToDevice, c->stream));
     RH_TRY(rhk_select(c, c->d_ranks, k, c->d_ranks + c->ranks_cap));
     RH_HIP(hipMemcpyAsync(idx_out, c->d_ranks + c->ranks_cap, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToHost, c->stream));

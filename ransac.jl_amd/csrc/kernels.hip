@@ -1119,12 +1119,14 @@ pack_live_kernel(int32_t *__restrict__ flags, int32_t n_flags, int32_t *__restri
     }
 }
 
+// (ranks / out may be pinned host memory: a call with a few ranks is then this one launch, nothing else)
 __global__ void select_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ word_prefix,
-                              int64_t nwords, int32_t total, const int64_t *__restrict__ ranks, int32_t k,
-                              int64_t *__restrict__ out)
+                              int64_t nwords, const int32_t *__restrict__ total_ptr, const int64_t *__restrict__ ranks,
+                              int32_t k, int64_t *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
+    const int32_t total = *total_ptr;   // the select directory's count of enabled points
     const int64_t r = ranks[i];
     if (r < 1 || r > total) { out[i] = 0; return; }
     // last word w with word_prefix[w] < r
@@ -1519,11 +1521,8 @@ int rhk_build_sel_list(rh_cloud *c)
 int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out)
 {
     if (k == 0) return RH_OK;
-    int32_t total = 0;
-    RH_HIP(hipMemcpyAsync(&total, c->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    RH_HIP(hipStreamSynchronize(c->stream));
     hipLaunchKernelGGL(select_kernel, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->enabled, c->word_prefix,
-                       c->nwords, total, d_ranks, k, d_out);
+                       c->nwords, c->d_total, d_ranks, k, d_out);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -26,3 +26,19 @@ for b in (1, 8, 15, 60, 256, 1024, 4096):
         L.check(lib.rh_score_batch(pc._h, arr, b, C.byref(cp), counts, None))
     dt = (time.perf_counter() - t0) / reps
     print("b=%5d  %.1f us per rh_score_batch call (host buffers in and out), checksum %d" % (b, 1e6 * dt, sum(counts[:b])), flush=True)
+
+# the enabled gather of samplepointcloud4! (fitting.jl:405-422): k-th enabled points, one call per minimal set
+import numpy as np
+total = pc.count_enabled()
+rng = np.random.default_rng(1)
+for k in (2, 64, 4096):
+    ranks = np.ascontiguousarray(rng.integers(1, total + 1, size=k), dtype=np.int64)
+    out = np.zeros(k, dtype=np.int64)
+    rp, op = ranks.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.POINTER(C.c_int64))
+    for _ in range(20):
+        L.check(lib.rh_select_enabled(pc._h, rp, k, op))
+    t0 = time.perf_counter()
+    for _ in range(300):
+        L.check(lib.rh_select_enabled(pc._h, rp, k, op))
+    dt = (time.perf_counter() - t0) / 300
+    print("k=%5d  %.1f us per rh_select_enabled call, checksum %d" % (k, 1e6 * dt, int(out.sum() % 1000003)), flush=True)
