@@ -810,7 +810,12 @@ __global__ void unpermute_masks_kernel(const uint64_t *__restrict__ in, const in
 // One candidate (kernarg -> SGPRs), the whole cloud in original order.  Each wave owns
 // 64-point words; mask word = ballot & enabled word; all-disabled words are skipped
 // without touching the point planes.  Per-1024-word popcount sums feed the compaction.
-constexpr int RH_RF_WPW = 4;   // 64-point words per wave per iteration (24 loads in flight per lane)
+// 64-point words per wave per iteration (12 loads in flight per lane).  Measured on the plane scan, 10M / 50M points
+// (real clouds, bench.py): 4 words 0.0804 / 0.369 ms, 2 words 0.0764 / 0.355, 1 word 0.0792 / 0.345 -- fewer words per
+// wave mean more waves in flight, and with one word the compiler sinks the second half of the loads below the
+// wave-level early-out of the exact test (a word whose 64 points all fail the first half never fetches the other
+// three planes: 0.048 ms on a cloud of random normals).
+constexpr int RH_RF_WPW = 2;
 
 template <int KIND>
 __global__ void __launch_bounds__(256)
@@ -1403,8 +1408,8 @@ int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double c
     static int env_blocks = -1;
     if (env_blocks < 0) { const char *e = getenv("RH_REFIT_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
     int64_t blocks = cdiv(c->nwords, 4 * RH_RF_WPW);
-    // one 4 x 64-point group per wave up to 32768 blocks (measured, plane scan: 10M points 0.0771 ms at 2048
-    // blocks, 0.0743 at 4096-9766; 50M points 0.364 ms at 2048, 0.359 at 16384, 0.350 at 32768-49152)
+    // one group of words per wave up to 32768 blocks, a grid-stride loop beyond (measured with 4-word groups, plane
+    // scan: 10M points 0.0771 ms at 2048 blocks, 0.0743 at 4096-9766; 50M points 0.364 ms at 2048, 0.350 at 32768+)
     const int64_t cap = env_blocks > 0 ? env_blocks : 32768;
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), blk(256);
