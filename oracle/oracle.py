@@ -86,13 +86,31 @@ class Result(C.Structure):
 
 def build(force=False):
     """Compile liboracle.so with gcc (Makefile in this directory)."""
-    src = os.path.join(_HERE, "ransac_oracle.c")
-    hdr = os.path.join(_HERE, "ransac_oracle.h")
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
-        return _SO
-    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-    return _SO
+    return _build_target(_SO, force)
+
+
+def _build_target(so, force=False):
+    deps = [os.path.join(_HERE, f) for f in ("ransac_oracle.c", "ransac_oracle.h", "orc_trig.h", "Makefile")]
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+        return so
+    subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
+    return so
+
+
+VARIANTS = {0: "default", 1: "fma", 2: "div", 3: "scaled", 4: "pairwise", 5: "libm"}
+_variant_libs = {}
+
+
+def variant_lib(v):
+    """liboracle_v<v>.so: the same restatement under another reading of the StaticArrays rounding order
+    (ransac_oracle.c header).  Measurement tooling only -- parity tests always use lib()."""
+    if v == 0:
+        return lib()
+    if v not in _variant_libs:
+        L = _bind(C.CDLL(_build_target(os.path.join(_HERE, "liboracle_v%d.so" % v))))
+        assert L.orc_variant() == v
+        _variant_libs[v] = L
+    return _variant_libs[v]
 
 
 _lib = None
@@ -103,7 +121,11 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_SO)
+    _lib = _bind(C.CDLL(_SO))
+    return _lib
+
+
+def _bind(L):
     dp = C.POINTER(C.c_double)
     i64p = C.POINTER(C.c_int64)
     u64p = C.POINTER(C.c_uint64)
@@ -115,6 +137,10 @@ def lib():
         "orc_params_finalize": (None, [pp]),
         "orc_shape_finalize": (None, [sp]),
         "orc_compatible": (C.c_int, [sp, dp, dp, C.c_double, C.c_double]),
+        "orc_compat_values": (None, [sp, dp, dp, dp]),
+        "orc_variant": (C.c_int, []),
+        "orc_score_masks_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p, C.c_int32]),
+        "orc_margin_census_mt": (None, [C.c_void_p, sp, C.c_int32, pp, dp, C.c_int, i64p, C.c_int32]),
         "orc_confidence_interval": (C.c_int, [C.c_double, C.c_double, C.POINTER(CI)]),
         "orc_notsoconfident": (CI, [C.c_double, C.c_double]),
         "orc_isoverlap": (C.c_int, [CI, CI]),
@@ -160,7 +186,6 @@ def lib():
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
-    _lib = L
     return L
 
 
@@ -210,18 +235,19 @@ def shapes_array(shapes):
 class Cloud:
     """Mirror of the pieces of RANSACCloud (octree.jl:37-59) the path reads."""
 
-    def __init__(self, xyz, nrm, subset1_1based):
+    def __init__(self, xyz, nrm, subset1_1based, L=None):
+        self.L = L if L is not None else lib()
         self.xyz = _f64(xyz).reshape(-1, 3)
         self.nrm = _f64(nrm).reshape(-1, 3)
         self.subset1 = np.ascontiguousarray(subset1_1based, dtype=np.int64)
         self.n = self.xyz.shape[0]
         self.s = self.subset1.shape[0]
-        self.h = lib().orc_cloud_create(_dp(self.xyz), _dp(self.nrm), self.n,
+        self.h = self.L.orc_cloud_create(_dp(self.xyz), _dp(self.nrm), self.n,
                                         self.subset1.ctypes.data_as(C.POINTER(C.c_int64)), self.s)
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_cloud_destroy(self.h)
+            self.L.orc_cloud_destroy(self.h)
             self.h = None
 
     @property
@@ -230,24 +256,24 @@ class Cloud:
 
     def set_enabled(self, chunks):
         chunks = np.ascontiguousarray(chunks, dtype=np.uint64)
-        lib().orc_cloud_set_enabled(self.h, chunks.ctypes.data_as(C.POINTER(C.c_uint64)), chunks.size)
+        self.L.orc_cloud_set_enabled(self.h, chunks.ctypes.data_as(C.POINTER(C.c_uint64)), chunks.size)
 
     def get_enabled(self):
         out = np.zeros(self.nchunks, dtype=np.uint64)
-        lib().orc_cloud_get_enabled(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size)
+        self.L.orc_cloud_get_enabled(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size)
         return out
 
     def enable_all(self):
-        lib().orc_cloud_enable_all(self.h)
+        self.L.orc_cloud_enable_all(self.h)
 
     def count_enabled(self):
-        return lib().orc_cloud_count_enabled(self.h)
+        return self.L.orc_cloud_count_enabled(self.h)
 
     def scorecandidate(self, shape, params, want_mask=False):
         inp = np.zeros(max(1, self.s), dtype=np.int64)
         w = (self.s + 63) // 64
         mask = np.zeros(max(1, w), dtype=np.uint64) if want_mask else None
-        cnt = lib().orc_scorecandidate(self.h, C.byref(shape), C.byref(params),
+        cnt = self.L.orc_scorecandidate(self.h, C.byref(shape), C.byref(params),
                                        inp.ctypes.data_as(C.POINTER(C.c_int64)),
                                        mask.ctypes.data_as(C.POINTER(C.c_uint64)) if want_mask else None)
         return (cnt, inp[:cnt].copy(), mask[:w]) if want_mask else (cnt, inp[:cnt].copy())
@@ -258,28 +284,49 @@ class Cloud:
         counts = np.zeros(max(1, b), dtype=np.int32)
         w = (self.s + 63) // 64
         masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64) if want_masks else None
-        lib().orc_score_batch(self.h, arr, b, C.byref(params),
+        self.L.orc_score_batch(self.h, arr, b, C.byref(params),
                               counts.ctypes.data_as(C.POINTER(C.c_int32)),
                               masks.ctypes.data_as(C.POINTER(C.c_uint64)) if want_masks else None)
         return (counts[:b], masks[:b, :w]) if want_masks else counts[:b]
+
+    def score_masks_mt(self, shapes, params, nthreads):
+        """Counts and masks, candidates spread over `nthreads` host threads."""
+        b = len(shapes)
+        arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
+        counts = np.zeros(max(1, b), dtype=np.int32)
+        w = (self.s + 63) // 64
+        masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64)
+        self.L.orc_score_masks_mt(self.h, arr, b, C.byref(params), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  masks.ctypes.data_as(C.POINTER(C.c_uint64)), nthreads)
+        return counts[:b], masks[:b, :w]
+
+    def margin_census(self, shapes, params, edges, nthreads):
+        """Tests whose distance / angle side lies within edges[k] of its threshold: (2, len(edges)) counts."""
+        b = len(shapes)
+        arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
+        e = _f64(edges)
+        hist = np.zeros((2, e.size), dtype=np.int64)
+        self.L.orc_margin_census_mt(self.h, arr, b, C.byref(params), _dp(e), e.size,
+                                    hist.ctypes.data_as(C.POINTER(C.c_int64)), nthreads)
+        return hist
 
     def score_batch_mt(self, shapes, params, nthreads):
         """Counts only, candidates spread over `nthreads` host threads (OpenMP)."""
         b = len(shapes)
         arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
         counts = np.zeros(max(1, b), dtype=np.int32)
-        lib().orc_score_batch_mt(self.h, arr, b, C.byref(params), counts.ctypes.data_as(C.POINTER(C.c_int32)), nthreads)
+        self.L.orc_score_batch_mt(self.h, arr, b, C.byref(params), counts.ctypes.data_as(C.POINTER(C.c_int32)), nthreads)
         return counts[:b]
 
     def refit(self, shape, params):
         out = np.zeros(max(1, self.n), dtype=np.int64)
-        cnt = lib().orc_refit(self.h, C.byref(shape), C.byref(params),
+        cnt = self.L.orc_refit(self.h, C.byref(shape), C.byref(params),
                               out.ctypes.data_as(C.POINTER(C.c_int64)), self.n)
         return out[:cnt].copy()
 
     def refit_lsq(self, shape, params, max_iter=10):
         out, n, rms, it = Shape(), C.c_int64(), C.c_double(), C.c_int32()
-        rc = lib().orc_refit_lsq(self.h, C.byref(shape), C.byref(params), max_iter, C.byref(out), C.byref(n),
+        rc = self.L.orc_refit_lsq(self.h, C.byref(shape), C.byref(params), max_iter, C.byref(out), C.byref(n),
                                  C.byref(rms), C.byref(it))
         if rc:
             raise RuntimeError("orc_refit_lsq failed: %d" % rc)
@@ -287,20 +334,20 @@ class Cloud:
 
     def invalidate(self, idx_1based):
         idx = np.ascontiguousarray(idx_1based, dtype=np.int64)
-        lib().orc_invalidate(self.h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size)
+        self.L.orc_invalidate(self.h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size)
 
     def select_enabled(self, k):
-        return lib().orc_select_enabled(self.h, int(k))
+        return self.L.orc_select_enabled(self.h, int(k))
 
     def ransac(self, params, seed=1234, stream=None, octree_depth=1):
         rng = Rng()
-        lib().orc_rng_seed(C.byref(rng), seed)
+        self.L.orc_rng_seed(C.byref(rng), seed)
         if stream is not None:
             stream = np.ascontiguousarray(stream, dtype=np.uint64)
             rng.stream = stream.ctypes.data_as(C.POINTER(C.c_uint64))
             rng.stream_len = stream.size
         res = Result()
-        rc = lib().orc_ransac(self.h, _dp(self.xyz), _dp(self.nrm), C.byref(params),
+        rc = self.L.orc_ransac(self.h, _dp(self.xyz), _dp(self.nrm), C.byref(params),
                               C.byref(rng), octree_depth, C.byref(res))
         out = {"rc": rc, "iterations": res.iterations, "candidates_scored": res.candidates_scored,
                "scored_left": res.scored_left, "seconds": res.seconds, "draws": rng.draws, "shapes": []}
@@ -309,7 +356,7 @@ class Cloud:
             sh = Shape.from_buffer_copy(bytes(e.shape))
             idx = np.ctypeslib.as_array(e.inpoints, shape=(max(1, e.n_inpoints),))[: e.n_inpoints].copy()
             out["shapes"].append({"shape": sh, "inpoints": idx, "score_E": e.score_E, "iteration": e.iteration})
-        lib().orc_result_free(C.byref(res))
+        self.L.orc_result_free(C.byref(res))
         return out
 
 

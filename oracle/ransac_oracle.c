@@ -11,16 +11,40 @@
  *   normalize(a)  = inv(norm(a)) * a                  (reciprocal-multiply)
  *   cross(a,b)    = (a2*b3-a3*b2, a3*b1-a1*b3, a1*b2-a2*b1)
  *   (M*v)_i       = (M_i1*v1 + M_i2*v2) + M_i3*v3
+ *
+ * ROUNDING-ORDER VARIANTS (-DORC_VARIANT=n, see Makefile: liboracle_v<n>.so).  The semantics above
+ * cannot be checked against Julia here, so tests/golden/make_rounding_sensitivity.py measures how many
+ * inlier decisions change when they are replaced by the other plausible readings:
+ *   0  the default above
+ *   1  "fma":      every a*b + c of dot / norm / cross / M*v and of the shape formulas fused (muladd)
+ *   2  "div":      normalize(a) = a / norm(a)
+ *   3  "scaled":   norm(a) = m * sqrt(sum((a_i / m)^2)), m = max |a_i|   (LinearAlgebra.generic_norm2)
+ *   4  "pairwise": dot(a,b) = a1*b1 + (a2*b2 + a3*b3), same for the sum of squares
+ *   5  "libm":     the cone's acos / cos / sin from the platform libm instead of orc_trig.h
+ * The variants are test tooling for that measurement only; every parity test uses variant 0.
  */
 #include "ransac_oracle.h"
 
 #include <math.h>
 
-/* acos / cos / sin of the cone code: the fdlibm-algorithm kernels shared with the product
- * (ransac.jl_amd/csrc/det_math.h; the same algorithms Julia's own Base.acos/sin/cos port), so that a cone
- * fitted by the oracle, by the product's host code and by the product's device code has identical bits.
- * tests/test_abi.py checks them against the platform libm (<= 1 ulp). */
-#include "../ransac.jl_amd/csrc/det_math.h"
+#ifndef ORC_VARIANT
+#define ORC_VARIANT 0
+#endif
+
+/* acos / cos / sin of the cone code (fit3pointcone cone.jl:58, rodrigues utilities.jl:21-22): the oracle's
+ * OWN restatement of the fdlibm algorithms (orc_trig.h; what Julia's Base.acos / sin / cos port) -- nothing
+ * of the product is included here.  tests/test_oracle_golden.py checks it against the platform libm
+ * (<= 1 ulp) and, bit for bit, against the product's rh_* twins through the C ABI. */
+#include "orc_trig.h"
+#if ORC_VARIANT == 5
+#define ORC_ACOS(x) acos(x)
+#define ORC_COS(x) cos(x)
+#define ORC_SIN(x) sin(x)
+#else
+#define ORC_ACOS(x) orc_acos(x)
+#define ORC_COS(x) orc_cos(x)
+#define ORC_SIN(x) orc_sin(x)
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -34,12 +58,40 @@ static inline v3 vadd(v3 a, v3 b) { v3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; 
 static inline v3 vscale(v3 a, double s) { v3 r = { a.x * s, a.y * s, a.z * s }; return r; }
 static inline v3 vdiv(v3 a, double s) { v3 r = { a.x / s, a.y / s, a.z / s }; return r; }
 static inline v3 vneg(v3 a) { v3 r = { -a.x, -a.y, -a.z }; return r; }
-static inline double vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-static inline double vnorm(v3 a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); }
+/* a*b + c and a*b - c*d as the variant reads them (MA: one rounding with "fma") */
+#if ORC_VARIANT == 1
+#define MA(a, b, c) fma((a), (b), (c))
+#define MS2(a, b, c, d) fma((a), (b), -((c) * (d)))      /* a*b - c*d */
+#else
+#define MA(a, b, c) ((a) * (b) + (c))
+#define MS2(a, b, c, d) ((a) * (b) - (c) * (d))
+#endif
+#if ORC_VARIANT == 4
+static inline double sum3(double a1b1, double a2, double b2, double a3, double b3) { return a1b1 + (a2 * b2 + a3 * b3); }
+#else
+static inline double sum3(double a1b1, double a2, double b2, double a3, double b3) { return MA(a3, b3, MA(a2, b2, a1b1)); }
+#endif
+static inline double vdot(v3 a, v3 b) { return sum3(a.x * b.x, a.y, b.y, a.z, b.z); }
+#if ORC_VARIANT == 3
+static inline double vnorm(v3 a)
+{
+    double m = fabs(a.x) > fabs(a.y) ? fabs(a.x) : fabs(a.y);
+    if (fabs(a.z) > m) m = fabs(a.z);
+    if (m == 0.0 || m != m || m > 1.7976931348623157e308) return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z);
+    double x = a.x / m, y = a.y / m, z = a.z / m;
+    return m * sqrt((x * x + y * y) + z * z);
+}
+#else
+static inline double vnorm(v3 a) { return sqrt(sum3(a.x * a.x, a.y, a.y, a.z, a.z)); }
+#endif
+#if ORC_VARIANT == 2
+static inline v3 vnormalize(v3 a) { double nr = vnorm(a); v3 r = { a.x / nr, a.y / nr, a.z / nr }; return r; }
+#else
 static inline v3 vnormalize(v3 a) { double inv = 1.0 / vnorm(a); v3 r = { inv * a.x, inv * a.y, inv * a.z }; return r; }
+#endif
 static inline v3 vcross(v3 a, v3 b)
 {
-    v3 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+    v3 r = { MS2(a.y, b.z, a.z, b.y), MS2(a.z, b.x, a.x, b.z), MS2(a.x, b.y, a.y, b.x) };
     return r;
 }
 
@@ -86,8 +138,8 @@ void orc_shape_finalize(orc_shape *s)
     if (s->kind == ORC_CONE) {
         /* rodriguesrad(rot_ax, -cone.opang/2): cone.jl:76; cos/sin at utilities.jl:21-22 */
         double th = -s->v[6] / 2;
-        s->v[7] = rh_cos(th);
-        s->v[8] = rh_sin(th);
+        s->v[7] = ORC_COS(th);
+        s->v[8] = ORC_SIN(th);
     }
 }
 
@@ -95,12 +147,12 @@ void orc_shape_finalize(orc_shape *s)
 /* pluscrossprod!(A, value, v): utilities.jl:32-43.  A row-major 3x3. */
 void orc_pluscrossprod(double A[9], double value, const double v[3])
 {
-    A[0 * 3 + 1] -= value * v[2];
-    A[0 * 3 + 2] += value * v[1];
-    A[1 * 3 + 0] += value * v[2];
-    A[1 * 3 + 2] -= value * v[0];
-    A[2 * 3 + 0] -= value * v[1];
-    A[2 * 3 + 1] += value * v[0];
+    A[0 * 3 + 1] = MA(-value, v[2], A[0 * 3 + 1]);
+    A[0 * 3 + 2] = MA(value, v[1], A[0 * 3 + 2]);
+    A[1 * 3 + 0] = MA(value, v[2], A[1 * 3 + 0]);
+    A[1 * 3 + 2] = MA(-value, v[0], A[1 * 3 + 2]);
+    A[2 * 3 + 0] = MA(-value, v[1], A[2 * 3 + 0]);
+    A[2 * 3 + 1] = MA(value, v[0], A[2 * 3 + 1]);
 }
 
 /* rodrigues(nv::StaticArray, theta) with precomputed cos/sin: utilities.jl:19-24
@@ -112,7 +164,7 @@ static void rodrigues_cs(v3 nv, double c, double s, double R[9])
         for (int j = 0; j < 3; j++) {
             double nn = n[i] * n[j];
             double id = (i == j) ? 1.0 : 0.0;
-            R[i * 3 + j] = nn + c * (id - nn);
+            R[i * 3 + j] = MA(c, id - nn, nn);
         }
     orc_pluscrossprod(R, s, n);
 }
@@ -155,7 +207,9 @@ static int compat_cylinder(const orc_shape *s, v3 p, v3 n, double eps, double co
     v3 a = V(&s->v[0]), c = V(&s->v[3]);
     double R = s->v[6];
     /* curr_norm = points[i] - a*dot(a, points[i]-c) - c */
-    v3 curr_norm = vsub(vsub(p, vscale(a, vdot(a, vsub(p, c)))), c);
+    double sd = vdot(a, vsub(p, c));
+    v3 pa = { MA(-a.x, sd, p.x), MA(-a.y, sd, p.y), MA(-a.z, sd, p.z) };   /* p - a*sd */
+    v3 curr_norm = vsub(pa, c);
     if (fabs(vnorm(curr_norm) - R) < eps) {
         if (s->outwards)
             return vdot(vnormalize(curr_norm), n) > cosa;
@@ -178,9 +232,9 @@ static void project2cone(const orc_shape *s, v3 p, double *dist, v3 *normal)
     v3 nvn = vnormalize(rot_ax);
     rodrigues_cs(nvn, s->v[7], s->v[8], R);
     v3 rc = {
-        (R[0] * comp_n.x + R[1] * comp_n.y) + R[2] * comp_n.z,
-        (R[3] * comp_n.x + R[4] * comp_n.y) + R[5] * comp_n.z,
-        (R[6] * comp_n.x + R[7] * comp_n.y) + R[8] * comp_n.z,
+        sum3(R[0] * comp_n.x, R[1], comp_n.y, R[2], comp_n.z),
+        sum3(R[3] * comp_n.x, R[4], comp_n.y, R[5], comp_n.z),
+        sum3(R[6] * comp_n.x, R[7], comp_n.y, R[8], comp_n.z),
     };
     v3 current_normal = vnormalize(rc);
     *dist = vdot(vneg(current_normal), vneg(to_point));
@@ -214,6 +268,46 @@ int orc_compatible(const orc_shape *s, const double p[3], const double n[3], dou
 {
     return compat(s, V(p), V(n), eps, cos_alpha);
 }
+
+/* The two compared quantities of one test, for the near-threshold census of
+ * tests/golden/make_rounding_sensitivity.py: out[0] = the distance side (|d|, |norm - R| or |dist|, compared
+ * with eps), out[1] = the angle side (the dot product compared with cos(alpha)). */
+void orc_compat_values(const orc_shape *s, const double pp[3], const double nn[3], double out[2])
+{
+    v3 p = V(pp), n = V(nn);
+    switch (s->kind) {
+    case ORC_PLANE: {
+        v3 normal = V(&s->v[3]);
+        out[0] = fabs(vdot(vnormalize(normal), vsub(p, V(&s->v[0]))));
+        out[1] = vdot(normal, n);
+        break;
+    }
+    case ORC_SPHERE: {
+        v3 o = V(&s->v[0]);
+        out[0] = fabs(vnorm(vsub(p, o)) - s->v[3]);
+        out[1] = s->outwards ? vdot(vnormalize(vsub(p, o)), n) : vdot(vnormalize(vsub(o, p)), n);
+        break;
+    }
+    case ORC_CYLINDER: {
+        v3 a = V(&s->v[0]), c = V(&s->v[3]);
+        double sd = vdot(a, vsub(p, c));
+        v3 pa = { MA(-a.x, sd, p.x), MA(-a.y, sd, p.y), MA(-a.z, sd, p.z) };
+        v3 cn = vsub(pa, c);
+        out[0] = fabs(vnorm(cn) - s->v[6]);
+        out[1] = s->outwards ? vdot(vnormalize(cn), n) : vdot(vneg(vnormalize(cn)), n);
+        break;
+    }
+    default: {
+        double dist;
+        v3 cn;
+        project2cone(s, p, &dist, &cn);
+        out[0] = fabs(dist);
+        out[1] = s->outwards ? vdot(cn, n) : vdot(vneg(cn), n);
+    }
+    }
+}
+
+int orc_variant(void) { return ORC_VARIANT; }
 
 /* ------------------------------------------------- confidence intervals */
 
@@ -387,6 +481,42 @@ void orc_score_batch_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int32_t i = 0; i < b; i++)
         counts[i] = (int32_t)orc_scorecandidate(c, &s[i], p, NULL, NULL);
+}
+
+/* masks (b x ceil(s/64) words, subset order) with the candidates spread over host threads: tooling of the
+ * rounding-sensitivity measurement and of the bench's oracle checks */
+void orc_score_masks_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                        int32_t *counts, uint64_t *masks, int32_t nthreads)
+{
+    int64_t w = (c->s + 63) / 64;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (int32_t i = 0; i < b; i++)
+        counts[i] = (int32_t)orc_scorecandidate(c, &s[i], p, NULL, masks ? masks + (size_t)i * w : NULL);
+}
+
+/* census of near-threshold decisions over subset 1: hist[0][k] counts tests whose distance side lies within
+ * edges[k] of eps, hist[1][k] the same for the angle side and cos(alpha) (absolute differences; nedges <= 8) */
+void orc_margin_census_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                          const double *edges, int nedges, int64_t *hist /* 2 x nedges */, int32_t nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    int64_t h0[8] = { 0 }, h1[8] = { 0 };
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : h0[:8], h1[:8])
+    for (int32_t i = 0; i < b; i++) {
+        double eps = p->eps[s[i].kind], cosa = p->cos_alpha[s[i].kind];
+        for (int64_t j = 0; j < c->s; j++) {
+            int64_t i0 = c->subset1[j] - 1;
+            double v[2];
+            orc_compat_values(&s[i], &c->xyz[3 * i0], &c->nrm[3 * i0], v);
+            double m0 = fabs(v[0] - eps), m1 = fabs(v[1] - cosa);
+            for (int k = 0; k < nedges; k++) {
+                if (m0 <= edges[k]) h0[k]++;
+                if (m1 <= edges[k]) h1[k]++;
+            }
+        }
+    }
+    for (int k = 0; k < nedges; k++) { hist[k] = h0[k]; hist[nedges + k] = h1[k]; }
 }
 
 /* refit: plane.jl:137-143, sphere.jl:179-190, cylinder.jl:228-234, cone.jl:176-182 */
@@ -886,7 +1016,7 @@ int orc_fit3pointcone(const double *p, const double *n, orc_shape *out)
     v3 dirv = vnormalize(vsub(midp, ap));
     if (vdot(ax, dirv) < 0) ax = vscale(ax, -1.0);
     double angles[3];
-    for (int i = 0; i < 3; i++) angles[i] = rh_acos(clamp1(vdot(vnormalize(vsub(V(p + 3 * i), ap)), ax)));
+    for (int i = 0; i < 3; i++) angles[i] = ORC_ACOS(clamp1(vdot(vnormalize(vsub(V(p + 3 * i), ap)), ax)));
     double opangle = 2 * ((angles[0] + angles[1]) + angles[2]) / 3;
     memset(out, 0, sizeof *out);
     out->kind = ORC_CONE;

@@ -45,8 +45,8 @@ enum { ORC_PLANE = 0, ORC_SPHERE = 1, ORC_CYLINDER = 2, ORC_CONE = 3 };
  *   CONE     (cone.jl:11-19)      v[0..2]=apex   v[3..5]=axis   v[6]=opang
  *                                 v[7]=cos(-opang/2) v[8]=sin(-opang/2) outwards
  * v[7], v[8] are host-computed (the reference evaluates cos/sin inside
- * rodrigues, utilities.jl:21-22). orc_shape_finalize fills them with the fdlibm-algorithm kernels of
- * det_math.h (what Julia's Base.sin/cos port; <= 1 ulp from any libm). */
+ * rodrigues, utilities.jl:21-22). orc_shape_finalize fills them with the oracle's own fdlibm-algorithm
+ * kernels (orc_trig.h; what Julia's Base.sin/cos port; <= 1 ulp from any libm). */
 typedef struct {
     int32_t kind;
     int32_t outwards;
@@ -94,6 +94,10 @@ void orc_shape_finalize(orc_shape *s);   /* fill cone cos/sin fields */
 int orc_compatible(const orc_shape *s, const double p[3], const double n[3],
                    double eps, double cos_alpha);
 
+/* the two compared quantities of one test (distance side vs eps, angle side vs cos alpha) */
+void orc_compat_values(const orc_shape *s, const double p[3], const double n[3], double out[2]);
+int orc_variant(void); /* the rounding-order variant this build restates (0 = default; ransac_oracle.c header) */
+
 /* ---- confidence interval / score statistics (confidenceintervals.jl) ---- */
 typedef struct { double min, max, E; } orc_ci;
 int orc_confidence_interval(double x, double y, orc_ci *out); /* -1 = "out of order" */
@@ -123,6 +127,10 @@ void orc_score_batch(const orc_cloud *c, const orc_shape *s, int32_t b, const or
                      int32_t *counts, uint64_t *masks /* b x ceil(s/64) or NULL */);
 void orc_score_batch_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
                         int32_t *counts, int32_t nthreads);   /* OpenMP over candidates (bench steelman) */
+void orc_score_masks_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                        int32_t *counts, uint64_t *masks, int32_t nthreads);
+void orc_margin_census_mt(const orc_cloud *c, const orc_shape *s, int32_t b, const orc_params *p,
+                          const double *edges, int nedges, int64_t *hist, int32_t nthreads);
 /* refit (plane.jl:137-143 etc.): ascending 1-based indices; returns count */
 int64_t orc_refit(const orc_cloud *c, const orc_shape *s, const orc_params *p,
                   int64_t *idx_out, int64_t cap);

@@ -317,13 +317,18 @@ class RANSACCloud:
     def set_enabled(self, mask_or_chunks):
         a = np.asarray(mask_or_chunks)
         if a.dtype == np.uint64:
-            ch = np.ascontiguousarray(a)
+            ch = np.ascontiguousarray(a).reshape(-1)
+            if ch.size != self.nchunks:
+                raise ValueError("set_enabled: %d chunks given, the cloud has %d (ceil(size / 64))" % (ch.size, self.nchunks))
         else:
+            if a.size != self.size:
+                raise ValueError("set_enabled: mask of length %d for a cloud of %d points" % (a.size, self.size))
             bits = np.zeros(self.nchunks * 64, dtype=np.uint8)
-            bits[: self.size] = a.astype(np.uint8)
+            bits[: self.size] = a.reshape(-1).astype(np.uint8)
             ch = np.packbits(bits, bitorder="little").view(np.uint64)
+        n_given = ch.size   # the library checks this against its own word count
         ch = np.ascontiguousarray(ch if ch.size else np.zeros(1, dtype=np.uint64))
-        check(lib().rh_cloud_set_enabled(self._h, _p(ch, C.c_uint64), self.nchunks))
+        check(lib().rh_cloud_set_enabled(self._h, _p(ch, C.c_uint64), n_given))
 
     def enable_all(self):
         check(lib().rh_cloud_enable_all(self._h))

@@ -21,12 +21,29 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+STAMP = SO + ".stamp"
+
+
+def source_hash():
+    """sha256 over the sources, the public header, the flags and this file: what the library was built from
+    (modification times do not survive a copy of the tree, e.g. onto a GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith((".hip", ".h", ".cpp"))) + [os.path.join(ROOT, "include", "ransac_hip.h"), __file__]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS + SOURCES).encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(SO):
+    if not os.path.exists(SO) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "ransac_hip.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -34,12 +51,13 @@ def build(force=False, verbose=False):
         return SO
     cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     for s in SOURCES:
-        path = os.path.join(CSRC, s)
-        cmd += (["-x", "hip", path] if s.endswith(".hip") else ["-x", "hip", path])
+        cmd += ["-x", "hip", os.path.join(CSRC, s)]
     cmd += ["-o", SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return SO
 
 

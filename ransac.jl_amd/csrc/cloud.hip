@@ -764,15 +764,15 @@ extern "C" int rh_invalidate(rh_cloud *c, const int64_t *idx, int64_t n)
     RH_TRY(enter(c));
     if (n < 0 || (n > 0 && !idx)) { rh_set_error("rh_invalidate: bad arguments"); return RH_E_INVALID; }
     if (n == 0) return RH_OK;
-    if (n > c->n) {   // idx_out is the staging buffer; longer lists (duplicates) go in pieces
-        for (int64_t o = 0; o < n; o += c->n) RH_TRY(rh_invalidate(c, idx + o, std::min<int64_t>(c->n, n - o)));
-        return RH_OK;
-    }
-    for (int64_t k = 0; k < n; k++)
+    for (int64_t k = 0; k < n; k++)   // before anything else: an empty cloud has no valid index at all
         if (idx[k] < 1 || idx[k] > c->n) {
             rh_set_error("rh_invalidate: index %lld outside 1..%lld", (long long)idx[k], (long long)c->n);
             return RH_E_INVALID;   // the reference would throw a BoundsError
         }
+    if (n > c->n) {   // idx_out is the staging buffer; longer lists (duplicates) go in pieces (c->n >= 1 here)
+        for (int64_t o = 0; o < n; o += c->n) RH_TRY(rh_invalidate(c, idx + o, std::min<int64_t>(c->n, n - o)));
+        return RH_OK;
+    }
     RH_HIP(hipMemcpyAsync(c->idx_out, idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     RH_TRY(rhk_invalidate_idx(c, c->idx_out, n));
     RH_TRY(rhk_rebuild_sub_enabled(c, false));

@@ -13,16 +13,15 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no libransac_hip.so (it is git-ignored): compile it once (hipcc cross-compiles gfx950
-    without a GPU), exactly as __graft_entry__.build() does.  The package itself never builds or falls back on
-    import -- it fails loudly when the library is missing."""
-    so = os.path.join(ROOT, "ransac.jl_amd", "libransac_hip.so")
-    if not os.path.exists(so):
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("rh_build", os.path.join(ROOT, "ransac.jl_amd", "build.py"))
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        mod.build()
+    """(Re)build libransac_hip.so whenever it is missing or older than its sources (content hash, build.py):
+    hipcc cross-compiles gfx950 without a GPU, exactly as __graft_entry__.build() does, so the suite -- the
+    bit-parity tests included -- never runs against a stale binary.  A no-op when the library is current.  The
+    package itself never builds or falls back on import: it fails loudly when the library is missing."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rh_build", os.path.join(ROOT, "ransac.jl_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
 
 
 @pytest.fixture(scope="session")
