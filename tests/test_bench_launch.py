@@ -1,0 +1,54 @@
+"""bench.py's launch contract (no GPU needed): `--gpus N` started plainly launches N ranks itself before any GPU
+call and fails -- never silently runs fewer ranks; a WORLD_SIZE that contradicts --gpus is an error."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.device_count() > 0
+
+
+def test_world_size_contradicting_gpus_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.skipif(_has_gpu(), reason="on a GPU box the gpu-marked test covers the self-launch")
+def test_plain_start_with_gpus_2_launches_ranks_and_fails_loudly_without_gpus():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank exit codes [1, 1]" in r.stderr          # both ranks were started; nothing fell back to one rank
+    assert r.stdout.strip() == ""                        # and no result line was printed
+
+
+@pytest.mark.gpu
+def test_self_launch_on_one_gpu_box():
+    """One GPU: `--gpus 2` must fail (rank 1 has no GPU); with the two ranks sharing GPU 0 over gloo the script launches
+    itself and reports n_gpus = 2 and rccl_ranks_seen = 2."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU here")
+    small = ["--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--workload", "cfg2", "--no-cpu", "--no-e2e", "--no-cfg2", "--no-cfg5"]
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + small, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "no fallback" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + small, env=_env(RH_BENCH_SHARE_GPU0="1", RH_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["config"]["candidates_per_step"] == 8192

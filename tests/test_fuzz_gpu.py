@@ -1,0 +1,54 @@
+"""A bounded, fixed-seed slice of the two fuzzers (tools/fuzz_score.py, tools/fuzz_e2e.py) inside the suite, so that
+a green GPU run means what DESIGN.md section 5 claims from the long fuzz campaigns: random clouds, sizes around the tile
+/ group boundaries, coordinate scales 1 .. 1e4, random enabled patterns, thresholds from tiny to huge, candidates from
+jittered ground truth to degenerate (NaN / inf / zero axes), both score kernels, masks or counts; and whole rh_ransac
+runs over random shape mixes, iteration parameters, score / sphere / sampling / octree modes and driver switches --
+all compared with the oracle bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+_ENV = ("RH_SCORE_PATH", "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
+        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT")
+
+
+@pytest.fixture(autouse=True)
+def _restore_env():
+    old = {k: os.environ.get(k) for k in _ENV}
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("seed,ncases", [(20261, 100), (20262, 100), (20263, 100)])
+def test_score_fuzz_slice(seed, ncases):
+    import fuzz_score
+    rng = np.random.default_rng(seed)
+    bad = []
+    for case in range(ncases):
+        ok, desc = fuzz_score.one(case + seed % 1000, rng)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("seed,ncases", [(31, 15), (32, 15)])
+def test_e2e_fuzz_slice(seed, ncases):
+    import fuzz_e2e
+    rng = np.random.default_rng(seed)
+    bad = []
+    for case in range(ncases):
+        ok, desc = fuzz_e2e.one(case + 100 * seed, rng)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad[:3]

@@ -548,36 +548,57 @@ def test_largestconncomp_random_bitmaps(shape, density, seed):
         assert np.array_equal(got, orc.largestconncomp(bm, conn8=conn8))
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
 def test_full_size_properties(cfg):
-    """BASELINE configs[1] and configs[2] at full size (1M / 10M points, r = 32, B = 4096):
-    size-independent properties, plus an oracle spot check on a slice of the batch."""
+    """BASELINE configs[1], [2] and [4] at full size (1M / 10M / 50M points, r = 32, B = 4096; cfg5 with cones):
+    size-independent properties, plus an oracle check on a slice of the batch that holds every kind."""
     c = synth.config(cfg)
     n = c["xyz"].shape[0]
     subs = synth.make_subsets(n, c["r"], c["seed"])
     pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
-    cp = R.params_to_c(R.ransacparameters())
+    types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder] + ([R.FittedCone] if cfg == "cfg5" else [])
+    cp = R.params_to_c(R.ransacparameters(types))
     cands = make_candidates(c["truth"], 4096, seed=8)
     arr = shape_array(cands)
-    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    nmask = 4096 if cfg != "cfg5" else 480           # cfg5: 24 415 mask words per candidate -- masks for 10 rounds of the 48 primitives
+    counts_m, masks = R.score_batch(pc, shape_array(cands[:nmask]), cp, want_masks=True)
     pop = np.bitwise_count(masks).sum(axis=1, dtype=np.int64)
-    assert np.array_equal(pop, counts)                    # checksum of checksums
-    assert np.array_equal(R.score_batch(pc, arr, cp), counts)   # idempotent, both instantiations
+    assert np.array_equal(pop, counts_m)                  # checksum of checksums
+    counts = R.score_batch(pc, arr, cp)
+    assert np.array_equal(counts[:nmask], counts_m)       # idempotent, both instantiations
+    assert np.array_equal(R.score_batch(pc, arr, cp), counts)
     assert counts.max() <= subs[0].size and counts.sum() > 4096 * 100
     oc = orc.Cloud(c["xyz"], c["nrm"], subs[0])
-    sel = list(range(0, 4096, 97))
+    sel = list(range(0, 4096, 97)) if cfg != "cfg5" else list(range(0, 4096, 43))    # cfg5: 96 candidates, 16 of them cones
+    kinds_in = {cands[i].kind for i in sel}
+    assert kinds_in == ({L.PLANE, L.SPHERE, L.CYLINDER, L.CONE} if cfg == "cfg5" else {L.PLANE, L.SPHERE, L.CYLINDER})
     sub_arr = shape_array([cands[i] for i in sel])
-    assert np.array_equal(oc.score_batch(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp)), counts[sel])
+    ocounts = oc.score_batch_mt(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp), 16)
+    assert np.array_equal(ocounts, counts[sel])
+    if cfg == "cfg5":
+        cone_sel = [i for i in sel if cands[i].kind == L.CONE]
+        assert len(cone_sel) >= 8 and counts[cone_sel].max() > 1000       # cones of the batch really collect inliers
+        # masks of a few candidates of every kind, bit for bit
+        msel = [i for i in sel if i < nmask][:12]
+        oc_c, oc_m = oc.score_masks_mt(to_orc_shapes(shape_array([cands[i] for i in msel]), len(msel)), to_orc_params(cp), 16)
+        assert np.array_equal(oc_m, masks[msel]) and np.array_equal(oc_c, counts[msel])
     # refit: ascending, all enabled before, none after invalidation, disjoint extractions
     seen = np.zeros(n, dtype=bool)
-    for cand in cands[:6]:
+    todo = cands[:6] if cfg != "cfg5" else [cands[0], cands[16], cands[28], cands[40], cands[47]]   # cfg5: every kind, two cones
+    for j, cand in enumerate(todo):
         ex = R.refit(cand, pc, cp)
         assert np.all(np.diff(ex.inpoints) > 0) and not seen[ex.inpoints - 1].any()
+        if cfg == "cfg5" and j in (0, 3):      # a plane and a cone scan against the oracle's list, on the enabled set as it stands
+            assert np.array_equal(ex.inpoints, oc.refit(to_orc_shapes(shape_array([cand]), 1)[0], to_orc_params(cp)))
         seen[ex.inpoints - 1] = True
         R.invalidate_indexes(pc, ex.inpoints)
+        oc.invalidate(ex.inpoints)
         assert R.refit(cand, pc, cp).inpoints.size == 0
     assert pc.count_enabled() == n - int(seen.sum())
     assert np.array_equal(pc.isenabled, ~seen)
+    if cfg == "cfg5":   # and the batch again on the thinned cloud (enabled bits in play at full size)
+        again = R.score_batch(pc, sub_arr, cp)
+        assert np.array_equal(again, oc.score_batch_mt(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp), 16))
 
 
 def test_full_size_ransac_cfg3_replays_through_the_abi():
