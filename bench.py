@@ -137,24 +137,45 @@ def self_launch(args):
     relayed; any rank failing fails the run -- there is no fallback to fewer ranks."""
     import socket
     import subprocess
+    import tempfile
+    if not os.environ.get("RH_BENCH_SHARE_GPU0"):
+        import torch   # device_count() reads the driver's device list without initialising HIP in this process
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); one rank per GPU, no fallback to fewer ranks "
+                             "(RH_BENCH_SHARE_GPU0=1 RH_BENCH_BACKEND=gloo rehearses the N > 1 flow on one GPU)"
+                             % (args.gpus, have))
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RH_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
-    sys.stdout.write(out0 or "")
-    sys.stdout.flush()
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # wait for all; the first rank that fails takes the others down (they would wait for it in the rendezvous forever)
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, q in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = q.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    q.kill()            # exactly the processes started above
+                    codes[i] = q.wait()
+            break
+        time.sleep(0.1)
     if any(codes):
         raise SystemExit("bench.py --gpus %d: rank exit codes %s -- no result (it never falls back to fewer ranks)"
                          % (args.gpus, codes))
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
 
 
 def shapes_to_c(R, L, cands):

@@ -24,6 +24,31 @@ def pytest_sessionstart(session):
     mod.build()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_box_heartbeat():
+    """On a GPU box (gpurun sets GRAFT_REPO_ROOT) a run that writes nothing for 7 minutes is taken to be hung; the
+    full-size tests (50M-point cloud + oracle legs) are silent for minutes.  A daemon thread appends a line per
+    minute to gpurun_out/pytest_heartbeat.log while the session runs."""
+    if not os.environ.get("GRAFT_REPO_ROOT"):
+        yield
+        return
+    import threading
+    import time
+    stop = threading.Event()
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+
+    def beat():
+        t0 = time.time()
+        while not stop.wait(60.0):
+            with open(os.path.join(d, "pytest_heartbeat.log"), "a") as f:
+                f.write("pytest alive %.0f s: %s\n" % (time.time() - t0, os.environ.get("PYTEST_CURRENT_TEST", "")))
+    th = threading.Thread(target=beat, daemon=True)
+    th.start()
+    yield
+    stop.set()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

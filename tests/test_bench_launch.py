@@ -29,12 +29,15 @@ def test_world_size_contradicting_gpus_is_an_error():
 
 
 @pytest.mark.skipif(_has_gpu(), reason="on a GPU box the gpu-marked test covers the self-launch")
-def test_plain_start_with_gpus_2_launches_ranks_and_fails_loudly_without_gpus():
+def test_plain_start_with_gpus_2_fails_loudly_without_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(),
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0
-    assert "rank exit codes [1, 1]" in r.stderr          # both ranks were started; nothing fell back to one rank
-    assert r.stdout.strip() == ""                        # and no result line was printed
+    assert r.returncode != 0 and "no fallback to fewer ranks" in r.stderr
+    assert r.stdout.strip() == ""                        # no result line was printed
+    # with the device-count check waived the launcher starts both ranks; each fails (no GPU), nothing falls back
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=_env(RH_BENCH_SHARE_GPU0="1", RH_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rank exit codes" in r.stderr and r.stdout.strip() == ""
 
 
 @pytest.mark.gpu
