@@ -1,10 +1,8 @@
 """Build-time invariants of the hand-written kernels, checked on the gfx950 ISA hipcc emits (no GPU needed).
 
-The culled score kernels prefetch the next candidate's 96-byte record with an asm pair: `sprefetch_issue`
-starts two scalar loads whose SGPR tuples are written asynchronously, `sprefetch_wait` is the matching
-s_waitcnt.  That is only correct while the compiler neither moves nor spills those SGPRs in between (it does
-not know they are still in flight).  This test reads the ISA and fails if any instruction between an issue
-and the next wait touches the tuples, and records the spill counts of the score kernels."""
+Performance tripwires only -- no correctness property of the kernels depends on what is checked here: the score
+kernels must not spill vector registers, and their candidate records must arrive through compiler-tracked scalar
+loads (no inline-asm memory access)."""
 import os
 import re
 import shutil
@@ -42,35 +40,22 @@ def _kernel_bodies(lines):
         i += 1
 
 
-def _regs(line):
-    found = {int(r) for r in re.findall(r"\bs(\d+)\b", line)}
-    for a, b in re.findall(r"s\[(\d+):(\d+)\]", line):
-        found |= set(range(int(a), int(b) + 1))
-    return found
-
-
-def test_scalar_prefetch_registers_are_untouched_between_issue_and_wait(isa):
-    kernels = issues = 0
+def test_no_inline_asm_memory_access_in_the_score_kernels(isa):
+    """Round 1 prefetched the next candidate's record with an asm pair of scalar loads whose SGPR tuples the compiler
+    did not know were in flight (correct only while it neither moved nor spilled them: an ISA grep was the guard).
+    The records are now read through the constant address space (rh_ld_prep_const, score_device.h): ordinary scalar
+    loads the compiler tracks itself.  Nothing in the score kernels may load through inline asm any more."""
+    kernels = 0
     for name, body in _kernel_bodies(isa):
         kernels += 1
-        i = 0
-        while i < len(body):
-            m = re.search(r"s_load_dwordx16 s\[(\d+):(\d+)\]", body[i])
-            if m and "ASMSTART" in body[i - 1]:
-                m2 = re.search(r"s_load_dwordx8 s\[(\d+):(\d+)\]", body[i + 1])
-                assert m2, "sprefetch_issue is a dwordx16 + dwordx8 pair"
-                live = set(range(int(m.group(1)), int(m.group(2)) + 1)) | set(range(int(m2.group(1)), int(m2.group(2)) + 1))
-                issues += 1
-                j = i + 3   # past the pair and ASMEND
-                while j < len(body) - 1:
-                    if "ASMSTART" in body[j] and ("s_waitcnt lgkmcnt(0)" in body[j + 1] or "s_load_dwordx16" in body[j + 1]):
-                        break
-                    touched = _regs(body[j].split(";")[0]) & live
-                    assert not touched, "%s: line %d touches in-flight prefetch registers %s: %s" % (
-                        name, j, sorted(touched), body[j].strip())
+        for i, line in enumerate(body):
+            if "ASMSTART" in line:
+                j = i + 1
+                while "ASMEND" not in body[j]:
+                    assert "s_load" not in body[j] and "s_waitcnt" not in body[j], (name, body[j])
                     j += 1
-            i += 1
-    assert kernels >= 8 and issues >= 16     # per-kind and merged variants, two issue sites each
+        assert any("s_load_dwordx" in l for l in body)      # the candidate records do arrive through scalar loads
+    assert kernels >= 8
 
 
 def test_score_kernels_do_not_spill_vector_registers(isa):

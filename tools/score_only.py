@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The bench's timed step alone (cfg3 cloud, 4096 jittered candidates, rh_score_batch_dev) for kernel A/B runs under
+rocprofv3: prints ms per step from HIP events.  RH_* switches are read by the library."""
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ransac_jl_amd as R
+from ransac_jl_amd import _lib as L, dist as rdist, synth
+import bench
+
+wl = os.environ.get("WL", "cfg3")
+prim = ["plane"] * 16 + ["sphere"] * 12 + ["cylinder"] * 12
+types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+n, seed, scanner = 10_000_000, 3, None
+if wl == "cfg5":
+    prim += ["cone"] * 8; types += [R.FittedCone]; n, seed, scanner = 50_000_000, 5, [synth.BOX / 2] * 3
+xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=seed, scanner=scanner)
+subs = synth.make_subsets(n, 32, seed=seed)
+pc = R.RANSACCloud(xyz, nrm, subs)
+cp = R.params_to_c(R.ransacparameters(types), score_mode=L.SCORE_F64)
+cands = synth.jittered_candidates(truth, 4096, seed=0)
+arr = bench.shapes_to_c(R, L, cands)
+batch = rdist.DeviceBatch(pc, arr, 4096)
+counts = torch.zeros(4096, dtype=torch.int32, device="cuda")
+lib = R.lib()
+def step():
+    L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), 4096, C.byref(cp), C.c_void_p(counts.data_ptr()), None))
+for _ in range(int(os.environ.get("PRE", "200"))): step()
+L.check(lib.rh_cloud_sync(pc._h))
+steps = int(os.environ.get("STEPS", "100"))
+L.check(lib.rh_timer_start(pc._h))
+for _ in range(steps): step()
+ms = C.c_float(); L.check(lib.rh_timer_stop(pc._h, C.byref(ms)))
+print("ms_per_step %.4f  sum(counts) %d" % (ms.value / steps, int(counts.sum().item())))
