@@ -221,6 +221,22 @@ int rh_ransac(rh_cloud *c, const double *xyz_aos, const double *nrm_aos, const r
               rh_rng *rng, rh_result *out);
 void rh_result_free(rh_result *r);
 
+/* ---- one scene on several GPUs of a node (no counterpart in the reference, which is single-threaded:
+ *      src/iterations.jl:35-162 run by `world` processes, one per GPU) ----
+ * rh_mp_open is collective: every rank calls it with the same name (a POSIX shared-memory name, "/..."), rank 0
+ * creates the segment.  slot_bytes bounds one rank's candidate list of one window (<= 0: 1 MiB).  rh_ransac_mp:
+ * every rank holds a replica of the cloud in the same state and passes the same parameters and seed; the minimal sets
+ * of every iteration are dealt round-robin to the ranks, the ranks exchange their windows' candidate lists through
+ * the segment, and every rank returns exactly what rh_ransac returns for the same inputs. */
+typedef struct rh_mp rh_mp;
+int rh_mp_open(const char *shm_name, int32_t rank, int32_t world, int64_t slot_bytes, rh_mp **out);
+int rh_mp_close(rh_mp *m);
+/* the exchange on its own: every rank contributes `bytes` bytes (the same number everywhere), out gets world x bytes in
+ * rank order; host memory only */
+int rh_mp_allgather(rh_mp *m, const void *payload, int64_t bytes, void *out);
+int rh_ransac_mp(rh_cloud *c, const double *xyz_aos, const double *nrm_aos, const rh_params *p,
+                 rh_rng *rng, rh_mp *mp, rh_result *out);
+
 /* ---- parameter-space bitmap + largest connected component
  *      (src/parameterspacebitmap.jl:12-60, 69-109; dead code upstream) ----
  * bitmap: xs*ys bytes, column-major like a Julia BitMatrix (pixel [x,y] at x + xs*y,

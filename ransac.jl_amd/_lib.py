@@ -97,6 +97,10 @@ SIGNATURES = {
     "rh_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rh_cloud_sync": (C.c_int, [_vp]),
     "rh_dev_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "rh_mp_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_vp)]),
+    "rh_mp_close": (C.c_int, [_vp]),
+    "rh_mp_allgather": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "rh_ransac_mp": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(Params), C.POINTER(Rng), _vp, C.POINTER(Result)]),
     "rh_dev_free": (C.c_int, [_vp, _vp]),
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),

@@ -555,12 +555,43 @@ class _ResultOwner:
             pass
 
 
+class MpGroup:
+    """The processes of one node that run ransac() on ONE scene together (rh_mp, include/ransac_hip.h): one process per
+    GPU, each with a replica of the cloud.  Collective constructor: every rank passes the same name."""
+
+    def __init__(self, name, rank, world, slot_bytes=0):
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        check(lib().rh_mp_open(name.encode(), self.rank, self.world, int(slot_bytes), C.byref(h)))
+        self._h = h
+
+    def allgather(self, payload):
+        """bytes of equal length from every rank -> list of `world` bytes objects, in rank order"""
+        payload = bytes(payload)
+        out = C.create_string_buffer(len(payload) * self.world)
+        check(lib().rh_mp_allgather(self._h, payload, len(payload), out))
+        return [out.raw[i * len(payload):(i + 1) * len(payload)] for i in range(self.world)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rh_mp_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=None,
            score_mode=L.SCORE_INT64_WRAP, sphere_uses_enabled=False, sampling_streams=0, octree_sampling=False,
-           return_stats=False):
+           return_stats=False, mp=None):
     """ransac(pc, params[, setenabled]; reset_rand) -> (Vector{ExtractedShape}, seconds)
     (iterations.jl:14-21, 35-162).  `reset_rand` reseeds the generator with 1234 like
-    Random.seed!(1234); `stream` injects raw 64-bit draws (rand(1:n) = 1 + floor(u*n/2^64))."""
+    Random.seed!(1234); `stream` injects raw 64-bit draws (rand(1:n) = 1 + floor(u*n/2^64)).
+    mp: an MpGroup -- the loop is then run by all its ranks together on this one scene (rh_ransac_mp: the minimal
+    sets of every iteration dealt round-robin to the ranks); every rank gets the same result as a single process."""
     if setenabled:
         pc.enable_all()
     cp = params if isinstance(params, L.Params) else params_to_c(params, score_mode, sphere_uses_enabled, sampling_streams, octree_sampling)
@@ -572,8 +603,12 @@ def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=Non
         rng.stream = _p(keep, C.c_uint64)
         rng.stream_len = keep.size
     res = L.Result()
-    check(lib().rh_ransac(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
-                          C.byref(rng), C.byref(res)))
+    if mp is not None:
+        check(lib().rh_ransac_mp(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
+                                 C.byref(rng), mp._h, C.byref(res)))
+    else:
+        check(lib().rh_ransac(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
+                              C.byref(rng), C.byref(res)))
     # the index lists stay where rh_ransac put them (one pinned block per run): every `inpoints` is a
     # zero-copy view whose base keeps the result alive; rh_result_free runs when the last view is gone
     owner = _ResultOwner(res)

@@ -33,6 +33,12 @@
 #include <string.h>
 #include <time.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -48,6 +54,147 @@ double now_s()
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+
+}  // namespace
+
+// ---- rh_mp: the processes of ONE NODE that run rh_ransac_mp on the same scene (one process per GPU, every one
+// with a replica of the cloud).  They exchange the candidate lists of their windows -- a few records per window --
+// through a POSIX shared-memory segment: the payload is tiny and the exchange sits on the loop's critical path, so
+// what matters is latency (a microsecond through host memory; a collective over the fabric costs tens).  Each rank
+// owns two slots (window sequence number parity) and a flag per slot; publishing = write the slot, then store the
+// sequence number with release semantics; collecting = wait for every rank's flag to reach the sequence number.
+struct rh_mp {
+    int rank = 0, world = 1;
+    int64_t slot_bytes = 0;
+    size_t map_bytes = 0;
+    char *base = nullptr;
+    uint64_t seq = 0;            // exchanges done so far (the same on every rank)
+    char name[128];
+};
+
+namespace {
+
+constexpr uint64_t RH_MP_MAGIC = 0x52484d5032303236ULL;   // "RHMP2026"
+constexpr size_t RH_MP_HDR = 4096;                        // magic, world, then one 64-byte line per (rank, parity) flag
+
+inline volatile uint64_t *mp_flag(rh_mp *m, int rank, int parity) { return (volatile uint64_t *)(m->base + 256 + 64 * (size_t)(rank * 2 + parity)); }
+inline char *mp_slot(rh_mp *m, int rank, int parity) { return m->base + RH_MP_HDR + (size_t)(rank * 2 + parity) * (size_t)m->slot_bytes; }
+
+// every rank publishes `bytes` of payload; afterwards payload r of every rank r can be read with mp_slot(m, r, parity)
+// until the exchange after the next one.  Returns the parity used.
+int mp_exchange(rh_mp *m, const void *payload, int64_t bytes, int *parity_out)
+{
+    if (bytes > m->slot_bytes) {
+        rh_set_error("rh_ransac_mp: a window's candidate list (%lld bytes) does not fit the exchange slot (%lld)", (long long)bytes,
+                     (long long)m->slot_bytes);
+        return RH_E_CAPACITY;
+    }
+    m->seq++;
+    const int par = (int)(m->seq & 1);
+    memcpy(mp_slot(m, m->rank, par), payload, (size_t)bytes);
+    __atomic_store_n((uint64_t *)mp_flag(m, m->rank, par), m->seq, __ATOMIC_RELEASE);
+    const double t0 = now_s();
+    for (int r = 0; r < m->world; r++) {
+        uint64_t spins = 0;
+        while (__atomic_load_n((uint64_t *)mp_flag(m, r, par), __ATOMIC_ACQUIRE) < m->seq) {
+            if (++spins > 2000) {
+                sched_yield();
+                if ((spins & 1023) == 0 && now_s() - t0 > 60.0) {
+                    rh_set_error("rh_ransac_mp: rank %d did not reach exchange %llu within 60 s (rank %d waited)", r,
+                                 (unsigned long long)m->seq, m->rank);
+                    return RH_E_INTERNAL;
+                }
+            }
+        }
+    }
+    *parity_out = par;
+    return RH_OK;
+}
+
+}  // namespace
+
+extern "C" int rh_mp_open(const char *name, int32_t rank, int32_t world, int64_t slot_bytes, rh_mp **out)
+{
+    if (!name || !out || world < 1 || rank < 0 || rank >= world || world > 64 || strlen(name) >= 120) {
+        rh_set_error("rh_mp_open: bad arguments");
+        return RH_E_INVALID;
+    }
+    if (slot_bytes <= 0) slot_bytes = (int64_t)1 << 20;
+    slot_bytes = (slot_bytes + 4095) / 4096 * 4096;
+    rh_mp *m = new rh_mp;
+    m->rank = rank; m->world = world; m->slot_bytes = slot_bytes;
+    m->map_bytes = RH_MP_HDR + (size_t)world * 2 * (size_t)slot_bytes;
+    snprintf(m->name, sizeof m->name, "%s", name);
+    int fd = -1;
+    const double t0 = now_s();
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)m->map_bytes) != 0) {
+            rh_set_error("rh_mp_open: cannot create shared memory %s (%lld bytes)", name, (long long)m->map_bytes);
+            if (fd >= 0) close(fd);
+            delete m;
+            return RH_E_NOMEM;
+        }
+    } else {
+        for (;;) {   // wait for rank 0 to create and size the segment
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= m->map_bytes) break;
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (now_s() - t0 > 60.0) { rh_set_error("rh_mp_open: rank 0 did not create %s within 60 s", name); delete m; return RH_E_INTERNAL; }
+            usleep(1000);
+        }
+    }
+    void *mem = mmap(nullptr, m->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) { rh_set_error("rh_mp_open: mmap of %s failed", name); delete m; return RH_E_NOMEM; }
+    m->base = (char *)mem;
+    if (rank == 0) {   // a fresh segment is zero-filled: flags start at 0; publish the header last
+        ((volatile int32_t *)(m->base + 8))[0] = world;
+        __atomic_store_n((uint64_t *)m->base, RH_MP_MAGIC, __ATOMIC_RELEASE);
+    } else {
+        while (__atomic_load_n((uint64_t *)m->base, __ATOMIC_ACQUIRE) != RH_MP_MAGIC) {
+            if (now_s() - t0 > 60.0) { rh_set_error("rh_mp_open: %s was never initialised", name); munmap(mem, m->map_bytes); delete m; return RH_E_INTERNAL; }
+            usleep(200);
+        }
+        if (((volatile int32_t *)(m->base + 8))[0] != world) {
+            rh_set_error("rh_mp_open: %s was created for %d ranks, this is rank %d of %d", name, ((volatile int32_t *)(m->base + 8))[0], rank, world);
+            munmap(mem, m->map_bytes);
+            delete m;
+            return RH_E_INVALID;
+        }
+    }
+    // everybody has mapped the segment once this first exchange returns: the name can go (no leak if a rank dies later)
+    int par = 0;
+    const int32_t hello = rank;
+    int rc = mp_exchange(m, &hello, sizeof hello, &par);
+    if (rc != RH_OK) { munmap(mem, m->map_bytes); delete m; return rc; }
+    if (rank == 0) (void)shm_unlink(name);
+    *out = m;
+    return RH_OK;
+}
+
+// the exchange on its own (host memory only, no GPU involved): every rank contributes `bytes` bytes (the same number on
+// every rank), out receives world x bytes in rank order
+extern "C" int rh_mp_allgather(rh_mp *m, const void *payload, int64_t bytes, void *out)
+{
+    if (!m || bytes < 0 || (bytes > 0 && (!payload || !out))) { rh_set_error("rh_mp_allgather: bad arguments"); return RH_E_INVALID; }
+    int par = 0;
+    RH_TRY(mp_exchange(m, payload, bytes, &par));
+    for (int r = 0; r < m->world; r++) memcpy((char *)out + (size_t)r * (size_t)bytes, mp_slot(m, r, par), (size_t)bytes);
+    return RH_OK;
+}
+
+extern "C" int rh_mp_close(rh_mp *m)
+{
+    if (!m) return RH_OK;
+    if (m->base) munmap(m->base, m->map_bytes);
+    delete m;
+    return RH_OK;
+}
+
+namespace {
 
 // host mirror of pc.isenabled with a rank directory for "k-th enabled point"
 struct EnabledMirror {
@@ -310,6 +457,10 @@ struct Driver {
     std::vector<rh_prep> prep_h[4];
     std::vector<int64_t> sd;
     std::vector<double> fp, fn;
+
+    rh_mp *mp = nullptr;                    // rh_ransac_mp: the processes sharing this scene (null: one process)
+    std::vector<char> mp_buf;
+    std::vector<unsigned long long> mp_draws;
 
     Window win[2];
     static constexpr int32_t ENTRIES_HEAD = 4096;   // list entries that travel with the window (pack_window_kernel copies min(count, this))
@@ -887,8 +1038,8 @@ struct Driver {
             int32_t cnt = ((const int32_t *)A.h_status)[0];
             const int32_t gave_up = ((const int32_t *)A.h_status)[1];
             const unsigned long long *draws = (const unsigned long long *)(A.h_status + 8);
-            if (gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
-            if (cnt > A.entries_cap) {   // the list overflowed: grow it and draw the window again
+            if (gave_up && mp == nullptr) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
+            if (cnt > A.entries_cap && mp == nullptr) {   // the list overflowed: grow it and draw the window again
                 RUNH(hipStreamSynchronize(c->stream));
                 B.pending = false;
                 (void)hipFree(A.d_entries);
@@ -902,6 +1053,8 @@ struct Driver {
                 continue;
             }
             cnt_est = cnt;
+            const bool overflow = cnt > A.entries_cap;   // (only reachable with mp: handled collectively below)
+            if (overflow) cnt = 0;
             entries.resize((size_t)cnt);
             wcounts.resize((size_t)cnt);
             if (cnt > 0) {
@@ -916,6 +1069,72 @@ struct Driver {
                                             hipMemcpyDeviceToHost, c->stream));
                     RUNH(hipStreamSynchronize(c->stream));
                 }
+            }
+            if (mp != nullptr) {
+                // Every process drew its share of the window's minimal sets (set j of an iteration belongs to rank
+                // j % world): publish the local list -- entries, their counts, the draws per iteration -- and collect
+                // everybody's.  The union, in slot order, is the list one process would have produced; from here on every
+                // rank replays the same window and takes the same decisions (extractions included, each on its replica).
+                struct Hdr { int32_t cnt, overflow, gave_up, W, scored, pad; };
+                const size_t bytes = sizeof(Hdr) + sizeof(unsigned long long) * (size_t)W + (sizeof(rh_cand_entry) + sizeof(int32_t)) * (size_t)cnt;
+                mp_buf.resize(bytes);
+                Hdr h = { cnt, overflow ? 1 : 0, gave_up, W, A.scored ? 1 : 0, 0 };
+                char *q = mp_buf.data();
+                memcpy(q, &h, sizeof h); q += sizeof h;
+                memcpy(q, draws, sizeof(unsigned long long) * (size_t)W); q += sizeof(unsigned long long) * (size_t)W;
+                if (cnt > 0) {
+                    memcpy(q, entries.data(), sizeof(rh_cand_entry) * (size_t)cnt); q += sizeof(rh_cand_entry) * (size_t)cnt;
+                    memcpy(q, wcounts.data(), sizeof(int32_t) * (size_t)cnt);
+                }
+                int par = 0;
+                RUN(mp_exchange(mp, mp_buf.data(), (int64_t)bytes, &par));
+                bool any_overflow = false, any_gave_up = false;
+                int64_t total = 0;
+                for (int r = 0; r < mp->world; r++) {
+                    Hdr hr;
+                    memcpy(&hr, mp_slot(mp, r, par), sizeof hr);
+                    if (hr.W != W || hr.scored != h.scored) { rh_set_error("rh_ransac_mp: rank %d is at another window (W %d vs %d)", r, hr.W, W); return RH_E_INTERNAL; }
+                    any_overflow |= hr.overflow != 0;
+                    any_gave_up |= hr.gave_up != 0;
+                    total += hr.cnt;
+                }
+                if (any_gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
+                if (any_overflow) {   // some rank's list overflowed: it grows, and everybody draws the window again
+                    RUNH(hipStreamSynchronize(c->stream));
+                    B.pending = false;
+                    if (overflow) {
+                        (void)hipFree(A.d_entries);
+                        A.d_entries = nullptr;
+                        A.entries_cap = cnt_est + cnt_est / 4;
+                        RUNH(hipMalloc((void **)&A.d_entries, sizeof(rh_cand_entry) * (size_t)A.entries_cap));
+                        (void)hipFree(A.d_counts);
+                        A.d_counts = nullptr;
+                        RUNH(hipMalloc((void **)&A.d_counts, sizeof(int32_t) * (size_t)A.entries_cap));
+                    }
+                    t_sample += now_s() - t0;
+                    continue;
+                }
+                if (total > (int64_t)INT32_MAX / 2) { rh_set_error("rh_ransac_mp: window with %lld candidates", (long long)total); return RH_E_CAPACITY; }
+                mp_draws.assign((size_t)W, 0ULL);
+                entries.resize((size_t)total);
+                wcounts.resize((size_t)total);
+                size_t at = 0;
+                for (int r = 0; r < mp->world; r++) {
+                    const char *src = mp_slot(mp, r, par);
+                    Hdr hr;
+                    memcpy(&hr, src, sizeof hr); src += sizeof hr;
+                    for (int32_t i = 0; i < W; i++) { unsigned long long d; memcpy(&d, src + 8 * (size_t)i, 8); mp_draws[(size_t)i] += d; }
+                    src += sizeof(unsigned long long) * (size_t)W;
+                    if (hr.cnt > 0) {
+                        memcpy(entries.data() + at, src, sizeof(rh_cand_entry) * (size_t)hr.cnt); src += sizeof(rh_cand_entry) * (size_t)hr.cnt;
+                        memcpy(wcounts.data() + at, src, sizeof(int32_t) * (size_t)hr.cnt);
+                        at += (size_t)hr.cnt;
+                    }
+                }
+                cnt = (int32_t)total;
+                draws = mp_draws.data();
+            }
+            if (cnt > 0) {
                 // candidate order of the reference = slot order; the counts travel with their entries
                 order.resize((size_t)cnt);
                 for (int32_t i = 0; i < cnt; i++) order[(size_t)i] = i;
@@ -980,8 +1199,37 @@ struct Driver {
 
 }  // namespace
 
+static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng, rh_mp *mp,
+                       rh_result *out);
+
 extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng,
                          rh_result *out)
+{
+    return ransac_impl(c, xyz, nrm, p, rng, nullptr, out);
+}
+
+// ransac() on ONE scene by the `world` processes of `mp` (one per GPU, each with a replica of the cloud in the same
+// state): the minimal sets of every iteration are dealt round-robin to the ranks -- sampling, fits and scoring of
+// a window shrink by the number of ranks -- and the ranks exchange their windows' candidate lists through `mp`
+// (host shared memory: the lists are tiny).  Every rank replays the merged window, takes the same decisions and runs
+// every extraction on its own replica, so every rank returns the result rh_ransac returns for the same inputs, bit
+// for bit, and leaves its cloud in the same state.  Needs sampling_streams = 1 (per-set random streams).
+extern "C" int rh_ransac_mp(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng, rh_mp *mp,
+                            rh_result *out)
+{
+    if (!mp) { rh_set_error("rh_ransac_mp: mp is NULL"); return RH_E_INVALID; }
+    if (!c || !p) { rh_set_error("rh_ransac_mp: NULL argument"); return RH_E_INVALID; }
+    if (!p->sampling_streams) { rh_set_error("rh_ransac_mp needs sampling_streams = 1 (one random stream per minimal set)"); return RH_E_INVALID; }
+    c->mp_rank = mp->rank;
+    c->mp_world = mp->world;
+    const int rc = ransac_impl(c, xyz, nrm, p, rng, mp->world > 1 ? mp : nullptr, out);
+    c->mp_rank = 0;
+    c->mp_world = 1;
+    return rc;
+}
+
+static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng, rh_mp *mp,
+                       rh_result *out)
 {
     if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
     memset(out, 0, sizeof *out);
@@ -1008,8 +1256,13 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
 
     bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;
     if (getenv("RH_HOST_SAMPLER")) device_sampler = false;   // A/B and tests: the same streams drawn on the host
+    if (mp != nullptr && !device_sampler) {
+        rh_set_error("rh_ransac_mp: the minimal sets are dealt to the ranks by the device sampler (drawN <= 8, minsubsetN > 0, no RH_HOST_SAMPLER)");
+        return RH_E_INVALID;
+    }
     Driver d;
     d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
+    d.mp = mp;
     d.host_sampling = !device_sampler;
     RH_TRY(d.init());
     const double t_init = now_s() - t_start;

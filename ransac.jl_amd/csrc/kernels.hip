@@ -484,20 +484,36 @@ group_bounds_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, i
     }
 }
 
-// masks in internal (k-d leaf) order -> subset order; `out` must be zeroed
-__global__ void unpermute_masks_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ perm, int64_t swords,
-                                       int64_t total_words, uint64_t *__restrict__ out)
+// masks in internal (k-d leaf) order -> subset order.  One block per (candidate row, output segment): the segment of
+// the output row is assembled in LDS -- every set bit of the row's input words is one LDS atomicOr at its subset
+// position -- and written out once, coalesced, so the output needs neither a memset nor global atomics (the first
+// version issued one global atomicOr per inlier: 12.4M of them on the cfg3 batch, 0.48 ms).
+constexpr int RH_UNPERM_SEG_WORDS = 16384;   // 128 KB of LDS per block of 1024 threads (one block per CU then: 16 waves)
+
+__global__ void __launch_bounds__(1024)
+unpermute_masks_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ perm, int64_t swords,
+                       uint64_t *__restrict__ out)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_words) return;
-    uint64_t m = in[t];
-    const int64_t row = t / swords, w = t - row * swords;
-    while (m != 0) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        const int32_t j = perm[(w << 6) + b];
-        atomicOr((unsigned long long *)&out[row * swords + (j >> 6)], 1ULL << (j & 63));
+    extern __shared__ unsigned long long seg[];
+    const int64_t row = blockIdx.x;
+    const int64_t w0 = (int64_t)blockIdx.y * RH_UNPERM_SEG_WORDS;
+    const int nw = (int)(swords - w0 < RH_UNPERM_SEG_WORDS ? swords - w0 : RH_UNPERM_SEG_WORDS);
+    for (int t = threadIdx.x; t < nw; t += 1024) seg[t] = 0ULL;
+    __syncthreads();
+    const uint64_t *__restrict__ src = in + row * swords;
+    const int64_t lo = w0 << 6, hi = lo + ((int64_t)nw << 6);
+    for (int64_t w = threadIdx.x; w < swords; w += 1024) {
+        uint64_t m = src[w];
+        while (m != 0) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t j = perm[(w << 6) + b];
+            if (j >= lo && j < hi) atomicOr(&seg[(j - lo) >> 6], 1ULL << (j & 63));
+        }
     }
+    __syncthreads();
+    uint64_t *__restrict__ dst = out + row * swords + w0;
+    for (int t = threadIdx.x; t < nw; t += 1024) dst[t] = seg[t];
 }
 
 // ------------------------------------------------------------- refit ------
@@ -1395,11 +1411,20 @@ int rhk_group_bounds(rh_cloud *c)
 
 int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out)
 {
-    const int64_t total = (int64_t)b * c->swords;
-    if (total == 0) return RH_OK;
-    RH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * (size_t)total, c->stream));
-    hipLaunchKernelGGL(unpermute_masks_kernel, dim3(cdiv(total, 256)), dim3(256), 0, c->stream, d_in, c->sub_perm,
-                       c->swords, total, d_out);
+    if (b == 0 || c->swords == 0) return RH_OK;
+    const int nseg = cdiv(c->swords, RH_UNPERM_SEG_WORDS);
+    const size_t lds = sizeof(uint64_t) * (size_t)std::min<int64_t>(c->swords, RH_UNPERM_SEG_WORDS);
+    static bool attr_set = false;
+    if (!attr_set) {   // more than the default 64 KB of dynamic LDS
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute_masks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(uint64_t) * RH_UNPERM_SEG_WORDS)));
+        attr_set = true;
+    }
+    for (int32_t r0 = 0; r0 < b; r0 += 65535 * 32) {   // grid.x limit (2^31 - 1) is far away; keep launches bounded anyway
+        const int32_t rows = std::min<int32_t>(b - r0, 65535 * 32);
+        hipLaunchKernelGGL(unpermute_masks_kernel, dim3((unsigned)rows, (unsigned)nseg), dim3(1024), lds, c->stream,
+                           d_in + (int64_t)r0 * c->swords, c->sub_perm, c->swords, d_out + (int64_t)r0 * c->swords);
+    }
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

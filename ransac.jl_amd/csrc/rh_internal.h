@@ -133,6 +133,9 @@ struct rh_cloud {
     int64_t *d_ranks = nullptr;        // select in/out
     int64_t ranks_cap = 0;
 
+    // rh_ransac_mp: this process's share of every iteration's minimal sets (set j belongs to rank j % world)
+    int32_t mp_rank = 0, mp_world = 1;
+
     // rh_ransac's reusable buffers, parked here between calls (driver.hip owns the layout and the deleter)
     void *drv_cache = nullptr;
     void (*drv_cache_free)(rh_cloud *, void *) = nullptr;

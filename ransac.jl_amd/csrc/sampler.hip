@@ -10,6 +10,13 @@
 
 namespace {
 
+// The minimal sets of an iteration this process draws: j = lo + jl * step, jl < m_local.  One process: (0, 1,
+// minsubsetN).  rh_ransac_mp deals the sets of every iteration round-robin to the processes that share a scene
+// (driver.hip): a set's draws are a pure function of (seed, iteration, j), so who draws it changes nothing.
+struct SetShard {
+    int32_t lo, step, m_local;
+};
+
 struct DevEnabled {
     const uint64_t *w;
     const int32_t *prefix;   // exclusive popcount prefix per word
@@ -133,13 +140,14 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
                    const rhfit::OctView oc, const double *__restrict__ Pwin, int32_t drawN_rt, int32_t minsubsetN,
                    uint64_t seed, int64_t k0, int32_t n_iters, double *__restrict__ ws, int32_t *__restrict__ set_level,
                    unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag,
-                   const double *__restrict__ crec)
+                   const double *__restrict__ crec, SetShard sh)
 {
+    // thread t = (iteration, local set): this rank's sets of an iteration are j = lo + jl * step (one process: 0, 1)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)n_iters * minsubsetN;
+    const int64_t total = (int64_t)n_iters * sh.m_local;
     if (t >= total) return;
-    const int32_t it = (int32_t)(t / minsubsetN);
-    const int32_t j = (int32_t)(t - (int64_t)it * minsubsetN);
+    const int32_t it = (int32_t)(t / sh.m_local);
+    const int32_t j = sh.lo + (int32_t)(t - (int64_t)it * sh.m_local) * sh.step;
     uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
     constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
     int64_t sd[CAP];
@@ -189,7 +197,8 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
 template <int DN, bool CONE>
 __global__ void __launch_bounds__(128)
 fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_level, int64_t total, const rh_params prm,
-                rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count, int32_t *__restrict__ nk_zero)
+                rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count, int32_t *__restrict__ nk_zero,
+                SetShard sh)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;   // the kind bins prep_entries_kernel fills next
@@ -224,7 +233,10 @@ fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_l
         if (!fitted) continue;
         const int32_t pos = atomicAdd(out_count, 1);
         if (pos < cap) {
-            out[pos].slot = (int64_t)t * prm.n_shape_types + ti;
+            // the slot is GLOBAL (iteration, set, type): the same whatever the number of processes sharing the window
+            const int64_t it = t / sh.m_local;
+            const int64_t tg = it * prm.minsubsetN + sh.lo + (t - it * sh.m_local) * sh.step;
+            out[pos].slot = tg * prm.n_shape_types + ti;
             out[pos].level = level;
             out[pos].pad = 0;
             out[pos].shape = s;
@@ -262,14 +274,14 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
                         int32_t n_enabled, const rh_params prm,
                         uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out, int32_t cap,
                         int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
-                        int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero)
+                        int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero, SetShard sh)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;
-    const int64_t total = (int64_t)n_iters * prm.minsubsetN;
+    const int64_t total = (int64_t)n_iters * sh.m_local;
     if (t >= total) return;
-    const int32_t it = (int32_t)(t / prm.minsubsetN);
-    const int32_t j = (int32_t)(t - (int64_t)it * prm.minsubsetN);
+    const int32_t it = (int32_t)(t / sh.m_local);
+    const int32_t j = sh.lo + (int32_t)(t - (int64_t)it * sh.m_local) * sh.step;
     uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
     constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
     int64_t sd[CAP];
@@ -357,7 +369,7 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
         if (!fitted) continue;
         const int32_t pos = atomicAdd(out_count, 1);
         if (pos < cap) {
-            out[pos].slot = (int64_t)t * prm.n_shape_types + ti;
+            out[pos].slot = ((int64_t)it * prm.minsubsetN + j) * prm.n_shape_types + ti;   // global (iteration, set, type)
             out[pos].level = 1;
             out[pos].pad = 0;
             out[pos].shape = s;
@@ -389,7 +401,11 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
     // (the block is a multiple of 64 bytes: one aligned fill; the driver's windows keep it zero themselves)
     if (!status_is_zero) RH_HIP(hipMemsetAsync(d_status, 0, (size_t)((8 + 8 * (int64_t)n_iters + 63) / 64 * 64), c->stream));
-    const int64_t total = (int64_t)n_iters * prm->minsubsetN;
+    SetShard sh;
+    sh.lo = c->mp_rank;
+    sh.step = c->mp_world > 0 ? c->mp_world : 1;
+    sh.m_local = prm->minsubsetN > sh.lo ? (prm->minsubsetN - sh.lo + sh.step - 1) / sh.step : 0;
+    const int64_t total = (int64_t)n_iters * sh.m_local;
     if (total == 0) return RH_OK;
     // hand-over workspace (grown on demand; a window of 128 x 4096 sets of 3 points is 75 MB)
     const int64_t need = total * 6 * prm->drawN;
@@ -451,19 +467,19 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
         const dim3 gk((unsigned)((total + 127) / 128));
         if (prm->drawN == 3)
             hipLaunchKernelGGL(sample_fit_ranks_kernel<3>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
-                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh);
         else
             hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
-                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero);
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh);
         RH_HIP(hipGetLastError());
         return RH_OK;
     }
 #define RH_SAMPLE(DN)                                                                                                  \
     hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
-                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec)
+                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec, sh)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
-                       d_out, cap, d_count, d_nk_zero)
+                       d_out, cap, d_count, d_nk_zero, sh)
     if (prm->drawN == 3) {   // the reference's default: fully unrolled, no scratch
         RH_SAMPLE(3);
         if (cone) RH_FIT(3, true); else RH_FIT(3, false);
