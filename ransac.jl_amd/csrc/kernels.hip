@@ -516,6 +516,23 @@ unpermute_masks_kernel(const uint64_t *__restrict__ in, const int32_t *__restric
     for (int t = threadIdx.x; t < nw; t += 1024) dst[t] = seg[t];
 }
 
+// the same for rows too long for one LDS segment (cfg5: 24 415 words): one thread per input word, one global atomicOr per
+// inlier into the zeroed output (at that size the masks are sparse and two full passes over the rows cost more)
+__global__ void unpermute_masks_atomic_kernel(const uint64_t *__restrict__ in, const int32_t *__restrict__ perm, int64_t swords,
+                                              int64_t total_words, uint64_t *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_words) return;
+    uint64_t m = in[t];
+    const int64_t row = t / swords, w = t - row * swords;
+    while (m != 0) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const int32_t j = perm[(w << 6) + b];
+        atomicOr((unsigned long long *)&out[row * swords + (j >> 6)], 1ULL << (j & 63));
+    }
+}
+
 // ------------------------------------------------------------- refit ------
 // One candidate (kernarg -> SGPRs), the whole cloud in original order.  Each wave owns
 // 64-point words; mask word = ballot & enabled word; all-disabled words are skipped
@@ -1412,6 +1429,14 @@ int rhk_group_bounds(rh_cloud *c)
 int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out)
 {
     if (b == 0 || c->swords == 0) return RH_OK;
+    if (c->swords > RH_UNPERM_SEG_WORDS) {
+        const int64_t total = (int64_t)b * c->swords;
+        RH_HIP(hipMemsetAsync(d_out, 0, sizeof(uint64_t) * (size_t)total, c->stream));
+        hipLaunchKernelGGL(unpermute_masks_atomic_kernel, dim3(cdiv(total, 256)), dim3(256), 0, c->stream, d_in, c->sub_perm,
+                           c->swords, total, d_out);
+        RH_HIP(hipGetLastError());
+        return RH_OK;
+    }
     const int nseg = cdiv(c->swords, RH_UNPERM_SEG_WORDS);
     const size_t lds = sizeof(uint64_t) * (size_t)std::min<int64_t>(c->swords, RH_UNPERM_SEG_WORDS);
     static bool attr_set = false;
