@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<round>/ (tools/profile_round.sh) into the files kept under profiles/<round>/:
+kernel_stats_*.csv, bench_*.json, pmc_hbm_traffic.json (KB per dispatch), pmc_sq_counters.json (per dispatch, summed over
+the chip) and pmc_meta.json (source hash of the library the passes were taken on -- bench.py marks a replay stale when
+the library has changed since)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(dirs):
+    acc = defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            per = defaultdict(float)
+            for r in csv.DictReader(open(f)):
+                per[(r["Kernel_Name"], r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])   # one row per XCD
+            for (k, c, _), v in per.items():
+                acc[(k, c)].append(v)
+    return acc
+
+
+def main(rnd):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    dst = os.path.join(ROOT, "profiles", rnd)
+    os.makedirs(dst, exist_ok=True)
+    for name in ("bench_default_unprofiled.json", "bench_score_only_under_rocprof.json", "bench_under_rocprof.json"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    for sub, out in (("score_only", "kernel_stats_bench_score_only.csv"), ("with_e2e", "kernel_stats_bench_with_e2e.csv")):
+        f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if f:
+            shutil.copy(f[0], os.path.join(dst, out))
+    acc = counters([os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write")])
+    rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean_KB": sum(v) / len(v), "max_KB": max(v)} for (k, c), v in acc.items()]
+    rows.sort(key=lambda r: (r["counter"], r["kernel"]))
+    json.dump(rows, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
+    acc = counters([os.path.join(src, "pmc_sq1"), os.path.join(src, "pmc_sq2")])
+    rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for (k, c), v in acc.items()]
+    rows.sort(key=lambda r: (r["kernel"], r["counter"]))
+    json.dump(rows, open(os.path.join(dst, "pmc_sq_counters.json"), "w"), indent=1)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_b", os.path.join(ROOT, "ransac.jl_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    json.dump({"lib_source_hash": b.source_hash(), "command": "tools/profile_round.sh " + rnd,
+               "passes": "bench.py --no-cpu --no-cfg5 --no-cfg2 --no-e2e --steps 3 --warmup 1 --prewarm-ms 0, one rocprofv3 --pmc run per counter group"},
+              open(os.path.join(dst, "pmc_meta.json"), "w"), indent=1)
+    for r in rows:
+        if "score_groups_all" in r["kernel"] and r["counter"] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"):
+            print(r["counter"], r["mean"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r2")

@@ -1,19 +1,31 @@
 #!/bin/bash
-# Collects the round's profiles on a GPU box (run through gpurun from the repo root):
-#   kernel-trace + stats of the bench (score only, and with the end-to-end legs), and two PMC passes
-#   (FETCH_SIZE, WRITE_SIZE; counters in their own runs, kernel-trace only).  Output: gpurun_out/prof/
+# Collects a round's profiles on a GPU box (run through gpurun from the repo root): tools/profile_round.sh r2
+#   1. the default bench line, un-profiled;
+#   2. rocprofv3 --kernel-trace --stats of the bench (score only, and with the end-to-end legs);
+#   3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, and two SQ passes of 8 counters.
+# Output: gpurun_out/prof_<round>/ (copy what is to be judged into profiles/<round>/, tools/collect_profiles.py does it).
 set -e
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof
+RND=${1:-r2}
+OUT=$ROOT/gpurun_out/prof_$RND
 rm -rf "$OUT"; mkdir -p "$OUT"
 python bench.py > "$OUT/bench_default_unprofiled.json" 2> "$OUT/bench_default.err"
+echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-cfg5 --no-cfg2 > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 "$ROOT/bench.py" --no-cpu --no-cfg5 --no-cfg2 > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-cfg5 --no-cfg2 --steps 3 --warmup 1 > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-cfg5 --no-cfg2 --steps 3 --warmup 1 > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
+echo "stats 1 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
+echo "stats 2 done"
+S="$B --no-e2e --steps 3 --warmup 1 --prewarm-ms 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $S > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $S > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+echo "pmc hbm done"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_sq1" -- python3 $S > "$OUT/pmc_sq1.json" 2> "$OUT/pmc_sq1.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq2" -- python3 $S > "$OUT/pmc_sq2.json" 2> "$OUT/pmc_sq2.err"
+echo "pmc sq done"
 # the traces are large: keep the stats and the counter tables only
-find "$OUT" -name '*kernel_trace.csv' -path '*score_only*' -delete
-find "$OUT" -name '*kernel_trace.csv' -path '*with_e2e*' -delete
-find "$OUT" -name '*kernel_trace.csv' -path '*pmc_*' -delete
-ls -R "$OUT" | head -50
+find "$OUT" -name '*kernel_trace.csv' -delete
+cd "$ROOT"
+echo "now run: python3 tools/collect_profiles.py $RND (in the build container, after gpurun merged gpurun_out/)"
+ls "$OUT" | head -40
