@@ -254,17 +254,26 @@ fromC(s::RhShape) =
 (sampling, fits, scoring, refit, invalidation, candidate liveness on the GPU; `sampling_streams = 1`
 draws every minimal set from its own counter-based stream so that whole windows of iterations run
 on the device).  Same return value as `ransac`.
+`mp`: a handle from `mp_open` -- the loop is then run by all processes of that group together on this one
+scene (`rh_ransac_mp`: one process per GPU of a node, every one with the same cloud; the minimal sets of every
+iteration are dealt round-robin to the ranks); every rank gets the single-process result.
 """
-function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_streams::Integer = 1)
+function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_streams::Integer = 1, mp::Ptr{Cvoid} = C_NULL)
     pc = h.pc
     push_enabled!(h)
     cp = Ref(toC(params; sampling_streams = sampling_streams))
     rng = Ref(RhRng((0, 0, 0, 0), C_NULL, 0, 0, 0))
     ccall((:rh_rng_seed, LIB), Cvoid, (Ptr{RhRng}, UInt64), rng, UInt64(seed))
     res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL))
-    GC.@preserve pc check(ccall((:rh_ransac, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
-        h.handle, pointer(reinterpret(Cdouble, pc.vertices)), pointer(reinterpret(Cdouble, pc.normals)), cp, rng, res))
+    if mp == C_NULL
+        GC.@preserve pc check(ccall((:rh_ransac, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
+            h.handle, pointer(reinterpret(Cdouble, pc.vertices)), pointer(reinterpret(Cdouble, pc.normals)), cp, rng, res))
+    else
+        GC.@preserve pc check(ccall((:rh_ransac_mp, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{Cvoid}, Ptr{RhResult}),
+            h.handle, pointer(reinterpret(Cdouble, pc.vertices)), pointer(reinterpret(Cdouble, pc.normals)), cp, rng, mp, res))
+    end
     extracted = ExtractedShape[]
     for i in 1:res[].n_shapes
         e = unsafe_load(res[].shapes, i)
@@ -275,5 +284,14 @@ function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_strea
     pull_enabled!(h)          # the cloud's isenabled now reflects the extractions
     return extracted, secs
 end
+
+# the processes of one node that share a scene (collective: every rank calls it with the same name; rank 0 creates
+# the shared-memory segment).  `MPI.Comm_rank` / `Comm_size` or the launcher's environment give rank and world.
+function mp_open(name::AbstractString, rank::Integer, world::Integer; slot_bytes::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rh_mp_open, LIB), Cint, (Cstring, Int32, Int32, Int64, Ptr{Ptr{Cvoid}}), name, rank, world, slot_bytes, h))
+    return h[]
+end
+mp_close(mp::Ptr{Cvoid}) = ccall((:rh_mp_close, LIB), Cint, (Ptr{Cvoid},), mp)
 
 end # module
