@@ -120,6 +120,15 @@ void rh_shape_finalize(rh_shape *s);
  * subset order; all points start enabled (src/octree.jl:84). */
 int rh_cloud_create(const double *xyz_aos, const double *nrm_aos, int64_t n,
                     const int64_t *subset1_idx_1based, int64_t s, int device, rh_cloud **out);
+/* RANSACCloud(...; force_eltype = Float32) (src/octree.jl:102-109): xyz_aos / nrm_aos are Julia's
+ * Vector{SVector{3,Float32}} memory as is.  On such a cloud rh_score_batch(_dev), rh_refit, rh_invalidate,
+ * rh_select_enabled and the enabled-bit calls work and every per-point operation is a binary32 operation (the shapes'
+ * fields are rounded to binary32 on entry; rh_shape_finalize_f32 prepares a Float32 shape: fields rounded, the cone's
+ * cos / sin as binary32); eps and cos_alpha stay doubles and are compared after exact promotion, like Julia compares a
+ * Float32 with a Float64.  rh_ransac and rh_refit_lsq are Float64-only. */
+int rh_cloud_create_f32(const float *xyz_aos, const float *nrm_aos, int64_t n,
+                        const int64_t *subset1_idx_1based, int64_t s, int device, rh_cloud **out);
+void rh_shape_finalize_f32(rh_shape *s);
 int rh_cloud_destroy(rh_cloud *c);
 int rh_cloud_info(const rh_cloud *c, int64_t *n, int64_t *s, int *device);
 /* pc.isenabled (BitVector.chunks) in / out; nchunks must be ceil(n/64) */

@@ -90,7 +90,7 @@ def build(force=False):
 
 
 def _build_target(so, force=False):
-    deps = [os.path.join(_HERE, f) for f in ("ransac_oracle.c", "ransac_oracle.h", "orc_trig.h", "Makefile")]
+    deps = [os.path.join(_HERE, f) for f in ("ransac_oracle.c", "orc_f32.c", "ransac_oracle.h", "orc_trig.h", "Makefile")]
     if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
         return so
     subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
@@ -139,6 +139,17 @@ def _bind(L):
         "orc_compatible": (C.c_int, [sp, dp, dp, C.c_double, C.c_double]),
         "orc_compat_values": (None, [sp, dp, dp, dp]),
         "orc_variant": (C.c_int, []),
+        "orc32_shape_finalize": (None, [sp]),
+        "orc32_compatible": (C.c_int, [sp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double, C.c_double]),
+        "orc32_cloud_create": (C.c_void_p, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64, i64p, C.c_int64]),
+        "orc32_cloud_destroy": (None, [C.c_void_p]),
+        "orc32_cloud_enable_all": (None, [C.c_void_p]),
+        "orc32_cloud_set_enabled": (None, [C.c_void_p, u64p, C.c_int64]),
+        "orc32_cloud_get_enabled": (None, [C.c_void_p, u64p, C.c_int64]),
+        "orc32_scorecandidate": (C.c_int64, [C.c_void_p, sp, pp, i64p, u64p]),
+        "orc32_score_masks_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p, C.c_int32]),
+        "orc32_refit": (C.c_int64, [C.c_void_p, sp, pp, i64p, C.c_int64]),
+        "orc32_invalidate": (None, [C.c_void_p, i64p, C.c_int64]),
         "orc_score_masks_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p, C.c_int32]),
         "orc_margin_census_mt": (None, [C.c_void_p, sp, C.c_int32, pp, dp, C.c_int, i64p, C.c_int32]),
         "orc_confidence_interval": (C.c_int, [C.c_double, C.c_double, C.POINTER(CI)]),
@@ -358,6 +369,77 @@ class Cloud:
             out["shapes"].append({"shape": sh, "inpoints": idx, "score_E": e.score_E, "iteration": e.iteration})
         self.L.orc_result_free(C.byref(res))
         return out
+
+
+class Cloud32:
+    """The Float32 twin of Cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): orc_f32.c."""
+
+    def __init__(self, xyz, nrm, subset1_1based):
+        self.L = lib()
+        self.xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self.nrm = np.ascontiguousarray(nrm, dtype=np.float32).reshape(-1, 3)
+        self.subset1 = np.ascontiguousarray(subset1_1based, dtype=np.int64)
+        self.n, self.s = self.xyz.shape[0], self.subset1.shape[0]
+        fp = C.POINTER(C.c_float)
+        self.h = self.L.orc32_cloud_create(self.xyz.ctypes.data_as(fp), self.nrm.ctypes.data_as(fp), self.n,
+                                           self.subset1.ctypes.data_as(C.POINTER(C.c_int64)), self.s)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc32_cloud_destroy(self.h)
+            self.h = None
+
+    @property
+    def nchunks(self):
+        return (self.n + 63) // 64
+
+    def set_enabled(self, chunks):
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64)
+        self.L.orc32_cloud_set_enabled(self.h, chunks.ctypes.data_as(C.POINTER(C.c_uint64)), chunks.size)
+
+    def get_enabled(self):
+        out = np.zeros(self.nchunks, dtype=np.uint64)
+        self.L.orc32_cloud_get_enabled(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size)
+        return out
+
+    def enable_all(self):
+        self.L.orc32_cloud_enable_all(self.h)
+
+    def score_batch(self, shapes, params, want_masks=False, nthreads=8):
+        b = len(shapes)
+        arr = shapes if isinstance(shapes, C.Array) else shapes_array(shapes)
+        counts = np.zeros(max(1, b), dtype=np.int32)
+        w = (self.s + 63) // 64
+        masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64) if want_masks else None
+        self.L.orc32_score_masks_mt(self.h, arr, b, C.byref(params), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    masks.ctypes.data_as(C.POINTER(C.c_uint64)) if want_masks else None, nthreads)
+        return (counts[:b], masks[:b, :w]) if want_masks else counts[:b]
+
+    def refit(self, shape, params):
+        out = np.zeros(max(1, self.n), dtype=np.int64)
+        cnt = self.L.orc32_refit(self.h, C.byref(shape), C.byref(params), out.ctypes.data_as(C.POINTER(C.c_int64)), self.n)
+        return out[:cnt].copy()
+
+    def invalidate(self, idx_1based):
+        idx = np.ascontiguousarray(idx_1based, dtype=np.int64)
+        self.L.orc32_invalidate(self.h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size)
+
+
+def make_shape32(kind, outwards, v):
+    """A Float32 shape: fields rounded to binary32, the cone's cos / sin as binary32."""
+    s = Shape()
+    s.kind = kind
+    s.outwards = int(bool(outwards))
+    for i, x in enumerate(v):
+        s.v[i] = float(x)
+    lib().orc32_shape_finalize(C.byref(s))
+    return s
+
+
+def compatible32(shape, p, n, eps, cos_alpha):
+    p, n = np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(n, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    return bool(lib().orc32_compatible(C.byref(shape), p.ctypes.data_as(fp), n.ctypes.data_as(fp), eps, cos_alpha))
 
 
 def fit(kind, p, n, params):

@@ -1,0 +1,254 @@
+/*
+ * orc_f32.c -- CPU oracle for Float32 clouds (TEST INFRASTRUCTURE ONLY; see ransac_oracle.h).
+ *
+ * The reference builds a cloud of SVector{3,Float32} when asked to (RANSACCloud(...; force_eltype = Float32),
+ * src/octree.jl:102-109); shapes fitted to such a cloud are Float32 as well, so every operation of the four
+ * compatibles* (plane.jl:114-130 + project2plane :82-95, sphere.jl:144-172, cylinder.jl:194-221, cone.jl:132-153 +
+ * project2cone :68-85 + rodrigues utilities.jl:19-24,32-43,61-64) is a binary32 operation in the same order as the
+ * binary64 path.  The parameters stay what the caller made them: eps and cos(alpha) are Float64 unless
+ * setfloattype (utilities.jl:488-504) converted them, and Julia compares a Float32 with a Float64 after promoting the
+ * Float32 exactly -- here: the binary32 result is converted to double and compared with the double threshold (a
+ * caller with Float32 parameters passes their values).  cos / sin of -opang/2 are host-computed (orc_shape v[7], v[8])
+ * like in the binary64 path; orc32_shape_finalize rounds the oracle's binary64 values to binary32.
+ *
+ * This file is the binary32 twin of the per-point part of ransac_oracle.c: the same statements with `float`.
+ * Shapes arrive as orc_shape (double fields); every field is converted to float on entry (exact for values that are
+ * binary32 numbers, which is what a Float32 shape holds).  Build: -ffp-contract=off, no double promotion anywhere in
+ * the arithmetic (every literal is a float literal).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "orc_trig.h"
+#include "ransac_oracle.h"
+
+typedef struct { float x, y, z; } f3;
+
+static inline f3 F(const float *p) { f3 r = { p[0], p[1], p[2] }; return r; }
+static inline f3 Fd(const double *p) { f3 r = { (float)p[0], (float)p[1], (float)p[2] }; return r; }
+static inline f3 fsub(f3 a, f3 b) { f3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+static inline f3 fscale(f3 a, float s) { f3 r = { a.x * s, a.y * s, a.z * s }; return r; }
+static inline f3 fneg(f3 a) { f3 r = { -a.x, -a.y, -a.z }; return r; }
+static inline float fdot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float fnorm(f3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+static inline f3 fnormalize(f3 a) { float inv = 1.0f / fnorm(a); f3 r = { inv * a.x, inv * a.y, inv * a.z }; return r; }
+static inline f3 fcross(f3 a, f3 b)
+{
+    f3 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+    return r;
+}
+
+void orc32_shape_finalize(orc_shape *s)
+{
+    for (int i = 0; i < 7; i++) s->v[i] = (double)(float)s->v[i];   /* a Float32 shape holds binary32 numbers */
+    if (s->kind == ORC_CONE) {
+        /* rodriguesrad(rot_ax, -cone.opang/2) on a Float32 opang: cos / sin of a Float32 are Float32 */
+        float th = -(float)s->v[6] / 2.0f;
+        s->v[7] = (double)(float)orc_cos((double)th);
+        s->v[8] = (double)(float)orc_sin((double)th);
+    }
+}
+
+/* compatiblesPlane: plane.jl:114-130, project2plane :82-95, isparallel utilities.jl:115-117 */
+static int compat_plane32(const orc_shape *s, f3 p, f3 n, double eps, double cosa)
+{
+    f3 point = Fd(&s->v[0]), normal = Fd(&s->v[3]);
+    f3 o_z = fnormalize(normal);
+    float d = fdot(o_z, fsub(p, point));
+    return ((double)fdot(normal, n) > cosa) && ((double)fabsf(d) < eps);
+}
+
+/* compatiblesSphere: sphere.jl:144-172 */
+static int compat_sphere32(const orc_shape *s, f3 p, f3 n, double eps, double cosa)
+{
+    f3 o = Fd(&s->v[0]);
+    float R = (float)s->v[3];
+    if (s->outwards)
+        return ((double)fdot(fnormalize(fsub(p, o)), n) > cosa) && ((double)fabsf(fnorm(fsub(p, o)) - R) < eps);
+    else
+        return ((double)fdot(fnormalize(fsub(o, p)), n) > cosa) && ((double)fabsf(fnorm(fsub(p, o)) - R) < eps);
+}
+
+/* compatiblesCylinder: cylinder.jl:194-221 */
+static int compat_cylinder32(const orc_shape *s, f3 p, f3 n, double eps, double cosa)
+{
+    f3 a = Fd(&s->v[0]), c = Fd(&s->v[3]);
+    float R = (float)s->v[6];
+    f3 curr_norm = fsub(fsub(p, fscale(a, fdot(a, fsub(p, c)))), c);
+    if ((double)fabsf(fnorm(curr_norm) - R) < eps) {
+        if (s->outwards)
+            return (double)fdot(fnormalize(curr_norm), n) > cosa;
+        else
+            return (double)fdot(fneg(fnormalize(curr_norm)), n) > cosa;
+    }
+    return 0;
+}
+
+/* project2cone: cone.jl:68-85 with rodriguesrad / rodrigues / pluscrossprod! utilities.jl:61-64, 19-24, 32-43 */
+static void project2cone32(const orc_shape *s, f3 p, float *dist, f3 *normal)
+{
+    f3 apex = Fd(&s->v[0]), axis = Fd(&s->v[3]);
+    const float c = (float)s->v[7], sn = (float)s->v[8];
+    f3 to_point = fsub(apex, p);
+    f3 to_pointn = fnormalize(to_point);
+    f3 rot_ax = fnormalize(fcross(axis, to_pointn));
+    f3 comp_n = fnormalize(fcross(axis, rot_ax));
+    f3 nvn = fnormalize(rot_ax);                       /* rodriguesrad re-normalizes the axis */
+    float nv[3] = { nvn.x, nvn.y, nvn.z }, R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            float nn = nv[i] * nv[j];
+            float id = (i == j) ? 1.0f : 0.0f;
+            R[i * 3 + j] = nn + c * (id - nn);
+        }
+    R[0 * 3 + 1] -= sn * nv[2];
+    R[0 * 3 + 2] += sn * nv[1];
+    R[1 * 3 + 0] += sn * nv[2];
+    R[1 * 3 + 2] -= sn * nv[0];
+    R[2 * 3 + 0] -= sn * nv[1];
+    R[2 * 3 + 1] += sn * nv[0];
+    f3 rc = {
+        (R[0] * comp_n.x + R[1] * comp_n.y) + R[2] * comp_n.z,
+        (R[3] * comp_n.x + R[4] * comp_n.y) + R[5] * comp_n.z,
+        (R[6] * comp_n.x + R[7] * comp_n.y) + R[8] * comp_n.z,
+    };
+    f3 current_normal = fnormalize(rc);
+    *dist = fdot(fneg(current_normal), fneg(to_point));
+    *normal = current_normal;
+}
+
+/* compatiblesCone: cone.jl:132-153 */
+static int compat_cone32(const orc_shape *s, f3 p, f3 n, double eps, double cosa)
+{
+    float dist;
+    f3 cn;
+    project2cone32(s, p, &dist, &cn);
+    if (s->outwards)
+        return ((double)fdot(cn, n) > cosa) && ((double)fabsf(dist) < eps);
+    else
+        return ((double)fdot(fneg(cn), n) > cosa) && ((double)fabsf(dist) < eps);
+}
+
+static inline int compat32(const orc_shape *s, f3 p, f3 n, double eps, double cosa)
+{
+    switch (s->kind) {
+    case ORC_PLANE: return compat_plane32(s, p, n, eps, cosa);
+    case ORC_SPHERE: return compat_sphere32(s, p, n, eps, cosa);
+    case ORC_CYLINDER: return compat_cylinder32(s, p, n, eps, cosa);
+    case ORC_CONE: return compat_cone32(s, p, n, eps, cosa);
+    }
+    return 0;
+}
+
+int orc32_compatible(const orc_shape *s, const float p[3], const float n[3], double eps, double cos_alpha)
+{
+    return compat32(s, F(p), F(n), eps, cos_alpha);
+}
+
+/* ------------------------------------------------------------------ cloud */
+struct orc_cloud32 {
+    int64_t n, s, nchunks;
+    float *xyz, *nrm;    /* AoS, like Vector{SVector{3,Float32}} */
+    int64_t *subset1;    /* 1-based */
+    uint64_t *enabled;
+};
+
+orc_cloud32 *orc32_cloud_create(const float *xyz, const float *nrm, int64_t n, const int64_t *subset1, int64_t s)
+{
+    orc_cloud32 *c = (orc_cloud32 *)calloc(1, sizeof *c);
+    c->n = n;
+    c->s = s;
+    c->nchunks = (n + 63) / 64;
+    c->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    c->nrm = (float *)malloc(sizeof(float) * 3 * (size_t)(n ? n : 1));
+    memcpy(c->xyz, xyz, sizeof(float) * 3 * (size_t)n);
+    memcpy(c->nrm, nrm, sizeof(float) * 3 * (size_t)n);
+    c->subset1 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(s ? s : 1));
+    memcpy(c->subset1, subset1, sizeof(int64_t) * (size_t)s);
+    c->enabled = (uint64_t *)calloc((size_t)(c->nchunks ? c->nchunks : 1), 8);
+    orc32_cloud_enable_all(c);
+    return c;
+}
+
+void orc32_cloud_destroy(orc_cloud32 *c)
+{
+    if (!c) return;
+    free(c->xyz); free(c->nrm); free(c->subset1); free(c->enabled);
+    free(c);
+}
+
+void orc32_cloud_enable_all(orc_cloud32 *c)
+{
+    for (int64_t i = 0; i < c->nchunks; i++) c->enabled[i] = ~0ULL;
+    if (c->n % 64) c->enabled[c->nchunks - 1] = (~0ULL) >> (64 - c->n % 64);
+}
+
+void orc32_cloud_set_enabled(orc_cloud32 *c, const uint64_t *chunks, int64_t nchunks)
+{
+    int64_t m = nchunks < c->nchunks ? nchunks : c->nchunks;
+    memcpy(c->enabled, chunks, 8 * (size_t)m);
+    if (c->n % 64 && m == c->nchunks) c->enabled[c->nchunks - 1] &= (~0ULL) >> (64 - c->n % 64);
+}
+
+void orc32_cloud_get_enabled(const orc_cloud32 *c, uint64_t *chunks, int64_t nchunks)
+{
+    int64_t m = nchunks < c->nchunks ? nchunks : c->nchunks;
+    memcpy(chunks, c->enabled, 8 * (size_t)m);
+}
+
+static inline int is_enabled32(const orc_cloud32 *c, int64_t i0) { return (int)((c->enabled[i0 >> 6] >> (i0 & 63)) & 1); }
+
+/* scorecandidate: plane.jl:61-71, sphere.jl:118-134 (Q4: ignores isenabled), cylinder.jl:172-183, cone.jl:155-167 */
+int64_t orc32_scorecandidate(const orc_cloud32 *c, const orc_shape *s, const orc_params *p, int64_t *inpoints, uint64_t *mask)
+{
+    double eps = p->eps[s->kind], cosa = p->cos_alpha[s->kind];
+    int use_en = (s->kind != ORC_SPHERE) || p->sphere_uses_enabled;
+    int64_t cnt = 0;
+    if (mask) memset(mask, 0, 8 * (size_t)((c->s + 63) / 64));
+    for (int64_t j = 0; j < c->s; j++) {
+        int64_t i0 = c->subset1[j] - 1;
+        int ok = compat32(s, F(&c->xyz[3 * i0]), F(&c->nrm[3 * i0]), eps, cosa);
+        if (use_en) ok = ok & is_enabled32(c, i0);
+        if (ok) {
+            if (inpoints) inpoints[cnt] = i0 + 1;
+            if (mask) mask[j >> 6] |= 1ULL << (j & 63);
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+void orc32_score_masks_mt(const orc_cloud32 *c, const orc_shape *s, int32_t b, const orc_params *p, int32_t *counts,
+                          uint64_t *masks, int32_t nthreads)
+{
+    int64_t w = (c->s + 63) / 64;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (int32_t i = 0; i < b; i++)
+        counts[i] = (int32_t)orc32_scorecandidate(c, &s[i], p, NULL, masks ? masks + (size_t)i * w : NULL);
+}
+
+/* refit: plane.jl:137-143, sphere.jl:179-190, cylinder.jl:228-234, cone.jl:176-182 */
+int64_t orc32_refit(const orc_cloud32 *c, const orc_shape *s, const orc_params *p, int64_t *idx_out, int64_t cap)
+{
+    double eps = p->eps[s->kind], cosa = p->cos_alpha[s->kind];
+    int64_t cnt = 0;
+    for (int64_t i0 = 0; i0 < c->n; i0++) {
+        if (!is_enabled32(c, i0)) continue;
+        if (compat32(s, F(&c->xyz[3 * i0]), F(&c->nrm[3 * i0]), eps, cosa)) {
+            if (cnt < cap) idx_out[cnt] = i0 + 1;
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+/* invalidate_indexes!: fitting.jl:197-202 */
+void orc32_invalidate(orc_cloud32 *c, const int64_t *idx, int64_t n)
+{
+    for (int64_t k = 0; k < n; k++) {
+        int64_t i0 = idx[k] - 1;
+        c->enabled[i0 >> 6] &= ~(1ULL << (i0 & 63));
+    }
+}

@@ -142,6 +142,23 @@ int orc_refit_lsq(const orc_cloud *c, const orc_shape *s, const orc_params *p, i
 /* k-th (1-based) enabled point in ascending index order, 1-based; 0 if none */
 int64_t orc_select_enabled(const orc_cloud *c, int64_t k);
 
+/* ---- Float32 clouds (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): orc_f32.c, the binary32 twin of the
+ *      per-point part.  Shapes are orc_shape whose fields hold binary32 numbers (orc32_shape_finalize rounds them and
+ *      fills the cone's cos / sin as binary32); eps / cos_alpha stay double and are compared after exact promotion. ---- */
+typedef struct orc_cloud32 orc_cloud32;
+void orc32_shape_finalize(orc_shape *s);
+int orc32_compatible(const orc_shape *s, const float p[3], const float n[3], double eps, double cos_alpha);
+orc_cloud32 *orc32_cloud_create(const float *xyz, const float *nrm, int64_t n, const int64_t *subset1_1based, int64_t s);
+void orc32_cloud_destroy(orc_cloud32 *c);
+void orc32_cloud_enable_all(orc_cloud32 *c);
+void orc32_cloud_set_enabled(orc_cloud32 *c, const uint64_t *chunks, int64_t nchunks);
+void orc32_cloud_get_enabled(const orc_cloud32 *c, uint64_t *chunks, int64_t nchunks);
+int64_t orc32_scorecandidate(const orc_cloud32 *c, const orc_shape *s, const orc_params *p, int64_t *inpoints, uint64_t *mask);
+void orc32_score_masks_mt(const orc_cloud32 *c, const orc_shape *s, int32_t b, const orc_params *p, int32_t *counts,
+                          uint64_t *masks /* or NULL */, int32_t nthreads);
+int64_t orc32_refit(const orc_cloud32 *c, const orc_shape *s, const orc_params *p, int64_t *idx_out, int64_t cap);
+void orc32_invalidate(orc_cloud32 *c, const int64_t *idx_1based, int64_t n);
+
 /* ---- minimal-set fits: p,n are lp x 3 AoS; return 1 = fitted, 0 = nothing ---- */
 int orc_fit(int kind, const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out);
 int orc_fit2pointsphere(const double *v, const double *n, const orc_params *prm, orc_shape *out);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "rh_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rh_cloud_sync": (C.c_int, [_vp]),
     "rh_dev_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "rh_cloud_create_f32": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "rh_shape_finalize_f32": (None, [C.POINTER(Shape)]),
     "rh_mp_open": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_vp)]),
     "rh_mp_close": (C.c_int, [_vp]),
     "rh_mp_allgather": (C.c_int, [_vp, _vp, C.c_int64, _vp]),

@@ -270,7 +270,16 @@ class RANSACCloud:
     normals, subset 1 and the enabled bits live in HBM on `device`; the host keeps the arrays
     it was given (for the O(1) minimal-set fits) and the subset index lists."""
 
-    def __init__(self, vertices, normals, subsets, device=0, seed=None):
+    def __init__(self, vertices, normals, subsets, device=0, seed=None, force_eltype=None):
+        """force_eltype = numpy.float32: a Float32 cloud (octree.jl:102-109) -- scoring and refit then compute in
+        binary32 like the reference does on such a cloud; rh_ransac / refit_lsq stay Float64-only."""
+        self.is_f32 = force_eltype is not None and np.dtype(force_eltype) == np.float32
+        if force_eltype is not None and not self.is_f32 and np.dtype(force_eltype) != np.float64:
+            raise ValueError("force_eltype must be float32 or float64")
+        if self.is_f32:
+            self.vertices32 = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+            self.normals32 = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+            vertices, normals = self.vertices32.astype(np.float64), self.normals32.astype(np.float64)
         self.vertices = _f64(vertices).reshape(-1, 3)
         self.normals = _f64(normals).reshape(-1, 3)
         assert self.vertices.shape == self.normals.shape, "Every point must have a normal."
@@ -287,8 +296,12 @@ class RANSACCloud:
         self.device = device
         h = C.c_void_p()
         s1 = self.subsets[0]
-        check(lib().rh_cloud_create(_p(self.vertices, C.c_double), _p(self.normals, C.c_double), self.size,
-                                    _p(s1, C.c_int64), s1.size, device, C.byref(h)))
+        if self.is_f32:
+            check(lib().rh_cloud_create_f32(_p(self.vertices32, C.c_float), _p(self.normals32, C.c_float), self.size,
+                                            _p(s1, C.c_int64), s1.size, device, C.byref(h)))
+        else:
+            check(lib().rh_cloud_create(_p(self.vertices, C.c_double), _p(self.normals, C.c_double), self.size,
+                                        _p(s1, C.c_int64), s1.size, device, C.byref(h)))
         self._h = h
 
     def __del__(self):
@@ -360,18 +373,28 @@ def fit(T, p, n, pc, params):
     return shape_from_c(out) if ok.value else None
 
 
-def _shape_array(cands):
+def _shape_array(cands, f32=False):
     arr = (L.Shape * max(1, len(cands)))()
     for i, s in enumerate(cands):
         arr[i] = s if isinstance(s, L.Shape) else s.to_c()
+        if f32:
+            lib().rh_shape_finalize_f32(C.byref(arr[i]))
     return arr
+
+
+def shape_f32(s):
+    """The Float32 form of a shape (what `fit` returns on a Float32 cloud): fields rounded to binary32, a cone's
+    cos / sin of -opang/2 as binary32 (rh_shape_finalize_f32).  Returns the C record."""
+    cs = L.Shape.from_buffer_copy(bytes(s if isinstance(s, L.Shape) else s.to_c()))
+    lib().rh_shape_finalize_f32(C.byref(cs))
+    return cs
 
 
 def score_batch(pc, candidates, params, want_masks=False):
     """One launch for the whole batch, all shape kinds (replaces the loop of scorecandidates!,
     fitting.jl:181-190).  Returns counts[b] (and masks[b, ceil(S/64)] over subset positions)."""
     b = len(candidates)
-    arr = candidates if isinstance(candidates, C.Array) else _shape_array(candidates)
+    arr = candidates if isinstance(candidates, C.Array) else _shape_array(candidates, getattr(pc, "is_f32", False))
     counts = np.zeros(max(1, b), dtype=np.int32)
     w = (pc.subsets[0].size + 63) // 64
     masks = np.zeros((max(1, b), max(1, w)), dtype=np.uint64) if want_masks else None
@@ -514,7 +537,7 @@ def refit(s, pc, params):
     """refit(s, pc, params) -> ExtractedShape (shapes/plane.jl:137-143 ...)."""
     out = np.zeros(max(1, pc.size), dtype=np.int64)
     n = C.c_int64()
-    cs = s if isinstance(s, L.Shape) else s.to_c()
+    cs = s if isinstance(s, L.Shape) else (shape_f32(s) if getattr(pc, "is_f32", False) else s.to_c())
     check(lib().rh_refit(pc._h, C.byref(cs), C.byref(_cparams(params)), _p(out, C.c_int64), pc.size, C.byref(n)))
     return ExtractedShape(s if not isinstance(s, L.Shape) else shape_from_c(s), out[: n.value].copy())
 

@@ -88,6 +88,11 @@ int rh_ensure_batch(rh_cloud *c, int64_t b)
     RH_TRY(dev_alloc(&c->d_prep, 4 * cap));
     RH_TRY(dev_alloc(&c->d_orig, 4 * cap));
     RH_TRY(dev_alloc(&c->d_counts, cap));
+    if (c->f32) {
+        (void)hipFree(c->d_prep32);
+        c->d_prep32 = nullptr;
+        RH_HIP(hipMalloc(&c->d_prep32, (size_t)(4 * cap) * 12 * sizeof(float)));
+    }
     c->batch_cap = cap;
     return RH_OK;
 }
@@ -138,6 +143,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
+    (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
     (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb);
@@ -460,6 +466,31 @@ extern "C" int rh_cloud_destroy(rh_cloud *c)
     return RH_OK;
 }
 
+// RANSACCloud(vertices, normals, subsets; force_eltype = Float32) (src/octree.jl:102-109): xyz / nrm are Julia's
+// Vector{SVector{3,Float32}} memory as is.  The cloud is built like a Float64 cloud from the exactly converted values
+// (k-d leaf order, boxes, enabled bits, index plumbing) and gets float copies of its two point sets on top; scoring and
+// refit then compute in binary32 (f32.hip).
+extern "C" int rh_cloud_create_f32(const float *xyz, const float *nrm, int64_t n, const int64_t *subset1, int64_t s, int device,
+                                   rh_cloud **out)
+{
+    if (!out) { rh_set_error("out is NULL"); return RH_E_INVALID; }
+    *out = nullptr;
+    if (n < 0 || (n > 0 && (!xyz || !nrm))) { rh_set_error("rh_cloud_create_f32: bad arguments"); return RH_E_INVALID; }
+    std::vector<double> x64((size_t)(3 * n)), n64((size_t)(3 * n));
+    for (int64_t i = 0; i < 3 * n; i++) { x64[(size_t)i] = (double)xyz[i]; n64[(size_t)i] = (double)nrm[i]; }
+    rh_cloud *c = nullptr;
+    RH_TRY(rh_cloud_create(x64.data(), n64.data(), n, subset1, s, device, &c));
+    c->f32 = true;
+    c->use_groups = false;   // the culled scorer is Float64-only: Float32 clouds are scored by the brute-force float kernel
+    int rc = dev_alloc(&c->full32, 6 * std::max<int64_t>(c->n_pad, 1));
+    if (rc == RH_OK) rc = dev_alloc(&c->sub32, 6 * std::max<int64_t>(c->s_pad, 1));
+    if (rc == RH_OK) rc = rhk_f32_build(c);
+    if (rc == RH_OK && hipStreamSynchronize(c->stream) != hipSuccess) { rh_set_error("rh_cloud_create_f32: device error"); rc = RH_E_NODEVICE; }
+    if (rc != RH_OK) { cloud_free(c); return rc; }
+    *out = c;
+    return RH_OK;
+}
+
 extern "C" int rh_cloud_info(const rh_cloud *c, int64_t *n, int64_t *s, int *device)
 {
     if (!c) { rh_set_error("cloud is NULL"); return RH_E_INVALID; }
@@ -551,6 +582,15 @@ static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_p
                              const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], int32_t total_bound,
                              int32_t *d_counts, uint64_t *d_masks_int, float *ms_kind)
 {
+    if (c->f32) {   // Float32 cloud: float records from the batch's shapes, float kernels (f32.hip)
+        if (c->f32_shapes == nullptr) { rh_set_error("internal: Float32 scoring without the batch's shapes"); return RH_E_INTERNAL; }
+        const uint64_t *en[4];
+        for (int k = 0; k < 4; k++) en[k] = enabled_for_kind(c, k, p);
+        for (int k = 0; k < 4; k++)
+            if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
+        return rhk_score_all_f32(c, c->f32_shapes, c->f32_via_orig, en, d_orig, off, d_nk, nk_bound, p->eps, p->cos_alpha,
+                                 d_counts, d_masks_int);
+    }
     static int merged = -1;
     if (merged < 0) { const char *e = getenv("RH_SCORE_MERGED"); merged = e ? atoi(e) : 1; }
     if (c->use_groups && merged && !ms_kind) {
@@ -596,7 +636,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     // upload, score launch, read-back.  (Measured: 30 -> 23 us at b = 1, 38 -> 31 us at b = 15; from ~6 KB on the
     // single larger transfer is slower than three small ones, so larger batches upload shapes, positions and
     // bin sizes separately and a kernel prepares the records and zeroes the counts.)
-    const bool staged = b <= 32;
+    const bool staged = b <= 32 && !c->f32;   // (the staged form carries prepared Float64 records only)
     const size_t rec_bytes = sizeof(rh_prep) >= sizeof(rh_shape) ? sizeof(rh_prep) : sizeof(rh_shape);
     const size_t o_orig = (size_t)b * rec_bytes, o_nk = (o_orig + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
     const size_t o_counts = o_nk + 64, stage_bytes = o_counts + (size_t)b * sizeof(int32_t);
@@ -648,6 +688,8 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     const int64_t off64[4] = { off[0], off[1], off[2], off[3] };
+    c->f32_shapes = c->d_shapes;   // sorted like the bins
+    c->f32_via_orig = 0;
     RH_TRY(score_bins_subset(c, p, d_prep_use, d_orig_use, off64, d_nk_use, nk, b, d_counts_use, d_masks_int, nullptr));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     RH_HIP(hipMemcpyAsync(h_counts, d_counts_use, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
@@ -685,6 +727,8 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     const int64_t off[4] = { 0, c->batch_cap, 2 * (int64_t)c->batch_cap, 3 * (int64_t)c->batch_cap };
     const int32_t bound[4] = { b, b, b, b };
+    c->f32_shapes = d_shapes;      // the caller's order: the float records go through d_orig
+    c->f32_via_orig = 1;
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
         ms_kind[4] = 0.f;
         RH_HIP(hipEventRecord(c->evk[0], c->stream));
@@ -731,7 +775,8 @@ extern "C" int rh_refit(rh_cloud *c, const rh_shape *shape, const rh_params *p, 
     rh_prep_host(*shape, &P);
     c->select_valid = false;   // block_sums / d_total are shared with the select directory
     RH_HIP(hipEventRecord(c->evk[0], c->stream));
-    RH_TRY(rhk_refit_mask(c, P, shape->kind, p->eps[shape->kind], p->cos_alpha[shape->kind]));
+    if (c->f32) RH_TRY(rhk_refit_mask_f32(c, *shape, p->eps[shape->kind], p->cos_alpha[shape->kind]));
+    else RH_TRY(rhk_refit_mask(c, P, shape->kind, p->eps[shape->kind], p->cos_alpha[shape->kind]));
     RH_HIP(hipEventRecord(c->evk[1], c->stream));
     RH_TRY(rhk_compact_mask(c, c->refit_mask, c->nwords, c->idx_out, c->n, c->d_total));
     RH_HIP(hipEventRecord(c->evk[2], c->stream));

@@ -1233,6 +1233,7 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
 {
     if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
     memset(out, 0, sizeof *out);
+    if (c->f32) { rh_set_error("rh_ransac: Float32 clouds support rh_score_batch / rh_refit / rh_invalidate / rh_select_enabled only"); return RH_E_INVALID; }
     RH_TRY(rh_validate_params(p));
     if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
     if (p->drawN < 2 || p->drawN > 16) {   // @assert drawN > 1: src/fitting.jl:386

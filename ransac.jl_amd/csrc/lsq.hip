@@ -200,6 +200,7 @@ void frame(const double a[3], double e1[3], double e2[3])   // orthonormal e1, e
 extern "C" int rh_refit_lsq(rh_cloud *c, const rh_shape *shape, const rh_params *p, int32_t max_iter, rh_shape *out,
                             int64_t *n_used, double *rms, int32_t *iters_done)
 {
+    if (c && c->f32) { rh_set_error("rh_refit_lsq: not available on Float32 clouds"); return RH_E_INVALID; }
     if (!c || !shape || !p || !out) { rh_set_error("rh_refit_lsq: NULL argument"); return RH_E_INVALID; }
     if (shape->kind < 0 || shape->kind > 3) { rh_set_error("unknown shape kind %d", shape->kind); return RH_E_INVALID; }
     RH_TRY(rh_validate_params(p));

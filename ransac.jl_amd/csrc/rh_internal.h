@@ -133,6 +133,14 @@ struct rh_cloud {
     int64_t *d_ranks = nullptr;        // select in/out
     int64_t ranks_cap = 0;
 
+    // Float32 clouds (rh_cloud_create_f32; f32.hip): float copies of the two point sets and float candidate records
+    bool f32 = false;
+    float *full32 = nullptr;           // 6 planes x n_pad, original order (the refit scan streams these: 24 B per point)
+    float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
+    void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
+    const rh_shape *f32_shapes = nullptr;   // the batch being scored: its shapes on the device ...
+    int f32_via_orig = 0;                   // ... indexed through d_orig (caller's order) or directly (sorted like the bins)
+
     // rh_ransac_mp: this process's share of every iteration's minimal sets (set j belongs to rank j % world)
     int32_t mp_rank = 0, mp_world = 1;
 
@@ -182,6 +190,12 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_o
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
                          const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
+// Float32 clouds (f32.hip)
+int rhk_f32_build(rh_cloud *c);
+int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const uint64_t *const en[4], const int32_t *d_orig,
+                      const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], const double eps[4],
+                      const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
+int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa);
 int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts);
 int rhk_group_bounds(rh_cloud *c);

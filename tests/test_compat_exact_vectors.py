@@ -53,6 +53,20 @@ def test_oracle_and_every_rounding_variant_give_the_hand_derived_answers(variant
         assert got == c["expect"], (variant, c["name"], c["derivation"])
 
 
+def test_float32_oracle_twin_gives_the_hand_derived_answers():
+    """orc_f32.c (the binary32 twin used for Float32 clouds) on every vector whose numbers are binary32 numbers: the
+    exact ones have no rounding in binary32 either, the robust ones keep their margin."""
+    n = 0
+    for c in VEC["compat"]:
+        rep = all(float(np.float32(x)) == x for x in c["v"][:7] + c["p"] + c["n"])
+        if c["mode"] in ("exact", "exact_distance") and not rep:
+            continue   # 2^-50 offsets do not exist in binary32
+        s = orc.make_shape32(KIND[c["kind"]], c["outwards"], c["v"])
+        assert orc.compatible32(s, c["p"], c["n"], c["eps"], c["cos_alpha"]) == c["expect"], (c["name"], c["derivation"])
+        n += 1
+    assert n >= 30
+
+
 def _score_case_arrays(sc):
     pts, nrm = np.array(sc["points"], dtype=float), np.array(sc["normals"], dtype=float)
     en = np.ones(len(pts), dtype=bool)

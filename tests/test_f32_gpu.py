@@ -1,0 +1,188 @@
+"""Float32 clouds (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109) through the C ABI against the oracle's
+binary32 twin (oracle/orc_f32.c): counts, masks, refit index lists, enabled bits -- bit-exact.  On such a cloud every
+per-point operation is a binary32 operation; eps / cos(alpha) stay doubles and are compared after exact promotion."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import ransac_jl_amd as R
+from oracle import oracle as orc
+from ransac_jl_amd import _lib as L
+from ransac_jl_amd import synth
+
+pytestmark = pytest.mark.gpu
+KMAP = {"plane": 0, "sphere": 1, "cylinder": 2, "cone": 3}
+
+
+def shapes32(truth, b, seed):
+    arr = (L.Shape * b)()
+    for i, (name, outw, v) in enumerate(synth.jittered_candidates(truth, b, seed=seed)):
+        arr[i].kind = KMAP[name]
+        arr[i].outwards = int(outw)
+        for j, x in enumerate(v):
+            arr[i].v[j] = float(x)
+        R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
+    return arr
+
+
+def to_orc(arr, b):
+    out = (orc.Shape * max(1, b))()
+    C.memmove(out, arr, C.sizeof(L.Shape) * b)
+    return out
+
+
+@pytest.fixture(scope="module")
+def scene32():
+    prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder", "cone", "cone"]
+    xyz, nrm, truth = synth.make_cloud(70_000, prim, 0.2, seed=41)
+    x32, n32 = xyz.astype(np.float32), nrm.astype(np.float32)
+    subs = synth.make_subsets(70_000, 3, seed=41)
+    pc = R.RANSACCloud(x32, n32, subs, force_eltype=np.float32)
+    oc = orc.Cloud32(x32, n32, subs[0])
+    return pc, oc, truth, x32, n32, subs
+
+
+def test_shape_finalize_f32_matches_the_oracle():
+    rng = np.random.default_rng(3)
+    for op in list(rng.uniform(0.02, 3.1, 500)) + [0.5, 1.0, math.pi / 2]:
+        a = orc.make_shape32(orc.CONE, True, [1.1, 2.2, 3.3, 0.6, 0.64, 0.48, float(op)])
+        b = L.Shape()
+        b.kind = L.CONE
+        b.outwards = 1
+        for i, x in enumerate([1.1, 2.2, 3.3, 0.6, 0.64, 0.48, float(op)]):
+            b.v[i] = x
+        R.lib().rh_shape_finalize_f32(C.byref(b))
+        assert bytes(a) == bytes(b)
+        assert all(float(np.float32(b.v[i])) == b.v[i] for i in range(9))
+
+
+def test_f32_counts_masks_refit_all_kinds(scene32):
+    pc, oc, truth, x32, n32, subs = scene32
+    cp = R.params_to_c(R.ransacparameters())
+    op = orc.Params.from_buffer_copy(bytes(cp))
+    arr = shapes32(truth, 203, seed=5)
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc(arr, 203), op, want_masks=True)
+    assert counts.sum() > 10000
+    assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)                 # counts-only instantiation
+    for k in range(4):
+        sel = [i for i in range(203) if arr[i].kind == k]
+        assert counts[sel].max() > 300, "kind %d never scored inliers" % k
+    # the float path is not the double path on the same numbers: some counts differ from a Float64 cloud of the same values
+    pc64 = R.RANSACCloud(x32.astype(np.float64), n32.astype(np.float64), subs)
+    c64 = R.score_batch(pc64, arr, cp)
+    assert (c64 != counts).any() and np.abs(c64 - counts).max() < 50
+    # refit + invalidate, every kind, enabled bits in play
+    seen = np.zeros(len(x32), dtype=bool)
+    tarr = shapes32(truth, 8, seed=0)
+    for i, t in enumerate(truth):   # the ground-truth primitives themselves (the jittered ones miss their points)
+        v = {"plane": list(t.get("point", [])) + list(t.get("normal", [])),
+             "sphere": list(t.get("center", [])) + [t.get("radius", 0)],
+             "cylinder": list(t.get("axis", [])) + list(t.get("center", [])) + [t.get("radius", 0)],
+             "cone": list(t.get("apex", [])) + list(t.get("axis", [])) + [t.get("opang", 0)]}[t["kind"]]
+        tarr[i].kind, tarr[i].outwards = KMAP[t["kind"]], 1
+        for j, x in enumerate(v):
+            tarr[i].v[j] = float(x)
+        R.lib().rh_shape_finalize_f32(C.byref(tarr[i]))
+    for i in (0, 2, 4, 6, 1):
+        ex = R.refit(tarr[i], pc, cp)
+        assert np.array_equal(ex.inpoints, oc.refit(to_orc(tarr, 8)[i], op))
+        assert ex.inpoints.size > 500 and not seen[ex.inpoints - 1].any()
+        seen[ex.inpoints - 1] = True
+        R.invalidate_indexes(pc, ex.inpoints)
+        oc.invalidate(ex.inpoints)
+    assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
+    counts2, masks2 = R.score_batch(pc, arr, cp, want_masks=True)
+    oc2, om2 = oc.score_batch(to_orc(arr, 203), op, want_masks=True)
+    assert np.array_equal(counts2, oc2) and np.array_equal(masks2, om2)
+    # Q4: the sphere scorer ignores the enabled bits unless told otherwise
+    cpf = R.params_to_c(R.ransacparameters(), sphere_uses_enabled=True)
+    c3 = R.score_batch(pc, arr, cpf)
+    assert np.array_equal(c3, oc.score_batch(to_orc(arr, 203), orc.Params.from_buffer_copy(bytes(cpf))))
+    pc.enable_all(); oc.enable_all()
+
+
+@pytest.mark.parametrize("eps,alpha_deg,seed", [(0.3, 5.0, 0), (0.01, 1.0, 1), (5.0, 60.0, 2)])
+def test_f32_fuzz_arbitrary_candidates(scene32, eps, alpha_deg, seed):
+    pc, oc, truth, x32, n32, subs = scene32
+    pc.enable_all(); oc.enable_all()
+    rng = np.random.default_rng(2000 + seed)
+    kinds = {k: {"ϵ": eps, "α": math.radians(alpha_deg)} for k in ("plane", "sphere", "cylinder", "cone")}
+    cp = R.params_to_c(R.ransacparameters(**kinds))
+    b = 120
+    arr = (L.Shape * b)()
+    for i in range(b):
+        s = arr[i]
+        s.kind = i % 4
+        s.outwards = int(rng.integers(0, 2))
+        v = np.zeros(10)
+        v[0:3] = rng.uniform(-20, 120, 3)
+        d = rng.normal(size=3)
+        scale = [1.0, 1.0, 1e-3, 7.5][int(rng.integers(0, 4))]
+        if s.kind == L.PLANE:
+            v[3:6] = d / np.linalg.norm(d) * scale
+        elif s.kind == L.SPHERE:
+            v[3] = [0.01, 1.0, 10.0, 60.0, -3.0][int(rng.integers(0, 5))]
+        elif s.kind == L.CYLINDER:
+            v[0:3] = d / np.linalg.norm(d) * scale
+            v[3:6] = rng.uniform(-20, 120, 3)
+            v[6] = [0.01, 1.0, 8.0, 80.0][int(rng.integers(0, 4))]
+        else:
+            v[3:6] = d / np.linalg.norm(d) * scale
+            v[6] = rng.uniform(0.01, 3.1)
+        if i % 31 == 30:
+            v[int(rng.integers(0, 7))] = [float("nan"), float("inf"), 1e30][int(rng.integers(0, 3))]
+        for j in range(10):
+            s.v[j] = float(v[j])
+        R.lib().rh_shape_finalize_f32(C.byref(s))
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc(arr, b), orc.Params.from_buffer_copy(bytes(cp)), want_masks=True)
+    assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+
+
+def test_f32_device_batch_and_unsupported_calls(scene32):
+    pc, oc, truth, x32, n32, subs = scene32
+    pc.enable_all(); oc.enable_all()
+    from ransac_jl_amd import dist as rdist
+    import torch
+    cp = R.params_to_c(R.ransacparameters())
+    arr = shapes32(truth, 300, seed=9)
+    batch = rdist.DeviceBatch(pc, arr, 300)
+    counts = torch.zeros(300, dtype=torch.int32, device="cuda")
+    L.check(R.lib().rh_score_batch_dev(pc._h, batch.slice_ptr(0), 300, C.byref(cp), C.c_void_p(counts.data_ptr()), None))
+    L.check(R.lib().rh_cloud_sync(pc._h))
+    assert np.array_equal(counts.cpu().numpy(), oc.score_batch(to_orc(arr, 300), orc.Params.from_buffer_copy(bytes(cp))))
+    batch.free()
+    with pytest.raises(R.RansacHipError):
+        R.ransac(pc, cp, seed=1)
+    with pytest.raises(R.RansacHipError):
+        R.refit_lsq(arr[0], pc, cp)
+
+
+def test_f32_full_size_refit_halves_the_bytes():
+    """cfg3 at full size as a Float32 cloud: refit lists equal the oracle's on a plane and a cylinder; the scan streams
+    24 bytes per point."""
+    c = synth.config("cfg3")
+    x32, n32 = c["xyz"].astype(np.float32), c["nrm"].astype(np.float32)
+    subs = synth.make_subsets(len(x32), c["r"], c["seed"])
+    pc = R.RANSACCloud(x32, n32, subs, force_eltype=np.float32)
+    oc = orc.Cloud32(x32, n32, subs[0])
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder]))
+    op = orc.Params.from_buffer_copy(bytes(cp))
+    arr = shapes32(c["truth"], 80, seed=8)
+    for ti in (0, 30):   # a ground-truth plane and a ground-truth cylinder
+        t = c["truth"][ti]
+        sh = (R.FittedPlane(t["point"], t["normal"]) if t["kind"] == "plane" else
+              R.FittedCylinder(t["axis"], t["center"], t["radius"], True))
+        cs = R.shape_f32(sh)
+        ex = R.refit(cs, pc, cp)
+        assert ex.inpoints.size > 100_000
+        assert np.array_equal(ex.inpoints, oc.refit(orc.Shape.from_buffer_copy(bytes(cs)), op))
+    a, b = C.c_float(), C.c_float()
+    L.check(R.lib().rh_last_refit_ms(pc._h, C.byref(a), C.byref(b)))
+    assert a.value < 0.08          # the Float64 scan of the same cloud takes 0.081 ms
+    counts = R.score_batch(pc, arr, cp)
+    assert np.array_equal(counts, oc.score_batch(to_orc(arr, 80), op, nthreads=16))
