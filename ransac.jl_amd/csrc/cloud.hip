@@ -481,7 +481,8 @@ extern "C" int rh_cloud_create_f32(const float *xyz, const float *nrm, int64_t n
     rh_cloud *c = nullptr;
     RH_TRY(rh_cloud_create(x64.data(), n64.data(), n, subset1, s, device, &c));
     c->f32 = true;
-    c->use_groups = false;   // the culled scorer is Float64-only: Float32 clouds are scored by the brute-force float kernel
+    c->f32_groups = c->use_groups;   // culled kernel with a binary32 exact test where a Float64 cloud would use the culled kernel
+    c->use_groups = false;           // (the Float64 dispatch below never runs for this cloud)
     int rc = dev_alloc(&c->full32, 6 * std::max<int64_t>(c->n_pad, 1));
     if (rc == RH_OK) rc = dev_alloc(&c->sub32, 6 * std::max<int64_t>(c->s_pad, 1));
     if (rc == RH_OK) rc = rhk_f32_build(c);
@@ -588,6 +589,21 @@ static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_p
         for (int k = 0; k < 4; k++) en[k] = enabled_for_kind(c, k, p);
         for (int k = 0; k < 4; k++)
             if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
+        if (c->f32_groups) {   // the culled kernel with the exact test in binary32
+            int nmax = 0;
+            for (int k = 0; k < 4; k++) nmax = std::max(nmax, (int)nk_bound[k]);
+            RH_TRY(rhk_prep_f32(c, c->f32_shapes, c->f32_via_orig, d_orig, off, d_nk, nmax));
+            const rh_prep *pr[4];
+            const int32_t *og[4], *nk[4];
+            const void *p32[4];
+            for (int k = 0; k < 4; k++) {
+                pr[k] = d_prep + off[k];
+                og[k] = d_orig + off[k];
+                nk[k] = d_nk + k;
+                p32[k] = (const char *)c->d_prep32 + (size_t)off[k] * 12 * sizeof(float);
+            }
+            return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, p32);
+        }
         return rhk_score_all_f32(c, c->f32_shapes, c->f32_via_orig, en, d_orig, off, d_nk, nk_bound, p->eps, p->cos_alpha,
                                  d_counts, d_masks_int);
     }

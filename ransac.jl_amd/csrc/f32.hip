@@ -9,10 +9,11 @@
 // What a Float32 cloud has on the device: everything a Float64 cloud has (the points converted exactly to double feed the
 // k-d leaf order, the enabled-bit machinery, masks and index lists), plus float copies of the two point sets --
 // `full32` (original order, 24 bytes per point: what the refit scan streams, half the bytes of the Float64 scan) and
-// `sub32` (subset 1 in k-d leaf order) -- and float candidate records.  This round: batched scoring (brute force over
-// the float planes: a wave keeps 4 x 64 points in registers and walks 64-candidate tiles, records through scalar
-// loads), refit, masks, enabled bits.  The culled scorer, rh_ransac and rh_refit_lsq stay Float64-only (the culling
-// stages would need their conservative margins re-derived for binary32 rounding).
+// `sub32` (subset 1 in k-d leaf order) -- and float candidate records.  Batched scoring runs on the culled kernel of
+// kernels.hip with the exact test in binary32 (its box tests and band prefilter stay binary64 on the converted values,
+// with margins widened for binary32 rounding: box_slack32, score_device.h) from 8192 subset points on, and on the
+// brute-force float kernel below for smaller subsets (RH_SCORE_PATH=brute forces it); refit, masks and the enabled
+// bits work as on a Float64 cloud.  rh_ransac and rh_refit_lsq stay Float64-only.
 //
 // The four tests below are the float twins of score_device.h, statement by statement; the oracle's twin is
 // oracle/orc_f32.c.
@@ -20,124 +21,11 @@
 
 #include "det_math.h"
 #include "rh_internal.h"
+#include "score_device32.h"
 
 namespace {
 
-#define WB32(cond) __builtin_amdgcn_ballot_w64(cond)
-
-struct rh_prepf {
-    float f[12];
-};
-
-#define RH_CONST32 __attribute__((address_space(4)))
-__device__ __forceinline__ rh_prepf ld_prepf(const rh_prepf *p)
-{
-    const RH_CONST32 rh_prepf *q = (const RH_CONST32 rh_prepf *)(uintptr_t)p;   // wave-uniform: scalar loads
-    rh_prepf o;
-#pragma unroll
-    for (int i = 0; i < 12; i++) o.f[i] = q->f[i];
-    return o;
-}
-
-// plane: compatiblesPlane plane.jl:114-130 (+ project2plane :82-95), isparallel utilities.jl:115-117
-__device__ __forceinline__ uint64_t test_plane32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                                 double eps, double cosa)
-{
-    const float dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
-    const uint64_t mn = WB32((double)dn > cosa);
-    if (mn == 0) return 0;
-    const float vx = px - P.f[0], vy = py - P.f[1], vz = pz - P.f[2];
-    const float d = (P.f[6] * vx + P.f[7] * vy) + P.f[8] * vz;
-    return mn & WB32((double)fabsf(d) < eps);
-}
-
-// sphere: compatiblesSphere sphere.jl:144-172 (inward: sgn * dot, exact)
-__device__ __forceinline__ uint64_t test_sphere32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                                  double eps, double cosa)
-{
-    const float dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
-    const float nr = sqrtf((dx * dx + dy * dy) + dz * dz);
-    const uint64_t md = WB32((double)fabsf(nr - P.f[3]) < eps);
-    if (md == 0) return 0;
-    const float inv = 1.0f / nr;
-    const float ux = inv * dx, uy = inv * dy, uz = inv * dz;
-    const float dt = (ux * nx + uy * ny) + uz * nz;
-    return WB32((double)(P.f[4] * dt) > cosa) & md;
-}
-
-// cylinder: compatiblesCylinder cylinder.jl:194-221
-__device__ __forceinline__ uint64_t test_cylinder32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                                    double eps, double cosa)
-{
-    const float ax = P.f[0], ay = P.f[1], az = P.f[2];
-    const float cx = P.f[3], cy = P.f[4], cz = P.f[5];
-    const float tx = px - cx, ty = py - cy, tz = pz - cz;
-    const float sd = (ax * tx + ay * ty) + az * tz;
-    const float qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
-    const float nr = sqrtf((qx * qx + qy * qy) + qz * qz);
-    const uint64_t md = WB32((double)fabsf(nr - P.f[6]) < eps);
-    if (md == 0) return 0;
-    const float inv = 1.0f / nr;
-    const float ux = inv * qx, uy = inv * qy, uz = inv * qz;
-    const float dt = (ux * nx + uy * ny) + uz * nz;
-    return md & WB32((double)(P.f[7] * dt) > cosa);
-}
-
-// cone: compatiblesCone cone.jl:132-153, project2cone :68-85, rodriguesrad / rodrigues / pluscrossprod! utilities.jl:61-64,19-24,32-43
-__device__ __forceinline__ uint64_t test_cone32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                                double eps, double cosa)
-{
-    const float ax = P.f[3], ay = P.f[4], az = P.f[5];
-    const float c = P.f[6], s = P.f[7];
-    const float tx = P.f[0] - px, ty = P.f[1] - py, tz = P.f[2] - pz;
-    float inv = 1.0f / sqrtf((tx * tx + ty * ty) + tz * tz);
-    const float tnx = inv * tx, tny = inv * ty, tnz = inv * tz;
-    float kx = ay * tnz - az * tny, ky = az * tnx - ax * tnz, kz = ax * tny - ay * tnx;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float rx = inv * kx, ry = inv * ky, rz = inv * kz;
-    kx = ay * rz - az * ry; ky = az * rx - ax * rz; kz = ax * ry - ay * rx;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float mx = inv * kx, my = inv * ky, mz = inv * kz;
-    inv = 1.0f / sqrtf((rx * rx + ry * ry) + rz * rz);
-    const float vx = inv * rx, vy = inv * ry, vz = inv * rz;
-    const float nxx = vx * vx, nxy = vx * vy, nxz = vx * vz, nyy = vy * vy, nyz = vy * vz, nzz = vz * vz;
-    const float R00 = nxx + c * (1.0f - nxx);
-    float R01 = nxy + c * (0.0f - nxy);
-    float R02 = nxz + c * (0.0f - nxz);
-    float R10 = R01;
-    const float R11 = nyy + c * (1.0f - nyy);
-    float R12 = nyz + c * (0.0f - nyz);
-    float R20 = R02;
-    float R21 = R12;
-    const float R22 = nzz + c * (1.0f - nzz);
-    R01 -= s * vz; R02 += s * vy;
-    R10 += s * vz; R12 -= s * vx;
-    R20 -= s * vy; R21 += s * vx;
-    kx = (R00 * mx + R01 * my) + R02 * mz;
-    ky = (R10 * mx + R11 * my) + R12 * mz;
-    kz = (R20 * mx + R21 * my) + R22 * mz;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float gx = inv * kx, gy = inv * ky, gz = inv * kz;
-    const float dist = ((-gx) * (-tx) + (-gy) * (-ty)) + (-gz) * (-tz);
-    const float dt = (gx * nx + gy * ny) + gz * nz;
-    return WB32((double)(P.f[8] * dt) > cosa) & WB32((double)fabsf(dist) < eps);
-}
-
-template <int KIND>
-__device__ __forceinline__ uint64_t test_point32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                                 double eps, double cosa)
-{
-    if (KIND == RH_PLANE) return test_plane32(P, px, py, pz, nx, ny, nz, eps, cosa);
-    if (KIND == RH_SPHERE) return test_sphere32(P, px, py, pz, nx, ny, nz, eps, cosa);
-    if (KIND == RH_CYLINDER) return test_cylinder32(P, px, py, pz, nx, ny, nz, eps, cosa);
-    return test_cone32(P, px, py, pz, nx, ny, nz, eps, cosa);
-}
-
-__device__ __forceinline__ uint64_t valid_mask32(int64_t base, int64_t s)
-{
-    const int64_t left = s - base;
-    return left >= 64 ? ~0ULL : (left <= 0 ? 0ULL : ((1ULL << left) - 1ULL));
-}
+using namespace rhdev32;
 
 // float record of a candidate: the fields of the shape rounded to binary32 (exact for a Float32 shape), per-candidate
 // constants in binary32 with the reference's operations (normalize(plane.normal), plane.jl:85)
@@ -314,6 +202,18 @@ int rhk_f32_build(rh_cloud *c)
     return RH_OK;
 }
 
+int rhk_prep_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const int32_t *d_orig, const int64_t off[4],
+                 const int32_t *d_nk, int32_t nmax)
+{
+    if (nmax <= 0) return RH_OK;
+    Off4 o4;
+    for (int k = 0; k < 4; k++) o4.o[k] = off[k];
+    hipLaunchKernelGGL(prep32_kernel, dim3(cdiv32(nmax, 256)), dim3(256), 0, c->stream, d_shapes, via_orig, d_orig, o4, d_nk,
+                       (rh_prepf *)c->d_prep32);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 // all kinds of a binned batch (the Float64 path's bins: orig / nk, bin k at off[k]) against subset 1; masks (optional) in
 // INTERNAL order like the other scorers
 int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const uint64_t *const en[4], const int32_t *d_orig,
@@ -324,9 +224,7 @@ int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const
     for (int k = 0; k < 4; k++) nmax = std::max(nmax, (int)nk_bound[k]);
     if (nmax == 0 || c->s == 0) return RH_OK;
     rh_prepf *prep32 = (rh_prepf *)c->d_prep32;
-    Off4 o4;
-    for (int k = 0; k < 4; k++) o4.o[k] = off[k];
-    hipLaunchKernelGGL(prep32_kernel, dim3(cdiv32(nmax, 256)), dim3(256), 0, c->stream, d_shapes, via_orig, d_orig, o4, d_nk, prep32);
+    RH_TRY(rhk_prep_f32(c, d_shapes, via_orig, d_orig, off, d_nk, nmax));
     const int64_t ntiles = (c->s + RH_SC_TILE - 1) / RH_SC_TILE;
     for (int k = 0; k < 4; k++) {
         if (nk_bound[k] == 0) continue;

@@ -16,10 +16,12 @@
 
 #include "rh_internal.h"
 #include "score_device.h"
+#include "score_device32.h"
 
 namespace {
 
 using namespace rhdev;
+using namespace rhdev32;
 
 // -------------------------------------------------------------- prep ------
 __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
@@ -220,11 +222,14 @@ struct G2Shared {
     int next_chunk;
 };
 
-template <int KIND, bool MASK, int NT>
+// F32: a Float32 cloud -- staging, box tests and band prefilter as for Float64 (binary64 on the exactly converted values,
+// with the wider margins of box_slack32), the EXACT test in binary32 on the float record of the candidate (prep32)
+template <int KIND, bool MASK, int NT, bool F32 = false>
 __device__ __forceinline__ void
 score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const double *__restrict__ pts, int64_t stride, int64_t s,
                   const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
-                  int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
+                  int64_t ngroups, const rh_prep *__restrict__ prep, const rh_prepf *__restrict__ prep32,
+                  const int32_t *__restrict__ orig,
                   const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
                   int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
 {
@@ -284,11 +289,11 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
         rh_pre Ql = { 0.0, 0.0, 0.0, 0.0, 0.0 };
         if (ci < nk) {
             const rh_prep Pl = prep[ci];
-            const double slack = box_slack(Pl, coord_mag);
+            const double slack = F32 ? box_slack32<KIND>(Pl, coord_mag) : box_slack(Pl, coord_mag);
 #pragma unroll 4
             for (int g = 0; g < RH_G2_TG; g++) {
                 if (len[g] == 0) continue;
-                const bool skip = box_skip<KIND>(Pl, lb[0][g], lb[1][g], lb[2][g], lb[3][g], lb[4][g], lb[5][g],
+                const bool skip = box_skip<KIND, F32>(Pl, lb[0][g], lb[1][g], lb[2][g], lb[3][g], lb[4][g], lb[5][g],
                                                  lb[6][g], eps, slack);
                 surv |= skip ? 0u : (1u << g);
             }
@@ -312,9 +317,15 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                 const bool act = lane < k;
                 const unsigned e = act ? pq[wv][(qh + lane) & 127] : 0u;
                 const int l2 = (int)(e >> 8), i2 = (int)(e & 255u);
-                const rh_prep Pv = prep[cbase + l2];
                 const rh_f64x2 a = lp[0][i2], b = lp[1][i2], c = lp[2][i2];
-                const uint64_t r = test_point<KIND>(Pv, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
+                uint64_t r;
+                if (F32) {
+                    const rh_prepf Pv = prep32[cbase + l2];
+                    r = test_point32<KIND>(Pv, (float)a.x, (float)a.y, (float)b.x, (float)b.y, (float)c.x, (float)c.y, eps, cosa);
+                } else {
+                    const rh_prep Pv = prep[cbase + l2];
+                    r = test_point<KIND>(Pv, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
+                }
                 if (act && ((r >> lane) & 1ULL)) atomicAdd(&pcnt[wv][l2], 1);
             };
             if (todo != 0) {
@@ -336,7 +347,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                         const int i = (g << 6) + lane;
                         const rh_f64x2 a = lp[0][i];
                         const double z = lp[1][i].x;
-                        const uint64_t m = pre_test<KIND>(P, Q, a.x, a.y, z);
+                        const uint64_t m = pre_test<KIND, F32>(P, Q, a.x, a.y, z);
                         if (m != 0) {
                             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
                             if ((m >> lane) & 1ULL) pq[wv][(qh + qn + rank) & 127] = (uint16_t)((l << 8) | i);
@@ -357,11 +368,16 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
         } else if (todo != 0) {
             // ---- stage 2: lane = point, exact test for the surviving (candidate, group) pairs
             int l = __builtin_ctzll(todo);
-            rh_prep P = rh_ld_prep_const(&prep[cbase + l]);
+            // (Float32 cloud: this path only needs the float record; the double one serves the other instantiation)
+            rh_prep P;
+            rh_prepf P32;
+            if (F32) P32 = ld_prepf(&prep32[cbase + l]); else P = rh_ld_prep_const(&prep[cbase + l]);
             for (;;) {
                 todo &= todo - 1;
                 const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
-                const rh_prep Pn = rh_ld_prep_const(&prep[cbase + ln]);   // lands while this candidate's groups run
+                rh_prep Pn;
+                rh_prepf Pn32;
+                if (F32) Pn32 = ld_prepf(&prep32[cbase + ln]); else Pn = rh_ld_prep_const(&prep[cbase + ln]);   // lands while this candidate's groups run
                 unsigned rem = __builtin_amdgcn_readlane(surv, l);
                 int n = 0;
                 while (rem != 0) {
@@ -369,14 +385,15 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                     rem &= rem - 1;
                     const int i = (g << 6) + lane;
                     const rh_f64x2 a = lp[0][i], b = lp[1][i], c = lp[2][i];
-                    const uint64_t m = test_point<KIND>(P, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
+                    const uint64_t m = F32 ? test_point32<KIND>(P32, (float)a.x, (float)a.y, (float)b.x, (float)b.y, (float)c.x, (float)c.y, eps, cosa)
+                                           : test_point<KIND>(P, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
                     n += __popcll(m);
                     if (MASK) {
                         if (lane == 0 && m != 0) masks[(int64_t)orig[cbase + l] * mask_stride + g0 + g] = m;
                     }
                 }
                 acc = (lane == l) ? n : acc;
-                P = Pn;
+                if (F32) P32 = Pn32; else P = Pn;
                 if (todo == 0) break;
                 l = ln;
             }
@@ -399,7 +416,7 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
     const int chunk_lo = (int)blockIdx.y * cpb, chunk_hi = min(nchunks, chunk_lo + cpb);
     if (chunk_lo >= chunk_hi) return;
     score_groups_body<KIND, MASK, NT>(sh, chunk_lo, chunk_hi, pts, stride, s, enabled_words, gb, gstride, ngroups, prep,
-                                      orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg);
+                                      nullptr, orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg);
 }
 
 // All four kinds in ONE launch.  The 64-candidate chunks of the four kind bins are laid end to end,
@@ -408,13 +425,14 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
 // floor (tile staging, box tests, tail) is paid once and the cheap kinds fill the tail.
 struct G2KindArgs {
     const rh_prep *prep;
+    const rh_prepf *prep32;   // Float32 clouds: the float records of the same bins (else null)
     const int32_t *orig, *nk;
     const uint64_t *en;
     double eps, cosa;
 };
 struct G2AllArgs { G2KindArgs k[4]; };
 
-template <bool MASK>
+template <bool MASK, bool F32 = false>
 __global__ void __launch_bounds__(256)
 score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const double *__restrict__ gb,
                         int64_t gstride, int64_t ngroups, const G2AllArgs A, double coord_mag,
@@ -434,9 +452,9 @@ score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t 
         const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
         if (slo < shi) {                                                                                               \
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile in LDS */              \
-            score_groups_body<K, MASK, 256>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,             \
-                                            A.k[K].prep, A.k[K].orig, A.k[K].nk, A.k[K].eps, A.k[K].cosa, coord_mag,   \
-                                            counts, masks, mask_stride, dbg);                                         \
+            score_groups_body<K, MASK, 256, F32>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,        \
+                                                 A.k[K].prep, A.k[K].prep32, A.k[K].orig, A.k[K].nk, A.k[K].eps,      \
+                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg);            \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -1374,7 +1392,8 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_pr
 // all kinds against subset 1 in one launch; nk_total_bound >= the number of candidates over all kinds
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
-                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int)
+                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
+                         const void *const prep32[4])
 {
     const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
     const int nchunks = cdiv(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
@@ -1389,9 +1408,16 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     if (rows < 1) rows = 1;
     if (rows > 65535) rows = 65535;
     G2AllArgs A;
-    for (int k = 0; k < 4; k++) A.k[k] = { prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
+    for (int k = 0; k < 4; k++) A.k[k] = { prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
     dim3 grid((unsigned)ntiles, (unsigned)rows);
-    if (d_masks_int)
+    if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
+        if (d_masks_int)
+            hipLaunchKernelGGL((score_groups_all_kernel<true, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
+                               c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
+        else
+            hipLaunchKernelGGL((score_groups_all_kernel<false, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
+                               c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
+    } else if (d_masks_int)
         hipLaunchKernelGGL((score_groups_all_kernel<true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
                            c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
     else

@@ -135,6 +135,7 @@ struct rh_cloud {
 
     // Float32 clouds (rh_cloud_create_f32; f32.hip): float copies of the two point sets and float candidate records
     bool f32 = false;
+    bool f32_groups = false;           // scored by the culled kernel (exact test in binary32); else by the brute-force float kernel
     float *full32 = nullptr;           // 6 planes x n_pad, original order (the refit scan streams these: 24 B per point)
     float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
     void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
@@ -189,7 +190,10 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_o
                           int32_t *d_counts, uint64_t *d_masks_int_or_null);
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
-                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
+                         const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
+                         const void *const prep32[4] = nullptr);   // prep32: Float32 cloud, float records of the same bins
+int rhk_prep_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const int32_t *d_orig, const int64_t off[4],
+                 const int32_t *d_nk, int32_t nmax);               // fills c->d_prep32 (f32.hip)
 // Float32 clouds (f32.hip)
 int rhk_f32_build(rh_cloud *c);
 int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const uint64_t *const en[4], const int32_t *d_orig,

@@ -160,7 +160,23 @@ static __device__ __forceinline__ double box_slack(const rh_prep &P, double coor
                    fabs(P.f[5]) + fabs(P.f[6]));
 }
 
+// Float32 clouds: the conservative stages still run in binary64 on the exactly converted values (they bound the
+// REAL-valued distance), the exact test runs in binary32 (score_device32.h).  Its result differs from the real value by
+// the binary32 rounding of ~10-30 operations on terms of the size of the coordinates and parameters -- and, for a
+// cylinder, of |a|^2 (p - c) (the axis is used as stored, cylinder.jl:207) -- so the slack is 2^-16 of that magnitude:
+// 256 binary32 ulps, ~10x the worst chain (the Float64 slack is 1e-9 of it: 4.5e6 ulps).
 template <int KIND>
+static __device__ __forceinline__ double box_slack32(const rh_prep &P, double coord_mag)
+{
+    double m = 1.0 + coord_mag + fabs(P.f[0]) + fabs(P.f[1]) + fabs(P.f[2]) + fabs(P.f[3]) + fabs(P.f[4]) + fabs(P.f[5]) + fabs(P.f[6]);
+    if (KIND == RH_CYLINDER) {
+        const double a2 = (P.f[0] * P.f[0] + P.f[1] * P.f[1]) + P.f[2] * P.f[2];
+        m *= fmax(1.0, a2);
+    }
+    return 1.52587890625e-05 * m;
+}
+
+template <int KIND, bool F32 = false>
 static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, double cy, double cz, double hx, double hy,
                                          double hz, double hr, double eps, double slack)
 {
@@ -221,8 +237,9 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
         const double sinang = sqrt(((ay * tnz - az * tny) * (ay * tnz - az * tny) + (az * tnx - ax * tnz) * (az * tnx - ax * tnz)) +
                                    (ax * tny - ay * tnx) * (ax * tny - ay * tnx));
         const double an = sqrt((ax * ax + ay * ay) + az * az);
-        const bool well = (sinang > 1e-6 * an) & (ta > 0.0);
-        return well & (fabs(dist) > ((hr + eps) + slack) + 1e-6 * (hr + fabs(dist)));
+        // (binary32 exact test: its frame degrades as 2^-24 / sin(angle to the axis): only skip well away from the axis)
+        const bool well = (sinang > (F32 ? 3e-2 : 1e-6) * an) & (ta > 0.0);
+        return well & (fabs(dist) > ((hr + eps) + slack) + (F32 ? 1e-4 : 1e-6) * (hr + fabs(dist)));
     }
 }
 
@@ -275,7 +292,7 @@ static __device__ __forceinline__ double rl_f64(double v, int l)
 }
 
 // wave mask of the points that may pass the distance half of the exact test
-template <int KIND>
+template <int KIND, bool F32 = false>
 static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_pre &Q, double px, double py, double pz)
 {
     if (KIND == RH_SPHERE) {
@@ -298,10 +315,11 @@ static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_p
     const double rho2 = tt - h * h;
     const double u = Q.d * h;
     const double lo = u - Q.e, hi = u + Q.e;
-    const double s2 = 1e-9 * tt + 1e-300;
+    const double s2 = (F32 ? 1e-5 : 1e-9) * tt + 1e-300;
     const double hi2 = hi * hi * (1.0 + 1e-9) + s2, lo2 = lo * lo * (1.0 - 1e-9) - s2;
     // next to the axis the reference's frame is ill-conditioned: hand those points to the exact test
-    const uint64_t near_axis = WB(rho2 <= 1e-10 * tt);
+    // (binary32 exact test: within ~0.03 rad of the axis, where its frame loses more than the slack covers)
+    const uint64_t near_axis = WB(rho2 <= (F32 ? 1e-3 : 1e-10) * tt);
     return near_axis | (WB(hi > 0.0) & WB(rho2 <= hi2) & (WB(lo <= 0.0) | WB(rho2 >= lo2)));
 }
 

@@ -33,8 +33,22 @@ def to_orc(arr, b):
     return out
 
 
-@pytest.fixture(scope="module")
-def scene32():
+@pytest.fixture(scope="module", params=["groups", "brute"])
+def scene32(request):
+    """both scorers: the culled kernel with the exact test in binary32, and the brute-force float kernel"""
+    import os
+    old = os.environ.get("RH_SCORE_PATH")
+    os.environ["RH_SCORE_PATH"] = request.param
+    try:
+        yield _scene32()
+    finally:
+        if old is None:
+            os.environ.pop("RH_SCORE_PATH", None)
+        else:
+            os.environ["RH_SCORE_PATH"] = old
+
+
+def _scene32():
     prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder", "cone", "cone"]
     xyz, nrm, truth = synth.make_cloud(70_000, prim, 0.2, seed=41)
     x32, n32 = xyz.astype(np.float32), nrm.astype(np.float32)

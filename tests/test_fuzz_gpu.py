@@ -42,6 +42,20 @@ def test_score_fuzz_slice(seed, ncases):
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("seed,ncases", [(41001, 100), (41002, 100)])
+def test_score_fuzz_slice_float32(seed, ncases):
+    """The same fuzzer on Float32 clouds: the culled kernel's box tests and band prefilter (binary64, margins widened for
+    binary32 rounding) must never drop a pair the binary32 exact test accepts -- counts and masks against orc_f32.c."""
+    import fuzz_score
+    rng = np.random.default_rng(seed)
+    bad = []
+    for case in range(ncases):
+        ok, desc = fuzz_score.one(case + seed % 1000, rng, f32=True)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("seed,ncases", [(31, 15), (32, 15)])
 def test_e2e_fuzz_slice(seed, ncases):
     import fuzz_e2e

@@ -45,7 +45,7 @@ def rand_shape(rng, truth, scale):
     return s
 
 
-def one(case, rng):
+def one(case, rng, f32=False):
     scale = float(rng.choice([1.0, 100.0, 100.0, 1e4]))
     n = int(rng.choice([700, 4096, 8192, 8193, 20_000, 65_536, 150_001]))
     names = list(rng.choice(list(KMAP), size=int(rng.integers(1, 6))))
@@ -58,8 +58,13 @@ def one(case, rng):
     r = int(rng.choice([1, 2, 3, 16]))
     subs = synth.make_subsets(n, r, seed=case)
     os.environ["RH_SCORE_PATH"] = str(rng.choice(["groups", "groups", "brute"]))
-    pc = R.RANSACCloud(xyz, nrm, subs)
-    oc = orc.Cloud(xyz, nrm, subs[0])
+    if f32:   # a Float32 cloud: binary32 arithmetic on both sides (oracle/orc_f32.c)
+        xyz, nrm = xyz.astype(np.float32), nrm.astype(np.float32)
+        pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
+        oc = orc.Cloud32(xyz, nrm, subs[0])
+    else:
+        pc = R.RANSACCloud(xyz, nrm, subs)
+        oc = orc.Cloud(xyz, nrm, subs[0])
     en = rng.random(n) < float(rng.choice([1.0, 0.9, 0.3, 0.01]))
     pc.set_enabled(en)
     bits = np.zeros(((n + 63) // 64) * 64, dtype=np.uint8); bits[:n] = en
@@ -71,6 +76,9 @@ def one(case, rng):
     cp = R.params_to_c(params, score_mode=L.SCORE_F64, sphere_uses_enabled=bool(rng.integers(0, 2)))
     b = int(rng.choice([1, 7, 64, 65, 300]))
     arr = (L.Shape * b)(*[rand_shape(rng, truth, scale) for _ in range(b)])
+    if f32:
+        for i in range(b):
+            R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
     want_masks = bool(rng.integers(0, 2))
     got = R.score_batch(pc, arr, cp, want_masks=want_masks)
     oarr = (orc.Shape * b)()

@@ -17,10 +17,14 @@ if wl == "cfg5":
     prim += ["cone"] * 8; types += [R.FittedCone]; n, seed, scanner = 50_000_000, 5, [synth.BOX / 2] * 3
 xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=seed, scanner=scanner)
 subs = synth.make_subsets(n, 32, seed=seed)
-pc = R.RANSACCloud(xyz, nrm, subs)
+f32 = bool(os.environ.get("F32"))   # a Float32 cloud (binary32 exact tests; shapes rounded to binary32)
+pc = R.RANSACCloud(xyz.astype(np.float32), nrm.astype(np.float32), subs, force_eltype=np.float32) if f32 else R.RANSACCloud(xyz, nrm, subs)
 cp = R.params_to_c(R.ransacparameters(types), score_mode=L.SCORE_F64)
 cands = synth.jittered_candidates(truth, 4096, seed=0)
 arr = bench.shapes_to_c(R, L, cands)
+if f32:
+    for i in range(4096):
+        R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
 batch = rdist.DeviceBatch(pc, arr, 4096)
 counts = torch.zeros(4096, dtype=torch.int32, device="cuda")
 lib = R.lib()
@@ -33,3 +37,12 @@ L.check(lib.rh_timer_start(pc._h))
 for _ in range(steps): step()
 ms = C.c_float(); L.check(lib.rh_timer_stop(pc._h, C.byref(ms)))
 print("ms_per_step %.4f  sum(counts) %d" % (ms.value / steps, int(counts.sum().item())))
+if os.environ.get("REFIT"):
+    t = truth[0]
+    sh = R.FittedPlane(t["point"], t["normal"])
+    cs = R.shape_f32(sh) if f32 else sh.to_c()
+    idx = np.zeros(n, dtype=np.int64); nout = C.c_int64(); acc = []
+    for _ in range(6):
+        L.check(lib.rh_refit(pc._h, C.byref(cs), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
+        a, b = C.c_float(), C.c_float(); L.check(lib.rh_last_refit_ms(pc._h, C.byref(a), C.byref(b))); acc.append(a.value)
+    print("refit scan ms %.4f (%d inliers), %.0f GB/s on %s bytes/point" % (min(acc[1:]), nout.value, n * (24.125 if f32 else 48.125) / min(acc[1:]) / 1e6, "24.125" if f32 else "48.125"))
