@@ -68,6 +68,7 @@ def parse():
                          "in) with the oracle (OpenMP over candidates) and fail on a mismatch; independent of --no-cpu")
     ap.add_argument("--e2e-runs", type=int, default=5, help="timed rh_ransac runs of the end-to-end leg (median reported)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
+    ap.add_argument("--no-f32", action="store_true", help="skip the Float32-cloud leg")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
@@ -568,6 +569,72 @@ def main():
                                          "(48.125 B/point); HIP events on the library's stream; host wall adds the "
                                          "compaction, two syncs and the D2H of the index list"}
 
+        # ---- the same workload as a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): every
+        # per-point operation in binary32, the refit scan streams 24 bytes per point instead of 48
+        if world == 1 and not args.no_f32:
+            try:
+                from oracle import oracle as orc
+                t0 = time.time()
+                x32, n32 = xyz.astype(np.float32), nrm.astype(np.float32)
+                pc32 = R.RANSACCloud(x32, n32, subs, device=local_rank, force_eltype=np.float32)
+                arr32 = (L.Shape * b_global).from_buffer_copy(bytes(arr))
+                for i in range(b_global):
+                    lib.rh_shape_finalize_f32(C.byref(arr32[i]))
+                batch32 = rdist.DeviceBatch(pc32, arr32, b_global)
+                c32 = torch.zeros(b_global, dtype=torch.int32, device="cuda")
+
+                def step32():
+                    L.check(lib.rh_score_batch_dev(pc32._h, batch32.slice_ptr(0), b_global, C.byref(cp), C.c_void_p(c32.data_ptr()), None))
+                for _ in range(100):
+                    step32()
+                L.check(lib.rh_cloud_sync(pc32._h))
+                L.check(lib.rh_timer_start(pc32._h))
+                for _ in range(100):
+                    step32()
+                ev32 = C.c_float()
+                L.check(lib.rh_timer_stop(pc32._h, C.byref(ev32)))
+                c32h = c32.cpu().numpy()
+                # oracle (binary32 twin) on a spread sample of the batch
+                sel = list(range(0, b_global, max(1, b_global // 256)))[:256]
+                oc32 = orc.Cloud32(x32, n32, subs[0])
+                o32 = (orc.Shape * len(sel))()
+                for j, i in enumerate(sel):
+                    o32[j] = orc.Shape.from_buffer_copy(bytes(arr32[i]))
+                chk = oc32.score_batch(o32, orc.Params.from_buffer_copy(bytes(cp)), nthreads=16)
+                if not np.array_equal(chk, c32h[sel]):
+                    raise SystemExit("PARITY FAILURE: Float32 cloud counts differ from the binary32 oracle")
+                cs = R.shape_f32(R.FittedPlane(truth[0]["point"], truth[0]["normal"]))
+                idx32 = np.zeros(n, dtype=np.int64)
+                n32o = C.c_int64()
+                scans = []
+                for _ in range(6):
+                    L.check(lib.rh_refit(pc32._h, C.byref(cs), C.byref(cp), idx32.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(n32o)))
+                    a_, b_ = C.c_float(), C.c_float()
+                    L.check(lib.rh_last_refit_ms(pc32._h, C.byref(a_), C.byref(b_)))
+                    scans.append(a_.value)
+                oref = oc32.refit(orc.Shape.from_buffer_copy(bytes(cs)), orc.Params.from_buffer_copy(bytes(cp)))
+                if not np.array_equal(oref, idx32[:n32o.value]):
+                    raise SystemExit("PARITY FAILURE: Float32 refit list differs from the binary32 oracle")
+                t_scan32 = 1e-3 * sorted(scans[1:])[len(scans[1:]) // 2]
+                b32 = n * 24.125
+                out["float32"] = {
+                    "candidates_per_sec": b_global / (ev32.value * 1e-3 / 100), "ms_per_step": ev32.value / 100,
+                    "oracle_checked": len(sel),
+                    "roofline_refit": {"kernel": "refit32_mask_kernel<plane>", "bound": "hbm", "achieved": b32 / t_scan32 / 1e9,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b32 / t_scan32 / 1e9 / HBM_PEAK_GBS,
+                                       "ms_per_launch": 1e3 * t_scan32, "algorithmic_bytes_per_launch": b32, "inliers": int(n32o.value),
+                                       "traffic": None},
+                    "setup_seconds": time.time() - t0,
+                    "note": "the same cloud and batch as Float32 (shapes rounded to binary32): culled score kernel with the exact "
+                            "test in binary32, refit scan over 24.125 B per point; 256 counts and the refit list checked against the "
+                            "oracle's binary32 twin (oracle/orc_f32.c) in this run"}
+                batch32.free()
+                del pc32, oc32
+            except SystemExit:
+                raise
+            except Exception as e:
+                out["float32"] = {"error": repr(e)[:300]}
+
         # ---- what this box's HBM delivers to simple streaming kernels (torch ops as the probe) ------
         try:
             nbytes = 1 << 30
@@ -750,7 +817,7 @@ def main():
             import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu", "--no-e2e",
-                                    "--no-cfg5", "--no-cfg2"] + extra, capture_output=True, text=True, timeout=900)
+                                    "--no-cfg5", "--no-cfg2", "--no-f32"] + extra, capture_output=True, text=True, timeout=900)
                 if r.returncode != 0:
                     if "PARITY FAILURE" in (r.stderr or ""):   # a wrong result is never just a missing leg
                         raise SystemExit("%s leg: %s" % (name, r.stderr.strip().splitlines()[-1]))

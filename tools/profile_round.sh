@@ -12,7 +12,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 python bench.py > "$OUT/bench_default_unprofiled.json" 2> "$OUT/bench_default.err"
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2"
+B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
 echo "stats 1 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
