@@ -102,10 +102,18 @@ mutable struct HIPCloud{P}
         # Vector{SVector{3,Float64}} is n x 3 contiguous doubles: passed as is (zero copy on the host side)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         s1 = pc.subsets[1]
-        GC.@preserve pc check(ccall((:rh_cloud_create, LIB), Cint,
-            (Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Int64, Cint, Ptr{Ptr{Cvoid}}),
-            pointer(reinterpret(Float64, pc.vertices)), pointer(reinterpret(Float64, pc.normals)),
-            pc.size, s1, length(s1), device, h))
+        if eltype(eltype(pc.vertices)) == Float32
+            # RANSACCloud(...; force_eltype = Float32): Vector{SVector{3,Float32}} as is; scoring and refit then run in binary32
+            GC.@preserve pc check(ccall((:rh_cloud_create_f32, LIB), Cint,
+                (Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Int64}, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                pointer(reinterpret(Float32, pc.vertices)), pointer(reinterpret(Float32, pc.normals)),
+                pc.size, s1, length(s1), device, h))
+        else
+            GC.@preserve pc check(ccall((:rh_cloud_create, LIB), Cint,
+                (Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                pointer(reinterpret(Float64, pc.vertices)), pointer(reinterpret(Float64, pc.normals)),
+                pc.size, s1, length(s1), device, h))
+        end
         obj = new{typeof(pc)}(pc, h[])
         push_enabled!(obj)
         finalizer(o -> ccall((:rh_cloud_destroy, LIB), Cint, (Ptr{Cvoid},), o.handle), obj)
