@@ -166,6 +166,47 @@ def test_hip_kernels_give_the_hand_derived_answers(path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["groups", "brute"])
+def test_hip_float32_kernels_give_the_hand_derived_answers(path, monkeypatch):
+    """The vectors whose numbers are binary32 numbers on a Float32 cloud (rh_cloud_create_f32): both scorers and the
+    refit scan give the derived answer and equal the oracle's binary32 twin on the whole cloud."""
+    monkeypatch.setenv("RH_SCORE_PATH", path)
+    pts, nrm, where = _vector_cloud()
+    p32, n32 = pts.astype(np.float32), nrm.astype(np.float32)      # exact for the representable vectors (filler rounds)
+    n = len(pts)
+    sub = np.random.default_rng(3).permutation(n).astype(np.int64) + 1
+    subpos = np.empty(n, dtype=np.int64)
+    subpos[sub - 1] = np.arange(n)
+    pc = R.RANSACCloud(p32, n32, [sub], force_eltype=np.float32)
+    oc = orc.Cloud32(p32, n32, sub)
+    done = 0
+    for i, c in enumerate(VEC["compat"]):
+        rep = all(float(np.float32(x)) == x for x in c["v"][:7] + c["p"] + c["n"])
+        if c["mode"] in ("exact", "exact_distance") and not rep:
+            continue
+        cp = R.params_to_c(R.ransacparameters())
+        k = KIND[c["kind"]]
+        cp.eps[k] = c["eps"]
+        cp.cos_alpha[k] = c["cos_alpha"]
+        op = orc.Params.from_buffer_copy(bytes(cp))
+        os_ = orc.make_shape32(k, c["outwards"], c["v"])
+        s = L.Shape.from_buffer_copy(bytes(os_))
+        arr = (L.Shape * 1)(s)
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        j = int(subpos[where[i]])
+        got = bool((int(masks[0, j >> 6]) >> (j & 63)) & 1)
+        assert got == c["expect"], (path, c["name"], c["derivation"])
+        oarr = (orc.Shape * 1)(os_)
+        ocounts, omasks = oc.score_batch(oarr, op, want_masks=True)
+        assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+        ex = R.refit(s, pc, cp)
+        assert ((where[i] + 1) in set(ex.inpoints.tolist())) == c["expect"], (path, "refit", c["name"])
+        assert np.array_equal(ex.inpoints, oc.refit(oarr[0], op))
+        done += 1
+    assert done >= 30
+
+
+@pytest.mark.gpu
 def test_hip_scorecandidate_enabled_bits_q4():
     for sc in VEC["score"]:
         pts, nrm, en = _score_case_arrays(sc)
