@@ -541,21 +541,35 @@ def main():
         out["score_path"] = os.environ.get("RH_SCORE_PATH", "groups (culled)")
         out["event_ms_per_step"] = ev_ms.value / args.steps
 
-        # refit scan: HBM-bound
+        # refit: the streaming scan (HBM-bound: the roofline object) and the culled scan the library takes at this size
         t = truth[0]
         plane = R.FittedPlane(t["point"], t["normal"]).to_c()
-        idx = np.zeros(n, dtype=np.int64)
-        nout = C.c_int64()
-        L.check(lib.rh_refit(pc._h, C.byref(plane), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
-        t0 = time.perf_counter()
-        scan_ms, comp_ms = [], []
-        for _ in range(5):
-            L.check(lib.rh_refit(pc._h, C.byref(plane), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
-            a, b = C.c_float(), C.c_float()
-            L.check(lib.rh_last_refit_ms(pc._h, C.byref(a), C.byref(b)))
-            scan_ms.append(a.value); comp_ms.append(b.value)
-        t_refit = (time.perf_counter() - t0) / 5
-        t_scan = 1e-3 * sum(scan_ms) / len(scan_ms)
+
+        def time_refit(handle, cshape, path, reps=5):
+            """rh_refit `reps` times with RH_REFIT_PATH=path: (scan ms from HIP events, compaction ms, host wall s, index list)"""
+            old_path = os.environ.get("RH_REFIT_PATH")
+            os.environ["RH_REFIT_PATH"] = path
+            try:
+                idx = np.zeros(n, dtype=np.int64)
+                nout = C.c_int64()
+                L.check(lib.rh_refit(handle, C.byref(cshape), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
+                t0 = time.perf_counter()
+                scan_ms, comp_ms = [], []
+                for _ in range(reps):
+                    L.check(lib.rh_refit(handle, C.byref(cshape), C.byref(cp), idx.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(nout)))
+                    a, b = C.c_float(), C.c_float()
+                    L.check(lib.rh_last_refit_ms(handle, C.byref(a), C.byref(b)))
+                    scan_ms.append(a.value); comp_ms.append(b.value)
+                wall = (time.perf_counter() - t0) / reps
+                return sum(scan_ms) / len(scan_ms), sum(comp_ms) / len(comp_ms), wall, idx[:nout.value].copy()
+            finally:
+                if old_path is None:
+                    os.environ.pop("RH_REFIT_PATH", None)
+                else:
+                    os.environ["RH_REFIT_PATH"] = old_path
+
+        scan_ms, comp_ms, t_refit, list_scan = time_refit(pc._h, plane, "scan")
+        t_scan = 1e-3 * scan_ms
         rbytes = n * REFIT_BYTES_PER_POINT
         rpmc = pmc_replay("refit_mask_kernel<0>", pmc_ok)
         out["roofline_refit"] = {"kernel": "refit_mask_kernel<plane>", "bound": "hbm", "achieved": rbytes / t_scan / 1e9,
@@ -563,11 +577,21 @@ def main():
                                  "traffic": rpmc["traffic"], "traffic_replayed_from": rpmc["replayed_from"],
                                  "traffic_replay_is_stale": rpmc["stale"], "ms_per_launch": 1e3 * t_scan,
                                  "algorithmic_bytes_per_launch": rbytes,
-                                 "compaction_ms": sum(comp_ms) / len(comp_ms), "rh_refit_host_wall_ms": 1e3 * t_refit,
-                                 "inliers": int(nout.value),
-                                 "note": "the HBM-bound kernel of the path: one pass over the whole cloud "
-                                         "(48.125 B/point); HIP events on the library's stream; host wall adds the "
-                                         "compaction, two syncs and the D2H of the index list"}
+                                 "compaction_ms": comp_ms, "rh_refit_host_wall_ms": 1e3 * t_refit,
+                                 "inliers": int(len(list_scan)),
+                                 "note": "the HBM-bound kernel of the path (RH_REFIT_PATH=scan): one pass over the whole cloud "
+                                         "in original order (48.125 B/point); HIP events on the library's stream; host wall "
+                                         "adds the compaction, two syncs and the D2H of the index list.  Clouds of 2^18 "
+                                         "points and more take the culled scan instead: `refit_culled`"}
+        cul_ms, cul_comp, cul_wall, list_cul = time_refit(pc._h, plane, "culled")
+        if not np.array_equal(list_scan, list_cul):
+            raise SystemExit("PARITY FAILURE: the culled refit scan and the streaming scan disagree")
+        out["refit_culled"] = {"ms_per_refit_scan": cul_ms, "speedup_vs_streaming_scan": scan_ms / cul_ms,
+                               "compaction_ms": cul_comp, "rh_refit_host_wall_ms": 1e3 * cul_wall,
+                               "kernels": "refitk_boxes_kernel + refitk_groups_kernel + refitk_flags_kernel (korder.hip)",
+                               "note": "the same refit through the Morton-ordered copy of the cloud: box test per 64-point "
+                                       "group, exact test on the surviving groups only (a few percent of the cloud), index "
+                                       "list identical to the streaming scan's (checked in this run)"}
 
         # ---- the same workload as a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): every
         # per-point operation in binary32, the refit scan streams 24 bytes per point instead of 48
@@ -604,18 +628,13 @@ def main():
                 if not np.array_equal(chk, c32h[sel]):
                     raise SystemExit("PARITY FAILURE: Float32 cloud counts differ from the binary32 oracle")
                 cs = R.shape_f32(R.FittedPlane(truth[0]["point"], truth[0]["normal"]))
-                idx32 = np.zeros(n, dtype=np.int64)
-                n32o = C.c_int64()
-                scans = []
-                for _ in range(6):
-                    L.check(lib.rh_refit(pc32._h, C.byref(cs), C.byref(cp), idx32.ctypes.data_as(C.POINTER(C.c_int64)), n, C.byref(n32o)))
-                    a_, b_ = C.c_float(), C.c_float()
-                    L.check(lib.rh_last_refit_ms(pc32._h, C.byref(a_), C.byref(b_)))
-                    scans.append(a_.value)
+                scan32_ms, _c, _w, list32 = time_refit(pc32._h, cs, "scan")
+                cul32_ms, _c, _w, list32c = time_refit(pc32._h, cs, "culled")
                 oref = oc32.refit(orc.Shape.from_buffer_copy(bytes(cs)), orc.Params.from_buffer_copy(bytes(cp)))
-                if not np.array_equal(oref, idx32[:n32o.value]):
+                if not (np.array_equal(oref, list32) and np.array_equal(oref, list32c)):
                     raise SystemExit("PARITY FAILURE: Float32 refit list differs from the binary32 oracle")
-                t_scan32 = 1e-3 * sorted(scans[1:])[len(scans[1:]) // 2]
+                n32o = C.c_int64(len(list32))
+                t_scan32 = 1e-3 * scan32_ms
                 b32 = n * 24.125
                 out["float32"] = {
                     "candidates_per_sec": b_global / (ev32.value * 1e-3 / 100), "ms_per_step": ev32.value / 100,
@@ -624,6 +643,7 @@ def main():
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b32 / t_scan32 / 1e9 / HBM_PEAK_GBS,
                                        "ms_per_launch": 1e3 * t_scan32, "algorithmic_bytes_per_launch": b32, "inliers": int(n32o.value),
                                        "traffic": None},
+                    "refit_culled_ms": cul32_ms,
                     "setup_seconds": time.time() - t0,
                     "note": "the same cloud and batch as Float32 (shapes rounded to binary32): culled score kernel with the exact "
                             "test in binary32, refit scan over 24.125 B per point; 256 counts and the refit list checked against the "
@@ -830,7 +850,7 @@ def main():
                                           ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
                                            "algorithmic_bytes_per_launch", "inliers")},
                        "setup_seconds": c5["setup_seconds"], "note": note}
-                for k in ("oracle_checked", "oracle_check", "masks_out"):
+                for k in ("oracle_checked", "oracle_check", "masks_out", "refit_culled"):
                     if k in c5:
                         leg[k] = c5[k]
                 return leg

@@ -146,6 +146,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
+    (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
     (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
@@ -175,6 +176,10 @@ static int set_all_enabled(rh_cloud *c)
             RH_HIP(hipMemcpyAsync(c->enabled + (c->nwords - 1), &last, sizeof last, hipMemcpyHostToDevice, c->stream));
             RH_HIP(hipStreamSynchronize(c->stream));
         }
+        if (c->k_built) {   // the same n bits in Morton order
+            RH_HIP(hipMemcpyAsync(c->oct_men, c->enabled, sizeof(uint64_t) * (size_t)c->nwords, hipMemcpyDeviceToDevice, c->stream));
+            c->k_men_valid = true;
+        }
     }
     RH_TRY(rhk_rebuild_sub_enabled(c, true));
     c->select_valid = false;
@@ -183,45 +188,48 @@ static int set_all_enabled(rh_cloud *c)
     return RH_OK;
 }
 
-// linear (Morton) octree of the full cloud: codes in the bounding CUBE, sorted by (code, index);
-// depth = first level whose fullest cell holds <= 8 points (src/octree.jl:163-165), capped.
-int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth)
+// bounding cube of the cloud like the reference's octree (findAABB: src/utilities.jl:125-136; the cube's edge is the
+// largest extent) and the largest finite |coordinate|
+static void cloud_aabb(const double *xyz, int64_t n, double lo[3], double *size_out, double *mag_out)
 {
-    if (max_depth < 1) max_depth = 1;
-    if (max_depth > 21) max_depth = 21;
-    if (c->oct_built && c->oct_max_depth == max_depth) return rhk_oct_sync_enabled(c);
-    const int64_t n = c->n;
-    double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    double hi[3] = { 0, 0, 0 }, mag = 0;
+    for (int k = 0; k < 3; k++) lo[k] = 0;
     for (int k = 0; k < 3 && n > 0; k++) { lo[k] = xyz[k]; hi[k] = xyz[k]; }
     for (int64_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {   // findAABB: src/utilities.jl:125-136
+        for (int k = 0; k < 3; k++) {
             const double a = xyz[3 * i + k];
             lo[k] = lo[k] > a ? a : lo[k];
             hi[k] = hi[k] < a ? a : hi[k];
+            const double m = fabs(a);
+            if (m > mag && m - m == 0) mag = m;
         }
     double size = 0;
     for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > size) size = hi[k] - lo[k];
     size = size * (1 + 1e-9);
     if (!(size > 0)) size = 1;
-    std::vector<std::pair<uint64_t, int32_t>> keys((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        uint64_t code = 0;
-        for (int k = 0; k < 3; k++) {
-            const double t = (xyz[3 * i + k] - lo[k]) / size;
-            const double q = t * 2097152.0;
-            const uint64_t qi = !(q >= 0) ? 0 : (q >= 2097151.0 ? 2097151ULL : (uint64_t)q);
-            code |= spread21(qi) << k;
-        }
-        keys[(size_t)i] = std::make_pair(code, (int32_t)i);
-    }
-    std::sort(keys.begin(), keys.end());
+    *size_out = size;
+    *mag_out = mag;
+}
+
+// linear (Morton) octree of the full cloud: codes in the bounding CUBE, sorted by (code, index) -- the Morton order the
+// cloud was given on the device when it was created (korder.hip); here: the host twins and
+// depth = first level whose fullest cell holds <= 8 points (src/octree.jl:163-165), capped.
+int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth)
+{
+    (void)xyz;
+    if (max_depth < 1) max_depth = 1;
+    if (max_depth > 21) max_depth = 21;
+    if (c->oct_built && c->oct_max_depth == max_depth) return rhk_oct_sync_enabled(c);
+    const int64_t n = c->n;
+    if (n > 0 && !c->k_built) { rh_set_error("rh_octree_ensure: the cloud has no Morton order"); return RH_E_INTERNAL; }
     c->h_oct_code.resize((size_t)n);
     c->h_oct_perm.resize((size_t)n);
     c->h_oct_pos.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        c->h_oct_code[(size_t)i] = keys[(size_t)i].first;
-        c->h_oct_perm[(size_t)i] = keys[(size_t)i].second;
-        c->h_oct_pos[(size_t)keys[(size_t)i].second] = (int32_t)i;
+    if (n > 0) {
+        RH_HIP(hipMemcpyAsync(c->h_oct_code.data(), c->oct_code, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipMemcpyAsync(c->h_oct_perm.data(), c->oct_perm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipMemcpyAsync(c->h_oct_pos.data(), c->oct_pos, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipStreamSynchronize(c->stream));
     }
     int depth = max_depth;
     for (int l = 1; l <= max_depth; l++) {
@@ -234,19 +242,6 @@ int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth)
             if (++run > best) best = run;
         }
         if (best <= 8) { depth = l; break; }
-    }
-    if (!c->oct_code) {
-        RH_TRY(dev_alloc(&c->oct_code, n));
-        RH_TRY(dev_alloc(&c->oct_perm, n));
-        RH_TRY(dev_alloc(&c->oct_pos, n));
-        RH_TRY(dev_alloc(&c->oct_men, c->nwords));
-        RH_TRY(dev_alloc(&c->oct_prefix, c->nwords + 1));
-    }
-    if (n > 0) {
-        RH_HIP(hipMemcpyAsync(c->oct_code, c->h_oct_code.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        RH_HIP(hipMemcpyAsync(c->oct_perm, c->h_oct_perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        RH_HIP(hipMemcpyAsync(c->oct_pos, c->h_oct_pos.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        RH_HIP(hipStreamSynchronize(c->stream));
     }
     c->oct_depth = depth;
     c->oct_max_depth = max_depth;
@@ -356,6 +351,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
         CKH(hipMemcpyAsync(t_nrm, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
         CK(rhk_pack_records(c, t_xyz, t_nrm, n, c->rec));
+        cloud_aabb(xyz, n, c->k_lo, &c->k_size, &c->k_mag);
+        CK(rhk_korder_build(c, t_xyz, t_nrm, c->k_lo, c->k_size, c->k_mag));
         if (s > 0) {
             // internal order of subset 1: 64 consecutive points are spatially compact, which is what the
             // culled score kernel's per-group boxes need (k-d leaves, below)
@@ -486,6 +483,7 @@ extern "C" int rh_cloud_create_f32(const float *xyz, const float *nrm, int64_t n
     int rc = dev_alloc(&c->full32, 6 * std::max<int64_t>(c->n_pad, 1));
     if (rc == RH_OK) rc = dev_alloc(&c->sub32, 6 * std::max<int64_t>(c->s_pad, 1));
     if (rc == RH_OK) rc = rhk_f32_build(c);
+    if (rc == RH_OK) rc = rhk_korder_build_f32(c);
     if (rc == RH_OK && hipStreamSynchronize(c->stream) != hipSuccess) { rh_set_error("rh_cloud_create_f32: device error"); rc = RH_E_NODEVICE; }
     if (rc != RH_OK) { cloud_free(c); return rc; }
     *out = c;
@@ -516,6 +514,7 @@ extern "C" int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t
         return RH_E_INVALID;
     }
     if (c->nwords > 0) {
+        c->k_men_valid = false;
         RH_HIP(hipMemcpyAsync(c->enabled, chunks, sizeof(uint64_t) * (size_t)nchunks, hipMemcpyHostToDevice, c->stream));
         if (c->n % 64) {   // BitVector keeps the unused tail bits zero; enforce it
             const uint64_t last = chunks[nchunks - 1] & ((~0ULL) >> (64 - c->n % 64));

@@ -721,7 +721,7 @@ struct Driver {
         RUN(ensure_scratch(32 + 2 * sum_n));   // (may wait for the stream: before anything lands in the scratch)
         int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
         const int64_t ndis_old = c->n_dis;
-        RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind]));
+        RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind], true));
         if (list_copy_pending) {   // the previous list must have left idx_out before it is written again
             RUNH(hipStreamWaitEvent(c->stream, c->ev_copied, 0));
             list_copy_pending = false;

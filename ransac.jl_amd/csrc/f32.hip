@@ -258,11 +258,21 @@ int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const
     return RH_OK;
 }
 
-int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa)
+int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa, bool apply)
 {
+    c->k_applied = false;
+    c->k_sums_ready = false;
     if (c->nwords == 0) return RH_OK;
     rh_prepf P;
     prep_one32(shape, P);
+    if (rhk_refit_is_culled(c)) {   // box tests in binary64 on the shape's record, exact test in binary32 (korder.hip)
+        rh_prep P64;
+        rh_prep_host(shape, &P64);
+        RH_TRY(rhk_refitk_mask_f32(c, &P, P64, shape.kind, eps, cosa, apply));
+        c->k_applied = apply;
+        c->k_sums_ready = apply;
+        return RH_OK;
+    }
     int64_t blocks = cdiv32(c->nwords, 4 * RF32_WPW);
     if (blocks > 32768) blocks = 32768;
     dim3 grid((unsigned)blocks), blk(256);

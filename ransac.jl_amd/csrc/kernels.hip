@@ -658,12 +658,22 @@ scan_block_sums_kernel(int32_t *__restrict__ block_sums, int64_t nb, int32_t *__
 __global__ void __launch_bounds__(256)
 expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ block_prefix,
                    int64_t *__restrict__ idx_out, int64_t cap, int32_t *__restrict__ word_prefix_out,
-                   uint64_t *__restrict__ andnot_words, int32_t *__restrict__ andnot_sums)
+                   uint64_t *__restrict__ andnot_words, int32_t *__restrict__ andnot_sums,
+                   int32_t *__restrict__ raw_total = nullptr)
 {
     __shared__ int32_t wsum[4];
     __shared__ int32_t esum[4];
+    __shared__ int32_t psum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * RH_WORDS_PER_BLOCK;
+    // raw_total: block_prefix holds the blocks' popcounts, not their scan -- the block sums up its predecessors itself
+    // (a few hundred values) and the last block leaves the grand total: one launch less than scanning them first
+    int before = 0;
+    if (raw_total != nullptr) {
+        for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) before += block_prefix[k];
+        for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+        if (lane == 0) psum[wave] = before;
+    }
     uint64_t m[4];
     int pc[4], tsum = 0;
 #pragma unroll
@@ -697,7 +707,9 @@ expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int3
     if (andnot_words != nullptr && threadIdx.x == 0) andnot_sums[blockIdx.x] = esum[0] + esum[1] + esum[2] + esum[3];
     int woff = 0;
     for (int k = 0; k < wave; k++) woff += wsum[k];
-    int64_t run = (int64_t)block_prefix[blockIdx.x] + woff + inc - tsum;
+    const int32_t bpre = raw_total != nullptr ? (psum[0] + psum[1] + psum[2] + psum[3]) : block_prefix[blockIdx.x];
+    if (raw_total != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *raw_total = bpre + woff + inc;
+    int64_t run = (int64_t)bpre + woff + inc - tsum;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int64_t w = base + threadIdx.x * 4 + k;
@@ -718,13 +730,18 @@ expand_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int3
 
 // ------------------------------------------------- enabled maintenance ----
 __global__ void invalidate_idx_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t npoints,
-                                      uint64_t *__restrict__ enabled)
+                                      uint64_t *__restrict__ enabled, const int32_t *__restrict__ pos,
+                                      uint64_t *__restrict__ men)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t i0 = idx[k] - 1;
     if (i0 < 0 || i0 >= npoints) return;
     atomicAnd((unsigned long long *)&enabled[i0 >> 6], ~(1ULL << (i0 & 63)));
+    if (men != nullptr) {
+        const int32_t mp = pos[i0];
+        atomicAnd((unsigned long long *)&men[mp >> 6], ~(1ULL << (mp & 63)));
+    }
 }
 
 // One launch per change of the enabled bits: sub_enabled bit j = enabled[sub_idx0[j]], and the subset points
@@ -935,22 +952,6 @@ __global__ void oct_gather_enabled_kernel(const uint64_t *__restrict__ enabled, 
     if ((threadIdx.x & 63) == 0 && (j >> 6) < (n + 63) / 64) men[j >> 6] = w;
 }
 
-// clear in `men` the Morton positions of the points set in an original-order mask (one lane per bit measured the
-// same 50 us at 10M points: the time goes into same-word atomics -- an extracted shape is compact in Morton order)
-__global__ void oct_clear_mask_kernel(const uint64_t *__restrict__ mask, int64_t nwords, const int32_t *__restrict__ pos,
-                                      uint64_t *__restrict__ men)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    uint64_t m = mask[w];
-    while (m != 0) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        const int32_t mp = pos[(w << 6) + b];
-        atomicAnd((unsigned long long *)&men[mp >> 6], ~(1ULL << (mp & 63)));
-    }
-}
-
 __global__ void iota_kernel(int32_t *d, int32_t n, int32_t base)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1147,9 +1148,17 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
     return RH_E_INVALID;
 }
 
-int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa)
+int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa, bool apply)
 {
+    c->k_applied = false;
+    c->k_sums_ready = false;
     if (c->nwords == 0) return RH_OK;
+    if (rhk_refit_is_culled(c)) {
+        RH_TRY(rhk_refitk_mask(c, P, kind, eps, cosa, apply));
+        c->k_applied = apply;
+        c->k_sums_ready = apply;
+        return RH_OK;
+    }
     static int env_blocks = -1;
     if (env_blocks < 0) { const char *e = getenv("RH_REFIT_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
     int64_t blocks = cdiv(c->nwords, 4 * RH_RF_WPW);
@@ -1186,13 +1195,19 @@ int rhk_compact_refit_apply(rh_cloud *c)
 {
     c->select_valid = false;
     c->en_sums_valid = false;
-    if (c->nblocks > 0)
+    if (!c->k_applied) c->k_men_valid = false;   // (a culled scan with `apply` has cleared the Morton-order bits itself)
+    c->k_applied = false;
+    // (the culled scan's last pass has left the per-block popcounts of refit_mask in block_sums already)
+    if (c->nblocks > 0 && !c->k_sums_ready)
         hipLaunchKernelGGL(block_popc_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->refit_mask, c->nwords,
                            c->block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
+    c->k_sums_ready = false;
+    const bool raw = c->nblocks > 0 && c->nblocks <= 2048;   // the expansion sums the blocks before it itself
+    if (!raw) hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, c->stream, c->block_sums, c->nblocks, c->d_total);
     if (c->nblocks > 0)
         hipLaunchKernelGGL(expand_mask_kernel, dim3((unsigned)c->nblocks), dim3(256), 0, c->stream, c->refit_mask, c->nwords,
-                           c->block_sums, c->idx_out, c->n, (int32_t *)nullptr, c->enabled, c->en_block_sums);
+                           c->block_sums, c->idx_out, c->n, (int32_t *)nullptr, c->enabled, c->en_block_sums,
+                           raw ? c->d_total : (int32_t *)nullptr);
     RH_HIP(hipGetLastError());
     c->en_sums_valid = c->nblocks > 0;
     return RH_OK;
@@ -1202,7 +1217,9 @@ int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n)
 {
     if (n == 0) return RH_OK;
     c->en_sums_valid = false;
-    hipLaunchKernelGGL(invalidate_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_idx, n, c->n, c->enabled);
+    const bool both = c->k_built && c->k_men_valid;   // keep the Morton-order bits in step (else they are regathered later)
+    hipLaunchKernelGGL(invalidate_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, d_idx, n, c->n, c->enabled,
+                       both ? c->oct_pos : (const int32_t *)nullptr, both ? c->oct_men : (uint64_t *)nullptr);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1443,6 +1460,14 @@ int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const 
     return score_groups_dispatch(c, G, kind, nullptr, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, nullptr);
 }
 
+int rhk_group_bounds_of(rh_cloud *c, const double *pts, int64_t stride, int64_t count, int64_t ngroups, double *gb, int64_t gstride)
+{
+    if (ngroups == 0) return RH_OK;
+    hipLaunchKernelGGL(group_bounds_kernel, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, pts, stride, count, ngroups, gb, gstride);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 int rhk_group_bounds(rh_cloud *c)
 {
     if (c->ngroups == 0) return RH_OK;
@@ -1495,20 +1520,27 @@ int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t 
     return RH_OK;
 }
 
-int rhk_oct_sync_enabled(rh_cloud *c)
+int rhk_oct_gather_enabled(rh_cloud *c)
 {
     if (c->n == 0) return RH_OK;
     hipLaunchKernelGGL(oct_gather_enabled_kernel, dim3(cdiv(c->nwords * 64, 256)), dim3(256), 0, c->stream, c->enabled,
                        c->oct_perm, c->n, c->oct_men);
     RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_oct_sync_enabled(rh_cloud *c)
+{
+    if (c->n == 0) return RH_OK;
+    RH_TRY(rhk_korder_sync_enabled(c));
     return rhk_word_prefix(c, c->oct_men, c->nwords, c->oct_prefix);
 }
 
+// after an extraction (`enabled` already updated in stream order): the Morton-order bits follow -- the culled refit
+// scan has cleared them on its way (k_men_valid still set), after the plain scan they are regathered -- and the prefix
+// is rebuilt
 int rhk_oct_clear_mask(rh_cloud *c, const uint64_t *mask)
 {
-    if (c->nwords == 0) return RH_OK;
-    hipLaunchKernelGGL(oct_clear_mask_kernel, dim3(cdiv(c->nwords, 256)), dim3(256), 0, c->stream, mask, c->nwords,
-                       c->oct_pos, c->oct_men);
-    RH_HIP(hipGetLastError());
-    return rhk_word_prefix(c, c->oct_men, c->nwords, c->oct_prefix);
+    (void)mask;
+    return rhk_oct_sync_enabled(c);
 }

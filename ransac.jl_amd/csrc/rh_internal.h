@@ -50,6 +50,7 @@ constexpr int RH_WORDS_PER_BLOCK = 1024;                 // scan granularity (64
 constexpr int RH_G2_TG = 4;                              // 64-point groups per LDS tile of the culled score kernel
 constexpr int RH_G2_TILE = RH_G2_TG * 64;
 constexpr int64_t RH_G2_MIN_POINTS = 8192;               // below this the brute-force kernel is used
+constexpr int64_t RH_KREFIT_MIN = 1 << 18;               // clouds from this size on take the culled refit scan (korder.hip)
 
 // ---- the cloud --------------------------------------------------------------
 struct rh_cloud {
@@ -93,8 +94,22 @@ struct rh_cloud {
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
 
-    // linear (Morton) octree of the FULL cloud for octree_sampling = 1, built on first use
-    bool oct_built = false;
+    // The cloud in Morton order (korder.hip), built on the device with the cloud: the order of the linear octree of
+    // octree_sampling = 1 and of the culled refit scan.
+    bool k_built = false;
+    bool k_men_valid = false;          // oct_men mirrors `enabled` (else it is regathered on the next use)
+    bool k_applied = false;            // the refit scan in flight has already cleared its inliers in oct_men
+    bool k_sums_ready = false;         // ... and left the per-block popcounts of refit_mask in block_sums
+    double k_lo[3] = { 0, 0, 0 }, k_size = 1;   // bounding cube of the cloud (findAABB, utilities.jl:125-136)
+    double k_mag = 0;                  // max |coordinate| over the cloud (rounding slack of the box tests)
+    double *fullk = nullptr;           // 6 planes x n_pad, Morton order
+    float *fullk32 = nullptr;          // the same as float (Float32 clouds)
+    double *kgb = nullptr;             // 7 planes x kg_pad: box of every 64 consecutive points of fullk
+    int64_t kg_pad = 0;
+    int32_t *klist = nullptr;          // [nwords] groups that survive the box test of the scan in flight
+    int32_t *kctr = nullptr;           // [2] list length (zero between scans)
+    uint8_t *kflag = nullptr;          // [n_pad] one byte per point, original order: inlier of the scan in flight (zero between scans)
+    bool oct_built = false;            // depth + host twins of the octree (rh_octree_ensure)
     int oct_depth = 0, oct_max_depth = 0;
     uint64_t *oct_code = nullptr;      // [n] sorted Morton codes (device)
     int32_t *oct_perm = nullptr;       // [n] Morton position -> original index0
@@ -199,12 +214,23 @@ int rhk_f32_build(rh_cloud *c);
 int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const uint64_t *const en[4], const int32_t *d_orig,
                       const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], const double eps[4],
                       const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
-int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa);
+int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa, bool apply = false);
 int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts);
 int rhk_group_bounds(rh_cloud *c);
 int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out);
-int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa);
+// refit_mask = the shape's inliers among the enabled points (original order); `apply`: the caller follows up with
+// rhk_compact_refit_apply, so a culled scan may clear the Morton-order enabled bits on the way
+int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa, bool apply = false);
+// korder.hip
+int rhk_korder_build(rh_cloud *c, const double *d_xyz, const double *d_nrm, const double lo[3], double size, double mag);
+int rhk_korder_build_f32(rh_cloud *c);
+int rhk_korder_sync_enabled(rh_cloud *c);
+bool rhk_refit_is_culled(const rh_cloud *c);
+int rhk_refitk_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa, bool apply);
+int rhk_refitk_mask_f32(rh_cloud *c, const void *prepf, const rh_prep &P, int kind, double eps, double cosa, bool apply);
+int rhk_group_bounds_of(rh_cloud *c, const double *pts, int64_t stride, int64_t count, int64_t ngroups, double *gb, int64_t gstride);
+int rhk_oct_gather_enabled(rh_cloud *c);                                // oct_men = enabled in Morton order
 int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
                      int32_t *d_total);
 int rhk_invalidate_idx(rh_cloud *c, const int64_t *d_idx, int64_t n);

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 _ENV = ("RH_SCORE_PATH", "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
-        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT")
+        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH")
 
 
 @pytest.fixture(autouse=True)
@@ -51,6 +51,21 @@ def test_score_fuzz_slice_float32(seed, ncases):
     bad = []
     for case in range(ncases):
         ok, desc = fuzz_score.one(case + seed % 1000, rng, f32=True)
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("seed,ncases,f32", [(5101, 80, False), (5102, 80, False), (5103, 80, True)])
+def test_refit_fuzz_slice(seed, ncases, f32):
+    """refit / invalidate_indexes! against the oracle with the culled scan (Morton order + box tests, korder.hip) forced
+    on clouds of every size (and the plain scan on a quarter of the cases): NaN / inf points, random enabled patterns,
+    degenerate shapes, Float32 clouds."""
+    import fuzz_refit
+    rng = np.random.default_rng(seed)
+    bad = []
+    for case in range(ncases):
+        ok, desc = fuzz_refit.one(case + seed % 1000, rng, f32=f32)
         if not ok:
             bad.append(desc)
     assert not bad, bad[:5]

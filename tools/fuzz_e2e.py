@@ -32,7 +32,7 @@ def one(case, rng):
     if streams:
         env = rng.choice([None, None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_NO_FAST_EXTRACT"])
     for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_LONG_WINDOW_SETS",
-              "RH_NO_FAST_EXTRACT"):
+              "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH"):
         os.environ.pop(k, None)
     if env:
         os.environ[env] = "1"
@@ -40,6 +40,8 @@ def one(case, rng):
         os.environ["RH_LONG_WINDOW_SETS"] = "0"
     if rng.integers(0, 4) == 0:          # a quarter: liveness pass after the host has seen the list lengths
         os.environ["RH_NO_FAST_EXTRACT"] = "1"
+    # the culled refit scan (korder.hip) on these small clouds in two cases of three, the plain scan in the third
+    os.environ["RH_REFIT_PATH"] = str(rng.choice(["culled", "culled", "scan"]))
     pc = R.RANSACCloud(xyz, nrm, subs)
     oc = orc.Cloud(xyz, nrm, subs[0])
     cp = R.params_to_c(params, **kw)
