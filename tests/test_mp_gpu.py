@@ -61,9 +61,14 @@ def _rank(rank, world, name, which, octree, q):
         q.put((rank, None, repr(e)))
 
 
-@pytest.mark.parametrize("which,world,octree", [("small", 2, False), ("small", 3, False), ("cones", 2, False),
-                                                 ("small", 2, True), ("cfg2", 2, False)])
-def test_ransac_mp_equals_single_process(which, world, octree):
+@pytest.mark.parametrize("which,world,octree,refit_path", [("small", 2, False, None), ("small", 3, False, None),
+                                                            ("cones", 2, False, "culled"), ("small", 2, True, None),
+                                                            ("small", 2, True, "culled"), ("cfg2", 2, False, None)])
+def test_ransac_mp_equals_single_process(which, world, octree, refit_path, monkeypatch):
+    # refit_path: the culled refit scan (korder.hip) forced on these small clouds, in this process and in the ranks (cfg2
+    # takes it by its size); with the octree it also maintains the Morton-order enabled bits the sampler reads
+    if refit_path:
+        monkeypatch.setenv("RH_REFIT_PATH", refit_path)
     import ransac_jl_amd as R
     from ransac_jl_amd import _lib as L
     xyz, nrm, subs, it, cones = _scene(which)
