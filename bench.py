@@ -442,7 +442,7 @@ def main():
             kname = "score_groups_all_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
-            pmc_key = "score_groups_all_kernel<false>"
+            pmc_key = "score_groups_all_kernel<false, false>"
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
@@ -581,7 +581,7 @@ def main():
                                  "inliers": int(len(list_scan)),
                                  "note": "the HBM-bound kernel of the path (RH_REFIT_PATH=scan): one pass over the whole cloud "
                                          "in original order (48.125 B/point); HIP events on the library's stream; host wall "
-                                         "adds the compaction, two syncs and the D2H of the index list.  Clouds of 2^18 "
+                                         "adds the compaction, two syncs and the D2H of the index list.  Clouds of 2^21 "
                                          "points and more take the culled scan instead: `refit_culled`"}
         cul_ms, cul_comp, cul_wall, list_cul = time_refit(pc._h, plane, "culled")
         if not np.array_equal(list_scan, list_cul):

@@ -50,7 +50,7 @@ constexpr int RH_WORDS_PER_BLOCK = 1024;                 // scan granularity (64
 constexpr int RH_G2_TG = 4;                              // 64-point groups per LDS tile of the culled score kernel
 constexpr int RH_G2_TILE = RH_G2_TG * 64;
 constexpr int64_t RH_G2_MIN_POINTS = 8192;               // below this the brute-force kernel is used
-constexpr int64_t RH_KREFIT_MIN = 1 << 18;               // clouds from this size on take the culled refit scan (korder.hip)
+constexpr int64_t RH_KREFIT_MIN = 1 << 21;               // clouds from this size on take the culled refit scan (korder.hip): 1M points 17 us culled against 13 us streaming, 10M 24 against 80
 
 // ---- the cloud --------------------------------------------------------------
 struct rh_cloud {

@@ -63,10 +63,10 @@ def _rank(rank, world, name, which, octree, q):
 
 @pytest.mark.parametrize("which,world,octree,refit_path", [("small", 2, False, None), ("small", 3, False, None),
                                                             ("cones", 2, False, "culled"), ("small", 2, True, None),
-                                                            ("small", 2, True, "culled"), ("cfg2", 2, False, None)])
+                                                            ("small", 2, True, "culled"), ("cfg2", 2, False, "culled")])
 def test_ransac_mp_equals_single_process(which, world, octree, refit_path, monkeypatch):
-    # refit_path: the culled refit scan (korder.hip) forced on these small clouds, in this process and in the ranks (cfg2
-    # takes it by its size); with the octree it also maintains the Morton-order enabled bits the sampler reads
+    # refit_path: the culled refit scan (korder.hip; by default from 2^21 points on) forced on these clouds, in this process
+    # and in the ranks; with the octree it also maintains the Morton-order enabled bits the sampler reads
     if refit_path:
         monkeypatch.setenv("RH_REFIT_PATH", refit_path)
     import ransac_jl_amd as R

@@ -14,10 +14,20 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    """the files of the LATEST pass only: gpurun merges a run's output into gpurun_out/ beside what earlier runs left
+    there (other pids in the names), so everything older than the newest match by more than ten minutes is dropped"""
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        return []
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if os.path.getmtime(f) > t - 600]
+
+
 def counters(dirs):
     acc = defaultdict(list)
     for d in dirs:
-        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for f in newest(d + "/**/*counter_collection.csv"):
             per = defaultdict(float)
             for r in csv.DictReader(open(f)):
                 per[(r["Kernel_Name"], r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])   # one row per XCD
@@ -34,9 +44,9 @@ def main(rnd):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for sub, out in (("score_only", "kernel_stats_bench_score_only.csv"), ("with_e2e", "kernel_stats_bench_with_e2e.csv")):
-        f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        f = newest(os.path.join(src, sub, "**", "*kernel_stats.csv"))
         if f:
-            shutil.copy(f[0], os.path.join(dst, out))
+            shutil.copy(max(f, key=os.path.getmtime), os.path.join(dst, out))
     acc = counters([os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write")])
     rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean_KB": sum(v) / len(v), "max_KB": max(v)} for (k, c), v in acc.items()]
     rows.sort(key=lambda r: (r["counter"], r["kernel"]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The refit scan alone on the bench's cloud (cfg3, or WL=cfg5): every ground-truth primitive through rh_refit, scan time
-from HIP events (rh_last_refit_ms) per kind, with the culled scan (default from 2^18 points on) or RH_REFIT_PATH=scan.
+from HIP events (rh_last_refit_ms) per kind, with the culled scan (default from 2^21 points on) or RH_REFIT_PATH=scan.
 RH_KREFIT_DBG=1 prints how many groups survive the box test."""
 import ctypes as C, os, sys
 import numpy as np
