@@ -231,7 +231,8 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                   int64_t ngroups, const rh_prep *__restrict__ prep, const rh_prepf *__restrict__ prep32,
                   const int32_t *__restrict__ orig,
                   const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
-                  int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
+                  int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg,
+                  const int64_t tile)
 {
     static_assert(NT == 256, "four waves per block: one tile of RH_G2_TG groups, G2Shared::pq / pcnt rows");
     auto &lp = sh.lp;
@@ -244,7 +245,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
 
     const int nk = *nk_ptr;     // chunk_lo < chunk_hi <= ceil(nk / 64): 64-candidate chunks of this block
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t g0 = (int64_t)blockIdx.x * RH_G2_TG;
+    const int64_t g0 = tile * RH_G2_TG;
     const int64_t p0 = g0 * 64;
     const double qnan = __builtin_nan("");
 #pragma unroll
@@ -416,7 +417,7 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
     const int chunk_lo = (int)blockIdx.y * cpb, chunk_hi = min(nchunks, chunk_lo + cpb);
     if (chunk_lo >= chunk_hi) return;
     score_groups_body<KIND, MASK, NT>(sh, chunk_lo, chunk_hi, pts, stride, s, enabled_words, gb, gstride, ngroups, prep,
-                                      nullptr, orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg);
+                                      nullptr, orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg, blockIdx.x);
 }
 
 // All four kinds in ONE launch.  The 64-candidate chunks of the four kind bins are laid end to end,
@@ -430,7 +431,10 @@ struct G2KindArgs {
     const uint64_t *en;
     double eps, cosa;
 };
-struct G2AllArgs { G2KindArgs k[4]; };
+struct G2AllArgs {
+    G2KindArgs k[4];
+    int64_t ntiles;    // grid.x is padded beyond this (see rhk_score_all_groups)
+};
 
 template <bool MASK, bool F32 = false>
 __global__ void __launch_bounds__(256)
@@ -439,11 +443,15 @@ score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t 
                         int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
 {
     __shared__ G2Shared sh;
+    // (tile, candidate row) of this block; grid.x is padded to a multiple of 8 (the padding exits here)
+    const int64_t tile = blockIdx.x;
+    const int row = blockIdx.y, rows = gridDim.y;
+    if (tile >= A.ntiles) return;
     int nch[4], total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
-    const int cpb = (total + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int lo = (int)blockIdx.y * cpb, hi = min(total, lo + cpb);
+    const int cpb = (total + rows - 1) / rows;
+    const int lo = row * cpb, hi = min(total, lo + cpb);
     if (lo >= hi) return;
     int base = 0;
     bool ran = false;
@@ -454,7 +462,7 @@ score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t 
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile in LDS */              \
             score_groups_body<K, MASK, 256, F32>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,        \
                                                  A.k[K].prep, A.k[K].prep32, A.k[K].orig, A.k[K].nk, A.k[K].eps,      \
-                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg);            \
+                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg, tile);      \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -1426,7 +1434,15 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     if (rows > 65535) rows = 65535;
     G2AllArgs A;
     for (int k = 0; k < 4; k++) A.k[k] = { prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
-    dim3 grid((unsigned)ntiles, (unsigned)rows);
+    // XCD-aware launch: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with its own L2.  With
+    // grid.x padded to a multiple of 8 a tile meets the SAME XCD in every candidate row, so all rows but the first stage
+    // it from that L2 instead of HBM (0.1685 -> 0.165 ms on cfg3).  Measured and rejected: the rows of a tile back to
+    // back on its XCD (0.183 ms: the order "expensive kinds first" is what keeps the tail short) and one contiguous
+    // range of tiles per XCD (0.194 ms: tiles are spatial neighbours, so the XCDs get unequal work).  RH_G2_XCD=0: A/B.
+    static int env_swz = -1;
+    if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
+    A.ntiles = ntiles;
+    dim3 grid((unsigned)(env_swz ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
     if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
         if (d_masks_int)
             hipLaunchKernelGGL((score_groups_all_kernel<true, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
