@@ -1442,7 +1442,10 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     static int env_swz = -1;
     if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
     A.ntiles = ntiles;
-    dim3 grid((unsigned)(env_swz ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
+    // (only with >= 128 tiles per XCD: then the XCDs' shares even out -- with cfg2's 123 tiles, 15 per XCD and a few dense
+    // primitives, pinning tiles to XCDs unbalances them: 0.125 -> 0.165 ms)
+    const bool pad8 = env_swz && ntiles >= 1024;
+    dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
     if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
         if (d_masks_int)
             hipLaunchKernelGGL((score_groups_all_kernel<true, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
