@@ -261,11 +261,14 @@ struct EnabledMirror {
 
 constexpr int64_t LIVE_MAX = 4096;   // stores up to this size take the one-wait extraction path
 
+// (the shape itself -- 80 bytes -- lives in Driver::shapes, append-only for the length of a run: the compaction after an
+// extraction walks the whole store and moves 24-byte records instead of 96-byte ones)
 struct Stored {
-    rh_shape shape;
     double E;
     int32_t slot;    // index in the device store of its kind
     int32_t sigma;   // its count on subset 1
+    int32_t shape;   // index into Driver::shapes
+    int32_t kind;
 };
 
 // device-resident store of prepared candidates, one growable array per kind
@@ -407,11 +410,33 @@ void window_free(Window &w)
 // pinned scratch: a dozen hipMalloc / hipHostMalloc / hipFree pairs, ~3 ms per call): parked on the cloud
 // between calls, freed with it.  Only a run that ended cleanly parks its buffers (the windows' status blocks and
 // the liveness flags are zero then).
+// pinned staging blocks for the prepared records of large batches on their way into the device store (record()): a
+// ring of four, each guarded by an event -- a copy from pageable memory is a blocking staged copy inside the runtime
+// (~15 us per call, three calls per octree window)
+struct PinRing {
+    rh_prep *buf[4] = { nullptr, nullptr, nullptr, nullptr };
+    int64_t cap[4] = { 0, 0, 0, 0 };
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool busy[4] = { false, false, false, false };
+    int next = 0;
+};
+
+void pin_ring_free(PinRing &r)
+{
+    for (int i = 0; i < 4; i++) {
+        if (r.busy[i] && r.ev[i]) (void)hipEventSynchronize(r.ev[i]);
+        if (r.buf[i]) (void)hipHostFree(r.buf[i]);
+        if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
+        r.buf[i] = nullptr; r.cap[i] = 0; r.ev[i] = nullptr; r.busy[i] = false;
+    }
+}
+
 struct DriverCache {
     Window win[2];
     DeviceStore st;
     int32_t *h_scr = nullptr;
     int64_t h_scr_cap = 0;
+    PinRing ring;
 };
 
 void driver_cache_free(rh_cloud *c, void *p)
@@ -419,6 +444,7 @@ void driver_cache_free(rh_cloud *c, void *p)
     DriverCache *dc = (DriverCache *)p;
     if (!dc) return;
     (void)hipHostFree(dc->h_scr);
+    pin_ring_free(dc->ring);
     store_free(c, dc->st);
     for (Window &w : dc->win) window_free(w);
     delete dc;
@@ -434,6 +460,7 @@ struct Driver {
     EnabledMirror en;
     DeviceStore st;
     std::vector<Stored> store;              // scoredshapes, reference order
+    std::vector<rh_shape> shapes;           // the shapes of every candidate recorded in this run (Stored::shape)
     std::vector<rh_extracted> extracted;
     int64_t cc[4] = { 0, 0, 0, 0 };         // countcandidates (1-based like the reference)
     int64_t best = -1;                      // index into store of the running first maximum
@@ -455,6 +482,7 @@ struct Driver {
 
     // scratch
     std::vector<rh_prep> prep_h[4];
+    PinRing ring;
     std::vector<int64_t> sd;
     std::vector<double> fp, fn;
 
@@ -483,11 +511,14 @@ struct Driver {
             dc->win[0] = win[0]; dc->win[1] = win[1];
             dc->st = st;
             dc->h_scr = h_scr; dc->h_scr_cap = h_scr_cap;
+            dc->ring = ring;   // (the stream has been waited for above: no block is busy)
+            for (bool &b : dc->ring.busy) b = false;
             c->drv_cache = dc;
             c->drv_cache_free = driver_cache_free;
             return;
         }
         (void)hipHostFree(h_scr);
+        pin_ring_free(ring);
         store_free(c, st);
         for (Window &w : win) window_free(w);
     }
@@ -522,6 +553,7 @@ struct Driver {
             win[0] = dc->win[0]; win[1] = dc->win[1];
             st = dc->st;
             h_scr = dc->h_scr; h_scr_cap = dc->h_scr_cap;
+            ring = dc->ring;
             delete dc;
             for (int q = 0; q < 4; q++) st.n[q] = 0;
             for (Window &w : win) { w.pending = false; w.scored = false; }
@@ -665,18 +697,48 @@ struct Driver {
             rh_prep_host(cands[i], &prep_h[q].back());
             nk[q]++;
         }
+        // a large batch travels through a pinned block of the ring (truly asynchronous copies), a small one from where it is
+        rh_prep *pin = nullptr;
+        int slot_r = -1;
+        if (ncand >= 64) {
+            slot_r = ring.next;
+            ring.next = (ring.next + 1) & 3;
+            if (ring.busy[slot_r]) { RUNH(hipEventSynchronize(ring.ev[slot_r])); ring.busy[slot_r] = false; }
+            if (ring.cap[slot_r] < ncand) {
+                if (ring.buf[slot_r]) (void)hipHostFree(ring.buf[slot_r]);
+                ring.buf[slot_r] = nullptr;
+                ring.cap[slot_r] = 0;
+                const int64_t cap = std::max<int64_t>(2 * (int64_t)ncand, 4096);
+                RUNH(hipHostMalloc((void **)&ring.buf[slot_r], sizeof(rh_prep) * (size_t)cap));
+                ring.cap[slot_r] = cap;
+            }
+            if (!ring.ev[slot_r]) RUNH(hipEventCreateWithFlags(&ring.ev[slot_r], hipEventDisableTiming));
+            pin = ring.buf[slot_r];
+        }
+        int64_t poff = 0;
         for (int q = 0; q < 4; q++) {
             if (nk[q] == 0) continue;
             RUN(store_reserve(c, st, q, (int64_t)st.n[q] + nk[q]));
-            RUNH(hipMemcpyAsync(st.prep[q] + st.n[q], prep_h[q].data(), sizeof(rh_prep) * (size_t)nk[q], hipMemcpyHostToDevice,
-                                c->stream));
+            const rh_prep *src = prep_h[q].data();
+            if (pin != nullptr) {
+                memcpy(pin + poff, prep_h[q].data(), sizeof(rh_prep) * (size_t)nk[q]);
+                src = pin + poff;
+                poff += nk[q];
+            }
+            RUNH(hipMemcpyAsync(st.prep[q] + st.n[q], src, sizeof(rh_prep) * (size_t)nk[q], hipMemcpyHostToDevice, c->stream));
+        }
+        if (pin != nullptr) {
+            RUNH(hipEventRecord(ring.ev[slot_r], c->stream));
+            ring.busy[slot_r] = true;
         }
         int32_t slot_next[4] = { st.n[0], st.n[1], st.n[2], st.n[3] };
         for (int32_t i = 0; i < ncand; i++) {   // slots follow candidate order within a kind (stable sort)
             double lo, hi, E;
             RUN(rh_estimatescore(c->s, c->n, counts[i], p->score_mode, &lo, &hi, &E));
             Stored rec;
-            rec.shape = cands[i];
+            rec.shape = (int32_t)shapes.size();
+            shapes.push_back(cands[i]);
+            rec.kind = cands[i].kind;
             rec.E = E;
             rec.slot = slot_next[cands[i].kind]++;
             rec.sigma = counts[i];
@@ -700,7 +762,7 @@ struct Driver {
         if (!(ppp > p->prob_det)) return RH_OK;   // iterations.jl:123
         const double t0 = now_s();
         // refit: full-cloud scan + ascending compaction (plane.jl:137-143 ...)
-        const rh_shape bestshape = store[(size_t)best].shape;
+        const rh_shape bestshape = shapes[(size_t)store[(size_t)best].shape];
         const size_t extracted_pos = (size_t)best;   // deleteat!(scoredshapes, best.index): iterations.jl:136
         rh_prep P;
         rh_prep_host(bestshape, &P);
@@ -795,7 +857,7 @@ struct Driver {
         // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
         std::vector<char> dead_slot[4];
         for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 0);   // every slot is referenced by `store`
-        dead_slot[store[extracted_pos].shape.kind][(size_t)store[extracted_pos].slot] = 1;
+        dead_slot[store[extracted_pos].kind][(size_t)store[extracted_pos].slot] = 1;
         if (fast) {
             for (int q = 0; q < 4; q++)
                 for (int32_t sl = 0; sl < st.n[q]; sl++)
@@ -863,7 +925,7 @@ struct Driver {
         best = -1;
         double best_E = 0;
         for (size_t i = 0; i < store.size(); i++) {
-            const int q = store[i].shape.kind;
+            const int q = store[i].kind;
             const int32_t ns = remap[q][(size_t)store[i].slot];
             if (ns < 0 || i == extracted_pos) continue;
             if (wpos != i) store[wpos] = store[i];
