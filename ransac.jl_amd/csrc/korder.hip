@@ -109,7 +109,8 @@ refitk_boxes_kernel(const double *__restrict__ gb, int64_t gstride, int64_t ng, 
     if (keep) {
         int off = base_s;
         for (int k = 0; k < wave; k++) off += wcnt[k];
-        list[off + __popcll(b & ((1ULL << lane) - 1ULL))] = (int32_t)g;
+        off += __popcll(b & ((1ULL << lane) - 1ULL));
+        if (off < ng) list[off] = (int32_t)g;   // (always, unless an earlier scan died between its passes and left its count)
     }
 }
 
@@ -137,7 +138,7 @@ refitk_groups_kernel(const T *__restrict__ pts, int64_t stride, int64_t n, const
     const int lane = threadIdx.x & 63;
     const int wave0 = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)gridDim.x * 4;
-    const int count = __builtin_amdgcn_readfirstlane(*ctr);
+    const int count = min(__builtin_amdgcn_readfirstlane(*ctr), (int)((n + 63) >> 6));
     const T *__restrict__ X = pts, *__restrict__ Y = pts + stride, *__restrict__ Z = pts + 2 * stride;
     const T *__restrict__ NX = pts + 3 * stride, *__restrict__ NY = pts + 4 * stride, *__restrict__ NZ = pts + 5 * stride;
     for (int e = wave0; e < count; e += nwaves) {
