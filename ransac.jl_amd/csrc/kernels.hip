@@ -299,7 +299,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                 surv |= skip ? 0u : (1u << g);
             }
             if (dbg == 2) surv = (1u << RH_G2_TG) - 1u;
-            if (QUEUED) Ql = pre_make<KIND>(Pl, eps, slack);
+            if (QUEUED) Ql = pre_make<KIND>(Pl, eps, slack, coord_mag);
         }
         if (dbg == 1) surv = 0;
 
@@ -341,6 +341,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                     unsigned rem = __builtin_amdgcn_readlane(surv, l);
                     rh_pre Q;
                     Q.a = rl_f64(Ql.a, l); Q.b = rl_f64(Ql.b, l);
+                    if (KIND == RH_CYLINDER) Q.c = rl_f64(Ql.c, l);
                     if (KIND == RH_CONE) { Q.c = rl_f64(Ql.c, l); Q.d = rl_f64(Ql.d, l); Q.e = rl_f64(Ql.e, l); }
                     while (rem != 0) {
                         const int g = __builtin_ctz(rem);

@@ -176,14 +176,22 @@ static __device__ __forceinline__ double box_slack32(const rh_prep &P, double co
     return 1.52587890625e-05 * m;
 }
 
+// The conservative stages (box tests, band prefilter) may fuse: they only have to BOUND the exact test's distance, with
+// slacks 10^5 x any rounding, and v_fma_f64 issues at the rate of a multiply or an add -- a dot product is 3
+// instructions instead of 5.  (The exact tests never fuse: the library is built with -ffp-contract=off.)
+static __device__ __forceinline__ double dot3f(double ax, double ay, double az, double bx, double by, double bz)
+{
+    return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));
+}
+
 template <int KIND, bool F32 = false>
 static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, double cy, double cz, double hx, double hy,
                                          double hz, double hr, double eps, double slack)
 {
     if (KIND == RH_PLANE) {
         // d(p) = dot(o_z, p - point) is affine: over the box it stays within d(c) +- sum |o_z_i| h_i
-        const double d = (P.f[6] * (cx - P.f[0]) + P.f[7] * (cy - P.f[1])) + P.f[8] * (cz - P.f[2]);
-        const double ext = (fabs(P.f[6]) * hx + fabs(P.f[7]) * hy) + fabs(P.f[8]) * hz;
+        const double d = dot3f(P.f[6], P.f[7], P.f[8], cx - P.f[0], cy - P.f[1], cz - P.f[2]);
+        const double ext = dot3f(fabs(P.f[6]), fabs(P.f[7]), fabs(P.f[8]), hx, hy, hz);
         return fabs(d) > (ext + eps) + slack;
     }
     if (KIND == RH_SPHERE) {
@@ -192,7 +200,7 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
         const double ax = fabs(cx - P.f[0]), ay = fabs(cy - P.f[1]), az = fabs(cz - P.f[2]);
         const double nx = fmax(ax - hx, 0.0), ny = fmax(ay - hy, 0.0), nz = fmax(az - hz, 0.0);
         const double fx = ax + hx, fy = ay + hy, fz = az + hz;
-        const double dmin2 = (nx * nx + ny * ny) + nz * nz, dmax2 = (fx * fx + fy * fy) + fz * fz;
+        const double dmin2 = dot3f(nx, ny, nz, nx, ny, nz), dmax2 = dot3f(fx, fy, fz, fx, fy, fz);
         const double A = (P.f[3] + eps) + slack, B = (P.f[3] - eps) - slack;
         const double A2 = A > 0.0 ? A * A : (A <= 0.0 ? 0.0 : A);   // A <= 0: any positive distance is outside; NaN stays NaN
         return (dmin2 > A2) | ((B > 0.0) & (dmax2 < B * B));
@@ -201,10 +209,10 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
         // q(p) = (I - a a')(p - c0) is linear: |q(p) - q(c)| <= max(1, |1 - |a|^2|) * |p - c|; squares as above
         const double ax = P.f[0], ay = P.f[1], az = P.f[2];
         const double tx = cx - P.f[3], ty = cy - P.f[4], tz = cz - P.f[5];
-        const double sd = (ax * tx + ay * ty) + az * tz;
-        const double qx = (cx - ax * sd) - P.f[3], qy = (cy - ay * sd) - P.f[4], qz = (cz - az * sd) - P.f[5];
-        const double rho2 = (qx * qx + qy * qy) + qz * qz;
-        const double a2 = (ax * ax + ay * ay) + az * az;
+        const double sd = dot3f(ax, ay, az, tx, ty, tz);
+        const double qx = __builtin_fma(-ax, sd, tx), qy = __builtin_fma(-ay, sd, ty), qz = __builtin_fma(-az, sd, tz);
+        const double rho2 = dot3f(qx, qy, qz, qx, qy, qz);
+        const double a2 = dot3f(ax, ay, az, ax, ay, az);
         const double lip = fmax(1.0, fabs(1.0 - a2)) * hr;
         const double X = ((P.f[6] + eps) + slack) + lip, Y = ((P.f[6] - eps) - slack) - lip;
         const double X2 = X > 0.0 ? X * X : (X <= 0.0 ? 0.0 : X);
@@ -216,27 +224,29 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
         const double ax = P.f[3], ay = P.f[4], az = P.f[5];
         const double c = P.f[6], s = P.f[7];
         const double tx = P.f[0] - cx, ty = P.f[1] - cy, tz = P.f[2] - cz;
-        double inv = 1.0 / sqrt((tx * tx + ty * ty) + tz * tz);
+        const double ta2 = dot3f(tx, ty, tz, tx, ty, tz);
+        double inv = 1.0 / sqrt(ta2);
         const double tnx = inv * tx, tny = inv * ty, tnz = inv * tz;
-        double kx = ay * tnz - az * tny, ky = az * tnx - ax * tnz, kz = ax * tny - ay * tnx;
-        inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
-        const double rx = inv * kx, ry = inv * ky, rz = inv * kz;
-        kx = ay * rz - az * ry; ky = az * rx - ax * rz; kz = ax * ry - ay * rx;
-        inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
+        // (a x t^) -- cross products as fma(a, b, -(c d)): two instructions per component
+        const double k0x = __builtin_fma(ay, tnz, -(az * tny)), k0y = __builtin_fma(az, tnx, -(ax * tnz)), k0z = __builtin_fma(ax, tny, -(ay * tnx));
+        const double k02 = dot3f(k0x, k0y, k0z, k0x, k0y, k0z);
+        inv = 1.0 / sqrt(k02);
+        const double rx = inv * k0x, ry = inv * k0y, rz = inv * k0z;
+        double kx = __builtin_fma(ay, rz, -(az * ry)), ky = __builtin_fma(az, rx, -(ax * rz)), kz = __builtin_fma(ax, ry, -(ay * rx));
+        inv = 1.0 / sqrt(dot3f(kx, ky, kz, kx, ky, kz));
         const double mx = inv * kx, my = inv * ky, mz = inv * kz;
         // Rodrigues rotation of m about r by the angle whose cos/sin are (c, s): m c + (r x m) s + r (r.m)(1-c)
-        const double ux = ry * mz - rz * my, uy = rz * mx - rx * mz, uz = rx * my - ry * mx;
-        const double rm = (rx * mx + ry * my) + rz * mz;
-        const double gx = (mx * c + ux * s) + rx * rm * (1.0 - c);
-        const double gy = (my * c + uy * s) + ry * rm * (1.0 - c);
-        const double gz = (mz * c + uz * s) + rz * rm * (1.0 - c);
-        const double gn = sqrt((gx * gx + gy * gy) + gz * gz);
-        const double dist = ((gx * tx + gy * ty) + gz * tz) / gn;
+        const double ux = __builtin_fma(ry, mz, -(rz * my)), uy = __builtin_fma(rz, mx, -(rx * mz)), uz = __builtin_fma(rx, my, -(ry * mx));
+        const double rm = dot3f(rx, ry, rz, mx, my, mz) * (1.0 - c);
+        const double gx = __builtin_fma(rx, rm, __builtin_fma(ux, s, mx * c));
+        const double gy = __builtin_fma(ry, rm, __builtin_fma(uy, s, my * c));
+        const double gz = __builtin_fma(rz, rm, __builtin_fma(uz, s, mz * c));
+        const double gn = sqrt(dot3f(gx, gy, gz, gx, gy, gz));
+        const double dist = dot3f(gx, gy, gz, tx, ty, tz) / gn;
         // a centre on / next to the axis makes the frame ill-conditioned: never skip there
-        const double ta = sqrt((tx * tx + ty * ty) + tz * tz);
-        const double sinang = sqrt(((ay * tnz - az * tny) * (ay * tnz - az * tny) + (az * tnx - ax * tnz) * (az * tnx - ax * tnz)) +
-                                   (ax * tny - ay * tnx) * (ax * tny - ay * tnx));
-        const double an = sqrt((ax * ax + ay * ay) + az * az);
+        const double ta = sqrt(ta2);
+        const double sinang = sqrt(k02);
+        const double an = sqrt(dot3f(ax, ay, az, ax, ay, az));
         // (binary32 exact test: its frame degrades as 2^-24 / sin(angle to the axis): only skip well away from the axis)
         const bool well = (sinang > (F32 ? 3e-2 : 1e-6) * an) & (ta > 0.0);
         return well & (fabs(dist) > ((hr + eps) + slack) + (F32 ? 1e-4 : 1e-6) * (hr + fabs(dist)));
@@ -256,7 +266,7 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
 struct rh_pre { double a, b, c, d, e; };
 
 template <int KIND>
-static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, double slack)
+static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, double slack, double coord_mag)
 {
     rh_pre o = { -1.0, __builtin_inf(), 0.0, 0.0, 0.0 };
     if (KIND == RH_SPHERE || KIND == RH_CYLINDER) {
@@ -266,6 +276,19 @@ static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, 
         if (!(hi == hi)) hi2 = __builtin_inf();
         o.a = lo > 0.0 ? lo * lo * (1.0 - 1e-9) : -1.0;   // NaN -> -1: everything passes the lower bound
         o.b = hi2;
+        if (KIND == RH_CYLINDER) {
+            // The prefilter takes rho^2 in closed form: with t = p - c0, sd = a . t and q = t - a sd (the exact test's
+            // vector) |q|^2 = |t|^2 - (2 - |a|^2) sd^2 for ANY stored axis a.  Its rounding differs from the exact
+            // test's component form by a few ulp of |t|^2 (1 + |k| |a|^2), so the band is widened by 10^7 x that, as an
+            // absolute amount per candidate: M bounds every coordinate of p and c0, i.e. |t|^2 <= 12 M^2.
+            const double a2 = (P.f[0] * P.f[0] + P.f[1] * P.f[1]) + P.f[2] * P.f[2];
+            const double k = 2.0 - a2;
+            const double M = ((1.0 + coord_mag) + fabs(P.f[3])) + (fabs(P.f[4]) + fabs(P.f[5]));
+            const double s2 = 1.2e-8 * (M * M) * (1.0 + fabs(k) * a2);
+            o.c = k;
+            o.a = (s2 == s2) ? o.a - s2 : -1.0;
+            o.b = (s2 == s2) ? o.b + s2 : __builtin_inf();
+        }
         return o;
     }
     // cone: with t = p - apex, h = t . a^ (a^ = unit axis), rho^2 = |t|^2 - h^2 the reference's distance is
@@ -297,22 +320,22 @@ static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_p
 {
     if (KIND == RH_SPHERE) {
         const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
-        const double n2 = (dx * dx + dy * dy) + dz * dz;
+        const double n2 = dot3f(dx, dy, dz, dx, dy, dz);
         return WB(n2 >= Q.a) & WB(n2 <= Q.b);
     }
     if (KIND == RH_CYLINDER) {
         const double ax = P.f[0], ay = P.f[1], az = P.f[2];
         const double cx = P.f[3], cy = P.f[4], cz = P.f[5];
         const double tx = px - cx, ty = py - cy, tz = pz - cz;
-        const double sd = (ax * tx + ay * ty) + az * tz;
-        const double qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
-        const double n2 = (qx * qx + qy * qy) + qz * qz;
+        const double sd = dot3f(ax, ay, az, tx, ty, tz);
+        const double tt = dot3f(tx, ty, tz, tx, ty, tz);
+        const double n2 = __builtin_fma(-(Q.c * sd), sd, tt);   // = |t - a sd|^2 (pre_make): 13 instructions instead of 24
         return WB(n2 >= Q.a) & WB(n2 <= Q.b);
     }
     const double tx = px - P.f[0], ty = py - P.f[1], tz = pz - P.f[2];
-    const double tt = (tx * tx + ty * ty) + tz * tz;
-    const double h = (tx * Q.a + ty * Q.b) + tz * Q.c;
-    const double rho2 = tt - h * h;
+    const double tt = dot3f(tx, ty, tz, tx, ty, tz);
+    const double h = dot3f(tx, ty, tz, Q.a, Q.b, Q.c);
+    const double rho2 = __builtin_fma(-h, h, tt);
     const double u = Q.d * h;
     const double lo = u - Q.e, hi = u + Q.e;
     const double s2 = (F32 ? 1e-5 : 1e-9) * tt + 1e-300;
