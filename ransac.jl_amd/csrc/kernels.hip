@@ -24,6 +24,21 @@ using namespace rhdev;
 using namespace rhdev32;
 
 // -------------------------------------------------------------- prep ------
+// Per-candidate constants of the CONSERVATIVE stages (box tests, band prefilter), in the record's free slots so that
+// stage 1 does not recompute them per (chunk, tile): f[11] = sum |f[0..6]| (the magnitude behind box_slack); cylinder:
+// f[8] = 1 + |c0|_1, f[9] = k = 2 - |a|^2, f[10] = 1 + |k| |a|^2 (closed-form rho^2 of the prefilter, score_device.h).
+__host__ __device__ inline void prep_derived(rh_prep &o, int kind)
+{
+    o.f[11] = (((((fabs(o.f[0]) + fabs(o.f[1])) + fabs(o.f[2])) + fabs(o.f[3])) + fabs(o.f[4])) + fabs(o.f[5])) + fabs(o.f[6]);
+    if (kind == RH_CYLINDER) {
+        const double a2 = (o.f[0] * o.f[0] + o.f[1] * o.f[1]) + o.f[2] * o.f[2];
+        const double k = 2.0 - a2;
+        o.f[8] = (1.0 + fabs(o.f[3])) + (fabs(o.f[4]) + fabs(o.f[5]));
+        o.f[9] = k;
+        o.f[10] = 1.0 + fabs(k) * a2;
+    }
+}
+
 __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
 {
 #pragma unroll
@@ -52,6 +67,7 @@ __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
         o.f[8] = sgn;
         break;
     }
+    prep_derived(o, s.kind);
 }
 
 __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
@@ -1040,6 +1056,7 @@ void rh_prep_host(const rh_shape &s, rh_prep *o)
         o->f[8] = sgn;
         break;
     }
+    prep_derived(*o, s.kind);
 }
 
 int rhk_transpose_aos(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, const int32_t *d_gather,

@@ -156,8 +156,7 @@ static __device__ __forceinline__ uint64_t valid_mask(int64_t base, int64_t s)
 // kernel.  Every comparison is written so that NaN means "do not skip".
 static __device__ __forceinline__ double box_slack(const rh_prep &P, double coord_mag)
 {
-    return 1e-9 * (1.0 + coord_mag + fabs(P.f[0]) + fabs(P.f[1]) + fabs(P.f[2]) + fabs(P.f[3]) + fabs(P.f[4]) +
-                   fabs(P.f[5]) + fabs(P.f[6]));
+    return 1e-9 * ((1.0 + coord_mag) + P.f[11]);   // f[11] = sum |f[0..6]| (prep_derived, kernels.hip)
 }
 
 // Float32 clouds: the conservative stages still run in binary64 on the exactly converted values (they bound the
@@ -168,11 +167,8 @@ static __device__ __forceinline__ double box_slack(const rh_prep &P, double coor
 template <int KIND>
 static __device__ __forceinline__ double box_slack32(const rh_prep &P, double coord_mag)
 {
-    double m = 1.0 + coord_mag + fabs(P.f[0]) + fabs(P.f[1]) + fabs(P.f[2]) + fabs(P.f[3]) + fabs(P.f[4]) + fabs(P.f[5]) + fabs(P.f[6]);
-    if (KIND == RH_CYLINDER) {
-        const double a2 = (P.f[0] * P.f[0] + P.f[1] * P.f[1]) + P.f[2] * P.f[2];
-        m *= fmax(1.0, a2);
-    }
+    double m = (1.0 + coord_mag) + P.f[11];
+    if (KIND == RH_CYLINDER) m *= fmax(1.0, 2.0 - P.f[9]);   // |a|^2 = 2 - k (prep_derived)
     return 1.52587890625e-05 * m;
 }
 
@@ -212,8 +208,7 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
         const double sd = dot3f(ax, ay, az, tx, ty, tz);
         const double qx = __builtin_fma(-ax, sd, tx), qy = __builtin_fma(-ay, sd, ty), qz = __builtin_fma(-az, sd, tz);
         const double rho2 = dot3f(qx, qy, qz, qx, qy, qz);
-        const double a2 = dot3f(ax, ay, az, ax, ay, az);
-        const double lip = fmax(1.0, fabs(1.0 - a2)) * hr;
+        const double lip = fmax(1.0, fabs(P.f[9] - 1.0)) * hr;   // |1 - |a|^2| = |k - 1| (prep_derived)
         const double X = ((P.f[6] + eps) + slack) + lip, Y = ((P.f[6] - eps) - slack) - lip;
         const double X2 = X > 0.0 ? X * X : (X <= 0.0 ? 0.0 : X);
         return (rho2 > X2) | ((Y > 0.0) & (rho2 < Y * Y));
@@ -281,10 +276,9 @@ static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, 
             // vector) |q|^2 = |t|^2 - (2 - |a|^2) sd^2 for ANY stored axis a.  Its rounding differs from the exact
             // test's component form by a few ulp of |t|^2 (1 + |k| |a|^2), so the band is widened by 10^7 x that, as an
             // absolute amount per candidate: M bounds every coordinate of p and c0, i.e. |t|^2 <= 12 M^2.
-            const double a2 = (P.f[0] * P.f[0] + P.f[1] * P.f[1]) + P.f[2] * P.f[2];
-            const double k = 2.0 - a2;
-            const double M = ((1.0 + coord_mag) + fabs(P.f[3])) + (fabs(P.f[4]) + fabs(P.f[5]));
-            const double s2 = 1.2e-8 * (M * M) * (1.0 + fabs(k) * a2);
+            const double k = P.f[9];                    // 2 - |a|^2, f[10] = 1 + |k| |a|^2, f[8] = 1 + |c0|_1 (prep_derived)
+            const double M = coord_mag + P.f[8];
+            const double s2 = 1.2e-8 * (M * M) * P.f[10];
             o.c = k;
             o.a = (s2 == s2) ? o.a - s2 : -1.0;
             o.b = (s2 == s2) ? o.b + s2 : __builtin_inf();
