@@ -365,10 +365,11 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                         const int i = (g << 6) + lane;
                         const rh_f64x2 a = lp[0][i];
                         const double z = lp[1][i].x;
-                        const uint64_t m = pre_test<KIND, F32>(P, Q, a.x, a.y, z);
+                        const bool pass = pre_test<KIND, F32>(P, Q, a.x, a.y, z);
+                        const uint64_t m = WB(pass);
                         if (m != 0) {
                             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                            if ((m >> lane) & 1ULL) pq[wv][(qh + qn + rank) & 127] = (uint16_t)((l << 8) | i);
+                            if (pass) pq[wv][(qh + qn + rank) & 127] = (uint16_t)(((l << 8) | (g << 6)) | lane);
                             qn += __popcll(m);
                             if (qn >= 64) { drain(64); qh = (qh + 64) & 127; qn -= 64; }
                         }

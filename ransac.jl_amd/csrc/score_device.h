@@ -308,14 +308,15 @@ static __device__ __forceinline__ double rl_f64(double v, int l)
     return cv.d;
 }
 
-// wave mask of the points that may pass the distance half of the exact test
+// per lane: may this point pass the distance half of the exact test?  (a bool, not a wave mask: the caller predicates
+// its queue push on it directly -- extracting the lane's bit from a ballot again costs three vector instructions)
 template <int KIND, bool F32 = false>
-static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_pre &Q, double px, double py, double pz)
+static __device__ __forceinline__ bool pre_test(const rh_prep &P, const rh_pre &Q, double px, double py, double pz)
 {
     if (KIND == RH_SPHERE) {
         const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
         const double n2 = dot3f(dx, dy, dz, dx, dy, dz);
-        return WB(n2 >= Q.a) & WB(n2 <= Q.b);
+        return (n2 >= Q.a) & (n2 <= Q.b);
     }
     if (KIND == RH_CYLINDER) {
         const double ax = P.f[0], ay = P.f[1], az = P.f[2];
@@ -324,7 +325,7 @@ static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_p
         const double sd = dot3f(ax, ay, az, tx, ty, tz);
         const double tt = dot3f(tx, ty, tz, tx, ty, tz);
         const double n2 = __builtin_fma(-(Q.c * sd), sd, tt);   // = |t - a sd|^2 (pre_make): 13 instructions instead of 24
-        return WB(n2 >= Q.a) & WB(n2 <= Q.b);
+        return (n2 >= Q.a) & (n2 <= Q.b);
     }
     const double tx = px - P.f[0], ty = py - P.f[1], tz = pz - P.f[2];
     const double tt = dot3f(tx, ty, tz, tx, ty, tz);
@@ -336,8 +337,8 @@ static __device__ __forceinline__ uint64_t pre_test(const rh_prep &P, const rh_p
     const double hi2 = hi * hi * (1.0 + 1e-9) + s2, lo2 = lo * lo * (1.0 - 1e-9) - s2;
     // next to the axis the reference's frame is ill-conditioned: hand those points to the exact test
     // (binary32 exact test: within ~0.03 rad of the axis, where its frame loses more than the slack covers)
-    const uint64_t near_axis = WB(rho2 <= (F32 ? 1e-3 : 1e-10) * tt);
-    return near_axis | (WB(hi > 0.0) & WB(rho2 <= hi2) & (WB(lo <= 0.0) | WB(rho2 >= lo2)));
+    const bool near_axis = rho2 <= (F32 ? 1e-3 : 1e-10) * tt;
+    return near_axis | ((hi > 0.0) & (rho2 <= hi2) & ((lo <= 0.0) | (rho2 >= lo2)));
 }
 
 }  // namespace rhdev
