@@ -292,6 +292,12 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
     }
     if (tid == 0) next_chunk = chunk_lo;
     __syncthreads();
+    // which groups of the tile have an enabled point at all: once per block into a scalar (stage 1 asked the LDS word
+    // per group and chunk -- four blocking round trips per chunk)
+    unsigned live = 0;
+#pragma unroll
+    for (int g = 0; g < RH_G2_TG; g++) live |= len[g] != 0 ? (1u << g) : 0u;
+    live = __builtin_amdgcn_readfirstlane(live);
 
     for (;;) {
         int chunk = 0;
@@ -309,7 +315,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
             const double slack = F32 ? box_slack32<KIND>(Pl, coord_mag) : box_slack(Pl, coord_mag);
 #pragma unroll 4
             for (int g = 0; g < RH_G2_TG; g++) {
-                if (len[g] == 0) continue;
+                if (!((live >> g) & 1u)) continue;
                 const bool skip = box_skip<KIND, F32>(Pl, lb[0][g], lb[1][g], lb[2][g], lb[3][g], lb[4][g], lb[5][g],
                                                  lb[6][g], eps, slack);
                 surv |= skip ? 0u : (1u << g);
