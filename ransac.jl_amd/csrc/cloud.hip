@@ -86,6 +86,10 @@ int rh_ensure_batch(rh_cloud *c, int64_t b)
     c->batch_cap = 0;
     RH_TRY(dev_alloc(&c->d_shapes, cap));
     RH_TRY(dev_alloc(&c->d_prep, 4 * cap));
+    (void)hipFree(c->d_qpre);
+    c->d_qpre = nullptr;
+    c->qpre_valid = false;
+    RH_HIP(hipMalloc(&c->d_qpre, (size_t)(4 * cap) * 5 * sizeof(double)));
     RH_TRY(dev_alloc(&c->d_orig, 4 * cap));
     RH_TRY(dev_alloc(&c->d_counts, cap));
     if (c->f32) {
@@ -143,7 +147,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
-    (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32);
+    (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
     (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
@@ -692,6 +696,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         RH_HIP(hipMemcpyAsync(c->d_shapes, h_sorted, sizeof(rh_shape) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_nk, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        c->qpre_valid = false;
         RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts));   // zeroes d_counts as well
     }
     uint64_t *d_masks = nullptr, *d_masks_int = nullptr;
@@ -733,7 +738,7 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     int32_t *nk_cur = c->d_nk2 + 4 * c->nk2_flip, *nk_next = c->d_nk2 + 4 * (1 - c->nk2_flip);
     c->nk2_flip = 1 - c->nk2_flip;
-    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1));
+    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps));
     uint64_t *d_masks_int = nullptr;
     if (d_masks && c->swords > 0) {
         RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));

@@ -1049,7 +1049,7 @@ struct Driver {
                 // launch sizes from the previous windows' list lengths; any length is handled (the
                 // kernels read the true count), a longer list only gets fewer blocks per candidate
                 const int32_t bound = std::min<int32_t>(w.entries_cap, std::max<int32_t>(4 * cnt_est, 1024));
-                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts, 1));
+                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts, 1, p->eps));
                 const uint64_t *enw[4];
                 const rh_prep *pr[4];
                 const int32_t *og[4], *nkp[4];

@@ -87,9 +87,14 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
 // in the batch -- often hypotheses of the same primitive -- end up in different 64-candidate chunks.  A chunk of
 // near-identical candidates makes the tiles it touches 64 x heavier than the rest (measured on the cfg3 batch
 // sorted by primitive: 0.231 ms instead of 0.180).
+// qpre (optional): the band constants of the prefilter (pre_make) per binned candidate, so that the score kernel reads
+// them with the record instead of computing them per (chunk, tile) and broadcasting them with v_readlane
+struct PreArgs { double eps[4]; double coord_mag; int f32; };
+
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap,
-                                   int32_t *__restrict__ counts_zero, int32_t *__restrict__ nk_other, int32_t spread)
+                                   int32_t *__restrict__ counts_zero, int32_t *__restrict__ nk_other, int32_t spread,
+                                   rh_pre *__restrict__ qpre, const PreArgs QA)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -113,14 +118,18 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
         if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
     }
     if (kind < 0) return;
-    prep_one(s, prep[(int64_t)kind * cap + slot]);
+    rh_prep P;
+    prep_one(s, P);
+    prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
+    if (qpre != nullptr && kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
 }
 
 // the sampler's candidate list (count on the device): bin by kind like prep_binned_kernel, zero the counts
 __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
                                     int32_t cap_entries, rh_prep *__restrict__ prep, int32_t *__restrict__ orig,
-                                    int32_t *__restrict__ nk, int64_t cap, int32_t *__restrict__ counts)
+                                    int32_t *__restrict__ nk, int64_t cap, int32_t *__restrict__ counts,
+                                    rh_pre *__restrict__ qpre, const PreArgs QA)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -143,8 +152,11 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
         if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
     }
     if (kind < 0) return;
-    prep_one(s, prep[(int64_t)kind * cap + slot]);
+    rh_prep P;
+    prep_one(s, P);
+    prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
+    if (qpre != nullptr && kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
 }
 
 // ------------------------------------------------------------- score ------
@@ -240,7 +252,7 @@ struct G2Shared {
 
 // F32: a Float32 cloud -- staging, box tests and band prefilter as for Float64 (binary64 on the exactly converted values,
 // with the wider margins of box_slack32), the EXACT test in binary32 on the float record of the candidate (prep32)
-template <int KIND, bool MASK, int NT, bool F32 = false>
+template <int KIND, bool MASK, int NT, bool F32 = false, bool QARR = false>
 __device__ __forceinline__ void
 score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const double *__restrict__ pts, int64_t stride, int64_t s,
                   const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
@@ -248,7 +260,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                   const int32_t *__restrict__ orig,
                   const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
                   int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg,
-                  const int64_t tile)
+                  const int64_t tile, const rh_pre *__restrict__ qarr = nullptr)
 {
     static_assert(NT == 256, "four waves per block: one tile of RH_G2_TG groups, G2Shared::pq / pcnt rows");
     auto &lp = sh.lp;
@@ -321,7 +333,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                 surv |= skip ? 0u : (1u << g);
             }
             if (dbg == 2) surv = (1u << RH_G2_TG) - 1u;
-            if (QUEUED) Ql = pre_make<KIND>(Pl, eps, slack, coord_mag);
+            if (QUEUED && !QARR) Ql = pre_make<KIND>(Pl, eps, slack, coord_mag);   // (QARR: the prep kernel has left them in qarr)
         }
         if (dbg == 1) surv = 0;
 
@@ -354,17 +366,25 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
             if (todo != 0) {
                 int l = __builtin_ctzll(todo);
                 rh_prep P = rh_ld_prep_const(&prep[cbase + l]);
+                rh_pre Qs;
+                if constexpr (QARR) Qs = rh_ld_pre_const(&qarr[cbase + l]);
                 for (;;) {
                     todo &= todo - 1;
                     const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
                     // the NEXT candidate's record: requested here, used after this candidate's groups (scalar loads in
                     // flight while the group loop runs; the compiler owns the registers and the wait)
                     const rh_prep Pn = rh_ld_prep_const(&prep[cbase + ln]);
+                    rh_pre Qn;
+                    if constexpr (QARR) Qn = rh_ld_pre_const(&qarr[cbase + ln]);
                     unsigned rem = __builtin_amdgcn_readlane(surv, l);
                     rh_pre Q;
-                    Q.a = rl_f64(Ql.a, l); Q.b = rl_f64(Ql.b, l);
-                    if (KIND == RH_CYLINDER) Q.c = rl_f64(Ql.c, l);
-                    if (KIND == RH_CONE) { Q.c = rl_f64(Ql.c, l); Q.d = rl_f64(Ql.d, l); Q.e = rl_f64(Ql.e, l); }
+                    if constexpr (QARR) {
+                        Q = Qs;
+                    } else {
+                        Q.a = rl_f64(Ql.a, l); Q.b = rl_f64(Ql.b, l);
+                        if (KIND == RH_CYLINDER) Q.c = rl_f64(Ql.c, l);
+                        if (KIND == RH_CONE) { Q.c = rl_f64(Ql.c, l); Q.d = rl_f64(Ql.d, l); Q.e = rl_f64(Ql.e, l); }
+                    }
                     while (rem != 0) {
                         const int g = __builtin_ctz(rem);
                         rem &= rem - 1;
@@ -381,6 +401,7 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
                         }
                     }
                     P = Pn;
+                    if constexpr (QARR) Qs = Qn;
                     if (todo == 0) break;
                     l = ln;
                 }
@@ -449,6 +470,7 @@ score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
 // block runs the per-kind body on each segment of its row (almost always one).  The per-launch
 // floor (tile staging, box tests, tail) is paid once and the cheap kinds fill the tail.
 struct G2KindArgs {
+    const rh_pre *pre;        // band constants of the bin (prep kernels), or null
     const rh_prep *prep;
     const rh_prepf *prep32;   // Float32 clouds: the float records of the same bins (else null)
     const int32_t *orig, *nk;
@@ -460,7 +482,7 @@ struct G2AllArgs {
     int64_t ntiles;    // grid.x is padded beyond this (see rhk_score_all_groups)
 };
 
-template <bool MASK, bool F32 = false>
+template <bool MASK, bool F32 = false, bool QARR = false>
 __global__ void __launch_bounds__(256)
 score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const double *__restrict__ gb,
                         int64_t gstride, int64_t ngroups, const G2AllArgs A, double coord_mag,
@@ -484,9 +506,10 @@ score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t 
         const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
         if (slo < shi) {                                                                                               \
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile in LDS */              \
-            score_groups_body<K, MASK, 256, F32>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,        \
+            score_groups_body<K, MASK, 256, F32, QARR>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,  \
                                                  A.k[K].prep, A.k[K].prep32, A.k[K].orig, A.k[K].nk, A.k[K].eps,      \
-                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg, tile);      \
+                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg, tile,       \
+                                                 A.k[K].pre);                                                         \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -1133,13 +1156,27 @@ int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_
 }
 
 // prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
+static PreArgs pre_args(rh_cloud *c, const double *eps)
+{
+    PreArgs QA;
+    for (int k = 0; k < 4; k++) QA.eps[k] = eps ? eps[k] : 0.0;
+    QA.coord_mag = c->coord_mag;
+    QA.f32 = c->f32 ? 1 : 0;
+    // (what rhk_score_all_groups checks before it trusts c->d_qpre: made for these thresholds, for the bins in c->d_prep)
+    c->qpre_valid = eps != nullptr && c->d_qpre != nullptr;
+    for (int k = 0; k < 4; k++) c->qpre_eps[k] = QA.eps[k];
+    return QA;
+}
+
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero)
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps)
 {
     if (!nk_is_zero) RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    const PreArgs QA = pre_args(c, eps);
     if (launch_bound <= 0) return RH_OK;
     hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
-                       cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts);
+                       cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts,
+                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1155,14 +1192,17 @@ int32_t rh_spread_multiplier(int32_t b)
 }
 
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
-                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero)
+                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
+                    const double *eps)
 {
     if (!nk_is_zero) RH_HIP(hipMemsetAsync(d_nk, 0, 4 * sizeof(int32_t), c->stream));
+    PreArgs QA = pre_args(c, d_prep == c->d_prep && cap == c->batch_cap ? eps : nullptr);
     if (b == 0) return RH_OK;
     static int no_spread = -1;
     if (no_spread < 0) no_spread = getenv("RH_NO_SPREAD") ? 1 : 0;
     hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
-                       d_nk, cap, d_counts_to_zero, d_nk_other, no_spread ? 1 : rh_spread_multiplier(b));
+                       d_nk, cap, d_counts_to_zero, d_nk_other, no_spread ? 1 : rh_spread_multiplier(b),
+                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1457,8 +1497,14 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
     if (rows < 1) rows = 1;
     if (rows > 65535) rows = 65535;
+    // the band constants the prep kernel left for exactly these bins and thresholds (else the kernel makes them itself)
+    bool qarr = c->qpre_valid && c->d_qpre != nullptr && d_masks_int == nullptr && !getenv("RH_G2_NO_QARR");
+    for (int k = 0; k < 4 && qarr; k++)
+        qarr = prep[k] == c->d_prep + (int64_t)k * c->batch_cap && c->qpre_eps[k] == eps[k];
     G2AllArgs A;
-    for (int k = 0; k < 4; k++) A.k[k] = { prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
+    for (int k = 0; k < 4; k++)
+        A.k[k] = { qarr ? (const rh_pre *)c->d_qpre + (int64_t)k * c->batch_cap : nullptr, prep[k],
+                   prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
     // XCD-aware launch: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with its own L2.  With
     // grid.x padded to a multiple of 8 a tile meets the SAME XCD in every candidate row, so all rows but the first stage
     // it from that L2 instead of HBM (0.1685 -> 0.165 ms on cfg3).  Measured and rejected: the rows of a tile back to
@@ -1471,19 +1517,17 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     // primitives, pinning tiles to XCDs unbalances them: 0.125 -> 0.165 ms)
     const bool pad8 = env_swz && ntiles >= 1024;
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
+#define RH_G2_ALL(M, F, Q)                                                                                                  \
+    hipLaunchKernelGGL((score_groups_all_kernel<M, F, Q>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,        \
+                       c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg)
     if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
-        if (d_masks_int)
-            hipLaunchKernelGGL((score_groups_all_kernel<true, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
-                               c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
-        else
-            hipLaunchKernelGGL((score_groups_all_kernel<false, true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
-                               c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
-    } else if (d_masks_int)
-        hipLaunchKernelGGL((score_groups_all_kernel<true>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
-                           c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
-    else
-        hipLaunchKernelGGL((score_groups_all_kernel<false>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,
-                           c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg);
+        if (d_masks_int) RH_G2_ALL(true, true, false);
+        else if (qarr) RH_G2_ALL(false, true, true);
+        else RH_G2_ALL(false, true, false);
+    } else if (d_masks_int) RH_G2_ALL(true, false, false);
+    else if (qarr) RH_G2_ALL(false, false, true);
+    else RH_G2_ALL(false, false, false);
+#undef RH_G2_ALL
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -154,6 +154,9 @@ struct rh_cloud {
     float *full32 = nullptr;           // 6 planes x n_pad, original order (the refit scan streams these: 24 B per point)
     float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
     void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
+    void *d_qpre = nullptr;            // [4 * batch_cap] band constants of the prefilter (rhdev::rh_pre) of the bins in d_prep
+    bool qpre_valid = false;           // ... made by the last prep kernel, for the thresholds qpre_eps
+    double qpre_eps[4] = { 0, 0, 0, 0 };
     const rh_shape *f32_shapes = nullptr;   // the batch being scored: its shapes on the device ...
     int f32_via_orig = 0;                   // ... indexed through d_orig (caller's order) or directly (sorted like the bins)
 
@@ -190,9 +193,10 @@ int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_
                     int32_t *d_counts_to_zero = nullptr);
 struct rh_cand_entry;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero);
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps = nullptr);   // eps: also fill d_qpre
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
-                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero);
+                    int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
+                    const double *eps = nullptr);   // eps: also fill d_qpre (bins in c->d_prep only)
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates
 int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s,

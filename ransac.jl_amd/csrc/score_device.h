@@ -299,6 +299,24 @@ static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, 
     return o;
 }
 
+static __device__ __forceinline__ rh_pre rh_ld_pre_const(const rh_pre *p)
+{
+    const RH_CONST_AS rh_pre *q = (const RH_CONST_AS rh_pre *)(uintptr_t)p;   // wave-uniform: scalar loads of the fields used
+    rh_pre o;
+    o.a = q->a; o.b = q->b; o.c = q->c; o.d = q->d; o.e = q->e;
+    return o;
+}
+
+// pre_make for a kind known at run time (the prep kernels fill the batch's band constants with it)
+static __device__ __forceinline__ rh_pre pre_make_any(const rh_prep &P, int kind, double eps, double coord_mag, bool f32)
+{
+    rh_pre o = { -1.0, __builtin_inf(), 0.0, 0.0, 0.0 };
+    if (kind == RH_SPHERE) return pre_make<RH_SPHERE>(P, eps, f32 ? box_slack32<RH_SPHERE>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
+    if (kind == RH_CYLINDER) return pre_make<RH_CYLINDER>(P, eps, f32 ? box_slack32<RH_CYLINDER>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
+    if (kind == RH_CONE) return pre_make<RH_CONE>(P, eps, f32 ? box_slack32<RH_CONE>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
+    return o;
+}
+
 static __device__ __forceinline__ double rl_f64(double v, int l)
 {
     union { double d; uint32_t u[2]; } cv;
