@@ -318,6 +318,10 @@ score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const do
         if (chunk >= chunk_hi) break;
         const int cbase = chunk << 6;
         const int ci = cbase + lane;
+        // The boxes of the tile's groups are read from LDS again for every chunk: left alone, the compiler hoists the 24-28
+        // (wave-uniform!) doubles out of the chunk loop and carries them in 48-56 vector registers through stage 2,
+        // which is what set the kernel's register count (plane body: 76).
+        asm volatile("" ::: "memory");
 
         // ---- stage 1: lane = candidate, one box test per group of the tile
         unsigned surv = 0;
@@ -482,8 +486,11 @@ struct G2AllArgs {
     int64_t ntiles;    // grid.x is padded beyond this (see rhk_score_all_groups)
 };
 
-template <bool MASK, bool F32 = false, bool QARR = false>
-__global__ void __launch_bounds__(256)
+// WAVES: 0 = the register count the compiler arrives at (6 waves per SIMD: the cone body needs 75-79); 8 = capped at
+// 64 registers -- the plane / sphere / cylinder bodies fit (34 / 50 / 58 once the group boxes are not hoisted), the cone
+// body spills 7 registers and is still faster at 8 waves.  The host picks the variant by the size of the grid.
+template <bool MASK, bool F32 = false, bool QARR = false, int WAVES = 0>
+__global__ void __launch_bounds__(256, WAVES == 8 ? 8 : 1)
 score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const double *__restrict__ gb,
                         int64_t gstride, int64_t ngroups, const G2AllArgs A, double coord_mag,
                         int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
@@ -1517,16 +1524,26 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     // primitives, pinning tiles to XCDs unbalances them: 0.125 -> 0.165 ms)
     const bool pad8 = env_swz && ntiles >= 1024;
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-#define RH_G2_ALL(M, F, Q)                                                                                                  \
-    hipLaunchKernelGGL((score_groups_all_kernel<M, F, Q>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,        \
+#define RH_G2_ALL(M, F, Q, W)                                                                                               \
+    hipLaunchKernelGGL((score_groups_all_kernel<M, F, Q, W>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,     \
                        c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg)
+    static int env_w8 = -1;
+    if (env_w8 < 0) { const char *e = getenv("RH_G2_W8"); env_w8 = e ? atoi(e) : 1; }
+    // 8 waves per SIMD need 2048 resident blocks to fill the chip: worth it from ~4 rounds of them on (cfg3: 11 016
+    // blocks 0.1551 -> 0.1445 ms, cfg5 with its cones 0.676 -> 0.648; cfg2's 4 182 blocks 0.115 -> 0.120: not there)
+    const bool w8 = (env_w8 && (int64_t)grid.x * grid.y >= 8192) || env_w8 == 2;   // (2: forced, 0: never -- A/B)
     if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
-        if (d_masks_int) RH_G2_ALL(true, true, false);
-        else if (qarr) RH_G2_ALL(false, true, true);
-        else RH_G2_ALL(false, true, false);
-    } else if (d_masks_int) RH_G2_ALL(true, false, false);
-    else if (qarr) RH_G2_ALL(false, false, true);
-    else RH_G2_ALL(false, false, false);
+        if (d_masks_int) RH_G2_ALL(true, true, false, 0);
+        else if (qarr && w8) RH_G2_ALL(false, true, true, 8);
+        else if (qarr) RH_G2_ALL(false, true, true, 0);
+        else if (w8) RH_G2_ALL(false, true, false, 8);
+        else RH_G2_ALL(false, true, false, 0);
+    } else if (d_masks_int && w8) RH_G2_ALL(true, false, false, 8);
+    else if (d_masks_int) RH_G2_ALL(true, false, false, 0);
+    else if (qarr && w8) RH_G2_ALL(false, false, true, 8);
+    else if (qarr) RH_G2_ALL(false, false, true, 0);
+    else if (w8) RH_G2_ALL(false, false, false, 8);
+    else RH_G2_ALL(false, false, false, 0);
 #undef RH_G2_ALL
     RH_HIP(hipGetLastError());
     return RH_OK;
