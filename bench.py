@@ -442,7 +442,7 @@ def main():
             kname = "score_groups_all_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
-            pmc_key = "score_groups_all_kernel<false, false>"
+            pmc_key = "score_groups_all_kernel<false, false, true"   # counts only, Float64, band constants from the prep kernel: the timed step's launch
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
