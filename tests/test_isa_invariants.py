@@ -59,8 +59,17 @@ def test_no_inline_asm_memory_access_in_the_score_kernels(isa):
 
 
 def test_score_kernels_do_not_spill_vector_registers(isa):
+    """The score kernels at their natural register count never spill.  The variants capped at 64 registers (8 waves per
+    SIMD: the last template argument of score_groups_all_kernel is 8) may spill a handful -- the cone body needs ~75
+    registers; plane / sphere / cylinder fit -- and are measured faster all the same."""
     text = "\n".join(isa)
     blocks = re.findall(r"\.name:\s+(\S*score_groups\S*)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
     assert len(blocks) >= 8
+    capped = 0
     for name, spills in blocks:
-        assert int(spills) == 0, "%s spills %s VGPRs (scratch traffic in the hot loop)" % (name, spills)
+        if "score_groups_all_kernel" in name and "ELi8EE" in name:
+            capped += 1
+            assert int(spills) <= 12, "%s spills %s VGPRs: more than the cone body's handful" % (name, spills)
+        else:
+            assert int(spills) == 0, "%s spills %s VGPRs (scratch traffic in the hot loop)" % (name, spills)
+    assert capped >= 2
