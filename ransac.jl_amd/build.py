@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libransac_hip.so")
-SOURCES = ["kernels.hip", "f32.hip", "cloud.hip", "korder.hip", "driver.hip", "sampler.hip", "lsq.hip", "cc.hip", "fit.cpp"]
+SOURCES = ["kernels.hip", "score4.hip", "f32.hip", "cloud.hip", "korder.hip", "driver.hip", "sampler.hip", "lsq.hip", "cc.hip", "fit.cpp"]
 # -ffp-contract=off: never fuse a*b+c -- inlier sets must match the CPU path bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rh_internal.h"
+#include "score4_device.h"
 
 // ---------------------------------------------------------------- errors ----
 static thread_local char g_err[512] = "";
@@ -89,7 +90,10 @@ int rh_ensure_batch(rh_cloud *c, int64_t b)
     (void)hipFree(c->d_qpre);
     c->d_qpre = nullptr;
     c->qpre_valid = false;
-    RH_HIP(hipMalloc(&c->d_qpre, (size_t)(4 * cap) * 5 * sizeof(double)));
+    RH_HIP(hipMalloc(&c->d_qpre, (size_t)(4 * cap) * 64));   // rhdev::rh_pre (40 B) or rh4::rh_cls (64 B) per slot
+    (void)hipFree(c->d_box);
+    c->d_box = nullptr;
+    RH_TRY(dev_alloc(&c->d_box, (int64_t)rh4::RH_BOX_FIELDS * 4 * cap));
     RH_TRY(dev_alloc(&c->d_orig, 4 * cap));
     RH_TRY(dev_alloc(&c->d_counts, cap));
     if (c->f32) {
@@ -148,6 +152,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
+    (void)hipFree(c->d_box); (void)hipFree(c->gb32);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
     (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
@@ -323,6 +328,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     c->ngroups = (s + 63) / 64;
     c->ng_pad = ((c->ngroups + RH_G2_TG - 1) / RH_G2_TG) * RH_G2_TG + RH_G2_TG;
     CK(dev_alloc(&c->gb, 7 * c->ng_pad));
+    CK(dev_alloc(&c->gb32, 8 * c->ng_pad));
     CK(dev_alloc(&c->dis_gb, 7 * c->ng_pad));
     CKH(hipMemsetAsync(c->dis_gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     CKH(hipMemsetAsync(c->gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
@@ -376,6 +382,15 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
                 first = false;
             }
             c->coord_mag = mag;
+            double nmag = 0;
+            for (int64_t j = 0; j < s; j++) {
+                const double *nn = nrm + 3 * (subset1[j] - 1);
+                for (int k = 0; k < 3; k++) {
+                    const double v = fabs(nn[k]);
+                    if (v - v == 0 && v > nmag) nmag = v;   // (NaN / inf: score4_device.h, guards)
+                }
+            }
+            c->nrm_mag = nmag;
             // Internal order = leaves of a balanced k-d tree, 64 points each (median split along the widest
             // axis of the node's box, the left child always a multiple of 64 so that only the LAST group
             // is partial).  Against Morton order the groups' boxes are ~30 % smaller in radius and
@@ -582,9 +597,11 @@ static int score_kind_subset(rh_cloud *c, int k, const rh_params *p, const rh_pr
 }
 
 // all four kind bins (bin k at prep/orig + off[k], its size in d_nk[k]) against subset 1
+// d_cls: the bins' classifier records (64 B per slot, same offsets) for the v4 kernel, or null
 static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_prep, const int32_t *d_orig,
                              const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], int32_t total_bound,
-                             int32_t *d_counts, uint64_t *d_masks_int, float *ms_kind)
+                             int32_t *d_counts, uint64_t *d_masks_int, float *ms_kind, const void *d_cls = nullptr,
+                             const float *d_box = nullptr, int64_t bstride = 0)
 {
     if (c->f32) {   // Float32 cloud: float records from the batch's shapes, float kernels (f32.hip)
         if (c->f32_shapes == nullptr) { rh_set_error("internal: Float32 scoring without the batch's shapes"); return RH_E_INTERNAL; }
@@ -622,7 +639,14 @@ static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_p
             og[k] = d_orig + off[k];
             nk[k] = d_nk + k;
         }
-        return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int);
+        const void *cl[4];
+        const float *bx[4];
+        for (int k = 0; k < 4; k++) {
+            cl[k] = d_cls ? (const char *)d_cls + (size_t)off[k] * 64 : nullptr;
+            bx[k] = d_box ? d_box + off[k] : nullptr;
+        }
+        return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, nullptr,
+                                    d_cls ? cl : nullptr, d_box ? bx : nullptr, bstride);
     }
     for (int k = 0; k < 4; k++) {
         if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
@@ -658,9 +682,13 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     const bool staged = b <= 32 && !c->f32;   // (the staged form carries prepared Float64 records only)
     const size_t rec_bytes = sizeof(rh_prep) >= sizeof(rh_shape) ? sizeof(rh_prep) : sizeof(rh_shape);
     const size_t o_orig = (size_t)b * rec_bytes, o_nk = (o_orig + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
-    const size_t o_counts = o_nk + 64, stage_bytes = o_counts + (size_t)b * sizeof(int32_t);
+    // (staged, counts only, v4 kernel: the classifier records -- host twin of the prep kernels' cls_make -- ride along)
+    const bool staged_cls = staged && !masks_out && rh_score_v4_enabled(c);
+    const size_t o_counts = o_nk + 64, o_cls = (o_counts + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
+    const size_t o_box = o_cls + (size_t)b * 64;   // culling records: RH_BOX_FIELDS arrays of b floats
+    const size_t stage_bytes = staged_cls ? o_box + (size_t)rh4::RH_BOX_FIELDS * b * sizeof(float) : o_counts + (size_t)b * sizeof(int32_t);
     RH_TRY(rh_ensure_pin(c, (int64_t)stage_bytes));
-    if (staged && c->d_stage == nullptr) RH_HIP(hipMalloc((void **)&c->d_stage, 32 * (rec_bytes + 8) + 256));
+    if (staged && c->d_stage == nullptr) RH_HIP(hipMalloc((void **)&c->d_stage, 32 * (rec_bytes + 8 + 64 + 4 * rh4::RH_BOX_FIELDS) + 512));
     char *hp = (char *)c->h_pin, *dp = (char *)c->d_stage;
     rh_shape *h_sorted = (rh_shape *)hp;
     rh_prep *h_prep = (rh_prep *)hp;
@@ -677,12 +705,19 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     for (int32_t t = 0; t < b; t++) {
         const int32_t i = (int32_t)(((int64_t)t * spread) % b);
         const int k = shapes[i].kind;
-        if (staged) rh_prep_host(shapes[i], &h_prep[fill[k]]);
-        else h_sorted[fill[k]] = shapes[i];
+        if (staged) {
+            rh_prep_host(shapes[i], &h_prep[fill[k]]);
+            if (staged_cls)
+                rh4::cls_make(h_prep[fill[k]], k, p->eps[k], p->cos_alpha[k], c->coord_mag, c->nrm_mag, ((rh4::rh_cls *)(hp + o_cls))[fill[k]],
+                              (float *)(hp + o_box) + fill[k], b);
+        } else h_sorted[fill[k]] = shapes[i];
         h_orig[fill[k]] = i;
         fill[k]++;
     }
     const rh_prep *d_prep_use = c->d_prep;
+    const void *d_cls_use = nullptr;
+    const float *d_box_use = nullptr;
+    int64_t bstride_use = 0;
     const int32_t *d_orig_use = c->d_orig, *d_nk_use = c->d_nk;
     int32_t *d_counts_use = c->d_counts;
     if (staged) {
@@ -692,12 +727,14 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         d_orig_use = (const int32_t *)(dp + o_orig);
         d_nk_use = (const int32_t *)(dp + o_nk);
         d_counts_use = (int32_t *)(dp + o_counts);
+        if (staged_cls) { d_cls_use = dp + o_cls; d_box_use = (const float *)(dp + o_box); bstride_use = b; }
     } else {
         RH_HIP(hipMemcpyAsync(c->d_shapes, h_sorted, sizeof(rh_shape) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_nk, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         c->qpre_valid = false;
-        RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts));   // zeroes d_counts as well
+        RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts, p->eps, masks_out ? nullptr : p->cos_alpha));   // zeroes d_counts as well
+        if (c->qpre_v4) { d_cls_use = c->d_qpre; d_box_use = c->d_box; bstride_use = 4 * c->batch_cap; }
     }
     uint64_t *d_masks = nullptr, *d_masks_int = nullptr;
     if (masks_out && c->swords > 0) {
@@ -710,7 +747,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     const int64_t off64[4] = { off[0], off[1], off[2], off[3] };
     c->f32_shapes = c->d_shapes;   // sorted like the bins
     c->f32_via_orig = 0;
-    RH_TRY(score_bins_subset(c, p, d_prep_use, d_orig_use, off64, d_nk_use, nk, b, d_counts_use, d_masks_int, nullptr));
+    RH_TRY(score_bins_subset(c, p, d_prep_use, d_orig_use, off64, d_nk_use, nk, b, d_counts_use, d_masks_int, nullptr, d_cls_use, d_box_use, bstride_use));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     RH_HIP(hipMemcpyAsync(h_counts, d_counts_use, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
     if (d_masks)
@@ -738,7 +775,8 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     int32_t *nk_cur = c->d_nk2 + 4 * c->nk2_flip, *nk_next = c->d_nk2 + 4 * (1 - c->nk2_flip);
     c->nk2_flip = 1 - c->nk2_flip;
-    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps));
+    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps,
+                           d_masks ? nullptr : p->cos_alpha));
     uint64_t *d_masks_int = nullptr;
     if (d_masks && c->swords > 0) {
         RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
@@ -747,19 +785,20 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     const int64_t off[4] = { 0, c->batch_cap, 2 * (int64_t)c->batch_cap, 3 * (int64_t)c->batch_cap };
     const int32_t bound[4] = { b, b, b, b };
+    const void *d_cls = c->qpre_v4 && !d_masks_int ? c->d_qpre : nullptr;   // (made by rhk_prep_binned above)
     c->f32_shapes = d_shapes;      // the caller's order: the float records go through d_orig
     c->f32_via_orig = 1;
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
         ms_kind[4] = 0.f;
         RH_HIP(hipEventRecord(c->evk[0], c->stream));
-        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, nullptr));
+        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, nullptr, d_cls, c->d_box, 4 * c->batch_cap));
         RH_HIP(hipEventRecord(c->evk[1], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[1]));
         RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
         RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
         if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
-    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind));
+    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind, d_cls, c->d_box, 4 * c->batch_cap));
     if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     if (ms_kind) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));

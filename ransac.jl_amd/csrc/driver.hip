@@ -1049,7 +1049,7 @@ struct Driver {
                 // launch sizes from the previous windows' list lengths; any length is handled (the
                 // kernels read the true count), a longer list only gets fewer blocks per candidate
                 const int32_t bound = std::min<int32_t>(w.entries_cap, std::max<int32_t>(4 * cnt_est, 1024));
-                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts, 1, p->eps));
+                RUN(rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, w.entries_cap, w.d_counts, 1, p->eps, p->cos_alpha));
                 const uint64_t *enw[4];
                 const rh_prep *pr[4];
                 const int32_t *og[4], *nkp[4];
@@ -1059,7 +1059,14 @@ struct Driver {
                     og[q] = c->d_orig + (int64_t)q * c->batch_cap;
                     nkp[q] = c->d_nk + q;
                 }
-                RUN(rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr));
+                const void *clsw[4];
+                const float *boxw[4];
+                for (int q = 0; q < 4; q++) {
+                    clsw[q] = (const char *)c->d_qpre + (size_t)q * (size_t)c->batch_cap * 64;
+                    boxw[q] = c->d_box + (int64_t)q * c->batch_cap;
+                }
+                RUN(rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr, nullptr,
+                                         c->qpre_v4 ? clsw : nullptr, c->qpre_v4 ? boxw : nullptr, 4 * c->batch_cap));
                 w.scored = true;
             }
             // status + head of the list (+ counts) land in pinned host memory through one small kernel

@@ -17,6 +17,7 @@
 #include "rh_internal.h"
 #include "score_device.h"
 #include "score_device32.h"
+#include "score4_device.h"
 
 namespace {
 
@@ -70,13 +71,20 @@ __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
     prep_derived(o, s.kind);
 }
 
+struct PreArgs { double eps[4]; double cosa[4]; double coord_mag, nrm_mag; int f32; int v4; float *box; int64_t bstride; };
+
 __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
-                                   int32_t *__restrict__ counts_zero)
+                                   int32_t *__restrict__ counts_zero, rh4::rh_cls *__restrict__ cls, const PreArgs QA)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < b) {
-        prep_one(shapes[i], prep[i]);
+        rh_prep P;
+        const int kind = shapes[i].kind;
+        prep_one(shapes[i], P);
+        prep[i] = P;
         if (counts_zero != nullptr) counts_zero[i] = 0;
+        if (cls != nullptr && kind >= 0 && kind <= 3)
+            rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, cls[i], QA.box + i, QA.bstride);
     }
 }
 
@@ -89,7 +97,8 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
 // sorted by primitive: 0.231 ms instead of 0.180).
 // qpre (optional): the band constants of the prefilter (pre_make) per binned candidate, so that the score kernel reads
 // them with the record instead of computing them per (chunk, tile) and broadcasting them with v_readlane
-struct PreArgs { double eps[4]; double coord_mag; int f32; };
+// (PreArgs::v4: the record written beside a candidate is the binary32 classifier record, rh4::rh_cls of score4_device.h,
+// instead of rh_pre)
 
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap,
@@ -122,7 +131,11 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
     prep_one(s, P);
     prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
-    if (qpre != nullptr && kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
+    if (qpre != nullptr) {
+        if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
+                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride);
+        else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
+    }
 }
 
 // the sampler's candidate list (count on the device): bin by kind like prep_binned_kernel, zero the counts
@@ -156,7 +169,11 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
     prep_one(s, P);
     prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
-    if (qpre != nullptr && kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
+    if (qpre != nullptr) {
+        if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
+                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride);
+        else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
+    }
 }
 
 // ------------------------------------------------------------- score ------
@@ -1153,33 +1170,52 @@ int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int6
     return RH_OK;
 }
 
-int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep, int32_t *d_counts_to_zero)
+static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa);
+
+// eps + cosa (bins in c->d_prep only): also leave the v4 kernel's classifier records in c->d_qpre, slot for slot
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep, int32_t *d_counts_to_zero,
+                    const double *eps, const double *cosa)
 {
+    const bool own = d_prep == c->d_prep && eps != nullptr && cosa != nullptr;
+    const PreArgs QA = pre_args(c, own ? eps : nullptr, own ? cosa : nullptr);
+    c->qpre_valid = false;   // (no band constants of the older kernel are written here)
     if (b == 0) return RH_OK;
     hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep,
-                       d_counts_to_zero);
+                       d_counts_to_zero, QA.v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
 
 // prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
-static PreArgs pre_args(rh_cloud *c, const double *eps)
+bool rh_score_v4_enabled(const rh_cloud *c)
+{
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("RH_SCORE_V4"); env = e ? atoi(e) : 1; }
+    return env != 0 && !c->f32 && c->use_groups;
+}
+
+static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa)
 {
     PreArgs QA;
-    for (int k = 0; k < 4; k++) QA.eps[k] = eps ? eps[k] : 0.0;
+    for (int k = 0; k < 4; k++) { QA.eps[k] = eps ? eps[k] : 0.0; QA.cosa[k] = cosa ? cosa[k] : 0.0; }
     QA.coord_mag = c->coord_mag;
+    QA.nrm_mag = c->nrm_mag;
     QA.f32 = c->f32 ? 1 : 0;
+    QA.v4 = cosa != nullptr && rh_score_v4_enabled(c) && c->d_box != nullptr ? 1 : 0;
+    QA.box = c->d_box;
+    QA.bstride = 4 * c->batch_cap;
     // (what rhk_score_all_groups checks before it trusts c->d_qpre: made for these thresholds, for the bins in c->d_prep)
     c->qpre_valid = eps != nullptr && c->d_qpre != nullptr;
-    for (int k = 0; k < 4; k++) c->qpre_eps[k] = QA.eps[k];
+    c->qpre_v4 = QA.v4 != 0;
+    for (int k = 0; k < 4; k++) { c->qpre_eps[k] = QA.eps[k]; c->qpre_cosa[k] = QA.cosa[k]; }
     return QA;
 }
 
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps)
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps, const double *cosa)
 {
     if (!nk_is_zero) RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
-    const PreArgs QA = pre_args(c, eps);
+    const PreArgs QA = pre_args(c, eps, cosa);
     if (launch_bound <= 0) return RH_OK;
     hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
                        cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts,
@@ -1200,10 +1236,11 @@ int32_t rh_spread_multiplier(int32_t b)
 
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
-                    const double *eps)
+                    const double *eps, const double *cosa)
 {
     if (!nk_is_zero) RH_HIP(hipMemsetAsync(d_nk, 0, 4 * sizeof(int32_t), c->stream));
-    PreArgs QA = pre_args(c, d_prep == c->d_prep && cap == c->batch_cap ? eps : nullptr);
+    const bool own = d_prep == c->d_prep && cap == c->batch_cap;
+    PreArgs QA = pre_args(c, own ? eps : nullptr, own ? cosa : nullptr);
     if (b == 0) return RH_OK;
     static int no_spread = -1;
     if (no_spread < 0) no_spread = getenv("RH_NO_SPREAD") ? 1 : 0;
@@ -1490,7 +1527,7 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_pr
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
                          const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                         const void *const prep32[4])
+                         const void *const prep32[4], const void *const cls[4], const float *const box[4], int64_t bstride)
 {
     const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
     const int nchunks = cdiv(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
@@ -1508,6 +1545,10 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     bool qarr = c->qpre_valid && c->d_qpre != nullptr && d_masks_int == nullptr && !getenv("RH_G2_NO_QARR");
     for (int k = 0; k < 4 && qarr; k++)
         qarr = prep[k] == c->d_prep + (int64_t)k * c->batch_cap && c->qpre_eps[k] == eps[k];
+    // classifier records of exactly these bins and thresholds from the caller: the v4 kernel (score4.hip)
+    if (cls != nullptr && box != nullptr && d_masks_int == nullptr && prep32 == nullptr && rh_score_v4_enabled(c) && c->gb32 != nullptr)
+        return rhk_score4_all(c, en, prep, (const void *const *)cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts);
+    if (c->qpre_v4) qarr = false;   // (what lies beside the bins in d_qpre are not band constants)
     G2AllArgs A;
     for (int k = 0; k < 4; k++)
         A.k[k] = { qarr ? (const rh_pre *)c->d_qpre + (int64_t)k * c->batch_cap : nullptr, prep[k],
@@ -1579,7 +1620,7 @@ int rhk_group_bounds(rh_cloud *c)
     hipLaunchKernelGGL(group_bounds_kernel, dim3(cdiv(c->ngroups, 4)), dim3(256), 0, c->stream, c->sub, c->s_pad, c->s,
                        c->ngroups, c->gb, c->ng_pad);
     RH_HIP(hipGetLastError());
-    return RH_OK;
+    return rhk_gb32_build(c);   // the binary32 twins (v4 score kernel)
 }
 
 int rhk_unpermute_masks(rh_cloud *c, const uint64_t *d_in, int32_t b, uint64_t *d_out)

@@ -89,7 +89,9 @@ struct rh_cloud {
     double *gb = nullptr;              // 7 planes x ng_pad: box centre cx cy cz, half extents hx hy hz, radius hr
     int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
     double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
+    double nrm_mag = 0;                // max |normal component| over the subset (margins of the binary32 classifier)
     bool use_groups = false;           // culled scoring path available (s large enough)
+    float *gb32 = nullptr;             // the same boxes in binary32, 8 floats per group (v4 score kernel: scalar loads)
     double *dis_gb = nullptr;          // boxes of the dis segment in use (7 x ng_pad)
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror
@@ -155,8 +157,11 @@ struct rh_cloud {
     float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
     void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
     void *d_qpre = nullptr;            // [4 * batch_cap] band constants of the prefilter (rhdev::rh_pre) of the bins in d_prep
+    float *d_box = nullptr;            // [RH_BOX_FIELDS][4 * batch_cap] culling records of the same bins (v4 score kernel), structure of arrays
     bool qpre_valid = false;           // ... made by the last prep kernel, for the thresholds qpre_eps
     double qpre_eps[4] = { 0, 0, 0, 0 };
+    bool qpre_v4 = false;              // ... and they are classifier records of the v4 score kernel (rh4::rh_cls), made for qpre_cosa too
+    double qpre_cosa[4] = { 0, 0, 0, 0 };
     const rh_shape *f32_shapes = nullptr;   // the batch being scored: its shapes on the device ...
     int f32_via_orig = 0;                   // ... indexed through d_orig (caller's order) or directly (sorted like the bins)
 
@@ -190,13 +195,18 @@ int rhk_transpose_aos(rh_cloud *c, const double *d_aos_xyz, const double *d_aos_
 int rhk_fetch2_i32(rh_cloud *c, const int32_t *d_src0, const int32_t *d_src1, int32_t *h_pinned_dst);   // h[0..1] = *d0, *d1 in stream order (pinned h)
 int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int64_t n, double *d_rec);
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep,
-                    int32_t *d_counts_to_zero = nullptr);
+                    int32_t *d_counts_to_zero = nullptr, const double *eps = nullptr, const double *cosa = nullptr);
 struct rh_cand_entry;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps = nullptr);   // eps: also fill d_qpre
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps = nullptr,
+                     const double *cosa = nullptr);   // eps: also fill d_qpre; cosa too: with the v4 kernel's classifier records
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
-                    const double *eps = nullptr);   // eps: also fill d_qpre (bins in c->d_prep only)
+                    const double *eps = nullptr, const double *cosa = nullptr);   // eps (+ cosa): also fill d_qpre (bins in c->d_prep only)
+bool rh_score_v4_enabled(const rh_cloud *c);
+int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
+                   const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
+                   int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts);   // score4.hip
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates
 int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s,
@@ -210,7 +220,10 @@ int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_o
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
                          const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                         const void *const prep32[4] = nullptr);   // prep32: Float32 cloud, float records of the same bins
+                         const void *const prep32[4] = nullptr,    // prep32: Float32 cloud, float records of the same bins
+                         const void *const cls[4] = nullptr,       // cls / box: classifier and culling records (score4_device.h) of the
+                         const float *const box[4] = nullptr, int64_t bstride = 0);   // same bins and thresholds -> v4 kernel
+int rhk_gb32_build(rh_cloud *c);   // score4.hip: gb32 from gb
 int rhk_prep_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const int32_t *d_orig, const int64_t off[4],
                  const int32_t *d_nk, int32_t nmax);               // fills c->d_prep32 (f32.hip)
 // Float32 clouds (f32.hip)

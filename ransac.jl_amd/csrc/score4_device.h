@@ -1,0 +1,368 @@
+// score4_device.h -- the two-sided binary32 CLASSIFIER of the v4 score kernel (score4.hip), its per-candidate records and
+// the binary32 box tests of its culling stage.
+//
+// Idea.  The reference's per-point tests (compatibles{Plane,Sphere,Cylinder,Cone}, /root/reference/src/shapes/*.jl) are
+// binary64 and the score must reproduce their bits.  Almost every (candidate, point) pair, however, is nowhere near a
+// threshold: a binary32 evaluation of the same quantities (fused multiply-adds allowed; ~2.3 SIMD cycles per wave64
+// instruction against ~4.4 for binary64, 8 against 16+ for sqrt / rcp: tools/ubench/valu_rates.hip) already DECIDES it.
+// The classifier evaluates each compared quantity q (distance, normal deviation) in binary32 as q32 and compares it with
+// TWO thresholds, t - m and t + m, where m bounds |q32 - q64| rigorously (below).  Then
+//     q32 inside by more than m   ->  the binary64 test passes:  "sure"
+//     q32 outside by more than m  ->  the binary64 test fails
+//     otherwise                   ->  "ambiguous": the pair goes to the exact binary64 test (score_device.h), unchanged.
+// A point is an inlier iff every comparison passes, so  sure = AND of the sure bits,  maybe = AND of the "not surely
+// outside" bits,  ambiguous = maybe & ~sure.  Counts are therefore bit-identical to the exact test whatever the margins'
+// tightness; tightness only decides how many pairs take the slow path.
+//
+// Margins.  u = 2^-24.  Inputs are converted to binary32 (relative error u each), every binary32 operation adds (1 + d),
+// |d| <= u.  With M = max |coordinate| of the point set, Nm = max |normal component|, T = M + max |centre coordinate|:
+//   plane     dn = n . np                 |dn32 - dn| <= 5.05 u |n|_1 Nm
+//             d  = oz . p - oz . P0       |d32 - d|   <= 6.1 u (|oz|_1 M + |oz . P0|)
+//   sphere    dx = p - o (per component e = 2.01 u T);  nr = |dx|:  |nr32 - nr| <= sqrt(3) e + 4 u nr
+//             L = sgn dx . np - c nr  (c = cos alpha; the test is L > 0):
+//                                         |L32 - L| <= Nm (3 e + 8.7 u nr) + |c| (sqrt(3) e + 6 u nr)
+//   cylinder  q = t - a (a . t), t = p - c0: per component e_q = u T (3.01 + 8.04 |a|_inf |a|_1);  then as the sphere
+//             with e_q for e
+//   cone      closed form rho^2 = |t|^2 - (t . a^)^2 against (k h -+ e)^2 (prefilter only: survivors take the exact test)
+// Every margin is the first-order bound x RH_CLS_SAFETY (4) plus the conversion error of the threshold itself; the
+// binary64 side's own rounding (~1e-15 relative) disappears in that factor.  rh_dbg_cls_audit (score4.hip) evaluates
+// max |q32 - q64| / m over real batches with these very functions: tests require it to stay below 0.5.
+//
+// The plane record is SCALED: with wN, wD = powers of two >= 2 x margin, the kernel computes a = (dn - cN_hi) / wN and
+// b = (eD_lo - |d|) / wD directly (the scaling is folded into the coefficients, exactly), so that with t = min(a, b)
+//     sure <=> t > 0,   maybe <=> t > -1                       (two compares for both sides of both tests).
+//
+// Guards.  Non-finite or huge inputs would make binary32 overflow where binary64 does not, so a candidate is marked
+// EXACT-ONLY (field RH_CLS_FLAG = NaN) unless all its parameters are finite and below 2^20 (cylinder axis components
+// below 16) and M, Nm <= 2^20; a tile with an infinite or NaN value in an enabled point treats every candidate as
+// exact-only.  Exact-only means: every enabled point is ambiguous.  Disabled points are staged as zeros and masked out
+// (plane: their zero normal fails the angle test by itself, which needs cos(alpha) - margin > 0, else exact-only).
+#pragma once
+
+#include "rh_internal.h"
+
+namespace rh4 {
+
+constexpr double RH_CLS_U = 5.9604644775390625e-08;   // 2^-24
+constexpr double RH_CLS_SAFETY = 4.0;
+constexpr double RH_CLS_BIG = 1048576.0;               // 2^20
+
+// 64-byte record, gathered per lane (lane = (candidate, group) pair or (candidate, point) pair)
+struct rh_cls {
+    float f[16];
+};
+constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
+// plane:    0-2 n / wN | 3 -cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
+// sphere:   0-2 o | 3 R | 4 mid2 | 5 half2 | 6 eD_lo | 7 eD_hi | 8 cN_lo | 9 cN_hi | 10 sgn
+// cylinder: 0-2 a | 3-5 c0 | 6 R | 7 mid2 | 8 half2 | 9 eD_lo | 10 eD_hi | 11 cN_lo | 12 cN_hi | 13 sgn
+// cone:     0-2 apex | 3-5 a^ | 6 kk | 7 e | 8 alpha | 9 beta
+
+// culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
+// the box tests of stage 1 read, coalesced, with lane = candidate
+constexpr int RH_BOX_FIELDS = 10;
+// plane:    0-2 oz | 3 -(oz . P0) | 4 eps + slack
+// sphere:   0-2 o | 3 A2 | 4 B2
+// cylinder: 0-2 a | 3-5 c0 | 6 (R + eps) + slack | 7 (R - eps) - slack | 8 max(1, |1 - |a|^2|)
+// cone:     0-2 apex | 3-5 a^ | 6 kk | 7 1 / cn | 8 (eps + slack) / cn | 9 beta     (alpha is a constant)
+constexpr float RH_CONE_ALPHA = (float)((RH_CLS_SAFETY * 49.0 + 64.0) * RH_CLS_U);
+
+__host__ __device__ inline bool cls_fin(double v) { return v - v == 0.0; }
+
+// round a threshold to binary32 towards the SAFE side (lo thresholds down, hi thresholds up) by widening with its own ulp
+__host__ __device__ inline float cls_dn(double v) { return (float)(v - fabs(v) * (2.0 * RH_CLS_U) - 1e-37); }
+__host__ __device__ inline float cls_up(double v) { return (float)(v + fabs(v) * (2.0 * RH_CLS_U) + 1e-37); }
+
+// the smallest power of two >= v (v > 0, finite), by exponent arithmetic
+__host__ __device__ inline double cls_pow2ceil(double v)
+{
+    double p = 1.0;
+    while (p < v) p *= 2.0;
+    while (p * 0.5 >= v) p *= 0.5;
+    return p;
+}
+
+// the old kernel's slack of the conservative stages: covers the exact test's own binary64 rounding (score_device.h)
+__host__ __device__ inline double cls_slack64(const rh_prep &P, double M) { return 1e-9 * ((1.0 + M) + P.f[11]); }
+
+// P: the binary64 record of the candidate (rh_prep, kernels.hip prep_one, with prep_derived); eps, cosa: the kind's
+// thresholds; M, Nm: max |coordinate| / max |normal component| of the point set.  o: classifier record; box: the culling
+// record's fields go to box[f * bstride] (f < RH_BOX_FIELDS).
+__host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps, double cosa, double M, double Nm, rh_cls &o,
+                                         float *box, int64_t bstride)
+{
+    const double u = RH_CLS_U, S = RH_CLS_SAFETY;
+    const float fnan = __builtin_nanf("");
+    for (int i = 0; i < 16; i++) o.f[i] = 0.0f;
+    float bx[RH_BOX_FIELDS];
+    for (int i = 0; i < RH_BOX_FIELDS; i++) bx[i] = fnan;   // NaN fields: the box test never skips
+    bool ok = cls_fin(eps) && cls_fin(cosa) && cls_fin(M) && cls_fin(Nm) && M <= RH_CLS_BIG && Nm <= RH_CLS_BIG && fabs(eps) <= RH_CLS_BIG;
+    const double slack64 = cls_slack64(P, M);
+    if (kind == RH_PLANE) {
+        bool fin = true;
+        for (int i = 0; i < 9; i++) fin = fin && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
+        ok = ok && fin;
+        const double n1 = (fabs(P.f[3]) + fabs(P.f[4])) + fabs(P.f[5]);
+        const double z1 = (fabs(P.f[6]) + fabs(P.f[7])) + fabs(P.f[8]);
+        const double zp = (P.f[6] * P.f[0] + P.f[7] * P.f[1]) + P.f[8] * P.f[2];
+        const double mN = S * 5.05 * u * (n1 * Nm) + 4.0 * u * fabs(cosa) + 1e-30;
+        const double mD = S * 6.1 * u * (z1 * M + fabs(zp)) + 4.0 * u * fabs(eps) + 1e-30;
+        ok = ok && cls_fin(mN) && cls_fin(mD) && cls_fin(zp) && mN < 1e30 && mD < 1e30;
+        if (ok) {
+            const double wN = cls_pow2ceil(2.0 * mN), wD = cls_pow2ceil(2.0 * mD);
+            const double cNhi = cosa + 0.5 * wN, eDlo = eps - 0.5 * wD;
+            ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
+            o.f[0] = (float)(P.f[3] / wN); o.f[1] = (float)(P.f[4] / wN); o.f[2] = (float)(P.f[5] / wN);
+            o.f[3] = (float)(-cNhi / wN);
+            o.f[4] = (float)(P.f[6] / wD); o.f[5] = (float)(P.f[7] / wD); o.f[6] = (float)(P.f[8] / wD);
+            o.f[7] = (float)(-zp / wD);
+            o.f[8] = (float)(eDlo / wD);
+            for (int i = 0; i < 9; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
+        }
+        if (fin && cls_fin(zp) && cls_fin(eps) && cls_fin(M)) {
+            // box: d(centre) against eps + sum |oz_i| h_i; binary32 error of both sides + the binary64 test's own slack
+            const double sB = S * 10.1 * u * (z1 * M + fabs(zp)) + slack64;
+            bx[0] = (float)P.f[6]; bx[1] = (float)P.f[7]; bx[2] = (float)P.f[8];
+            bx[3] = (float)(-zp);
+            bx[4] = cls_up(eps + sB);
+        }
+    } else if (kind == RH_SPHERE || kind == RH_CYLINDER) {
+        const bool sph = kind == RH_SPHERE;
+        const int nf = sph ? 4 : 7;
+        bool fin = true;
+        for (int i = 0; i < nf; i++) fin = fin && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
+        ok = ok && fin;
+        const double R = sph ? P.f[3] : P.f[6], sgn = sph ? P.f[4] : P.f[7];
+        const double *ctr = sph ? &P.f[0] : &P.f[3];
+        const double T = M + fmax(fabs(ctr[0]), fmax(fabs(ctr[1]), fabs(ctr[2])));
+        double e, lipk = 1.0;   // e: error bound per component of the vector whose norm is taken
+        bool axis_ok = true;
+        if (sph) {
+            e = 2.01 * u * T;
+        } else {
+            const double a1 = (fabs(P.f[0]) + fabs(P.f[1])) + fabs(P.f[2]);
+            const double ai = fmax(fabs(P.f[0]), fmax(fabs(P.f[1]), fabs(P.f[2])));
+            axis_ok = ai <= 16.0;
+            ok = ok && axis_ok;
+            e = u * T * (3.01 + 8.04 * ai * a1);
+            lipk = fmax(1.0, fabs(P.f[9] - 1.0));   // |1 - |a|^2| = |k - 1| (prep_derived)
+        }
+        const double s3 = 1.7320508075688774;
+        const double mD = S * (s3 * e + 4.0 * u * (fabs(R) + fabs(eps))) + u * (fabs(R) + fabs(eps)) + 1e-30;
+        const double lo = R - eps - mD, hi = R + eps + mD;
+        // a point the distance half may accept lies at least this far from the centre / axis (its binary32 norm is above
+        // lo, its true norm within mD of that)
+        const double nrmin = lo - mD;
+        // margin of the normal half as a margin on cos(alpha): |L32 - L| / nr.  Without a positive lower bound on nr (the
+        // centre lies inside the band) or with a margin that is not small the normal half is never decided in binary32:
+        // NaN thresholds make "sure" false and "maybe" true.
+        double mN = nrmin > 0.0 ? S * ((3.0 * Nm + s3 * (fabs(cosa) + 0.25)) * e / nrmin + (8.7 * Nm + 6.0 * (fabs(cosa) + 0.25)) * u) + 1e-30
+                                : __builtin_nan("");
+        if (!(mN <= 0.25)) mN = __builtin_nan("");
+        // the band of the prefilter on the squared norm, as |n2 - mid2| <= half2
+        const double lo2 = lo > 0.0 ? lo * lo * (1.0 - 16.0 * u) : -1e-30;
+        const double hi2 = hi * hi * (1.0 + 16.0 * u);
+        const double mid2 = 0.5 * (lo2 + hi2);
+        const float half2 = hi > 0.0 ? cls_up(0.5 * (hi2 - lo2) * (1.0 + 8.0 * u) + 8.0 * u * fabs(mid2)) : -1.0f;   // hi <= 0: nothing passes
+        const int b = sph ? 4 : 7;
+        if (sph) { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)R; }
+        else { for (int i = 0; i < 6; i++) o.f[i] = (float)P.f[i]; o.f[6] = (float)R; }
+        o.f[b + 0] = (float)mid2;
+        o.f[b + 1] = half2;
+        o.f[b + 2] = cls_dn(eps - mD);
+        o.f[b + 3] = cls_up(eps + mD);
+        o.f[b + 4] = cls_dn(cosa - mN);   // (NaN stays NaN)
+        o.f[b + 5] = cls_up(cosa + mN);
+        o.f[b + 6] = (float)sgn;
+        ok = ok && cls_fin(mD) && (sgn == 1.0 || sgn == -1.0) && cls_fin(mid2);
+        if (fin && axis_ok && cls_fin(eps) && cls_fin(M)) {
+            // box: |p - o| (sphere) or the distance from the axis (cylinder, at the centre of the box +- Lipschitz) against
+            // R +- eps; binary32 error of the norm at the centre + of the squares + the binary64 test's own slack
+            const double sB = S * (s3 * e + 4.0 * u * (fabs(R) + fabs(eps)) + 4.0 * u * lipk * s3 * M) + slack64;
+            const double A = (R + eps) + sB, B = (R - eps) - sB;
+            if (cls_fin(A) && cls_fin(B)) {
+                if (sph) {
+                    bx[0] = (float)P.f[0]; bx[1] = (float)P.f[1]; bx[2] = (float)P.f[2];
+                    bx[3] = A > 0.0 ? cls_up(A * A * (1.0 + 16.0 * u)) : 0.0f;   // A <= 0: any positive distance is outside
+                    bx[4] = B > 0.0 ? cls_dn(B * B * (1.0 - 16.0 * u)) : -1.0f;  // B <= 0: never "inside the inner ball"
+                } else {
+                    for (int i = 0; i < 6; i++) bx[i] = (float)P.f[i];
+                    bx[6] = cls_up(A);
+                    bx[7] = cls_dn(B);
+                    bx[8] = cls_up(lipk);
+                }
+            }
+        }
+    } else {
+        // cone (prefilter only): with t = p - apex, h = t . a^, rho^2 = |t|^2 - h^2 the reference's distance is
+        // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = cos / sin of -opang/2): |dist| < eps <=> rho in (k h - e, k h + e),
+        // k = -s / c, e = eps sqrt(c^2 + s^2) / c   (c > 0) -- score_device.h pre_make<RH_CONE>
+        for (int i = 0; i < 8; i++) ok = ok && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
+        const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7];
+        const double an = sqrt((ax * ax + ay * ay) + az * az), cs = sqrt(c * c + sn * sn);
+        ok = ok && (c > 1e-6 * cs) && (an > 1e-300) && cls_fin(an);
+        const double ia = ok ? 1.0 / an : 0.0;
+        const double T = M + fmax(fabs(P.f[0]), fmax(fabs(P.f[1]), fabs(P.f[2])));
+        const double kk = ok ? -sn / c : 0.0;
+        const double cn = ok ? c / cs : 1.0;
+        // band half width: exact form + the f64 prefilter's slack + binary32 error of k h (|t| <= sqrt(3) T)
+        const double ek = S * 19.1 * fabs(kk) * u * T + 1e-8 * (1.0 + T) * (1.0 + fabs(kk));
+        const double e = ok ? (eps / cn) * (1.0 + 1e-9) + ek : 0.0;
+        const double beta = S * 1.75 * u * T * T + 1e-30;
+        o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2];
+        o.f[3] = (float)(ax * ia); o.f[4] = (float)(ay * ia); o.f[5] = (float)(az * ia);
+        o.f[6] = (float)kk;
+        o.f[7] = cls_up(e);
+        o.f[8] = RH_CONE_ALPHA;     // slack on rho^2 proportional to |t|^2
+        o.f[9] = cls_up(beta);      // absolute slack on rho^2
+        ok = ok && cls_fin(e) && cls_fin(kk) && fabs(kk) <= 1e6 && cls_fin(beta);
+        if (ok) {
+            // box: the same closed form at the centre of the box, the band widened by the radius of the box (the
+            // distance is 1-Lipschitz in p): half width (hr + eps + slack) / cn
+            bx[0] = o.f[0]; bx[1] = o.f[1]; bx[2] = o.f[2];
+            bx[3] = o.f[3]; bx[4] = o.f[4]; bx[5] = o.f[5];
+            bx[6] = o.f[6];
+            bx[7] = cls_up(1.0 / cn);
+            bx[8] = cls_up((eps + slack64) / cn * (1.0 + 1e-9) + ek);
+            bx[9] = o.f[9];
+        }
+    }
+    if (!ok) o.f[RH_CLS_FLAG] = fnan;
+    if (box != nullptr)
+        for (int i = 0; i < RH_BOX_FIELDS; i++) box[(int64_t)i * bstride] = bx[i];
+}
+
+// binary32 box of a 64-point group from its binary64 box (centre c, half extents h): the half extents absorb the
+// conversion of the centre and are rounded up; o = cx cy cz hx hy hz hr 0
+__host__ __device__ inline void box_to_f32(const double c[3], const double h[3], float o[8])
+{
+    double h2 = 0;
+    for (int k = 0; k < 3; k++) {
+        const float cf = (float)c[k];
+        const double hh = (h[k] + fabs(c[k] - (double)cf)) * (1.0 + 4.0 * RH_CLS_U) + 1e-37;
+        const float hf = cls_up(hh);
+        o[k] = cf;
+        o[3 + k] = hf;
+        h2 += (double)hf * (double)hf;
+    }
+    o[6] = cls_up(sqrt(h2));
+    o[7] = 0.0f;
+}
+
+#ifdef __HIPCC__
+#define WB4(cond) __builtin_amdgcn_ballot_w64(cond)
+
+// ---- stage 1: may the group's box be skipped for this candidate?  lane = candidate (B = its culling record),
+// the box is wave-uniform.  Every comparison is written so that NaN means "do not skip".
+struct rh_box32 { float cx, cy, cz, hx, hy, hz, hr; };
+
+template <int KIND>
+static __device__ __forceinline__ bool box_skip32(const float (&B)[RH_BOX_FIELDS], const rh_box32 &G)
+{
+    if (KIND == RH_PLANE) {
+        const float d = __builtin_fmaf(B[2], G.cz, __builtin_fmaf(B[1], G.cy, __builtin_fmaf(B[0], G.cx, B[3])));
+        const float ext = __builtin_fmaf(__builtin_fabsf(B[2]), G.hz, __builtin_fmaf(__builtin_fabsf(B[1]), G.hy, __builtin_fmaf(__builtin_fabsf(B[0]), G.hx, B[4])));
+        return __builtin_fabsf(d) > ext;
+    }
+    if (KIND == RH_SPHERE) {
+        const float ax = __builtin_fabsf(G.cx - B[0]), ay = __builtin_fabsf(G.cy - B[1]), az = __builtin_fabsf(G.cz - B[2]);
+        const float nx = fmaxf(ax - G.hx, 0.0f), ny = fmaxf(ay - G.hy, 0.0f), nz = fmaxf(az - G.hz, 0.0f);
+        const float fx = ax + G.hx, fy = ay + G.hy, fz = az + G.hz;
+        const float dmin2 = __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx));
+        const float dmax2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx)) * 1.000001f;
+        return (dmin2 * 0.999999f > B[3]) | (dmax2 < B[4]);
+    }
+    if (KIND == RH_CYLINDER) {
+        const float tx = G.cx - B[3], ty = G.cy - B[4], tz = G.cz - B[5];
+        const float sd = __builtin_fmaf(B[2], tz, __builtin_fmaf(B[1], ty, B[0] * tx));
+        const float qx = __builtin_fmaf(-B[0], sd, tx), qy = __builtin_fmaf(-B[1], sd, ty), qz = __builtin_fmaf(-B[2], sd, tz);
+        const float rho2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        const float lip = B[8] * G.hr * 1.000001f;
+        const float X = B[6] + lip, Y = B[7] - lip;
+        const float X2 = X > 0.0f ? X * X * 1.000001f : (X <= 0.0f ? 0.0f : X);   // NaN stays NaN
+        return (rho2 * 0.999999f > X2) | ((Y > 0.0f) & (rho2 * 1.000001f < Y * Y));
+    }
+    // cone: "surely outside the widened band", positive comparisons only
+    const float tx = G.cx - B[0], ty = G.cy - B[1], tz = G.cz - B[2];
+    const float tt = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
+    const float h = __builtin_fmaf(tz, B[5], __builtin_fmaf(ty, B[4], tx * B[3]));
+    const float rho2 = __builtin_fmaf(-h, h, tt);
+    const float s2 = __builtin_fmaf(RH_CONE_ALPHA, tt, B[9]);
+    const float e = __builtin_fmaf(G.hr, B[7], B[8]) * 1.000001f;
+    const float uu = B[6] * h;
+    const float lo = uu - e, hi = uu + e;
+    const float hi2 = __builtin_fmaf(hi, hi, s2), lo2 = __builtin_fmaf(lo, lo, -s2);
+    return (rho2 > s2) & ((hi <= 0.0f) | (rho2 > hi2) | ((lo > 0.0f) & (rho2 < lo2)));
+}
+
+// ---- plane: t = min(a, b) of the scaled record: sure <=> t > 0, maybe <=> t > -1
+static __device__ __forceinline__ float cls_plane_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+{
+    const float a = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
+    const float d = __builtin_fmaf(C.f[6], z, __builtin_fmaf(C.f[5], y, __builtin_fmaf(C.f[4], x, C.f[7])));
+    return fminf(a, C.f[8] - __builtin_fabsf(d));
+}
+
+// ---- band prefilter: may this point pass the distance half?  NaN -> false.
+template <int KIND>
+static __device__ __forceinline__ bool cls_pre(const rh_cls &C, float x, float y, float z)
+{
+    if (KIND == RH_SPHERE) {
+        const float dx = x - C.f[0], dy = y - C.f[1], dz = z - C.f[2];
+        const float n2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        return __builtin_fabsf(n2 - C.f[4]) <= C.f[5];
+    }
+    if (KIND == RH_CYLINDER) {
+        const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
+        const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
+        const float qx = __builtin_fmaf(-C.f[0], sd, tx), qy = __builtin_fmaf(-C.f[1], sd, ty), qz = __builtin_fmaf(-C.f[2], sd, tz);
+        const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+        return __builtin_fabsf(n2 - C.f[7]) <= C.f[8];
+    }
+    // cone
+    const float tx = x - C.f[0], ty = y - C.f[1], tz = z - C.f[2];
+    const float tt = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
+    const float h = __builtin_fmaf(tz, C.f[5], __builtin_fmaf(ty, C.f[4], tx * C.f[3]));
+    const float rho2 = __builtin_fmaf(-h, h, tt);
+    const float s2 = __builtin_fmaf(C.f[8], tt, C.f[9]);
+    const float uu = C.f[6] * h;
+    const float lo = uu - C.f[7], hi = uu + C.f[7];
+    const float hi2 = __builtin_fmaf(hi, hi, s2), lo2 = __builtin_fmaf(lo, lo, -s2);
+    // next to the axis the reference's frame is ill-conditioned: those points go to the exact test (rho2 <= s2 covers
+    // the f64 prefilter's 1e-10 |t|^2)
+    return (rho2 <= s2) | ((hi > 0.0f) & (rho2 <= hi2) & ((lo <= 0.0f) | (rho2 >= lo2)));
+}
+
+// ---- full two-sided test of one (candidate, point) pair per lane (sphere, cylinder): sure / maybe as lane predicates.
+// maybe uses the "not (surely outside)" form, so an exact-only record (NaN thresholds) and NaN normals give maybe = true.
+struct cls_bits { bool sure, maybe; };
+template <int KIND>
+static __device__ __forceinline__ void cls_full_q(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &xd, float &L, float &nr)
+{
+    float qx, qy, qz, R, sgn;
+    if (KIND == RH_SPHERE) {
+        qx = x - C.f[0]; qy = y - C.f[1]; qz = z - C.f[2]; R = C.f[3]; sgn = C.f[10];
+    } else {
+        const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
+        const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
+        qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
+        R = C.f[6]; sgn = C.f[13];
+    }
+    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    nr = __builtin_amdgcn_sqrtf(n2);
+    xd = __builtin_fabsf(nr - R);
+    L = sgn * __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx));
+}
+template <int KIND>
+static __device__ __forceinline__ cls_bits cls_full(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+{
+    float xd, L, nr;
+    cls_full_q<KIND>(C, x, y, z, nx, ny, nz, xd, L, nr);
+    const int b = KIND == RH_SPHERE ? 6 : 9;
+    cls_bits r;
+    r.sure = (xd < C.f[b]) & (L > C.f[b + 3] * nr);
+    r.maybe = !(xd >= C.f[b + 1]) & !(L <= C.f[b + 2] * nr);
+    return r;
+}
+#endif   // __HIPCC__
+
+}  // namespace rh4

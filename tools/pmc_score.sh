@@ -14,7 +14,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k=r["Kernel_Name"].replace("(anonymous namespace)::","")[:40]
     acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
 for k,v in acc.items():
-    if "score_groups_all" in k or "prep_binned" in k:
+    if "score_groups_all" in k or "prep_binned" in k or "score4" in k:
         print(k, "dispatches", len(n[k]))
         for c,x in sorted(v.items()): print("    %-28s %14.0f per dispatch" % (c, x/len(n[k])))
 PY
