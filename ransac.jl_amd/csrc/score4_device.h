@@ -53,8 +53,8 @@ struct rh_cls {
 };
 constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
 // plane:    0-2 n / wN | 3 -cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
-// sphere:   0-2 o | 3 R | 4 mid2 | 5 half2 | 6 eD_lo | 7 eD_hi | 8 cN_lo | 9 cN_hi | 10 sgn
-// cylinder: 0-2 a | 3-5 c0 | 6 R | 7 mid2 | 8 half2 | 9 eD_lo | 10 eD_hi | 11 cN_lo | 12 cN_hi | 13 sgn
+// sphere:   0-2 o | 3 R | 4 1 / wD | 5 eD_lo / wD | 6 sgn / wN | 7 -cN_hi / wN
+// cylinder: 0-2 a | 3-5 c0 | 6 R | 7 1 / wD | 8 eD_lo / wD | 9 sgn / wN | 10 -cN_hi / wN
 // cone:     0-2 apex | 3-5 a^ | 6 kk | 7 e | 8 alpha | 9 beta
 
 // culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
@@ -72,13 +72,14 @@ __host__ __device__ inline bool cls_fin(double v) { return v - v == 0.0; }
 __host__ __device__ inline float cls_dn(double v) { return (float)(v - fabs(v) * (2.0 * RH_CLS_U) - 1e-37); }
 __host__ __device__ inline float cls_up(double v) { return (float)(v + fabs(v) * (2.0 * RH_CLS_U) + 1e-37); }
 
-// the smallest power of two >= v (v > 0, finite), by exponent arithmetic
+// the smallest power of two >= v (v > 0, finite, normal), by exponent arithmetic
 __host__ __device__ inline double cls_pow2ceil(double v)
 {
-    double p = 1.0;
-    while (p < v) p *= 2.0;
-    while (p * 0.5 >= v) p *= 0.5;
-    return p;
+    union { double d; uint64_t u; } c;
+    c.d = v;
+    const uint64_t mant = c.u & 0x000FFFFFFFFFFFFFull;
+    c.u &= 0x7FF0000000000000ull;
+    return mant != 0 ? c.d * 2.0 : c.d;
 }
 
 // the old kernel's slack of the conservative stages: covers the exact test's own binary64 rounding (score_device.h)
@@ -148,32 +149,31 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         }
         const double s3 = 1.7320508075688774;
         const double mD = S * (s3 * e + 4.0 * u * (fabs(R) + fabs(eps))) + u * (fabs(R) + fabs(eps)) + 1e-30;
-        const double lo = R - eps - mD, hi = R + eps + mD;
-        // a point the distance half may accept lies at least this far from the centre / axis (its binary32 norm is above
-        // lo, its true norm within mD of that)
-        const double nrmin = lo - mD;
+        // a point the distance half may accept (|nr32 - R| < eps + wD / 2, wD < 4 mD) lies at least this far from the
+        // centre / axis
+        const double nrmin = R - eps - 3.0 * mD;
         // margin of the normal half as a margin on cos(alpha): |L32 - L| / nr.  Without a positive lower bound on nr (the
-        // centre lies inside the band) or with a margin that is not small the normal half is never decided in binary32:
-        // NaN thresholds make "sure" false and "maybe" true.
+        // centre lies inside the band) or with a margin that is not small the candidate is exact-only.
         double mN = nrmin > 0.0 ? S * ((3.0 * Nm + s3 * (fabs(cosa) + 0.25)) * e / nrmin + (8.7 * Nm + 6.0 * (fabs(cosa) + 0.25)) * u) + 1e-30
                                 : __builtin_nan("");
         if (!(mN <= 0.25)) mN = __builtin_nan("");
-        // the band of the prefilter on the squared norm, as |n2 - mid2| <= half2
-        const double lo2 = lo > 0.0 ? lo * lo * (1.0 - 16.0 * u) : -1e-30;
-        const double hi2 = hi * hi * (1.0 + 16.0 * u);
-        const double mid2 = 0.5 * (lo2 + hi2);
-        const float half2 = hi > 0.0 ? cls_up(0.5 * (hi2 - lo2) * (1.0 + 8.0 * u) + 8.0 * u * fabs(mid2)) : -1.0f;   // hi <= 0: nothing passes
+        // scaled like the plane record: a = (eD_lo - |nr - R|) / wD, b = (sgn (q . np) / nr - cN_hi) / wN, t = min(a, b);
+        // a point whose distance half fails surely has a <= -1 whatever b is
+        ok = ok && cls_fin(mD) && cls_fin(mN) && (sgn == 1.0 || sgn == -1.0) && mD < 1e30;
         const int b = sph ? 4 : 7;
         if (sph) { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)R; }
         else { for (int i = 0; i < 6; i++) o.f[i] = (float)P.f[i]; o.f[6] = (float)R; }
-        o.f[b + 0] = (float)mid2;
-        o.f[b + 1] = half2;
-        o.f[b + 2] = cls_dn(eps - mD);
-        o.f[b + 3] = cls_up(eps + mD);
-        o.f[b + 4] = cls_dn(cosa - mN);   // (NaN stays NaN)
-        o.f[b + 5] = cls_up(cosa + mN);
-        o.f[b + 6] = (float)sgn;
-        ok = ok && cls_fin(mD) && (sgn == 1.0 || sgn == -1.0) && cls_fin(mid2);
+        if (ok) {
+            const double mN2 = mN + 8.0 * u * Nm;   // + the rsq / multiply in place of the comparison against c * nr
+            const double wD = cls_pow2ceil(2.0 * mD), wN = cls_pow2ceil(2.0 * mN2);
+            const double eDlo = eps - 0.5 * wD, cNhi = cosa + 0.5 * wN;
+            ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
+            o.f[b + 0] = (float)(1.0 / wD);
+            o.f[b + 1] = (float)(eDlo / wD);
+            o.f[b + 2] = (float)(sgn / wN);
+            o.f[b + 3] = (float)(-cNhi / wN);
+            for (int i = 0; i < b + 4; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
+        }
         if (fin && axis_ok && cls_fin(eps) && cls_fin(M)) {
             // box: |p - o| (sphere) or the distance from the axis (cylinder, at the centre of the box +- Lipschitz) against
             // R +- eps; binary32 error of the norm at the centre + of the squares + the binary64 test's own slack
@@ -302,23 +302,49 @@ static __device__ __forceinline__ float cls_plane_t(const rh_cls &C, float x, fl
     return fminf(a, C.f[8] - __builtin_fabsf(d));
 }
 
-// ---- band prefilter: may this point pass the distance half?  NaN -> false.
+// ---- sphere / cylinder: the same t = min(a, b) from the scaled record (sure <=> t > 0, maybe <=> t > -1)
 template <int KIND>
-static __device__ __forceinline__ bool cls_pre(const rh_cls &C, float x, float y, float z)
+static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
+    float qx, qy, qz;
+    constexpr int b = KIND == RH_SPHERE ? 3 : 6;
     if (KIND == RH_SPHERE) {
-        const float dx = x - C.f[0], dy = y - C.f[1], dz = z - C.f[2];
-        const float n2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        return __builtin_fabsf(n2 - C.f[4]) <= C.f[5];
-    }
-    if (KIND == RH_CYLINDER) {
+        qx = x - C.f[0]; qy = y - C.f[1]; qz = z - C.f[2];
+    } else {
         const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
         const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
-        const float qx = __builtin_fmaf(-C.f[0], sd, tx), qy = __builtin_fmaf(-C.f[1], sd, ty), qz = __builtin_fmaf(-C.f[2], sd, tz);
-        const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-        return __builtin_fabsf(n2 - C.f[7]) <= C.f[8];
+        qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
     }
-    // cone
+    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    const float inr = __builtin_amdgcn_rsqf(n2);
+    const float nr = n2 * inr;
+    const float dt = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx)) * inr;
+    const float a = __builtin_fmaf(-__builtin_fabsf(nr - C.f[b]), C.f[b + 1], C.f[b + 2]);
+    const float bb = __builtin_fmaf(dt, C.f[b + 3], C.f[b + 4]);
+    return fminf(a, bb);
+}
+// the compared quantities themselves (audit): |nr - R| and sgn (q . np) / nr
+template <int KIND>
+static __device__ __forceinline__ void cls_round_q(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &xd, float &yn)
+{
+    float qx, qy, qz;
+    constexpr int b = KIND == RH_SPHERE ? 3 : 6;
+    if (KIND == RH_SPHERE) {
+        qx = x - C.f[0]; qy = y - C.f[1]; qz = z - C.f[2];
+    } else {
+        const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
+        const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
+        qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
+    }
+    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    const float inr = __builtin_amdgcn_rsqf(n2);
+    xd = __builtin_fabsf(n2 * inr - C.f[b]);
+    yn = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx)) * inr * (C.f[b + 3] < 0.0f ? -1.0f : 1.0f);
+}
+
+// ---- cone: band prefilter -- may this point pass the distance half?  NaN -> false.
+static __device__ __forceinline__ bool cls_pre_cone(const rh_cls &C, float x, float y, float z)
+{
     const float tx = x - C.f[0], ty = y - C.f[1], tz = z - C.f[2];
     const float tt = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
     const float h = __builtin_fmaf(tz, C.f[5], __builtin_fmaf(ty, C.f[4], tx * C.f[3]));
@@ -330,38 +356,6 @@ static __device__ __forceinline__ bool cls_pre(const rh_cls &C, float x, float y
     // next to the axis the reference's frame is ill-conditioned: those points go to the exact test (rho2 <= s2 covers
     // the f64 prefilter's 1e-10 |t|^2)
     return (rho2 <= s2) | ((hi > 0.0f) & (rho2 <= hi2) & ((lo <= 0.0f) | (rho2 >= lo2)));
-}
-
-// ---- full two-sided test of one (candidate, point) pair per lane (sphere, cylinder): sure / maybe as lane predicates.
-// maybe uses the "not (surely outside)" form, so an exact-only record (NaN thresholds) and NaN normals give maybe = true.
-struct cls_bits { bool sure, maybe; };
-template <int KIND>
-static __device__ __forceinline__ void cls_full_q(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &xd, float &L, float &nr)
-{
-    float qx, qy, qz, R, sgn;
-    if (KIND == RH_SPHERE) {
-        qx = x - C.f[0]; qy = y - C.f[1]; qz = z - C.f[2]; R = C.f[3]; sgn = C.f[10];
-    } else {
-        const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
-        const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
-        qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
-        R = C.f[6]; sgn = C.f[13];
-    }
-    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-    nr = __builtin_amdgcn_sqrtf(n2);
-    xd = __builtin_fabsf(nr - R);
-    L = sgn * __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx));
-}
-template <int KIND>
-static __device__ __forceinline__ cls_bits cls_full(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
-{
-    float xd, L, nr;
-    cls_full_q<KIND>(C, x, y, z, nx, ny, nz, xd, L, nr);
-    const int b = KIND == RH_SPHERE ? 6 : 9;
-    cls_bits r;
-    r.sure = (xd < C.f[b]) & (L > C.f[b + 3] * nr);
-    r.maybe = !(xd >= C.f[b + 1]) & !(L <= C.f[b + 2] * nr);
-    return r;
 }
 #endif   // __HIPCC__
 
