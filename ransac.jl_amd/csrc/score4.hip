@@ -40,20 +40,18 @@ typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int S4_TG = RH_G2_TG;          // groups per tile
 constexpr int S4_ROW = 65;               // padded row length of the tile arrays (bank spread of the per-lane rows)
 constexpr int S4_W = 4;                  // waves per block
-constexpr int S4_RING = 512;             // per-wave pair ring (entries): a batch of 64 and a chunk's 256 survivors fit with room to spare
-static_assert(S4_TG == 4, "entry encoding: 2 bits of group");
+constexpr int S4_R = 8;                  // 64-candidate chunks per block
+static_assert(S4_TG == 4 && S4_R * 64 * 4 <= 65536, "entry encoding: 2 bits of group, the rest of 16 for the candidate");
 
 struct S4Shared {
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
     rh_f32x2 pb[S4_TG][S4_ROW];          // (ny, nz)
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
-    uint32_t ring[S4_W][S4_RING];        // per-wave ring of surviving pairs: candidate slot << 2 | group
-    uint32_t left[S4_W * 64];            // the waves' last, partial batches of a kind, merged
+    uint16_t plist[S4_R * 64 * S4_TG];   // the block's surviving pairs: candidate of the row << 2 | group
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
     uint16_t qb[S4_W][128];              // cone: per-wave ring (slot-in-batch << 6 | point-in-group) for the exact test
     int weirdw[S4_TG];                   // per staging wave: an enabled point with a non-finite value
-    int anyoff[S4_TG];                   // per staging wave: its group has a valid point that is disabled
-    int nleft, next_chunk;
+    int npairs, next_batch;
 };
 
 static __device__ __forceinline__ void wave_lds_sync()
@@ -80,7 +78,6 @@ struct S4AllArgs {
     S4KindArgs k[4];
     int64_t ntiles, bstride, ngroups;
     const float *gb32;      // binary32 boxes of the groups, 8 floats each
-    unsigned long long *trace;   // debug (RH_S4_TRACE): 16 shader-clock stamps per wave, or null
 };
 
 template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLANE || KIND == RH_SPHERE ? 5 : (KIND == RH_CYLINDER ? 9 : 10); };
@@ -99,16 +96,16 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
     return (lane == 63 || kn != key) ? v : 0;
 }
 
-// one batch: the 64 pairs at the head of the wave's ring (n of them valid), one per lane
+// one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
 template <int KIND>
 static __device__ __forceinline__ void
-score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const int n, const double *__restrict__ pts,
+score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird)
 {
     const bool act = lane < n;
-    const uint32_t e = sh.ring[wv][(head + (act ? lane : 0)) & (S4_RING - 1)];
-    const int g = (int)(e & 3u), ci = (int)(e >> 2);
+    const uint32_t e = sh.plist[head + (act ? lane : 0)];
+    const int g = (int)(e & 3u), ci = cbase + (int)(e >> 2);
     const rh_f32x4 *__restrict__ rowa = &sh.pa[g][0];
     const rh_f32x2 *__restrict__ rowb = &sh.pb[g][0];
     const rh_cls *__restrict__ rec = &cls[ci];
@@ -137,7 +134,7 @@ score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const i
             const int k = __builtin_ctzll(redo);
             redo &= redo - 1;
             const uint32_t ek = __builtin_amdgcn_readlane(e, k);
-            const int g2 = (int)(ek & 3u), ci2 = (int)(ek >> 2);
+            const int g2 = (int)(ek & 3u), ci2 = cbase + (int)(ek >> 2);
             const rh_prep P = rh_ld_prep_const(&prep[ci2]);
             const int64_t gi = p0 + g2 * 64 + lane;
             const uint64_t mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
@@ -171,9 +168,9 @@ score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const i
             const bool on = lane < k;
             const unsigned e2 = on ? sh.qb[wv][(qbh + lane) & 127] : 0u;
             const int slot = (int)(e2 >> 6);
-            const uint32_t pe = sh.ring[wv][(head + slot) & (S4_RING - 1)];
+            const uint32_t pe = sh.plist[head + slot];
             const int64_t gi = p0 + (int)(pe & 3u) * 64 + (int)(e2 & 63u);
-            const rh_prep Pv = prep[pe >> 2];
+            const rh_prep Pv = prep[cbase + (int)(pe >> 2)];
             const uint64_t r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
                                                 pts[4 * stride + gi], pts[5 * stride + gi], eps, cosa);
             if (on && ((r >> lane) & 1ULL)) atomicAdd(&sh.cntb[wv][slot], 1);
@@ -200,48 +197,40 @@ score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const i
     if (v != 0) atomicAdd(&counts[orig[ci]], v);
 }
 
-// one kind on this block: every wave walks its chunks (box tests -> pair ring -> batches as the ring fills); the
-// waves' last, partial batches are merged and shared out again
+// one kind segment of the block's row: chunks [lo, hi) of the kind (at most S4_R).  Stage 1: the waves share the
+// chunks out, lane = candidate, box tests, survivors -> the block's pair list.  Stage 2: the waves take batches of 64
+// pairs from the list until it is empty.
 template <int KIND>
 static __device__ __forceinline__ void
-score4_kind(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const double *__restrict__ pts,
-            int64_t stride, const int64_t g0, const unsigned live, const bool weird, int32_t *__restrict__ counts, int dbg,
-            unsigned long long *tr, int &tslot)
+score4_segment(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
+               const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
+               int32_t *__restrict__ counts, int dbg)
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nk = *K.nk;
-    const int nch = (nk + 63) >> 6;
     constexpr int NB = S4Fields<KIND>::NBOX;
-    int head = 0, fill = 0;   // wave-uniform
-    float B[RH_BOX_FIELDS], Bn[RH_BOX_FIELDS];
-    // the block's waves take this block's chunks (every gridDim.y-th of the kind) one at a time from a common counter;
-    // the NEXT chunk is taken -- and its culling records requested -- before the current one is worked on
-    const int rows = (int)gridDim.y, row = (int)blockIdx.y;
-    const int nmine = nch > row ? (nch - row + rows - 1) / rows : 0;   // chunks row, row + rows, ... of the kind
-    auto grab = [&]() {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(&sh.next_chunk, 1);
-        return __builtin_amdgcn_readfirstlane(t);
-    };
-    int t = grab();
-    if (t < nmine) {
-        const int ci = ((row + t * rows) << 6) + lane;
+    // (the culling records of the wave's chunks are requested together, before the first box test)
+    constexpr int CPW = S4_R / S4_W;
+    float B[2][RH_BOX_FIELDS];
+    {
+        const int ci = ((lo + wv) << 6) + lane;
 #pragma unroll
-        for (int f = 0; f < NB; f++) B[f] = ci < nk ? K.box[(int64_t)f * bstride + ci] : 0.0f;
+        for (int f = 0; f < NB; f++) B[0][f] = (lo + wv < hi && ci < nk) ? K.box[(int64_t)f * bstride + ci] : 0.0f;
     }
-    while (t < nmine) {
-        const int c = row + t * rows;
-        const int ci = (c << 6) + lane;
-        const int tn = grab();
-        if (tn < nmine) {
-            const int cin = ((row + tn * rows) << 6) + lane;
 #pragma unroll
-            for (int f = 0; f < NB; f++) Bn[f] = cin < nk ? K.box[(int64_t)f * bstride + cin] : 0.0f;
+    for (int h = 0; h < CPW; h++) {
+        const int c = lo + wv + h * S4_W;
+        if (c >= hi) break;
+        const int ci = (c << 6) + lane;
+        if (h + 1 < CPW) {   // the next chunk's records: in flight during this chunk's tests
+            const int cin = ((c + S4_W) << 6) + lane;
+#pragma unroll
+            for (int f = 0; f < NB; f++) B[(h + 1) & 1][f] = (c + S4_W < hi && cin < nk) ? K.box[(int64_t)f * bstride + cin] : 0.0f;
         }
         unsigned surv = 0;
 #pragma unroll
-        for (int g = 0; g < S4_TG; g++) surv |= box_skip32<KIND>(B, G[g]) ? 0u : (1u << g);
+        for (int g = 0; g < S4_TG; g++) surv |= box_skip32<KIND>(B[h & 1], G[g]) ? 0u : (1u << g);
         if (dbg == 2) surv = 15u;
         surv &= live;
         if (ci >= nk || dbg == 1) surv = 0;
@@ -249,85 +238,64 @@ score4_kind(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const
         const int k = __popc(surv);
         const uint64_t b0 = WB(k & 1), b1 = WB(k & 2), b2 = WB(k & 4);
         const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-        if (tot != 0) {
-            auto mb = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
-            int pos = head + fill + mb(b0) + 2 * mb(b1) + 4 * mb(b2);
+        if (tot == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&sh.npairs, tot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        auto mb = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
+        int pos = base + mb(b0) + 2 * mb(b1) + 4 * mb(b2);
 #pragma unroll
-            for (int g = 0; g < S4_TG; g++) {
-                if ((surv >> g) & 1u) {
-                    sh.ring[wv][pos & (S4_RING - 1)] = ((uint32_t)ci << 2) | (uint32_t)g;
-                    pos++;
-                }
-            }
-            fill += tot;
-            if (fill >= 64) wave_lds_sync();
-            while (fill >= 64) {
-                score4_batch<KIND>(sh, wv, lane, head, 64, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa, counts, weird);
-                head = (head + 64) & (S4_RING - 1);
-                fill -= 64;
+        for (int g = 0; g < S4_TG; g++) {
+            if ((surv >> g) & 1u) {
+                sh.plist[pos] = (uint16_t)(((ci - (lo << 6)) << 2) | g);
+                pos++;
             }
         }
-#pragma unroll
-        for (int f = 0; f < NB; f++) B[f] = Bn[f];
-        t = tn;
-    }
-    if (tr != nullptr && lane == 0 && tslot < 16) tr[tslot] = __builtin_amdgcn_s_memtime();   // end of the wave's own chunks
-    tslot++;
-    // the partial batches of the block's waves, merged
-    if (fill > 0) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&sh.nleft, fill);
-        base = __builtin_amdgcn_readfirstlane(base);
-        wave_lds_sync();
-        if (lane < fill) sh.left[base + lane] = sh.ring[wv][(head + lane) & (S4_RING - 1)];
     }
     __syncthreads();
-    const int nleft = sh.nleft;
-    if (wv * 64 < nleft) {
-        const int n = min(64, nleft - wv * 64);
-        if (lane < n) sh.ring[wv][lane] = sh.left[wv * 64 + lane];
-        wave_lds_sync();
-        score4_batch<KIND>(sh, wv, lane, 0, n, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa, counts, weird);
+    const int npairs = sh.npairs;
+    for (;;) {
+        int bt = 0;
+        if (lane == 0) bt = atomicAdd(&sh.next_batch, 1);
+        bt = __builtin_amdgcn_readfirstlane(bt);
+        if (bt * 64 >= npairs) break;
+        score4_batch<KIND>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa,
+                           counts, weird);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { sh.nleft = 0; sh.next_chunk = 0; }
 }
 
-// the tile as binary32 with the enabled words of one kind applied (the first S4_TG waves: one point per thread)
+// the tile as binary32 with the enabled words of one kind applied (one point per thread)
 static __device__ __forceinline__ void s4_stage(S4Shared &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
                                                 const uint64_t *__restrict__ enabled_words, const int64_t p0)
 {
+    static_assert(S4_W == S4_TG, "one wave per group");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wv < S4_TG) {
-        const int64_t gi = p0 + tid;
-        // (the six loads go out before the enabled word is looked at: one round trip)
-        const double x = pts[gi], y = pts[stride + gi], z = pts[2 * stride + gi];
-        const double nx = pts[3 * stride + gi], ny = pts[4 * stride + gi], nz = pts[5 * stride + gi];
-        const uint64_t vall = valid_mask((gi >> 6) << 6, s);
-        uint64_t v = vall;
-        if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
-        const bool on = (v >> (gi & 63)) & 1ULL;
-        rh_f32x4 a = { 0.f, 0.f, 0.f, 0.f };
-        rh_f32x2 b = { 0.f, 0.f };
-        bool bad = false;
-        if (lane == 0) sh.anyoff[wv] = v != vall ? 1 : 0;
-        if (on) {
-            a.x = (float)x; a.y = (float)y; a.z = (float)z; a.w = (float)nx; b.x = (float)ny; b.y = (float)nz;
-            const float sum = (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w)) + (fabsf(b.x) + fabsf(b.y));
-            bad = !(sum < __builtin_inff());   // an infinite or NaN value (binary32 overflow included)
-        }
-        sh.pa[wv][lane] = a;
-        sh.pb[wv][lane] = b;
-        const uint64_t wb = WB(bad);
-        if (lane == 0) { sh.weirdw[wv] = wb != 0 ? 1 : 0; sh.len[wv] = v; }   // wave w stages group w: v is its word
+    const int64_t gi = p0 + tid;
+    // (the six loads go out before the enabled word is looked at: one round trip)
+    const double x = pts[gi], y = pts[stride + gi], z = pts[2 * stride + gi];
+    const double nx = pts[3 * stride + gi], ny = pts[4 * stride + gi], nz = pts[5 * stride + gi];
+    uint64_t v = valid_mask((gi >> 6) << 6, s);
+    if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
+    const bool on = (v >> (gi & 63)) & 1ULL;
+    rh_f32x4 a = { 0.f, 0.f, 0.f, 0.f };
+    rh_f32x2 b = { 0.f, 0.f };
+    bool bad = false;
+    if (on) {
+        a.x = (float)x; a.y = (float)y; a.z = (float)z; a.w = (float)nx; b.x = (float)ny; b.y = (float)nz;
+        const float sum = (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w)) + (fabsf(b.x) + fabsf(b.y));
+        bad = !(sum < __builtin_inff());   // an infinite or NaN value (binary32 overflow included)
     }
-    if (tid == 0) { sh.nleft = 0; sh.next_chunk = 0; }
+    sh.pa[wv][lane] = a;
+    sh.pb[wv][lane] = b;
+    const uint64_t wb = WB(bad);
+    if (lane == 0) { sh.weirdw[wv] = wb != 0 ? 1 : 0; sh.len[wv] = v; }   // wave w stages group w: v is its word
+    if (tid == 0) { sh.npairs = 0; sh.next_batch = 0; }
 }
 
-// grid: (tiles padded to a multiple of 8, rows).  The block stages its tile (again where a kind's enabled words
-// differ: the reference's sphere scorer ignores isenabled, sphere.jl:121,131 -- spheres run last for that) and runs the
-// kinds one after the other, the expensive ones first.
+// grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
+// the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of S4_R; a block runs the per-kind
+// segment(s) of its row (almost always one) on its tile.
 template <int WAVES>
 __global__ void __launch_bounds__(64 * S4_W, WAVES == 8 ? 8 : 1)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
@@ -336,6 +304,11 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     const int64_t tile = blockIdx.x;
     if (tile >= A.ntiles) return;
     const int64_t g0 = tile * S4_TG;
+    int nch[4], total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
+    const int lo = (int)blockIdx.y * S4_R, hi = min(total, lo + S4_R);
+    if (lo >= hi) return;
     // the boxes of the tile's groups: wave-uniform, in scalar registers for the whole block
     rh_box32 G[S4_TG];
     {
@@ -347,37 +320,30 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             G[g].cx = q[0]; G[g].cy = q[1]; G[g].cz = q[2]; G[g].hx = q[3]; G[g].hy = q[4]; G[g].hz = q[5]; G[g].hr = q[6];
         }
     }
-    const uint64_t *cur_en = nullptr;
-    bool staged = false, weird = false, anyoff = true;
+    int base = 0;
+    bool ran = false, weird = false;
     unsigned live = 0;
-    int tslot = 0;
-    unsigned long long *tr = A.trace ? A.trace + ((int64_t)((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * S4_W + (threadIdx.x >> 6)) * 16 : nullptr;
-#define RH_S4_STAMP() do { if (tr != nullptr && (threadIdx.x & 63) == 0 && tslot < 16) tr[tslot] = __builtin_amdgcn_s_memtime(); tslot++; } while (0)
-    RH_S4_STAMP();
-#define RH_S4_KIND(K)                                                                                                  \
-    if (*A.k[K].nk > 0) {                                                                                              \
-        /* (a tile without a disabled point looks the same under every kind's enabled words) */                      \
-        if (!staged || (A.k[K].en != cur_en && (anyoff || cur_en == nullptr))) {                                      \
-            if (staged) __syncthreads();                                                                               \
+#define RH_S4_BODY(K)                                                                                                  \
+    {                                                                                                                  \
+        const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
+        if (slo < shi) {                                                                                               \
+            if (ran) __syncthreads();   /* the previous segment's waves are done with the tile and the list */        \
             s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64);                                                          \
-            cur_en = A.k[K].en;                                                                                        \
-            staged = true;                                                                                             \
             __syncthreads();                                                                                           \
             live = 0;                                                                                                  \
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
-            anyoff = __builtin_amdgcn_readfirstlane(sh.anyoff[0] | sh.anyoff[1] | sh.anyoff[2] | sh.anyoff[3]) != 0;    \
+            if (live != 0) score4_segment<K>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg); \
+            ran = true;                                                                                                \
         }                                                                                                              \
-        RH_S4_STAMP();                                                                                                 \
-        if (live != 0) score4_kind<K>(sh, A.k[K], G, A.bstride, pts, stride, g0, live, weird, counts, dbg, tr, tslot);  \
-        RH_S4_STAMP();                                                                                                 \
+        base += nch[K];                                                                                                \
     }
-    RH_S4_KIND(RH_CONE)
-    RH_S4_KIND(RH_CYLINDER)
-    RH_S4_KIND(RH_PLANE)
-    RH_S4_KIND(RH_SPHERE)
-#undef RH_S4_KIND
+    RH_S4_BODY(RH_CONE)
+    RH_S4_BODY(RH_CYLINDER)
+    RH_S4_BODY(RH_SPHERE)
+    RH_S4_BODY(RH_PLANE)
+#undef RH_S4_BODY
 }
 
 // binary32 boxes of the groups from the binary64 ones (7 planes of gstride doubles): 8 floats per group
@@ -424,31 +390,11 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.bstride = bstride;
     A.ngroups = c->ngroups;
     A.gb32 = c->gb32;
-    A.trace = nullptr;
-    static int env_trace = -1;
-    if (env_trace < 0) { const char *e = getenv("RH_S4_TRACE"); env_trace = e ? atoi(e) : 0; }
-    // one block per tile while the batch is small; rows of ~16 chunks per wave beyond
-    int64_t rows = env_rows > 0 ? env_rows : std::max<int64_t>(3, nchunks / (S4_W * 8));
-    if (rows > 65535) rows = 65535;
+    int64_t rows = (nchunks + S4_R - 1) / S4_R;
+    if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-    static int trace_calls = 0;
-    size_t trace_n = 0;
-    if (env_trace && ++trace_calls == env_trace) {   // debug: the env_trace-th launch leaves its waves' time stamps in /tmp/rh_s4_trace.bin
-        trace_n = (size_t)grid.x * grid.y * S4_W * 16;
-        RH_HIP(hipMalloc((void **)&A.trace, trace_n * 8));
-        RH_HIP(hipMemsetAsync(A.trace, 0, trace_n * 8, c->stream));
-    }
     hipLaunchKernelGGL((score4_kernel<8>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-    if (A.trace != nullptr) {
-        std::vector<unsigned long long> h(trace_n);
-        RH_HIP(hipMemcpyAsync(h.data(), A.trace, trace_n * 8, hipMemcpyDeviceToHost, c->stream));
-        RH_HIP(hipStreamSynchronize(c->stream));
-        const char *path = getenv("RH_S4_TRACE_FILE");
-        FILE *f = fopen(path ? path : "/tmp/rh_s4_trace.bin", "wb");
-        if (f) { fwrite(h.data(), 8, trace_n, f); fclose(f); }
-        (void)hipFree(A.trace);
-    }
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

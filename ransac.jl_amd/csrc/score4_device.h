@@ -82,6 +82,15 @@ __host__ __device__ inline double cls_pow2ceil(double v)
     return mant != 0 ? c.d * 2.0 : c.d;
 }
 
+// 1 / p for a power of two p (normal, and 1 / p normal): exact, by exponent arithmetic
+__host__ __device__ inline double cls_pow2recip(double p)
+{
+    union { double d; uint64_t u; } c;
+    c.d = p;
+    c.u = (uint64_t)(2046 - (c.u >> 52)) << 52;
+    return c.d;
+}
+
 // the old kernel's slack of the conservative stages: covers the exact test's own binary64 rounding (score_device.h)
 __host__ __device__ inline double cls_slack64(const rh_prep &P, double M) { return 1e-9 * ((1.0 + M) + P.f[11]); }
 
@@ -110,13 +119,14 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         ok = ok && cls_fin(mN) && cls_fin(mD) && cls_fin(zp) && mN < 1e30 && mD < 1e30;
         if (ok) {
             const double wN = cls_pow2ceil(2.0 * mN), wD = cls_pow2ceil(2.0 * mD);
+            const double iN = cls_pow2recip(wN), iD = cls_pow2recip(wD);   // (multiplying by them scales exactly)
             const double cNhi = cosa + 0.5 * wN, eDlo = eps - 0.5 * wD;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
-            o.f[0] = (float)(P.f[3] / wN); o.f[1] = (float)(P.f[4] / wN); o.f[2] = (float)(P.f[5] / wN);
-            o.f[3] = (float)(-cNhi / wN);
-            o.f[4] = (float)(P.f[6] / wD); o.f[5] = (float)(P.f[7] / wD); o.f[6] = (float)(P.f[8] / wD);
-            o.f[7] = (float)(-zp / wD);
-            o.f[8] = (float)(eDlo / wD);
+            o.f[0] = (float)(P.f[3] * iN); o.f[1] = (float)(P.f[4] * iN); o.f[2] = (float)(P.f[5] * iN);
+            o.f[3] = (float)(-cNhi * iN);
+            o.f[4] = (float)(P.f[6] * iD); o.f[5] = (float)(P.f[7] * iD); o.f[6] = (float)(P.f[8] * iD);
+            o.f[7] = (float)(-zp * iD);
+            o.f[8] = (float)(eDlo * iD);
             for (int i = 0; i < 9; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
         if (fin && cls_fin(zp) && cls_fin(eps) && cls_fin(M)) {
@@ -128,13 +138,12 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         }
     } else if (kind == RH_SPHERE || kind == RH_CYLINDER) {
         const bool sph = kind == RH_SPHERE;
-        const int nf = sph ? 4 : 7;
         bool fin = true;
-        for (int i = 0; i < nf; i++) fin = fin && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
+        for (int i = 0; i < 7; i++) fin = fin && ((sph && i >= 4) || (cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG));   // (no run-time indices)
         ok = ok && fin;
         const double R = sph ? P.f[3] : P.f[6], sgn = sph ? P.f[4] : P.f[7];
-        const double *ctr = sph ? &P.f[0] : &P.f[3];
-        const double T = M + fmax(fabs(ctr[0]), fmax(fabs(ctr[1]), fabs(ctr[2])));
+        const double c0 = sph ? P.f[0] : P.f[3], c1 = sph ? P.f[1] : P.f[4], c2 = sph ? P.f[2] : P.f[5];
+        const double T = M + fmax(fabs(c0), fmax(fabs(c1), fabs(c2)));
         double e, lipk = 1.0;   // e: error bound per component of the vector whose norm is taken
         bool axis_ok = true;
         if (sph) {
@@ -160,19 +169,19 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         // scaled like the plane record: a = (eD_lo - |nr - R|) / wD, b = (sgn (q . np) / nr - cN_hi) / wN, t = min(a, b);
         // a point whose distance half fails surely has a <= -1 whatever b is
         ok = ok && cls_fin(mD) && cls_fin(mN) && (sgn == 1.0 || sgn == -1.0) && mD < 1e30;
-        const int b = sph ? 4 : 7;
+        // (constant indices only: a run-time index would move the record to scratch memory)
         if (sph) { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)R; }
-        else { for (int i = 0; i < 6; i++) o.f[i] = (float)P.f[i]; o.f[6] = (float)R; }
+        else { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)P.f[3]; o.f[4] = (float)P.f[4]; o.f[5] = (float)P.f[5]; o.f[6] = (float)R; }
         if (ok) {
             const double mN2 = mN + 8.0 * u * Nm;   // + the rsq / multiply in place of the comparison against c * nr
             const double wD = cls_pow2ceil(2.0 * mD), wN = cls_pow2ceil(2.0 * mN2);
             const double eDlo = eps - 0.5 * wD, cNhi = cosa + 0.5 * wN;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
-            o.f[b + 0] = (float)(1.0 / wD);
-            o.f[b + 1] = (float)(eDlo / wD);
-            o.f[b + 2] = (float)(sgn / wN);
-            o.f[b + 3] = (float)(-cNhi / wN);
-            for (int i = 0; i < b + 4; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
+            const double iN = cls_pow2recip(wN), iD = cls_pow2recip(wD);
+            const float s0 = (float)iD, s1 = (float)(eDlo * iD), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN);
+            if (sph) { o.f[4] = s0; o.f[5] = s1; o.f[6] = s2; o.f[7] = s3f; }
+            else { o.f[7] = s0; o.f[8] = s1; o.f[9] = s2; o.f[10] = s3f; }
+            ok = ok && fabs((double)s0) < 1e30 && fabs((double)s1) < 1e30 && fabs((double)s2) < 1e30 && fabs((double)s3f) < 1e30;
         }
         if (fin && axis_ok && cls_fin(eps) && cls_fin(M)) {
             // box: |p - o| (sphere) or the distance from the axis (cylinder, at the centre of the box +- Lipschitz) against
