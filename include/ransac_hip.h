@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 104
+#define RH_VERSION 105
 
 enum {
     RH_OK = 0,
@@ -281,6 +281,15 @@ int rh_dev_alloc(rh_cloud *c, int64_t bytes, void **d_out);
 int rh_dev_free(rh_cloud *c, void *d);
 int rh_dev_upload(rh_cloud *c, void *d_dst, const void *h_src, int64_t bytes);
 int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes);
+
+/* ---- diagnostics (tests) ---- */
+/* The batched score decides most (candidate, point) pairs with a binary32 evaluation of the reference's
+ * compatibles* quantities (plane.jl:114-130, sphere.jl:144-172, cylinder.jl:194-221) and keeps the binary64
+ * test for the pairs within a rounding margin of a threshold (csrc/score4_device.h).  This runs every
+ * candidate of `shapes` against every point of subset 1 and returns the worst binary32 error in units of
+ * the margin width: out[2k], out[2k+1] = max |a32 - a64|, |b32 - b64| for kind k (plane, sphere, cylinder;
+ * sound below 1/2), out[8+k] = pairs looked at.  Host shapes, synchronous. */
+int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, double *out /* [12] */);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     "rh_dev_free": (C.c_int, [_vp, _vp]),
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
 }
 
 _lib = None

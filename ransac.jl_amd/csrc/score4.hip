@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "rh_internal.h"
 #include "score_device.h"
 #include "score4_device.h"
@@ -40,14 +42,15 @@ typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int S4_TG = RH_G2_TG;          // groups per tile
 constexpr int S4_ROW = 65;               // padded row length of the tile arrays (bank spread of the per-lane rows)
 constexpr int S4_W = 4;                  // waves per block
-constexpr int S4_R = 8;                  // 64-candidate chunks per block
-static_assert(S4_TG == 4 && S4_R * 64 * 4 <= 65536, "entry encoding: 2 bits of group, the rest of 16 for the candidate");
-
+// R: 64-candidate chunks per block -- 8 on large subsets (cfg3: 0.108 ms; 4: 0.120, 12: 0.107, 16: 0.116), 4 where the
+// grid would otherwise be a few hundred blocks
+template <int R>
 struct S4Shared {
+    static_assert(S4_TG == 4 && R * 64 * 4 <= 65536 && R % S4_W == 0, "entry encoding: 2 bits of group, the rest of 16 for the candidate");
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
     rh_f32x2 pb[S4_TG][S4_ROW];          // (ny, nz)
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
-    uint16_t plist[S4_R * 64 * S4_TG];   // the block's surviving pairs: candidate of the row << 2 | group
+    uint16_t plist[R * 64 * S4_TG];      // the block's surviving pairs: candidate of the row << 2 | group
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
     uint16_t qb[S4_W][128];              // cone: per-wave ring (slot-in-batch << 6 | point-in-group) for the exact test
     int weirdw[S4_TG];                   // per staging wave: an enabled point with a non-finite value
@@ -97,9 +100,9 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
 }
 
 // one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
-template <int KIND>
+template <int KIND, int R>
 static __device__ __forceinline__ void
-score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
+score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird)
 {
@@ -200,9 +203,9 @@ score4_batch(S4Shared &sh, const int wv, const int lane, const int head, const i
 // one kind segment of the block's row: chunks [lo, hi) of the kind (at most S4_R).  Stage 1: the waves share the
 // chunks out, lane = candidate, box tests, survivors -> the block's pair list.  Stage 2: the waves take batches of 64
 // pairs from the list until it is empty.
-template <int KIND>
+template <int KIND, int R>
 static __device__ __forceinline__ void
-score4_segment(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
+score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
                int32_t *__restrict__ counts, int dbg)
 {
@@ -211,7 +214,7 @@ score4_segment(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], co
     const int nk = *K.nk;
     constexpr int NB = S4Fields<KIND>::NBOX;
     // (the culling records of the wave's chunks are requested together, before the first box test)
-    constexpr int CPW = S4_R / S4_W;
+    constexpr int CPW = R / S4_W;
     float B[2][RH_BOX_FIELDS];
     {
         const int ci = ((lo + wv) << 6) + lane;
@@ -259,13 +262,14 @@ score4_segment(S4Shared &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], co
         if (lane == 0) bt = atomicAdd(&sh.next_batch, 1);
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
-        score4_batch<KIND>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa,
+        score4_batch<KIND, R>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa,
                            counts, weird);
     }
 }
 
 // the tile as binary32 with the enabled words of one kind applied (one point per thread)
-static __device__ __forceinline__ void s4_stage(S4Shared &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
+template <int R>
+static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
                                                 const uint64_t *__restrict__ enabled_words, const int64_t p0)
 {
     static_assert(S4_W == S4_TG, "one wave per group");
@@ -294,20 +298,20 @@ static __device__ __forceinline__ void s4_stage(S4Shared &sh, const double *__re
 }
 
 // grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
-// the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of S4_R; a block runs the per-kind
+// the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of R; a block runs the per-kind
 // segment(s) of its row (almost always one) on its tile.
-template <int WAVES>
-__global__ void __launch_bounds__(64 * S4_W, WAVES == 8 ? 8 : 1)
+template <int R>
+__global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
-    __shared__ S4Shared sh;
+    __shared__ S4Shared<R> sh;
     const int64_t tile = blockIdx.x;
     if (tile >= A.ntiles) return;
     const int64_t g0 = tile * S4_TG;
     int nch[4], total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
-    const int lo = (int)blockIdx.y * S4_R, hi = min(total, lo + S4_R);
+    const int lo = (int)blockIdx.y * R, hi = min(total, lo + R);
     if (lo >= hi) return;
     // the boxes of the tile's groups: wave-uniform, in scalar registers for the whole block
     rh_box32 G[S4_TG];
@@ -334,7 +338,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
-            if (live != 0) score4_segment<K>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg); \
+            if (live != 0) score4_segment<K, R>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg); \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -344,6 +348,85 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     RH_S4_BODY(RH_SPHERE)
     RH_S4_BODY(RH_PLANE)
 #undef RH_S4_BODY
+}
+
+// ---- audit of the classifier's margins (tests): every (candidate, point) of a batch against subset 1.
+// a32 / b32 are what the score kernel computes (the very same functions); a64 / b64 the same scaled quantities from
+// the reference's binary64 arithmetic.  |x32 - x64| has to stay below 1/2 for the classification to be sound; by
+// construction (RH_CLS_SAFETY) it should stay below ~1/8.  out[kind * 2 + {0, 1}] = max over the batch of |a32 - a64|,
+// |b32 - b64| (b only where the distance half is not surely outside: a64 > -1.5); out[8 + kind] = pairs looked at.
+struct S4AuditCand { rh_prep P; rh_cls C; double cNhi, wN, eDlo, wD; int kind, usable; };
+
+__global__ void __launch_bounds__(256)
+cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AuditCand *__restrict__ cands, int ncand,
+                 unsigned long long *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (c >= ncand) return;
+    const S4AuditCand &Q = cands[c];
+    double ea = 0.0, eb = 0.0;
+    bool counted = false;
+    if (i < s && Q.usable) {
+        const double x = pts[i], y = pts[stride + i], z = pts[2 * stride + i];
+        const double nx = pts[3 * stride + i], ny = pts[4 * stride + i], nz = pts[5 * stride + i];
+        const rh_prep &P = Q.P;
+        float a32, b32;
+        double a64, b64;
+        if (Q.kind == RH_PLANE) {
+            cls_plane_ab(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32);
+            const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
+            const double d = (P.f[6] * (x - P.f[0]) + P.f[7] * (y - P.f[1])) + P.f[8] * (z - P.f[2]);
+            a64 = (dn - Q.cNhi) / Q.wN;
+            b64 = (Q.eDlo - fabs(d)) / Q.wD;
+            ea = fabs((double)a32 - a64);
+            eb = fabs((double)b32 - b64);
+            counted = true;
+        } else if (Q.kind == RH_SPHERE || Q.kind == RH_CYLINDER) {
+            double qx, qy, qz, R, sgn;
+            if (Q.kind == RH_SPHERE) {
+                cls_round_ab<RH_SPHERE>(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32);
+                qx = x - P.f[0]; qy = y - P.f[1]; qz = z - P.f[2]; R = P.f[3]; sgn = P.f[4];
+            } else {
+                cls_round_ab<RH_CYLINDER>(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32);
+                const double tx = x - P.f[3], ty = y - P.f[4], tz = z - P.f[5];
+                const double sd = (P.f[0] * tx + P.f[1] * ty) + P.f[2] * tz;
+                qx = (x - P.f[0] * sd) - P.f[3]; qy = (y - P.f[1] * sd) - P.f[4]; qz = (z - P.f[2] * sd) - P.f[5];
+                R = P.f[6]; sgn = P.f[7];
+            }
+            const double nr = sqrt((qx * qx + qy * qy) + qz * qz);
+            const double inv = 1.0 / nr;
+            const double dt = ((inv * qx) * nx + (inv * qy) * ny) + (inv * qz) * nz;
+            a64 = (Q.eDlo - fabs(nr - R)) / Q.wD;
+            b64 = (sgn * dt - Q.cNhi) / Q.wN;
+            ea = fabs((double)a32 - a64);
+            if (a64 > -1.5) eb = fabs((double)b32 - b64);
+            counted = true;
+        }
+        if (!(ea == ea)) ea = 1e30;   // a NaN on one side only is a failure
+        if (!(eb == eb)) eb = 1e30;
+    }
+    // block maximum, then one atomic per block (non-negative doubles order like their bit patterns)
+    __shared__ unsigned long long sa[4], sb[4];
+    __shared__ int sc[4];
+    unsigned long long ua = __builtin_bit_cast(unsigned long long, ea), ub = __builtin_bit_cast(unsigned long long, eb);
+    int cnt = counted ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long va = __shfl_down(ua, off), vb = __shfl_down(ub, off);
+        ua = va > ua ? va : ua;
+        ub = vb > ub ? vb : ub;
+        cnt += __shfl_down(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = ua; sb[threadIdx.x >> 6] = ub; sc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0 && Q.kind >= 0 && Q.kind < 3) {
+        unsigned long long ma = 0, mb = 0;
+        int n = 0;
+        for (int w = 0; w < 4; w++) { ma = sa[w] > ma ? sa[w] : ma; mb = sb[w] > mb ? sb[w] : mb; n += sc[w]; }
+        atomicMax(&out[Q.kind * 2], ma);
+        atomicMax(&out[Q.kind * 2 + 1], mb);
+        atomicAdd(&out[8 + Q.kind], (unsigned long long)n);
+    }
 }
 
 // binary32 boxes of the groups from the binary64 ones (7 planes of gstride doubles): 8 floats per group
@@ -379,10 +462,9 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     const int64_t ntiles = (c->ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
     if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
-    static int dbg = -1, env_swz = -1, env_rows = -1;
+    static int dbg = -1, env_swz = -1;
     if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
     if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
-    if (env_rows < 0) { const char *e = getenv("RH_S4_ROWS"); env_rows = e ? atoi(e) : 0; }
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
         A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
@@ -390,11 +472,56 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.bstride = bstride;
     A.ngroups = c->ngroups;
     A.gb32 = c->gb32;
-    int64_t rows = (nchunks + S4_R - 1) / S4_R;
+    static int env_r = -1;
+    if (env_r < 0) { const char *e = getenv("RH_S4_R"); env_r = e ? atoi(e) : 0; }
+    const int R = env_r == 4 || env_r == 8 ? env_r : (ntiles * ((nchunks + 7) / 8) < 3000 ? 4 : 8);
+    int64_t rows = (nchunks + R - 1) / R;
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-    hipLaunchKernelGGL((score4_kernel<8>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+    if (R == 4) hipLaunchKernelGGL((score4_kernel<4>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+    else hipLaunchKernelGGL((score4_kernel<8>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
     RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// diagnostics (tests): the classifier's worst binary32 error on a batch, in units of its margin widths (see
+// cls_audit_kernel); out[12]: per kind (plane, sphere, cylinder, -) the two maxima, then the numbers of pairs
+extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, double *out)
+{
+    if (c == nullptr || out == nullptr || p == nullptr || b < 0 || (b > 0 && shapes == nullptr)) { rh_set_error("rh_dbg_cls_audit: bad arguments"); return RH_E_INVALID; }
+    for (int i = 0; i < 12; i++) out[i] = 0.0;
+    if (b == 0 || c->s == 0) return RH_OK;
+    RH_HIP(hipSetDevice(c->device));
+    std::vector<S4AuditCand> h((size_t)b);
+    for (int32_t i = 0; i < b; i++) {
+        S4AuditCand &Q = h[(size_t)i];
+        Q.kind = shapes[i].kind;
+        Q.usable = 0;
+        if (Q.kind < 0 || Q.kind > 3) continue;
+        rh_prep_host(shapes[i], &Q.P);
+        double d4[4] = { 0, 0, 0, 0 };
+        cls_make(Q.P, Q.kind, p->eps[Q.kind], p->cos_alpha[Q.kind], c->coord_mag, c->nrm_mag, Q.C, nullptr, 0, d4);
+        Q.cNhi = d4[0]; Q.wN = d4[1]; Q.eDlo = d4[2]; Q.wD = d4[3];
+        Q.usable = Q.kind != RH_CONE && !(Q.C.f[RH_CLS_FLAG] != Q.C.f[RH_CLS_FLAG]) && Q.wN > 0 && Q.wD > 0;
+    }
+    S4AuditCand *d_c = nullptr;
+    unsigned long long *d_o = nullptr;
+    RH_HIP(hipMalloc((void **)&d_c, sizeof(S4AuditCand) * (size_t)b));
+    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 12));
+    RH_HIP(hipMemcpyAsync(d_c, h.data(), sizeof(S4AuditCand) * (size_t)b, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 12, c->stream));
+    for (int32_t c0 = 0; c0 < b; c0 += 32768) {
+        const int32_t nb = std::min<int32_t>(32768, b - c0);
+        hipLaunchKernelGGL(cls_audit_kernel, dim3((unsigned)cdiv4(c->s, 256), (unsigned)nb), dim3(256), 0, c->stream, c->sub, c->s_pad,
+                           c->s, d_c + c0, nb, d_o);
+    }
+    unsigned long long ho[12];
+    RH_HIP(hipMemcpyAsync(ho, d_o, sizeof ho, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_c);
+    (void)hipFree(d_o);
+    for (int i = 0; i < 8; i++) out[i] = __builtin_bit_cast(double, ho[i]);
+    for (int i = 8; i < 12; i++) out[i] = (double)ho[i];
     return RH_OK;
 }

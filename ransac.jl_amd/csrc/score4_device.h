@@ -16,7 +16,7 @@
 //
 // Margins.  u = 2^-24.  Inputs are converted to binary32 (relative error u each), every binary32 operation adds (1 + d),
 // |d| <= u.  With M = max |coordinate| of the point set, Nm = max |normal component|, T = M + max |centre coordinate|:
-//   plane     dn = n . np                 |dn32 - dn| <= 5.05 u |n|_1 Nm
+//   plane     dn = n . np - c             |.32 - .|   <= u (5.05 |n|_1 Nm + 4.1 |c|)      (c = cos alpha, added first)
 //             d  = oz . p - oz . P0       |d32 - d|   <= 6.1 u (|oz|_1 M + |oz . P0|)
 //   sphere    dx = p - o (per component e = 2.01 u T);  nr = |dx|:  |nr32 - nr| <= sqrt(3) e + 4 u nr
 //             L = sgn dx . np - c nr  (c = cos alpha; the test is L > 0):
@@ -26,7 +26,8 @@
 //   cone      closed form rho^2 = |t|^2 - (t . a^)^2 against (k h -+ e)^2 (prefilter only: survivors take the exact test)
 // Every margin is the first-order bound x RH_CLS_SAFETY (4) plus the conversion error of the threshold itself; the
 // binary64 side's own rounding (~1e-15 relative) disappears in that factor.  rh_dbg_cls_audit (score4.hip) evaluates
-// max |q32 - q64| / m over real batches with these very functions: tests require it to stay below 0.5.
+// max |q32 - q64| / (width of the ambiguity band, >= 2 m) over real batches with these very functions: sound below 1/2,
+// by construction below 1/8; tests/test_parity_gpu.py and tools/cls_audit.py hold it below 0.25.
 //
 // The plane record is SCALED: with wN, wD = powers of two >= 2 x margin, the kernel computes a = (dn - cN_hi) / wN and
 // b = (eD_lo - |d|) / wD directly (the scaling is folded into the coefficients, exactly), so that with t = min(a, b)
@@ -97,8 +98,9 @@ __host__ __device__ inline double cls_slack64(const rh_prep &P, double M) { retu
 // P: the binary64 record of the candidate (rh_prep, kernels.hip prep_one, with prep_derived); eps, cosa: the kind's
 // thresholds; M, Nm: max |coordinate| / max |normal component| of the point set.  o: classifier record; box: the culling
 // record's fields go to box[f * bstride] (f < RH_BOX_FIELDS).
+// dbg4 (audit): the unscaled thresholds and widths behind a scaled record: cN_hi, wN, eD_lo, wD
 __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps, double cosa, double M, double Nm, rh_cls &o,
-                                         float *box, int64_t bstride)
+                                         float *box, int64_t bstride, double *dbg4 = nullptr)
 {
     const double u = RH_CLS_U, S = RH_CLS_SAFETY;
     const float fnan = __builtin_nanf("");
@@ -114,8 +116,10 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         const double n1 = (fabs(P.f[3]) + fabs(P.f[4])) + fabs(P.f[5]);
         const double z1 = (fabs(P.f[6]) + fabs(P.f[7])) + fabs(P.f[8]);
         const double zp = (P.f[6] * P.f[0] + P.f[7] * P.f[1]) + P.f[8] * P.f[2];
-        const double mN = S * 5.05 * u * (n1 * Nm) + 4.0 * u * fabs(cosa) + 1e-30;
-        const double mD = S * 6.1 * u * (z1 * M + fabs(zp)) + 4.0 * u * fabs(eps) + 1e-30;
+        // (the threshold is the first addend of the fused chain: every partial sum is as large as it is, hence the
+        // 4.1 |cos alpha| and 4 |eps| beside the products' own 5.05 / 6.1)
+        const double mN = S * u * (5.05 * (n1 * Nm) + 4.1 * (fabs(cosa) + 1e-3)) + 1e-30;
+        const double mD = S * u * (6.1 * (z1 * M + fabs(zp)) + 4.0 * fabs(eps)) + 1e-30;
         ok = ok && cls_fin(mN) && cls_fin(mD) && cls_fin(zp) && mN < 1e30 && mD < 1e30;
         if (ok) {
             const double wN = cls_pow2ceil(2.0 * mN), wD = cls_pow2ceil(2.0 * mD);
@@ -127,6 +131,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             o.f[4] = (float)(P.f[6] * iD); o.f[5] = (float)(P.f[7] * iD); o.f[6] = (float)(P.f[8] * iD);
             o.f[7] = (float)(-zp * iD);
             o.f[8] = (float)(eDlo * iD);
+            if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             for (int i = 0; i < 9; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
         if (fin && cls_fin(zp) && cls_fin(eps) && cls_fin(M)) {
@@ -157,7 +162,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             lipk = fmax(1.0, fabs(P.f[9] - 1.0));   // |1 - |a|^2| = |k - 1| (prep_derived)
         }
         const double s3 = 1.7320508075688774;
-        const double mD = S * (s3 * e + 4.0 * u * (fabs(R) + fabs(eps))) + u * (fabs(R) + fabs(eps)) + 1e-30;
+        const double mD = S * (s3 * e + 5.0 * u * (fabs(R) + fabs(eps))) + 1e-30;
         // a point the distance half may accept (|nr32 - R| < eps + wD / 2, wD < 4 mD) lies at least this far from the
         // centre / axis
         const double nrmin = R - eps - 3.0 * mD;
@@ -179,6 +184,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
             const double iN = cls_pow2recip(wN), iD = cls_pow2recip(wD);
             const float s0 = (float)iD, s1 = (float)(eDlo * iD), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN);
+            if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             if (sph) { o.f[4] = s0; o.f[5] = s1; o.f[6] = s2; o.f[7] = s3f; }
             else { o.f[7] = s0; o.f[8] = s1; o.f[9] = s2; o.f[10] = s3f; }
             ok = ok && fabs((double)s0) < 1e30 && fabs((double)s1) < 1e30 && fabs((double)s2) < 1e30 && fabs((double)s3f) < 1e30;
@@ -304,16 +310,22 @@ static __device__ __forceinline__ bool box_skip32(const float (&B)[RH_BOX_FIELDS
 }
 
 // ---- plane: t = min(a, b) of the scaled record: sure <=> t > 0, maybe <=> t > -1
+static __device__ __forceinline__ void cls_plane_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &b)
+{
+    a = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
+    const float d = __builtin_fmaf(C.f[6], z, __builtin_fmaf(C.f[5], y, __builtin_fmaf(C.f[4], x, C.f[7])));
+    b = C.f[8] - __builtin_fabsf(d);
+}
 static __device__ __forceinline__ float cls_plane_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
-    const float a = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
-    const float d = __builtin_fmaf(C.f[6], z, __builtin_fmaf(C.f[5], y, __builtin_fmaf(C.f[4], x, C.f[7])));
-    return fminf(a, C.f[8] - __builtin_fabsf(d));
+    float a, b;
+    cls_plane_ab(C, x, y, z, nx, ny, nz, a, b);
+    return fminf(a, b);
 }
 
 // ---- sphere / cylinder: the same t = min(a, b) from the scaled record (sure <=> t > 0, maybe <=> t > -1)
 template <int KIND>
-static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+static __device__ __forceinline__ void cls_round_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &bb)
 {
     float qx, qy, qz;
     constexpr int b = KIND == RH_SPHERE ? 3 : 6;
@@ -328,27 +340,15 @@ static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, fl
     const float inr = __builtin_amdgcn_rsqf(n2);
     const float nr = n2 * inr;
     const float dt = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx)) * inr;
-    const float a = __builtin_fmaf(-__builtin_fabsf(nr - C.f[b]), C.f[b + 1], C.f[b + 2]);
-    const float bb = __builtin_fmaf(dt, C.f[b + 3], C.f[b + 4]);
-    return fminf(a, bb);
+    a = __builtin_fmaf(-__builtin_fabsf(nr - C.f[b]), C.f[b + 1], C.f[b + 2]);
+    bb = __builtin_fmaf(dt, C.f[b + 3], C.f[b + 4]);
 }
-// the compared quantities themselves (audit): |nr - R| and sgn (q . np) / nr
 template <int KIND>
-static __device__ __forceinline__ void cls_round_q(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &xd, float &yn)
+static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
-    float qx, qy, qz;
-    constexpr int b = KIND == RH_SPHERE ? 3 : 6;
-    if (KIND == RH_SPHERE) {
-        qx = x - C.f[0]; qy = y - C.f[1]; qz = z - C.f[2];
-    } else {
-        const float tx = x - C.f[3], ty = y - C.f[4], tz = z - C.f[5];
-        const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
-        qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
-    }
-    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
-    const float inr = __builtin_amdgcn_rsqf(n2);
-    xd = __builtin_fabsf(n2 * inr - C.f[b]);
-    yn = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx)) * inr * (C.f[b + 3] < 0.0f ? -1.0f : 1.0f);
+    float a, b;
+    cls_round_ab<KIND>(C, x, y, z, nx, ny, nz, a, b);
+    return fminf(a, b);
 }
 
 // ---- cone: band prefilter -- may this point pass the distance half?  NaN -> false.

@@ -88,6 +88,28 @@ def test_score_counts_and_masks_all_kinds(small_scene):
     assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
 
 
+def test_binary32_classifier_stays_inside_its_margins(small_scene):
+    """The batched score decides most pairs in binary32 and sends only those within a rounding margin of a
+    threshold to the binary64 test (csrc/score4_device.h).  The audit evaluates every (candidate, point) pair of
+    the batch with the kernel's own binary32 functions against the reference's binary64 arithmetic: the error has
+    to stay below 1/2 of the ambiguity band's width for the classification to be sound; the margins are built
+    with a safety factor of 4, so it stays below ~1/8."""
+    pc, oc, truth = small_scene
+    rng = np.random.default_rng(3)
+    for eps, alpha_deg in [(0.3, 5.0), (0.01, 1.0), (5.0, 60.0)]:
+        params = R.ransacparameters()
+        for k in ("plane", "sphere", "cylinder", "cone"):
+            params[k]["ϵ"] = eps
+            params[k]["α"] = math.radians(alpha_deg)
+        cp = R.params_to_c(params)
+        cands = make_candidates(truth, 96, seed=int(rng.integers(0, 1000)))
+        arr = shape_array(cands)
+        out = np.zeros(12)
+        L.check(R.lib().rh_dbg_cls_audit(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_double))))
+        assert out[8:11].min() > 1e5, out          # planes, spheres and cylinders were all looked at
+        assert out[:6].max() < 0.25, out           # sound below 0.5
+
+
 @pytest.mark.parametrize("eps,alpha_deg,seed", [(0.3, 5.0, 0), (0.01, 1.0, 1), (5.0, 60.0, 2), (40.0, 89.0, 3)])
 def test_score_fuzz_arbitrary_candidates(small_scene, eps, alpha_deg, seed):
     """Candidates nowhere near a primitive, degenerate, non-unit, huge, tiny, NaN / inf: the box culling

@@ -13,9 +13,11 @@ wl = os.environ.get("WL", "cfg3")
 prim = ["plane"] * 16 + ["sphere"] * 12 + ["cylinder"] * 12
 types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
 n, seed, scanner = 10_000_000, 3, None
+if wl == "cfg2":
+    prim = ["plane", "plane", "sphere", "sphere", "cylinder", "cylinder"]; n, seed = 1_000_000, 2
 if wl == "cfg5":
     prim += ["cone"] * 8; types += [R.FittedCone]; n, seed, scanner = 50_000_000, 5, [synth.BOX / 2] * 3
-xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=seed, scanner=scanner)
+xyz, nrm, truth = synth.make_cloud(n, prim, 0.0 if wl == "cfg2" else 0.30, seed=seed, scanner=scanner)
 subs = synth.make_subsets(n, 32, seed=seed)
 f32 = bool(os.environ.get("F32"))   # a Float32 cloud (binary32 exact tests; shapes rounded to binary32)
 pc = R.RANSACCloud(xyz.astype(np.float32), nrm.astype(np.float32), subs, force_eltype=np.float32) if f32 else R.RANSACCloud(xyz, nrm, subs)
