@@ -140,8 +140,18 @@ def self_launch(args):
     import subprocess
     import tempfile
     if not os.environ.get("RH_BENCH_SHARE_GPU0"):
-        import torch   # device_count() reads the driver's device list without initialising HIP in this process
-        have = torch.cuda.device_count()
+        # count the GPUs from the kernel driver's topology (sysfs): no torch, no HIP, no HSA in this process -- the
+        # launcher must never hold the devices its ranks are about to open.  (Every rank checks its own device again.)
+        have = 0
+        topo = "/sys/class/kfd/kfd/topology/nodes"
+        try:
+            for node in os.listdir(topo):
+                with open(os.path.join(topo, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    have += 1
+        except OSError:
+            have = 0   # no kfd driver in this system: no GPU
         if have < args.gpus:
             raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); one rank per GPU, no fallback to fewer ranks "
                              "(RH_BENCH_SHARE_GPU0=1 RH_BENCH_BACKEND=gloo rehearses the N > 1 flow on one GPU)"

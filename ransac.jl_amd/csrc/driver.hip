@@ -75,7 +75,11 @@ struct rh_mp {
 namespace {
 
 constexpr uint64_t RH_MP_MAGIC = 0x52484d5032303236ULL;   // "RHMP2026"
-constexpr size_t RH_MP_HDR = 4096;                        // magic, world, then one 64-byte line per (rank, parity) flag
+constexpr int RH_MP_MAX_WORLD = 64;
+// magic, world, then from byte 256 on one 64-byte line per (rank, parity) flag -- for the largest group rh_mp_open accepts
+// (with a 4096-byte header the flags of ranks >= 30 lay inside rank 0's first slot)
+constexpr size_t RH_MP_HDR = (256 + 64 * 2 * (size_t)RH_MP_MAX_WORLD + 4095) / 4096 * 4096;
+static_assert(256 + 64 * 2 * (size_t)RH_MP_MAX_WORLD <= RH_MP_HDR, "the flags must not reach into the slots");
 
 inline volatile uint64_t *mp_flag(rh_mp *m, int rank, int parity) { return (volatile uint64_t *)(m->base + 256 + 64 * (size_t)(rank * 2 + parity)); }
 inline char *mp_slot(rh_mp *m, int rank, int parity) { return m->base + RH_MP_HDR + (size_t)(rank * 2 + parity) * (size_t)m->slot_bytes; }
@@ -111,11 +115,42 @@ int mp_exchange(rh_mp *m, const void *payload, int64_t bytes, int *parity_out)
     return RH_OK;
 }
 
+// the same for payloads of any size (and different sizes per rank): the payload travels in pieces of the slot size;
+// every piece carries the rank's total, so after the first round all ranks agree on the number of rounds.
+// recv[r] = rank r's payload.
+int mp_exchange_any(rh_mp *m, const void *payload, int64_t bytes, std::vector<std::vector<char>> &recv)
+{
+    const int64_t cap = m->slot_bytes - 16;
+    recv.assign((size_t)m->world, std::vector<char>());
+    std::vector<char> piece((size_t)m->slot_bytes);
+    int64_t rounds = 1;
+    for (int64_t r = 0; r < rounds; r++) {
+        const int64_t off = std::min(bytes, r * cap), len = std::min(cap, bytes - off);
+        memcpy(piece.data(), &bytes, 8);
+        memcpy(piece.data() + 8, &len, 8);
+        if (len > 0) memcpy(piece.data() + 16, (const char *)payload + off, (size_t)len);
+        int par = 0;
+        RH_TRY(mp_exchange(m, piece.data(), 16 + len, &par));
+        for (int k = 0; k < m->world; k++) {
+            int64_t tot = 0, ln = 0;
+            memcpy(&tot, mp_slot(m, k, par), 8);
+            memcpy(&ln, mp_slot(m, k, par) + 8, 8);
+            if (tot < 0 || ln < 0 || ln > cap) { rh_set_error("rh_ransac_mp: corrupt exchange header from rank %d", k); return RH_E_INTERNAL; }
+            if (r == 0) {
+                recv[(size_t)k].reserve((size_t)tot);
+                rounds = std::max(rounds, (tot + cap - 1) / cap);
+            }
+            recv[(size_t)k].insert(recv[(size_t)k].end(), mp_slot(m, k, par) + 16, mp_slot(m, k, par) + 16 + ln);
+        }
+    }
+    return RH_OK;
+}
+
 }  // namespace
 
 extern "C" int rh_mp_open(const char *name, int32_t rank, int32_t world, int64_t slot_bytes, rh_mp **out)
 {
-    if (!name || !out || world < 1 || rank < 0 || rank >= world || world > 64 || strlen(name) >= 120) {
+    if (!name || !out || world < 1 || rank < 0 || rank >= world || world > RH_MP_MAX_WORLD || strlen(name) >= 120) {
         rh_set_error("rh_mp_open: bad arguments");
         return RH_E_INVALID;
     }
@@ -180,9 +215,12 @@ extern "C" int rh_mp_open(const char *name, int32_t rank, int32_t world, int64_t
 extern "C" int rh_mp_allgather(rh_mp *m, const void *payload, int64_t bytes, void *out)
 {
     if (!m || bytes < 0 || (bytes > 0 && (!payload || !out))) { rh_set_error("rh_mp_allgather: bad arguments"); return RH_E_INVALID; }
-    int par = 0;
-    RH_TRY(mp_exchange(m, payload, bytes, &par));
-    for (int r = 0; r < m->world; r++) memcpy((char *)out + (size_t)r * (size_t)bytes, mp_slot(m, r, par), (size_t)bytes);
+    std::vector<std::vector<char>> recv;   // (payloads beyond the slot size travel in pieces)
+    RH_TRY(mp_exchange_any(m, payload, bytes, recv));
+    for (int r = 0; r < m->world; r++) {
+        if ((int64_t)recv[(size_t)r].size() != bytes) { rh_set_error("rh_mp_allgather: rank %d sent %lld bytes, expected %lld", r, (long long)recv[(size_t)r].size(), (long long)bytes); return RH_E_INVALID; }
+        if (bytes > 0) memcpy((char *)out + (size_t)r * (size_t)bytes, recv[(size_t)r].data(), (size_t)bytes);
+    }
     return RH_OK;
 }
 
@@ -488,6 +526,7 @@ struct Driver {
 
     rh_mp *mp = nullptr;                    // rh_ransac_mp: the processes sharing this scene (null: one process)
     std::vector<char> mp_buf;
+    std::vector<std::vector<char>> mp_recv;
     std::vector<unsigned long long> mp_draws;
 
     Window win[2];
@@ -1155,13 +1194,14 @@ struct Driver {
                     memcpy(q, entries.data(), sizeof(rh_cand_entry) * (size_t)cnt); q += sizeof(rh_cand_entry) * (size_t)cnt;
                     memcpy(q, wcounts.data(), sizeof(int32_t) * (size_t)cnt);
                 }
-                int par = 0;
-                RUN(mp_exchange(mp, mp_buf.data(), (int64_t)bytes, &par));
+                // (a list longer than the exchange slot travels in pieces: mp_exchange_any)
+                RUN(mp_exchange_any(mp, mp_buf.data(), (int64_t)bytes, mp_recv));
                 bool any_overflow = false, any_gave_up = false;
                 int64_t total = 0;
                 for (int r = 0; r < mp->world; r++) {
                     Hdr hr;
-                    memcpy(&hr, mp_slot(mp, r, par), sizeof hr);
+                    if (mp_recv[(size_t)r].size() < sizeof hr) { rh_set_error("rh_ransac_mp: short exchange from rank %d", r); return RH_E_INTERNAL; }
+                    memcpy(&hr, mp_recv[(size_t)r].data(), sizeof hr);
                     if (hr.W != W || hr.scored != h.scored) { rh_set_error("rh_ransac_mp: rank %d is at another window (W %d vs %d)", r, hr.W, W); return RH_E_INTERNAL; }
                     any_overflow |= hr.overflow != 0;
                     any_gave_up |= hr.gave_up != 0;
@@ -1189,9 +1229,13 @@ struct Driver {
                 wcounts.resize((size_t)total);
                 size_t at = 0;
                 for (int r = 0; r < mp->world; r++) {
-                    const char *src = mp_slot(mp, r, par);
+                    const char *src = mp_recv[(size_t)r].data();
                     Hdr hr;
                     memcpy(&hr, src, sizeof hr); src += sizeof hr;
+                    if (mp_recv[(size_t)r].size() != sizeof hr + sizeof(unsigned long long) * (size_t)W + (sizeof(rh_cand_entry) + sizeof(int32_t)) * (size_t)hr.cnt) {
+                        rh_set_error("rh_ransac_mp: exchange from rank %d has the wrong length", r);
+                        return RH_E_INTERNAL;
+                    }
                     for (int32_t i = 0; i < W; i++) { unsigned long long d; memcpy(&d, src + 8 * (size_t)i, 8); mp_draws[(size_t)i] += d; }
                     src += sizeof(unsigned long long) * (size_t)W;
                     if (hr.cnt > 0) {
@@ -1289,6 +1333,10 @@ extern "C" int rh_ransac_mp(rh_cloud *c, const double *xyz, const double *nrm, c
     if (!mp) { rh_set_error("rh_ransac_mp: mp is NULL"); return RH_E_INVALID; }
     if (!c || !p) { rh_set_error("rh_ransac_mp: NULL argument"); return RH_E_INVALID; }
     if (!p->sampling_streams) { rh_set_error("rh_ransac_mp needs sampling_streams = 1 (one random stream per minimal set)"); return RH_E_INVALID; }
+    if (p->minsubsetN < mp->world) {   // (a rank without a single minimal set per iteration would have nothing to launch)
+        rh_set_error("rh_ransac_mp: minsubsetN = %d is below the number of ranks (%d)", p->minsubsetN, mp->world);
+        return RH_E_INVALID;
+    }
     c->mp_rank = mp->rank;
     c->mp_world = mp->world;
     const int rc = ransac_impl(c, xyz, nrm, p, rng, mp->world > 1 ? mp : nullptr, out);
