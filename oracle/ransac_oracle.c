@@ -367,6 +367,14 @@ orc_ci orc_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int s
     return orc_notsoconfident(-1 - gmin, -1 - gmax);
 }
 
+/* Decision trace (tests/golden/make_rounding_sensitivity.py): every evaluation of the extraction test
+ * `prob(E(best), s, N, drawN) > prob_det` (iterations.jl:114-123) of a run, four doubles each:
+ * iteration, best score E, s, ppp.  Off unless a buffer is set. */
+static double *g_trace_buf = NULL;
+static int64_t g_trace_cap = 0, g_trace_n = 0;
+void orc_trace_set(double *buf, int64_t cap_records) { g_trace_buf = buf; g_trace_cap = cap_records; g_trace_n = 0; }
+int64_t orc_trace_count(void) { return g_trace_n; }
+
 /* prob(n, s, N, k) = 1-(1-(n/N)^k)^s: utilities.jl:262.  Float64^Int is libm pow
  * in Julia <= 1.7 (llvm.pow); later versions differ in the last ulp [recalled]. */
 double orc_prob(double n, int64_t s, int64_t N, int64_t k)
@@ -1603,6 +1611,13 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
             double scr = st.scores[ind].E;
             int64_t sN = countcandidates[p->extract_s];
             double ppp = orc_prob(scr, sN, c->n, p->drawN);
+            if (g_trace_buf != NULL) {
+                if (g_trace_n < g_trace_cap) {
+                    double *q = g_trace_buf + 4 * g_trace_n;
+                    q[0] = (double)k; q[1] = scr; q[2] = (double)sN; q[3] = ppp;
+                }
+                g_trace_n++;
+            }
             if (ppp > p->prob_det) {
                 orc_shape bestshape = st.shapes[ind];
                 int64_t ne = orc_refit(c, &bestshape, p, refit_idx, c->n);

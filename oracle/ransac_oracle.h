@@ -104,6 +104,8 @@ int orc_confidence_interval(double x, double y, orc_ci *out); /* -1 = "out of or
 orc_ci orc_notsoconfident(double x, double y);
 int orc_isoverlap(orc_ci a, orc_ci b);
 orc_ci orc_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int score_mode);
+void orc_trace_set(double *buf, int64_t cap_records);   /* decision trace of orc_ransac: (iteration, E(best), s, ppp) per evaluated extraction test */
+int64_t orc_trace_count(void);
 double orc_prob(double n, int64_t s, int64_t N, int64_t k);
 
 /* ---- cloud ---- */
