@@ -117,6 +117,32 @@ int rh_ensure_masks(rh_cloud *c, int64_t words)
     return RH_OK;
 }
 
+// v4 score kernel with masks: internal-order rows of mstride4 words (only the non-zero ones get written) and one
+// occupancy byte per word, zero between batches
+static int ensure_masks4(rh_cloud *c, int64_t b)
+{
+    c->mstride4 = (c->ngroups + 7) / 8 * 8;
+    const int64_t words = b * c->mstride4;
+    if (words > c->masks_int_cap) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_masks_int);
+        c->d_masks_int = nullptr;
+        c->masks_int_cap = 0;
+        RH_TRY(dev_alloc(&c->d_masks_int, words));
+        c->masks_int_cap = words;
+    }
+    if (words > c->occ_cap) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_occ);
+        c->d_occ = nullptr;
+        c->occ_cap = 0;
+        RH_TRY(dev_alloc(&c->d_occ, words));
+        RH_HIP(hipMemsetAsync(c->d_occ, 0, (size_t)words, c->stream));
+        c->occ_cap = words;
+    }
+    return RH_OK;
+}
+
 static int ensure_masks_int(rh_cloud *c, int64_t words)
 {
     if (words <= c->masks_int_cap) return RH_OK;
@@ -152,7 +178,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
-    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_surv);
+    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_surv); (void)hipFree(c->d_occ);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
     (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
@@ -683,7 +709,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     const size_t rec_bytes = sizeof(rh_prep) >= sizeof(rh_shape) ? sizeof(rh_prep) : sizeof(rh_shape);
     const size_t o_orig = (size_t)b * rec_bytes, o_nk = (o_orig + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
     // (staged, counts only, v4 kernel: the classifier records -- host twin of the prep kernels' cls_make -- ride along)
-    const bool staged_cls = staged && !masks_out && rh_score_v4_enabled(c);
+    const bool staged_cls = staged && rh_score_v4_enabled(c);
     const size_t o_counts = o_nk + 64, o_cls = (o_counts + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
     const size_t o_box = o_cls + (size_t)b * 64;   // culling records: RH_BOX_FIELDS arrays of b floats
     const size_t stage_bytes = staged_cls ? o_box + (size_t)rh4::RH_BOX_FIELDS * b * sizeof(float) : o_counts + (size_t)b * sizeof(int32_t);
@@ -733,22 +759,30 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_nk, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         c->qpre_valid = false;
-        RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts, p->eps, masks_out ? nullptr : p->cos_alpha));   // zeroes d_counts as well
+        RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts, p->eps, p->cos_alpha));   // zeroes d_counts as well
         if (c->qpre_v4) { d_cls_use = c->d_qpre; d_box_use = c->d_box; bstride_use = 4 * c->batch_cap; }
     }
     uint64_t *d_masks = nullptr, *d_masks_int = nullptr;
+    c->masks4 = false;
     if (masks_out && c->swords > 0) {
         RH_TRY(rh_ensure_masks(c, (int64_t)b * c->swords));
-        RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
         d_masks = c->d_masks;
+        if (d_cls_use != nullptr) {   // the v4 kernel leaves sparse words + occupancy bytes: nothing to zero
+            RH_TRY(ensure_masks4(c, b));
+            c->masks4 = true;
+        } else {
+            RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
+            RH_HIP(hipMemsetAsync(c->d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+        }
         d_masks_int = c->d_masks_int;
-        RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     const int64_t off64[4] = { off[0], off[1], off[2], off[3] };
     c->f32_shapes = c->d_shapes;   // sorted like the bins
     c->f32_via_orig = 0;
     RH_TRY(score_bins_subset(c, p, d_prep_use, d_orig_use, off64, d_nk_use, nk, b, d_counts_use, d_masks_int, nullptr, d_cls_use, d_box_use, bstride_use));
-    if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
+    if (d_masks_int && c->masks4) RH_TRY(rhk_unpermute_masks4(c, d_masks_int, c->d_occ, c->mstride4, b, d_masks));
+    else if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
+    c->masks4 = false;
     RH_HIP(hipMemcpyAsync(h_counts, d_counts_use, sizeof(int32_t) * (size_t)b, hipMemcpyDeviceToHost, c->stream));
     if (d_masks)
         RH_HIP(hipMemcpyAsync(masks_out, d_masks, sizeof(uint64_t) * (size_t)b * (size_t)c->swords,
@@ -776,16 +810,22 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     int32_t *nk_cur = c->d_nk2 + 4 * c->nk2_flip, *nk_next = c->d_nk2 + 4 * (1 - c->nk2_flip);
     c->nk2_flip = 1 - c->nk2_flip;
     RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps,
-                           d_masks ? nullptr : p->cos_alpha));
+                           (d_masks && ms_kind) ? nullptr : p->cos_alpha));   // (the per-kind timing leg keeps the older kernels)
     uint64_t *d_masks_int = nullptr;
+    c->masks4 = false;
     if (d_masks && c->swords > 0) {
-        RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
+        if (c->qpre_v4 && !ms_kind) {   // the v4 kernel leaves sparse words + occupancy bytes: nothing to zero
+            RH_TRY(ensure_masks4(c, b));
+            c->masks4 = true;
+        } else {
+            RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
+            RH_HIP(hipMemsetAsync(c->d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+        }
         d_masks_int = c->d_masks_int;
-        RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     const int64_t off[4] = { 0, c->batch_cap, 2 * (int64_t)c->batch_cap, 3 * (int64_t)c->batch_cap };
     const int32_t bound[4] = { b, b, b, b };
-    const void *d_cls = c->qpre_v4 && !d_masks_int ? c->d_qpre : nullptr;   // (made by rhk_prep_binned above)
+    const void *d_cls = c->qpre_v4 && (!d_masks_int || c->masks4) ? c->d_qpre : nullptr;   // (made by rhk_prep_binned above)
     c->f32_shapes = d_shapes;      // the caller's order: the float records go through d_orig
     c->f32_via_orig = 1;
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
@@ -799,7 +839,9 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
         if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind, d_cls, c->d_box, 4 * c->batch_cap));
-    if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
+    if (d_masks_int && c->masks4) RH_TRY(rhk_unpermute_masks4(c, d_masks_int, c->d_occ, c->mstride4, b, d_masks));
+    else if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
+    c->masks4 = false;
     if (ms_kind) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[4]));

@@ -1546,8 +1546,9 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     for (int k = 0; k < 4 && qarr; k++)
         qarr = prep[k] == c->d_prep + (int64_t)k * c->batch_cap && c->qpre_eps[k] == eps[k];
     // classifier records of exactly these bins and thresholds from the caller: the v4 kernel (score4.hip)
-    if (cls != nullptr && box != nullptr && d_masks_int == nullptr && prep32 == nullptr && rh_score_v4_enabled(c) && c->gb32 != nullptr)
-        return rhk_score4_all(c, en, prep, (const void *const *)cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts);
+    if (cls != nullptr && box != nullptr && (d_masks_int == nullptr || c->masks4) && prep32 == nullptr && rh_score_v4_enabled(c) && c->gb32 != nullptr)
+        return rhk_score4_all(c, en, prep, (const void *const *)cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts,
+                              d_masks_int, d_masks_int ? c->d_occ : nullptr, c->mstride4);
     if (c->qpre_v4) qarr = false;   // (what lies beside the bins in d_qpre are not band constants)
     G2AllArgs A;
     for (int k = 0; k < 4; k++)

@@ -147,6 +147,10 @@ struct rh_cloud {
     int64_t masks_cap = 0;
     uint64_t *d_masks_int = nullptr;   // masks in internal order (before un-permuting)
     int64_t masks_int_cap = 0;
+    uint8_t *d_occ = nullptr;          // v4 score kernel: one byte per word of d_masks_int that exists (zero between batches)
+    int64_t occ_cap = 0;
+    bool masks4 = false;               // the batch being scored leaves its masks in the v4 form (rows mstride4 apart)
+    int64_t mstride4 = 0;
     int64_t *d_ranks = nullptr;        // select in/out
     int64_t ranks_cap = 0;
 
@@ -208,7 +212,9 @@ int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d
 bool rh_score_v4_enabled(const rh_cloud *c);
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
-                   int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts);   // score4.hip
+                   int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts,
+                   uint64_t *d_masks_int = nullptr, uint8_t *d_occ = nullptr, int64_t mstride = 0);   // masks: sparse words + occupancy bytes
+int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out);   // score4.hip
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates
 int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int64_t s,

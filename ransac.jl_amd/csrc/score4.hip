@@ -52,6 +52,7 @@ struct S4Shared {
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
     uint16_t plist[R * 64 * S4_TG];      // the block's surviving pairs: candidate of the row << 2 | group
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
+    unsigned long long maskb[S4_W][64];  // cone, masks wanted: per-wave inlier words of the batch's pairs
     uint16_t qb[S4_W][128];              // cone: per-wave ring (slot-in-batch << 6 | point-in-group) for the exact test
     int weirdw[S4_TG];                   // per staging wave: an enabled point with a non-finite value
     int npairs, next_batch;
@@ -81,6 +82,11 @@ struct S4AllArgs {
     S4KindArgs k[4];
     int64_t ntiles, bstride, ngroups;
     const float *gb32;      // binary32 boxes of the groups, 8 floats each
+    // masks wanted: word [candidate as the caller numbers it][group] of the inlier masks in INTERNAL (k-d leaf) order --
+    // only non-zero words are written, occ holds one byte per word that says so (zero on entry)
+    uint64_t *masks;
+    uint8_t *occ;
+    int64_t mstride;
 };
 
 template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLANE || KIND == RH_SPHERE ? 5 : (KIND == RH_CYLINDER ? 9 : 10); };
@@ -100,11 +106,12 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
 }
 
 // one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
-template <int KIND, int R>
+template <int KIND, int R, bool MASK>
 static __device__ __forceinline__ void
 score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
-             const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird)
+             const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
+             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0)
 {
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
@@ -113,6 +120,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
     const rh_f32x2 *__restrict__ rowb = &sh.pb[g][0];
     const rh_cls *__restrict__ rec = &cls[ci];
     int total = 0;
+    uint64_t word = 0;   // MASK: the inlier word of the lane's pair
     if (KIND != RH_CONE) {
         constexpr int NF = KIND == RH_PLANE ? 9 : (KIND == RH_SPHERE ? 8 : 11);
         rh_cls C;
@@ -120,17 +128,24 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         for (int f = 0; f < NF; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
         int cs = 0, cm = 0;
+        uint32_t wlo = 0, whi = 0;   // MASK: the pair's inlier word as far as it is sure
 #pragma unroll 8
         for (int j = 0; j < 64; j++) {
             const rh_f32x4 a = rowa[j];
             const rh_f32x2 b = rowb[j];
             const float t = KIND == RH_PLANE ? cls_plane_t(C, a.x, a.y, a.z, a.w, b.x, b.y)
                                              : cls_round_t<KIND == RH_PLANE ? RH_SPHERE : KIND>(C, a.x, a.y, a.z, a.w, b.x, b.y);
-            cs += t > 0.0f ? 1 : 0;
+            if (MASK) {
+                if (j < 32) wlo |= t > 0.0f ? (1u << j) : 0u; else whi |= t > 0.0f ? (1u << (j - 32)) : 0u;
+            } else {
+                cs += t > 0.0f ? 1 : 0;
+            }
             cm += t > -1.0f ? 1 : 0;
         }
+        if (MASK) cs = __popc(wlo) + __popc(whi);
         const bool amb = act && (cs != cm || exact_only);
         total = (act && !amb) ? cs : 0;
+        word = (act && !amb) ? (((uint64_t)whi << 32) | wlo) : 0ULL;
         // pairs the classifier could not decide: the exact test on the whole group, lane = point
         uint64_t redo = WB(amb);
         while (redo != 0) {
@@ -142,7 +157,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const int64_t gi = p0 + g2 * 64 + lane;
             const uint64_t mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
                                                    pts[4 * stride + gi], pts[5 * stride + gi], eps, cosa) & sh.len[g2];
-            if (lane == k) total = __popcll(mres);
+            if (lane == k) { total = __popcll(mres); word = mres; }
         }
     } else {
         rh_cls C;
@@ -164,6 +179,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         uint64_t mask = exact_only ? lg : ((((uint64_t)mhi << 32) | mlo) & lg);
         if (!act) mask = 0;
         sh.cntb[wv][lane] = 0;
+        if (MASK) sh.maskb[wv][lane] = 0ULL;
         int qbh = 0, qbn = 0;   // ring head / fill (wave-uniform)
         // lane = (pair, point) of the ring: the reference's binary64 test; the point comes from global memory
         auto drain_b = [&](int k) {
@@ -176,7 +192,10 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const rh_prep Pv = prep[cbase + (int)(pe >> 2)];
             const uint64_t r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
                                                 pts[4 * stride + gi], pts[5 * stride + gi], eps, cosa);
-            if (on && ((r >> lane) & 1ULL)) atomicAdd(&sh.cntb[wv][slot], 1);
+            if (on && ((r >> lane) & 1ULL)) {
+                atomicAdd(&sh.cntb[wv][slot], 1);
+                if (MASK) atomicOr(&sh.maskb[wv][slot], 1ULL << (e2 & 63u));
+            }
             qbh = (qbh + k) & 127;
             qbn -= k;
         };
@@ -194,6 +213,14 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         if (qbn > 0) drain_b(qbn);
         wave_lds_sync();
         total = sh.cntb[wv][lane];
+        if (MASK) word = sh.maskb[wv][lane];
+    }
+    if (MASK) {
+        if (act && word != 0) {
+            const int64_t row = orig[ci];
+            masks[row * mstride + g0 + g] = word;
+            occ[row * mstride + g0 + g] = 1;
+        }
     }
     // one global atomic per (candidate, tile) with inliers: the pairs of a candidate sit in adjacent lanes
     const int v = run_total(act ? total : 0, act ? ci : -1 - lane, lane);
@@ -203,11 +230,11 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 // one kind segment of the block's row: chunks [lo, hi) of the kind (at most S4_R).  Stage 1: the waves share the
 // chunks out, lane = candidate, box tests, survivors -> the block's pair list.  Stage 2: the waves take batches of 64
 // pairs from the list until it is empty.
-template <int KIND, int R>
+template <int KIND, int R, bool MASK>
 static __device__ __forceinline__ void
 score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
-               int32_t *__restrict__ counts, int dbg)
+               int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride)
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,8 +289,8 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG],
         if (lane == 0) bt = atomicAdd(&sh.next_batch, 1);
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
-        score4_batch<KIND, R>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig, K.eps, K.cosa,
-                           counts, weird);
+        score4_batch<KIND, R, MASK>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
+                                    K.eps, K.cosa, counts, weird, masks, occ, mstride, g0);
     }
 }
 
@@ -300,7 +327,7 @@ static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *_
 // grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
 // the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of R; a block runs the per-kind
 // segment(s) of its row (almost always one) on its tile.
-template <int R>
+template <int R, bool MASK>
 __global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
@@ -338,7 +365,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
-            if (live != 0) score4_segment<K, R>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg); \
+            if (live != 0) score4_segment<K, R, MASK>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -429,6 +456,72 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
     }
 }
 
+// ---- masks in internal (k-d leaf) order -> subset order, from the sparse words the score kernel left.  One block per
+// (candidate row, output segment): the segment of the output row is assembled in LDS -- the block walks the row's
+// occupancy bytes, and every set bit of a word that exists is one LDS atomicOr at its subset position (perm) -- and
+// written out once, coalesced: the output needs neither a memset nor global atomics, and the 160 MB of (mostly empty)
+// internal-order rows are never read or zeroed.  (A first form walked each word's bits in one thread: 64 dependent
+// position loads for a dense word, 0.30 ms per cfg3 batch.)  The occupancy bytes are cleared by a kernel of their own.
+constexpr int S4_UNP_WORDS = 6144;   // words per segment: 48 KB of LDS, three blocks of 512 threads per CU
+
+__global__ void __launch_bounds__(512)
+unpermute4_kernel(const uint64_t *__restrict__ in, const uint8_t *__restrict__ occ, int64_t mstride, int64_t ngroups,
+                  const int32_t *__restrict__ perm, int64_t swords, int64_t seg_words, uint64_t *__restrict__ out)
+{
+    extern __shared__ unsigned long long seg[];
+    __shared__ int nlist;
+    __shared__ int32_t list[2048];       // the row's words that exist (groups), in pieces of 2048
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = blockIdx.x;
+    const int64_t w0 = (int64_t)blockIdx.y * seg_words;
+    const int nw = (int)(swords - w0 < seg_words ? swords - w0 : seg_words);
+    for (int t = threadIdx.x; t < nw; t += 512) seg[t] = 0ULL;
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
+    const int64_t lo = w0 << 6, hi = lo + ((int64_t)nw << 6);
+    const uint8_t *__restrict__ orow = occ + row * mstride;
+    const uint64_t *__restrict__ src = in + row * mstride;
+    const int64_t n8 = (ngroups + 7) >> 3;           // 8 occupancy bytes per load (rows are padded to a multiple of 8 bytes)
+    for (int64_t q0 = 0; q0 < n8; q0 += 2048 / 8) {   // at most 2048 words per piece
+        const int64_t q = q0 + threadIdx.x;
+        if (threadIdx.x < 2048 / 8 && q < n8) {
+            uint64_t o8 = ((const uint64_t *)orow)[q];
+            while (o8 != 0) {
+                const int byte = __builtin_ctzll(o8) >> 3;
+                o8 &= ~(0xFFULL << (byte * 8));
+                list[atomicAdd(&nlist, 1)] = (int32_t)(q * 8 + byte);
+            }
+        }
+        __syncthreads();
+        // a wave per word, a lane per bit: the 64 positions of a group come in one coalesced load; four words in flight
+        const int n = nlist;
+        for (int i0 = wv * 4; i0 < n; i0 += 8 * 4) {
+            int32_t g[4], j[4];
+            uint64_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                g[k] = list[min(i0 + k, n - 1)];
+                m[k] = i0 + k < n ? src[g[k]] : 0ULL;
+                j[k] = perm[((int64_t)g[k] << 6) + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (((m[k] >> lane) & 1ULL) && j[k] >= lo && j[k] < hi) atomicOr(&seg[(j[k] - lo) >> 6], 1ULL << (j[k] & 63));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();
+    }
+    uint64_t *__restrict__ dst = out + row * swords + w0;
+    for (int t = threadIdx.x; t < nw; t += 512) dst[t] = seg[t];
+}
+
+__global__ void clear_occ_kernel(uint64_t *__restrict__ occ8, int64_t n8)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n8 && occ8[i] != 0) occ8[i] = 0;
+}
+
 // binary32 boxes of the groups from the binary64 ones (7 planes of gstride doubles): 8 floats per group
 __global__ void gb32_kernel(const double *__restrict__ gb, int64_t gstride, int64_t ngroups, float *__restrict__ out)
 {
@@ -457,7 +550,8 @@ int rhk_gb32_build(rh_cloud *c)
 // the v4 launch: cls[k] / box[k] = the classifier / culling records of bin prep[k], slot for slot, made for eps / cosa.
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
-                   int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts)
+                   int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
+                   uint8_t *d_occ, int64_t mstride)
 {
     const int64_t ntiles = (c->ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
@@ -472,6 +566,9 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.bstride = bstride;
     A.ngroups = c->ngroups;
     A.gb32 = c->gb32;
+    A.masks = d_masks_int;
+    A.occ = d_occ;
+    A.mstride = mstride;
     static int env_r = -1;
     if (env_r < 0) { const char *e = getenv("RH_S4_R"); env_r = e ? atoi(e) : 0; }
     const int R = env_r == 4 || env_r == 8 ? env_r : (ntiles * ((nchunks + 7) / 8) < 3000 ? 4 : 8);
@@ -479,8 +576,10 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-    if (R == 4) hipLaunchKernelGGL((score4_kernel<4>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-    else hipLaunchKernelGGL((score4_kernel<8>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+#define RH_S4_LAUNCH(RR, MM) hipLaunchKernelGGL((score4_kernel<RR, MM>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
+    if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true); else RH_S4_LAUNCH(8, true); }
+    else { if (R == 4) RH_S4_LAUNCH(4, false); else RH_S4_LAUNCH(8, false); }
+#undef RH_S4_LAUNCH
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -523,5 +622,25 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
     (void)hipFree(d_o);
     for (int i = 0; i < 8; i++) out[i] = __builtin_bit_cast(double, ho[i]);
     for (int i = 8; i < 12; i++) out[i] = (double)ho[i];
+    return RH_OK;
+}
+
+// masks the v4 score kernel left in internal order (sparse words + occupancy bytes, rows mstride apart) -> dense rows in
+// subset order; the occupancy bytes are zero again afterwards
+int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out)
+{
+    if (b == 0 || c->swords == 0) return RH_OK;
+    const int64_t seg_words = std::min<int64_t>(c->swords, S4_UNP_WORDS);
+    const int nseg = cdiv4(c->swords, seg_words);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * S4_UNP_WORDS)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(unpermute4_kernel, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream, d_in,
+                       d_occ, mstride, c->ngroups, c->sub_perm, c->swords, seg_words, d_out);
+    const int64_t n8 = (int64_t)b * mstride / 8;
+    hipLaunchKernelGGL(clear_occ_kernel, dim3((unsigned)cdiv4(n8, 256)), dim3(256), 0, c->stream, (uint64_t *)d_occ, n8);
+    RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -606,12 +606,28 @@ def test_full_size_properties(cfg):
         assert np.array_equal(oc_m, masks[msel]) and np.array_equal(oc_c, counts[msel])
     # refit: ascending, all enabled before, none after invalidation, disjoint extractions
     seen = np.zeros(n, dtype=bool)
-    todo = cands[:6] if cfg != "cfg5" else [cands[0], cands[16], cands[28], cands[40], cands[47]]   # cfg5: every kind, two cones
+    todo = cands[:6] if cfg == "cfg2" else [cands[0], cands[16], cands[28], cands[40], cands[47]]   # cfg5: every kind, two cones
+    if cfg == "cfg3":
+        todo = [cands[0], cands[16], cands[28], cands[1], cands[29], cands[2]]      # plane, sphere, cylinder, ...
     for j, cand in enumerate(todo):
         ex = R.refit(cand, pc, cp)
         assert np.all(np.diff(ex.inpoints) > 0) and not seen[ex.inpoints - 1].any()
         if cfg == "cfg5" and j in (0, 3):      # a plane and a cone scan against the oracle's list, on the enabled set as it stands
             assert np.array_equal(ex.inpoints, oc.refit(to_orc_shapes(shape_array([cand]), 1)[0], to_orc_params(cp)))
+        if cfg == "cfg3" and j in (0, 2):      # a plane and a cylinder: the 10M-point scan against the oracle's list, both scans
+            import os
+            want = oc.refit(to_orc_shapes(shape_array([cand]), 1)[0], to_orc_params(cp))
+            assert want.size > 1000 and np.array_equal(ex.inpoints, want)
+            old = os.environ.get("RH_REFIT_PATH")
+            try:
+                for path in ("scan", "culled"):        # (the switch is read on every refit)
+                    os.environ["RH_REFIT_PATH"] = path
+                    assert np.array_equal(R.refit(cand, pc, cp).inpoints, want), path
+            finally:
+                if old is None:
+                    os.environ.pop("RH_REFIT_PATH", None)
+                else:
+                    os.environ["RH_REFIT_PATH"] = old
         seen[ex.inpoints - 1] = True
         R.invalidate_indexes(pc, ex.inpoints)
         oc.invalidate(ex.inpoints)
