@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
+    ap.add_argument("--no-e2e-octree", action="store_true", help="skip the octree-sampling end-to-end leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline legs of the score step (the end-to-end prefix check stays)")
     return ap.parse_args()
 
 
@@ -95,7 +97,7 @@ def _lib_hash():
     return b.source_hash()
 
 
-def pmc_replay(kernel_key, enabled):
+def pmc_replay(kernel_key, enabled, suffix=""):
     """Per-launch hardware counters of one kernel REPLAYED from the committed PMC passes of the newest round
     (profiles/rN/pmc_hbm_traffic.json, pmc_sq_counters.json: separate rocprofv3 --pmc runs of this same command;
     tools/profile_round.sh).  They are not measured in this run -- the result says so (`replayed_from`) and
@@ -106,7 +108,8 @@ def pmc_replay(kernel_key, enabled):
     out = {"traffic": None, "sq": {}, "replayed_from": None, "stale": None}
     if not enabled:
         return out
-    ft, fs, fm = _newest_profile("pmc_hbm_traffic.json"), _newest_profile("pmc_sq_counters.json"), _newest_profile("pmc_meta.json")
+    # (suffix: "" = the default workload's passes, "_cfg5" = the passes taken with --workload cfg5)
+    ft, fs, fm = _newest_profile("pmc_hbm_traffic%s.json" % suffix), _newest_profile("pmc_sq_counters%s.json" % suffix), _newest_profile("pmc_meta.json")
     files = []
     if ft:
         rows = json.load(open(ft))
@@ -274,8 +277,17 @@ def main():
                                        scanner=[synth.BOX / 2] * 3 if args.workload == "cfg5" else None)
     subs = synth.make_subsets(n, 32, seed=wseed)
     S = subs[0].size
+    t_scene = time.time() - t0
     pc = R.RANSACCloud(xyz, nrm, subs, device=local_rank)
     t_setup = time.time() - t0
+    cms = (C.c_double * 4)()
+    L.check(R.lib().rh_cloud_create_ms(pc._h, cms))
+    cloud_create = {"ms_total": cms[0], "ms_kd_leaf_order_host": cms[1], "ms_before_kd": cms[2], "ms_after_kd": cms[3],
+                    "scene_generation_s": t_scene,
+                    "note": "rh_cloud_create alone (setup_seconds also holds numpy's scene generation): total wall time, of "
+                            "which the single-threaded host k-d leaf order of subset 1 (std::nth_element recursion; what gives the "
+                            "score kernel its compact 64-point groups), the part before it (allocations, H2D, AoS -> SoA, Morton "
+                            "order of the cloud on the device: rocPRIM radix sort) and the part after it"}
     params = R.ransacparameters(types)
     cp = R.params_to_c(params, score_mode=L.SCORE_F64)   # Int64 score wraps at this size
 
@@ -446,13 +458,15 @@ def main():
         for ki, k in enumerate(KINDS):
             nk = sum(1 for c in cands[lo:hi] if c[0] == k)
             if nk:
-                per_kind[k] = {"candidates": nk, "ms_separate_launch": acc[ki] / reps}
+                per_kind[k] = {"candidates": nk, "ms_separate_launch": acc[ki] / reps,
+                               "note": "diagnostic: the OLDER per-kind culled kernel (binary64, lane = point) launched alone"}
+        v4 = os.environ.get("RH_SCORE_V4", "1") != "0" and os.environ.get("RH_SCORE_PATH", "groups") == "groups" and S >= 8192
         merged = os.environ.get("RH_SCORE_MERGED", "1") != "0" and os.environ.get("RH_SCORE_PATH", "groups") == "groups"
         if merged:
-            kname = "score_groups_all_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
+            kname = ("score4_kernel" if v4 else "score_groups_all_kernel") + " (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
-            pmc_key = "score_groups_all_kernel<false, false, true"   # counts only, Float64, band constants from the prep kernel: the timed step's launch
+            pmc_key = "score4_kernel<8, false>" if v4 else "score_groups_all_kernel<false, false, true"   # counts only, Float64: the timed step's launch
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
@@ -461,26 +475,35 @@ def main():
             pmc_key = "score_groups_kernel<%d," % KINDS.index(dom)
         ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
         tests = ncand * S
-        # the committed PMC passes were taken on the default workload and batch split
-        pmc_ok = args.workload == "cfg3" and n == n_default and world == 1 and "RH_SCORE_PATH" not in os.environ
-        pmc = pmc_replay(pmc_key, pmc_ok)
+        # the committed PMC passes were taken on the default workloads and batch split
+        pmc_ok = args.workload in ("cfg3", "cfg5") and n == n_default and world == 1 and "RH_SCORE_PATH" not in os.environ
+        pmc = pmc_replay(pmc_key, pmc_ok, "" if args.workload == "cfg3" else "_" + args.workload)
         sq = pmc["sq"]
-        simd_issue_per_s = 1024 * 2.4e9 / 4            # 256 CUs x 4 SIMDs, one wave64 FP64 instruction per 4 cycles
+        # Issue model (tools/ubench/valu_rates.hip, this GPU, 8 waves per SIMD): SIMD cycles a wave64 instruction holds the
+        # vector issue port -- binary64 add 4.2 / mul 4.3 / fma 4.75 / sqrt-rcp-rsq 16.2, everything 32-bit 2.3 -- and
+        # 4.2 for a scalar instruction (one scalar ALU per CU).  1024 SIMDs x 2.4 GHz cycles per second are there.
+        CYC = {"SQ_INSTS_VALU_ADD_F64": 4.2, "SQ_INSTS_VALU_MUL_F64": 4.3, "SQ_INSTS_VALU_FMA_F64": 4.75, "SQ_INSTS_VALU_TRANS_F64": 16.2}
+        simd_cycles_per_s = 1024 * 2.4e9
         insts = sq.get("SQ_INSTS_VALU")
-        arith = None
-        if all(k in sq for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")):
-            arith = sum(sq[k] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        arith = vcyc = None
+        if insts is not None and all(k in sq for k in CYC):
+            arith = sum(sq[k] for k in CYC)
+            vcyc = sum(sq[k] * CYC[k] for k in CYC) + (insts - arith) * 2.3
+        scyc = None if "SQ_INSTS_SALU" not in sq else sq["SQ_INSTS_SALU"] * 4.2
         alg_bytes = tests * SCORE_BYTES_PER_TEST + ncand * (64 + 4)
         flops = sum(FLOPS_PER_TEST[k] * per_kind[k]["candidates"] * S for k in kinds_in)
         out["roofline"] = {
-            "kernel": kname, "bound": "fp64_valu_issue",
-            "achieved": None if insts is None else insts / sec, "peak": simd_issue_per_s, "unit": "wave64 VALU instructions/s",
-            "frac": None if insts is None else insts / sec / simd_issue_per_s,
-            "frac_fp64_arith": None if arith is None else arith / sec / simd_issue_per_s,
+            "kernel": kname, "bound": "valu_issue",
+            "achieved": None if vcyc is None else vcyc / sec, "peak": simd_cycles_per_s, "unit": "SIMD vector-issue cycles/s",
+            "frac": None if vcyc is None else vcyc / sec / simd_cycles_per_s,
+            "frac_scalar_issue": None if scyc is None else scyc / sec / simd_cycles_per_s,
+            "frac_fp64_arith": None if arith is None else sum(sq[k] * CYC[k] for k in CYC) / sec / simd_cycles_per_s,
+            "frac_unweighted_x4": None if insts is None else insts * 4 / sec / simd_cycles_per_s,
+            "sq_active_inst_valu": sq.get("SQ_ACTIVE_INST_VALU"), "sq_busy_cycles": sq.get("SQ_BUSY_CYCLES"), "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"),
             "traffic": pmc["traffic"],
             "traffic_frac_of_hbm_peak": None if pmc["traffic"] is None else pmc["traffic"] / sec / 1e9 / HBM_PEAK_GBS,
             "ms_per_launch": sec * 1e3, "ms_source": "HIP events on the library's stream, this run",
-            "valu_insts_per_launch": insts, "fp64_arith_insts_per_launch": arith,
+            "valu_insts_per_launch": insts, "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"), "fp64_arith_insts_per_launch": arith,
             "replayed_from": pmc["replayed_from"], "replay_is_stale": pmc["stale"],
             "effective_algorithmic": {
                 "GBs": alg_bytes / sec / 1e9, "bytes_per_launch": alg_bytes, "tests_per_launch": tests,
@@ -488,12 +511,15 @@ def main():
                 "note": "NOT a roofline: 48.25 B (SURVEY.md 8d) x every (candidate, point) pair of the batch / time.  The "
                         "kernel never streams those bytes -- tiles are staged once and box tests on the k-d leaves reject "
                         "~90 % of the (candidate, group) pairs, bit-exactly -- so this exceeds the HBM peak by design"},
-            "note": "The batched score is bound by the FP64 vector ALU, not by HBM (SURVEY.md 8d).  frac = vector-ALU "
-                    "issue slots filled = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time); frac_fp64_arith "
-                    "= the FP64 add / mul / fma / transcendental share of them (no FMA contraction is allowed: bit parity).  "
-                    "The launch time is measured here; the counter values are REPLAYED from the committed rocprofv3 --pmc "
-                    "passes named in replayed_from (replay_is_stale = the library has changed since).  traffic = HBM bytes "
-                    "per launch, 2 x FETCH_SIZE + WRITE_SIZE, same passes",
+            "note": "The batched score is bound by instruction issue, not by HBM (SURVEY.md 8d: every point is reused across the "
+                    "batch).  frac = the share of the chip's vector-issue cycles the launch fills, every instruction class "
+                    "weighted with its MEASURED issue cost (tools/ubench/valu_rates.hip: binary64 add 4.2 / mul 4.3 / fma 4.75 / "
+                    "transcendental 16.2 cycles, 32-bit 2.3); frac_scalar_issue = the same for the scalar port (4.2 cycles each); "
+                    "frac_unweighted_x4 = round 2's figure (every vector instruction priced as binary64).  The v4 kernel computes "
+                    "in binary32 with a rigorous two-sided classifier and runs the reference's binary64 test only on pairs it cannot "
+                    "decide (frac_fp64_arith is that remainder).  The launch time is measured here; the counter values are REPLAYED "
+                    "from the committed rocprofv3 --pmc passes named in replayed_from (replay_is_stale = the library has changed "
+                    "since).  traffic = HBM bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, same passes",
         }
         # the host-buffer form of the same step (rh_score_batch: H2D of the shapes, D2H of the counts, one sync)
         hcounts = np.zeros(hi - lo, dtype=np.int32)
@@ -692,7 +718,7 @@ def main():
         # ---- cpu_baseline: the oracle (port of the reference's single-threaded path) ------
         if world > 1:
             args.no_cpu = True   # the CPU legs belong to the N = 1 line (the other ranks would sit in the barrier for them)
-        if not args.no_cpu:
+        if not args.no_cpu and not args.no_cpu_baseline:
             from oracle import oracle as orc
             oc = orc.Cloud(xyz, nrm, subs[0])
             nb = 768
@@ -786,6 +812,8 @@ def main():
                                  "seconds_rh_ransac": st["seconds"], "iterations": st["iterations"], "minimal_sets": st["iterations"] * 4096,
                                  "minimal_sets_per_sec": st["iterations"] * 4096 / t_e2e,
                                  "candidates_scored": st["candidates_scored"], "last_extraction_iteration": last_it,
+                                 "seconds_to_last_extraction": st.get("seconds_to_last_extraction"),
+                                 "shapes_per_sec_to_last_extraction": (len(got) / st["seconds_to_last_extraction"]) if st.get("seconds_to_last_extraction") else None,
                                  "breakdown_s": {"sample_fit": st["seconds_host"], "score": st["seconds_score"],
                                                  "extract": st["seconds_extract"]},
                                  "largest_shapes": sorted((len(g.inpoints) for g in got), reverse=True)[:5],
@@ -797,27 +825,29 @@ def main():
             # fixed behaviour: level-weighted octree sampling (docs/src/ransac.md:73-96)
             ocp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1,
                                 octree_sampling=True)
-            pc.enable_all()
-            ocp.itermax = 4
-            R.ransac(pc, ocp, seed=99)                      # builds + caches the linear octree (setup)
-            pc.enable_all()
-            ocp.itermax = args.e2e_octree_iters
-            oruns = []
-            for _ in range(3):
+            if not args.no_e2e_octree:
                 pc.enable_all()
-                prewarm()
-                t0 = time.perf_counter()
-                goto_, _, sto = R.ransac(pc, ocp, seed=1234, return_stats=True)
-                oruns.append((time.perf_counter() - t0, sto))
-            t_oct, sto = sorted(oruns, key=lambda r: r[0])[1]
-            out["end_to_end_octree"] = {
-                "metric": "shapes_per_sec", "value": len(goto_) / t_oct, "shapes": len(goto_), "seconds": t_oct, "seconds_rh_ransac": sto["seconds"],
-                "runs": 3, "seconds_all_runs": [r[0] for r in oruns],
-                "iterations": sto["iterations"], "candidates_scored": sto["candidates_scored"],
-                "last_extraction_iteration": max([g.iteration for g in goto_], default=0),
-                "breakdown_s": {"sample_fit": sto["seconds_host"], "score": sto["seconds_score"], "extract": sto["seconds_extract"]},
-                "note": "median of 3 runs; same cloud, octree_sampling=1 (level-weighted cells of a linear Morton octree; not what the "
-                        "reference executes, SURVEY.md 0.5), minsubsetN=4096, itermax=%d" % args.e2e_octree_iters}
+                ocp.itermax = 4
+                R.ransac(pc, ocp, seed=99)                      # builds + caches the linear octree (setup)
+                pc.enable_all()
+                ocp.itermax = args.e2e_octree_iters
+                oruns = []
+                for _ in range(3):
+                    pc.enable_all()
+                    prewarm()
+                    t0 = time.perf_counter()
+                    goto_, _, sto = R.ransac(pc, ocp, seed=1234, return_stats=True)
+                    oruns.append((time.perf_counter() - t0, sto))
+                t_oct, sto = sorted(oruns, key=lambda r: r[0])[1]
+                out["end_to_end_octree"] = {
+                    "metric": "shapes_per_sec", "value": len(goto_) / t_oct, "shapes": len(goto_), "seconds": t_oct, "seconds_rh_ransac": sto["seconds"],
+                    "runs": 3, "seconds_all_runs": [r[0] for r in oruns],
+                    "iterations": sto["iterations"], "candidates_scored": sto["candidates_scored"],
+                    "last_extraction_iteration": max([g.iteration for g in goto_], default=0),
+                    "seconds_to_last_extraction": sto.get("seconds_to_last_extraction"),
+                    "breakdown_s": {"sample_fit": sto["seconds_host"], "score": sto["seconds_score"], "extract": sto["seconds_extract"]},
+                    "note": "median of 3 runs; same cloud, octree_sampling=1 (level-weighted cells of a linear Morton octree; not what the "
+                            "reference executes, SURVEY.md 0.5), minsubsetN=4096, itermax=%d" % args.e2e_octree_iters}
             if not args.no_cpu:
                 # CPU side of the same loop on a bounded prefix, and a parity check of that prefix
                 from oracle import oracle as orc
@@ -842,12 +872,13 @@ def main():
         if e2e_sharded is not None:
             out["end_to_end_sharded"] = e2e_sharded
         out["setup_seconds"] = t_setup
+        out["cloud_create"] = cloud_create
         # ---- the other single-GPU BASELINE configs on this GPU: child processes of the same script
         def child_leg(name, extra, note):
             import subprocess
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu", "--no-e2e",
-                                    "--no-cfg5", "--no-cfg2", "--no-f32"] + extra, capture_output=True, text=True, timeout=900)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cfg5", "--no-cfg2", "--no-f32"] +
+                                   ([] if "--e2e-iters" in extra else ["--no-e2e", "--no-cpu"]) + extra, capture_output=True, text=True, timeout=900)
                 if r.returncode != 0:
                     if "PARITY FAILURE" in (r.stderr or ""):   # a wrong result is never just a missing leg
                         raise SystemExit("%s leg: %s" % (name, r.stderr.strip().splitlines()[-1]))
@@ -860,7 +891,7 @@ def main():
                                           ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch",
                                            "algorithmic_bytes_per_launch", "inliers")},
                        "setup_seconds": c5["setup_seconds"], "note": note}
-                for k in ("oracle_checked", "oracle_check", "masks_out", "refit_culled"):
+                for k in ("oracle_checked", "oracle_check", "masks_out", "refit_culled", "cloud_create", "end_to_end", "roofline"):
                     if k in c5:
                         leg[k] = c5[k]
                 return leg
@@ -873,10 +904,13 @@ def main():
                                     "python bench.py --workload cfg2 --no-cpu --no-e2e --oracle-check 256 (child process): BASELINE "
                                     "configs[1], 1M points = 2 planes + 2 spheres + 2 cylinders without outliers, S = 31 250, B = 4096")
         if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
-            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "96"],
-                                    "python bench.py --workload cfg5 --no-cpu --no-e2e --steps 60 --warmup 10 --oracle-check 96 (child "
-                                    "process): one replica of the 50M-point cloud on this GPU, S = 1 562 500, cones in the batch; 96 "
-                                    "candidates of all four kinds checked against the oracle; the refit scan streams 2.4 GB")
+            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "96", "--e2e-iters", "4096", "--e2e-runs", "3",
+                                             "--e2e-cpu-iters", "48", "--no-e2e-octree", "--no-cpu-baseline"],
+                                    "python bench.py --workload cfg5 --steps 60 --warmup 10 --oracle-check 96 --e2e-iters 4096 --e2e-runs 3 "
+                                    "--e2e-cpu-iters 48 --no-e2e-octree --no-cpu-baseline (child process): one replica of the 50M-point cloud on "
+                                    "this GPU, S = 1 562 500, cones in the batch; 96 candidates of all four kinds checked against the "
+                                    "oracle; the refit scan streams 2.4 GB; a bounded end-to-end leg (4096 iterations, the oracle's loop "
+                                    "compared on a 48-iteration prefix)")
         print(json.dumps(out))
     batch.free()
     if points_mode:

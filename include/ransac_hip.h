@@ -220,6 +220,7 @@ typedef struct {
     double seconds_score;    /* device time in score launches + count read-back */
     double seconds_extract;  /* refit + invalidate + candidate liveness */
     double seconds_host;     /* sampling + fit + bookkeeping */
+    double seconds_to_last_extraction;   /* wall time from the start of the loop to the end of the last extraction (0: none) */
     void *arena;             /* internal: the pinned host block that holds every inpoints list */
 } rh_result;
 
@@ -281,6 +282,11 @@ int rh_dev_alloc(rh_cloud *c, int64_t bytes, void **d_out);
 int rh_dev_free(rh_cloud *c, void *d);
 int rh_dev_upload(rh_cloud *c, void *d_dst, const void *h_src, int64_t bytes);
 int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes);
+
+/* wall time of the rh_cloud_create call that made the cloud, ms: [0] total, [1] the host-side k-d leaf order of subset 1
+ * (what gives the culled score kernel its compact 64-point groups; single-threaded), [2] before it (allocations,
+ * uploads, AoS -> SoA, Morton order of the cloud on the device), [3] after it (subset gather, group boxes, enabled bits) */
+int rh_cloud_create_ms(const rh_cloud *c, double *out4);
 
 /* ---- diagnostics (tests) ---- */
 /* The batched score decides most (candidate, point) pairs with a binary32 evaluation of the reference's

@@ -248,6 +248,7 @@ mutable struct RhResult
     seconds_score::Cdouble
     seconds_extract::Cdouble
     seconds_host::Cdouble
+    seconds_to_last_extraction::Cdouble
     arena::Ptr{Cvoid}
 end
 

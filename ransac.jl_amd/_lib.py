@@ -44,7 +44,7 @@ class Result(C.Structure):
     _fields_ = [("shapes", C.POINTER(Extracted)), ("n_shapes", C.c_int64), ("iterations", C.c_int64),
                 ("candidates_scored", C.c_int64), ("scored_left", C.c_int64), ("seconds", C.c_double),
                 ("seconds_score", C.c_double), ("seconds_extract", C.c_double), ("seconds_host", C.c_double),
-                ("arena", C.c_void_p)]
+                ("seconds_to_last_extraction", C.c_double), ("arena", C.c_void_p)]
 
 
 class RansacHipError(RuntimeError):
@@ -107,6 +107,7 @@ SIGNATURES = {
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
+    "rh_cloud_create_ms": (C.c_int, [_vp, _dp]),
 }
 
 _lib = None

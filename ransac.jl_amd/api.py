@@ -649,7 +649,8 @@ def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=Non
         extracted.append(es)
     stats = {"iterations": res.iterations, "candidates_scored": res.candidates_scored,
              "scored_left": res.scored_left, "seconds": res.seconds, "seconds_score": res.seconds_score,
-             "seconds_extract": res.seconds_extract, "seconds_host": res.seconds_host, "draws": rng.draws}
+             "seconds_extract": res.seconds_extract, "seconds_host": res.seconds_host,
+             "seconds_to_last_extraction": res.seconds_to_last_extraction, "draws": rng.draws}
     del owner
     seconds = stats["seconds"]
     return (extracted, seconds, stats) if return_stats else (extracted, seconds)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <utility>
 #include <vector>
@@ -310,6 +311,9 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     if (ndev <= 0) { rh_set_error("no HIP device is visible; libransac_hip has no CPU fallback"); return RH_E_NODEVICE; }
     if (device < 0 || device >= ndev) { rh_set_error("device %d out of range (%d visible)", device, ndev); return RH_E_INVALID; }
     RH_HIP(hipSetDevice(device));
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double ms_kd = 0, ms_before_kd = 0;
 
     rh_cloud *c = new (std::nothrow) rh_cloud();
     if (!c) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
@@ -394,6 +398,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
             // culled score kernel's per-group boxes need (k-d leaves, below)
             h_idx = new (std::nothrow) int32_t[2 * (size_t)s];
             if (!h_idx) { rh_set_error("out of host memory"); return fail(RH_E_NOMEM); }
+            ms_before_kd = ms_since(tc0);
+            const auto tkd0 = std::chrono::steady_clock::now();
             double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 }, mag = 0;
             bool first = true;
             for (int64_t j = 0; j < s; j++) {
@@ -485,6 +491,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
                 h_perm[i] = order[(size_t)i];
                 h_idx[i] = (int32_t)(subset1[h_perm[i]] - 1);
             }
+            ms_kd = ms_since(tkd0);
             CKH(hipMemcpyAsync(c->sub_idx0, h_idx, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
             CKH(hipMemcpyAsync(c->sub_perm, h_perm, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
             CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, c->sub_idx0, s, c->sub, c->s_pad));
@@ -498,7 +505,21 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     (void)hipFree(t_xyz);
     (void)hipFree(t_nrm);
     delete[] h_idx;
+    c->create_ms[0] = ms_since(tc0);
+    c->create_ms[1] = ms_kd;
+    c->create_ms[2] = ms_before_kd;
+    c->create_ms[3] = c->create_ms[0] - ms_kd - ms_before_kd;
     *out = c;
+    return RH_OK;
+}
+
+// wall time of the rh_cloud_create that made this cloud, in ms: total, the host-side k-d leaf order of subset 1
+// (single-threaded), everything before it (allocations, uploads, AoS -> SoA, the Morton order of the cloud on the
+// device), everything after it (subset gather, group boxes, enabled bits)
+extern "C" int rh_cloud_create_ms(const rh_cloud *c, double *out4)
+{
+    if (!c || !out4) { rh_set_error("rh_cloud_create_ms: NULL argument"); return RH_E_INVALID; }
+    for (int i = 0; i < 4; i++) out4[i] = c->create_ms[i];
     return RH_OK;
 }
 

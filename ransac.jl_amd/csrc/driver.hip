@@ -503,6 +503,7 @@ struct Driver {
     int64_t cc[4] = { 0, 0, 0, 0 };         // countcandidates (1-based like the reference)
     int64_t best = -1;                      // index into store of the running first maximum
     double t_score = 0, t_extract = 0, t_sample = 0;
+    double t_last_extraction = 0;           // wall clock at the end of the latest extraction
     double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
     double tw[4] = { 0, 0, 0, 0 };           // windows: enqueue, wait, host list handling, record()
     int64_t nwin = 0;
@@ -866,6 +867,7 @@ struct Driver {
         ex.inpoints = arena + arena_used;
         arena_used += total;
         extracted.push_back(ex);
+        t_last_extraction = now_s();
         if (total > 0) {
             // pinned destination, on the copy stream: the 8 bytes per inlier cross PCIe while the compute stream
             // goes on with the next window; the next extraction waits for ev_copied before it rewrites idx_out
@@ -1402,6 +1404,7 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
     d.clean = true;
     c->select_valid = false;
     out->seconds = now_s() - t_start;
+    out->seconds_to_last_extraction = d.t_last_extraction > 0 ? d.t_last_extraction - t_start : 0.0;
     out->seconds_score = d.t_score;
     out->seconds_extract = d.t_extract;
     out->seconds_host = d.t_sample;

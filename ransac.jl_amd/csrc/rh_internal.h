@@ -88,6 +88,7 @@ struct rh_cloud {
     int32_t *sub_perm = nullptr;       // [s] internal (k-d leaf order) position -> subset position j
     double *gb = nullptr;              // 7 planes x ng_pad: box centre cx cy cz, half extents hx hy hz, radius hr
     int64_t ngroups = 0, ng_pad = 0;   // 64-point groups of the subset (internal order)
+    double create_ms[4] = { 0, 0, 0, 0 };   // rh_cloud_create: total, host k-d leaf order of subset 1, everything before it, everything after it
     double coord_mag = 0;              // max |coordinate| over the subset (rounding slack of the bounds)
     double nrm_mag = 0;                // max |normal component| over the subset (margins of the binary32 classifier)
     bool use_groups = false;           // culled scoring path available (s large enough)

@@ -462,7 +462,7 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
 // written out once, coalesced: the output needs neither a memset nor global atomics, and the 160 MB of (mostly empty)
 // internal-order rows are never read or zeroed.  (A first form walked each word's bits in one thread: 64 dependent
 // position loads for a dense word, 0.30 ms per cfg3 batch.)  The occupancy bytes are cleared by a kernel of their own.
-constexpr int S4_UNP_WORDS = 6144;   // words per segment: 48 KB of LDS, three blocks of 512 threads per CU
+constexpr int S4_UNP_WORDS = 8192;   // words per segment: 64 KB of LDS (cfg5, 24 415 words per row: 4096 1.99 ms, 6144 1.87, 8192 1.62, 12288 1.78)
 
 __global__ void __launch_bounds__(512)
 unpermute4_kernel(const uint64_t *__restrict__ in, const uint8_t *__restrict__ occ, int64_t mstride, int64_t ngroups,
@@ -630,11 +630,13 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out)
 {
     if (b == 0 || c->swords == 0) return RH_OK;
-    const int64_t seg_words = std::min<int64_t>(c->swords, S4_UNP_WORDS);
+    static int env_words = -1;
+    if (env_words < 0) { const char *e = getenv("RH_UNP_WORDS"); env_words = e ? atoi(e) : 0; }
+    const int64_t seg_words = std::min<int64_t>(c->swords, env_words > 0 ? std::min(env_words, 16384) : S4_UNP_WORDS);
     const int nseg = cdiv4(c->swords, seg_words);
     static bool attr_set = false;
     if (!attr_set) {
-        RH_HIP(hipFuncSetAttribute((const void *)unpermute4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * S4_UNP_WORDS)));
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
         attr_set = true;
     }
     hipLaunchKernelGGL(unpermute4_kernel, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream, d_in,
