@@ -669,7 +669,14 @@ static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_p
                 nk[k] = d_nk + k;
                 p32[k] = (const char *)c->d_prep32 + (size_t)off[k] * 12 * sizeof(float);
             }
-            return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, p32);
+            const void *cl[4];
+            const float *bx[4];
+            for (int k = 0; k < 4; k++) {
+                cl[k] = d_cls ? (const char *)d_cls + (size_t)off[k] * 64 : nullptr;
+                bx[k] = d_box ? d_box + off[k] : nullptr;
+            }
+            return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, p32,
+                                        d_cls ? cl : nullptr, d_box ? bx : nullptr, bstride);
         }
         return rhk_score_all_f32(c, c->f32_shapes, c->f32_via_orig, en, d_orig, off, d_nk, nk_bound, p->eps, p->cos_alpha,
                                  d_counts, d_masks_int);

@@ -84,7 +84,7 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
         prep[i] = P;
         if (counts_zero != nullptr) counts_zero[i] = 0;
         if (cls != nullptr && kind >= 0 && kind <= 3)
-            rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, cls[i], QA.box + i, QA.bstride);
+            rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, cls[i], QA.box + i, QA.bstride, nullptr, QA.f32 != 0);
     }
 }
 
@@ -133,7 +133,7 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
     orig[(int64_t)kind * cap + slot] = i;
     if (qpre != nullptr) {
         if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
-                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride);
+                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
         else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
     }
 }
@@ -171,7 +171,7 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
     orig[(int64_t)kind * cap + slot] = i;
     if (qpre != nullptr) {
         if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
-                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride);
+                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
         else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
     }
 }
@@ -1191,7 +1191,7 @@ bool rh_score_v4_enabled(const rh_cloud *c)
 {
     static int env = -1;
     if (env < 0) { const char *e = getenv("RH_SCORE_V4"); env = e ? atoi(e) : 1; }
-    return env != 0 && !c->f32 && c->use_groups;
+    return env != 0 && (c->f32 ? c->f32_groups : c->use_groups);
 }
 
 static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa)
@@ -1546,9 +1546,9 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
     for (int k = 0; k < 4 && qarr; k++)
         qarr = prep[k] == c->d_prep + (int64_t)k * c->batch_cap && c->qpre_eps[k] == eps[k];
     // classifier records of exactly these bins and thresholds from the caller: the v4 kernel (score4.hip)
-    if (cls != nullptr && box != nullptr && (d_masks_int == nullptr || c->masks4) && prep32 == nullptr && rh_score_v4_enabled(c) && c->gb32 != nullptr)
+    if (cls != nullptr && box != nullptr && (d_masks_int == nullptr || c->masks4) && rh_score_v4_enabled(c) && c->gb32 != nullptr)
         return rhk_score4_all(c, en, prep, (const void *const *)cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts,
-                              d_masks_int, d_masks_int ? c->d_occ : nullptr, c->mstride4);
+                              d_masks_int, d_masks_int ? c->d_occ : nullptr, c->mstride4, prep32);
     if (c->qpre_v4) qarr = false;   // (what lies beside the bins in d_qpre are not band constants)
     G2AllArgs A;
     for (int k = 0; k < 4; k++)

@@ -214,7 +214,8 @@ bool rh_score_v4_enabled(const rh_cloud *c);
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
                    int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts,
-                   uint64_t *d_masks_int = nullptr, uint8_t *d_occ = nullptr, int64_t mstride = 0);   // masks: sparse words + occupancy bytes
+                   uint64_t *d_masks_int = nullptr, uint8_t *d_occ = nullptr, int64_t mstride = 0,   // masks: sparse words + occupancy bytes
+                   const void *const prep32[4] = nullptr);   // Float32 cloud: binary32 records of the bins (exact tests in binary32)
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out);   // score4.hip
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates

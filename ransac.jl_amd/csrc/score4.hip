@@ -30,11 +30,13 @@
 #include "rh_internal.h"
 #include "score_device.h"
 #include "score4_device.h"
+#include "score_device32.h"
 
 namespace {
 
 using namespace rhdev;
 using namespace rh4;
+using namespace rhdev32;
 
 typedef float rh_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
@@ -74,6 +76,8 @@ struct S4KindArgs {
     const rh_cls *cls;      // classifier records of the bin
     const float *box;       // culling records of the bin: field f of slot i at box[f * bstride + i]
     const rh_prep *prep;    // binary64 records of the bin
+    const rh_prepf *prep32; // Float32 cloud: the binary32 records of the bin (score_device32.h) for its exact test, else null
+    float eps_up, cosa_dn;  // (unused)
     const int32_t *orig, *nk;
     const uint64_t *en;
     double eps, cosa;
@@ -89,7 +93,7 @@ struct S4AllArgs {
     int64_t mstride;
 };
 
-template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLANE || KIND == RH_SPHERE ? 5 : (KIND == RH_CYLINDER ? 9 : 10); };
+template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLANE || KIND == RH_SPHERE ? 5 : (KIND == RH_CYLINDER ? 9 : 11); };
 
 #define RH4_CONST_AS __attribute__((address_space(4)))
 
@@ -106,12 +110,13 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
 }
 
 // one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
-template <int KIND, int R, bool MASK>
+template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
 score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
-             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0)
+             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0,
+             const rh_prepf *__restrict__ prep32, const float eps_up, const float cosa_dn)
 {
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
@@ -153,10 +158,18 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             redo &= redo - 1;
             const uint32_t ek = __builtin_amdgcn_readlane(e, k);
             const int g2 = (int)(ek & 3u), ci2 = cbase + (int)(ek >> 2);
-            const rh_prep P = rh_ld_prep_const(&prep[ci2]);
             const int64_t gi = p0 + g2 * 64 + lane;
-            const uint64_t mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
-                                                   pts[4 * stride + gi], pts[5 * stride + gi], eps, cosa) & sh.len[g2];
+            uint64_t mres;
+            if (F32) {   // Float32 cloud: the reference's test is the binary32 one (the points are floats, stored exactly)
+                const rh_prepf Pf = ld_prepf(&prep32[ci2]);
+                mres = test_point32<KIND>(Pf, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
+                                          (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
+            } else {
+                const rh_prep P = rh_ld_prep_const(&prep[ci2]);
+                mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
+                                        pts[5 * stride + gi], eps, cosa);
+            }
+            mres &= sh.len[g2];
             if (lane == k) { total = __popcll(mres); word = mres; }
         }
     } else {
@@ -189,9 +202,16 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const int slot = (int)(e2 >> 6);
             const uint32_t pe = sh.plist[head + slot];
             const int64_t gi = p0 + (int)(pe & 3u) * 64 + (int)(e2 & 63u);
-            const rh_prep Pv = prep[cbase + (int)(pe >> 2)];
-            const uint64_t r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi],
-                                                pts[4 * stride + gi], pts[5 * stride + gi], eps, cosa);
+            uint64_t r;
+            if (F32) {
+                const rh_prepf Pv = prep32[cbase + (int)(pe >> 2)];
+                r = test_point32<KIND>(Pv, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
+                                       (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
+            } else {
+                const rh_prep Pv = prep[cbase + (int)(pe >> 2)];
+                r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
+                                     pts[5 * stride + gi], eps, cosa);
+            }
             if (on && ((r >> lane) & 1ULL)) {
                 atomicAdd(&sh.cntb[wv][slot], 1);
                 if (MASK) atomicOr(&sh.maskb[wv][slot], 1ULL << (e2 & 63u));
@@ -230,7 +250,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 // one kind segment of the block's row: chunks [lo, hi) of the kind (at most S4_R).  Stage 1: the waves share the
 // chunks out, lane = candidate, box tests, survivors -> the block's pair list.  Stage 2: the waves take batches of 64
 // pairs from the list until it is empty.
-template <int KIND, int R, bool MASK>
+template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
 score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
@@ -289,8 +309,8 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG],
         if (lane == 0) bt = atomicAdd(&sh.next_batch, 1);
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
-        score4_batch<KIND, R, MASK>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
-                                    K.eps, K.cosa, counts, weird, masks, occ, mstride, g0);
+        score4_batch<KIND, R, MASK, F32>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
+                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, K.prep32, K.eps_up, K.cosa_dn);
     }
 }
 
@@ -327,7 +347,7 @@ static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *_
 // grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
 // the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of R; a block runs the per-kind
 // segment(s) of its row (almost always one) on its tile.
-template <int R, bool MASK>
+template <int R, bool MASK, bool F32>
 __global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
@@ -365,7 +385,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
-            if (live != 0) score4_segment<K, R, MASK>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
+            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -551,7 +571,7 @@ int rhk_gb32_build(rh_cloud *c)
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
                    int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                   uint8_t *d_occ, int64_t mstride)
+                   uint8_t *d_occ, int64_t mstride, const void *const prep32[4])
 {
     const int64_t ntiles = (c->ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
@@ -561,7 +581,8 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
-        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
+        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, f32_round_up(eps[k]),
+                   f32_round_down(cosa[k]), orig[k], nk[k], en[k], eps[k], cosa[k] };
     A.ntiles = ntiles;
     A.bstride = bstride;
     A.ngroups = c->ngroups;
@@ -576,9 +597,12 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-#define RH_S4_LAUNCH(RR, MM) hipLaunchKernelGGL((score4_kernel<RR, MM>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
-    if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true); else RH_S4_LAUNCH(8, true); }
-    else { if (R == 4) RH_S4_LAUNCH(4, false); else RH_S4_LAUNCH(8, false); }
+#define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
+    if (prep32 != nullptr) {   // Float32 cloud: c->sub holds the exactly converted values
+        if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
+        else { if (R == 4) RH_S4_LAUNCH(4, false, true); else RH_S4_LAUNCH(8, false, true); }
+    } else if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, false); else RH_S4_LAUNCH(8, true, false); }
+    else { if (R == 4) RH_S4_LAUNCH(4, false, false); else RH_S4_LAUNCH(8, false, false); }
 #undef RH_S4_LAUNCH
     RH_HIP(hipGetLastError());
     return RH_OK;

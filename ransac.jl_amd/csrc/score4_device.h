@@ -60,11 +60,11 @@ constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
 
 // culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
 // the box tests of stage 1 read, coalesced, with lane = candidate
-constexpr int RH_BOX_FIELDS = 10;
+constexpr int RH_BOX_FIELDS = 11;
 // plane:    0-2 oz | 3 -(oz . P0) | 4 eps + slack
 // sphere:   0-2 o | 3 A2 | 4 B2
 // cylinder: 0-2 a | 3-5 c0 | 6 (R + eps) + slack | 7 (R - eps) - slack | 8 max(1, |1 - |a|^2|)
-// cone:     0-2 apex | 3-5 a^ | 6 kk | 7 1 / cn | 8 (eps + slack) / cn | 9 beta     (alpha is a constant)
+// cone:     0-2 apex | 3-5 a^ | 6 kk | 7 1 / cn | 8 (eps + slack) / cn | 9 beta | 10 alpha
 constexpr float RH_CONE_ALPHA = (float)((RH_CLS_SAFETY * 49.0 + 64.0) * RH_CLS_U);
 
 __host__ __device__ inline bool cls_fin(double v) { return v - v == 0.0; }
@@ -100,9 +100,12 @@ __host__ __device__ inline double cls_slack64(const rh_prep &P, double M) { retu
 // record's fields go to box[f * bstride] (f < RH_BOX_FIELDS).
 // dbg4 (audit): the unscaled thresholds and widths behind a scaled record: cN_hi, wN, eD_lo, wD
 __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps, double cosa, double M, double Nm, rh_cls &o,
-                                         float *box, int64_t bstride, double *dbg4 = nullptr)
+                                         float *box, int64_t bstride, double *dbg4 = nullptr, bool f32cloud = false)
 {
-    const double u = RH_CLS_U, S = RH_CLS_SAFETY;
+    // f32cloud: the EXACT test of this cloud is itself a binary32 chain without fused operations (Float32 cloud,
+    // score_device32.h: 1.3 - 2 x the rounding steps of the classifier's chain on the same magnitudes).  Every margin
+    // is tripled: one part for the classifier's own error, two for the exact chain's.
+    const double u = RH_CLS_U, S = f32cloud ? 3.0 * RH_CLS_SAFETY : RH_CLS_SAFETY;
     const float fnan = __builtin_nanf("");
     for (int i = 0; i < 16; i++) o.f[i] = 0.0f;
     float bx[RH_BOX_FIELDS];
@@ -220,7 +223,8 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         const double kk = ok ? -sn / c : 0.0;
         const double cn = ok ? c / cs : 1.0;
         // band half width: exact form + the f64 prefilter's slack + binary32 error of k h (|t| <= sqrt(3) T)
-        const double ek = S * 19.1 * fabs(kk) * u * T + 1e-8 * (1.0 + T) * (1.0 + fabs(kk));
+        // (Float32 cloud: the exact test's frame is a long binary32 chain, ~1e-5 relative near its band: score_device.h F32 margins)
+        const double ek = S * 19.1 * fabs(kk) * u * T + 1e-8 * (1.0 + T) * (1.0 + fabs(kk)) + (f32cloud ? 2e-5 * (1.0 + T) * (1.0 + fabs(kk)) : 0.0);
         const double e = ok ? (eps / cn) * (1.0 + 1e-9) + ek : 0.0;
         const double beta = S * 1.75 * u * T * T + 1e-30;
         o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2];
@@ -239,6 +243,9 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             bx[7] = cls_up(1.0 / cn);
             bx[8] = cls_up((eps + slack64) / cn * (1.0 + 1e-9) + ek);
             bx[9] = o.f[9];
+            // Float32 cloud: the exact test's frame degrades as 2^-24 / sin(angle to the axis) -- never skip a box whose
+            // centre lies within ~0.03 rad of the axis (rho^2 <= alpha |t|^2)
+            bx[10] = f32cloud ? 1e-3f : RH_CONE_ALPHA;
         }
     }
     if (!ok) o.f[RH_CLS_FLAG] = fnan;
@@ -301,7 +308,7 @@ static __device__ __forceinline__ bool box_skip32(const float (&B)[RH_BOX_FIELDS
     const float tt = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
     const float h = __builtin_fmaf(tz, B[5], __builtin_fmaf(ty, B[4], tx * B[3]));
     const float rho2 = __builtin_fmaf(-h, h, tt);
-    const float s2 = __builtin_fmaf(RH_CONE_ALPHA, tt, B[9]);
+    const float s2 = __builtin_fmaf(B[10], tt, B[9]);
     const float e = __builtin_fmaf(G.hr, B[7], B[8]) * 1.000001f;
     const float uu = B[6] * h;
     const float lo = uu - e, hi = uu + e;
