@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
+    ap.add_argument("--collective", choices=["torch", "lib"], default="torch",
+                    help="N > 1: who issues the score all-reduce -- torch.distributed (RCCL through PyTorch, dist.ShardedScorer) or the "
+                         "library itself (rh_comm_* of the C ABI: librccl directly, the path a Julia / C host uses)")
     ap.add_argument("--no-e2e-octree", action="store_true", help="skip the octree-sampling end-to-end leg")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline legs of the score step (the end-to-end prefix check stays)")
     return ap.parse_args()
@@ -326,8 +329,21 @@ def main():
     if multi and not os.environ.get("RH_BENCH_NO_OVERLAP"):
         scorer = rdist.ShardedScorer(b_global, rank, world, local, "cuda", same_stream=same_stream, points=points_mode)
 
+    # --collective lib: the all-reduce inside the C ABI (rh_score_batch_allreduce_dev), two count buffers in flight
+    libcomm = None
+    if multi and args.collective == "lib" and not points_mode:
+        libcomm = rdist.LibComm(pc, rank, world)
+        scorer = None
+        lib_bufs = [torch.zeros(b_global, dtype=torch.int32, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        lib_k = [0]
+
     def step():
-        if scorer is not None:
+        if libcomm is not None:
+            buf = lib_bufs[lib_k[0] & 1]
+            lib_k[0] += 1
+            libcomm.score_allreduce(batch.slice_ptr(lo), hi - lo, lo, b_global, cp, buf.data_ptr())
+        elif scorer is not None:
             scorer.submit()
         elif points_mode:
             rdist.score_batch_point_sharded(lambda out: local(0, b_global, out), counts)
@@ -338,6 +354,8 @@ def main():
                                            C.c_void_p(counts.data_ptr()), None))
 
     def fence():
+        if libcomm is not None:
+            libcomm.sync()      # every batch's collective has finished before the clock stops
         if scorer is not None:
             scorer.drain()      # every batch's collective has been waited for before the clock stops
         L.check(lib.rh_cloud_sync(pc._h))
@@ -368,7 +386,8 @@ def main():
         dt = float(tmax.item())
     ms_per_step = 1e3 * dt / args.steps
     value = b_global * args.steps / dt
-    counts_h = (scorer.result(scorer.k - 1) if scorer is not None else counts).cpu().numpy()
+    counts_h = (lib_bufs[(lib_k[0] - 1) & 1] if libcomm is not None else
+                scorer.result(scorer.k - 1) if scorer is not None else counts).cpu().numpy()
 
     out = {
         "metric": "candidates_scored_per_sec", "value": value, "unit": "candidates/s", "n_gpus": world,
@@ -385,6 +404,8 @@ def main():
         "tests_per_sec": value * S,
         "rccl_ranks_seen": ranks_seen,
         "collective_backend": (os.environ.get("RH_BENCH_BACKEND", "nccl") if multi else None),
+        "collective_issued_by": (("libransac_hip (rh_score_batch_allreduce_dev: librccl directly)" if libcomm is not None else
+                                 "torch.distributed (dist.ShardedScorer)") if multi else None),
     }
 
     # ---- N > 1, end to end: ONE scene run by all ranks together (rh_ransac_mp: the minimal sets of every iteration are

@@ -283,6 +283,26 @@ int rh_dev_free(rh_cloud *c, void *d);
 int rh_dev_upload(rh_cloud *c, void *d_dst, const void *h_src, int64_t bytes);
 int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes);
 
+/* ---- multi-GPU: candidate-sharded scoring with the score all-reduce inside the library ----
+ * Candidates are independent (src/fitting.jl:181-190).  One process per GPU, each with a replica of the cloud; every
+ * rank scores a slice of the batch, ONE RCCL all-reduce (sum, int32[b_total]) over xGMI gives every rank every count --
+ * integer sums: bit-identical to one GPU.  librccl is loaded on first use (a copy already in the process is shared).
+ *   rank 0:      rh_comm_unique_id(id)          ... the host program hands the 128 bytes to the other ranks ...
+ *   every rank:  rh_comm_create(cloud, rank, world, id, &comm)
+ *   per batch:   rh_score_batch_allreduce_dev(cloud, comm, d_my_shapes, b, offset, b_total, &params, d_counts_total)
+ *                (enqueues: zero, score into [offset, offset + b), all-reduce on the communicator's own stream -- so the
+ *                next batch's scoring overlaps it when the caller alternates two count buffers)
+ *   then:        rh_comm_fence(comm, cloud)  (the cloud's stream waits, no host sync)  or  rh_comm_sync(comm)  (host waits) */
+#define RH_COMM_ID_BYTES 128
+typedef struct rh_comm rh_comm;
+int rh_comm_unique_id(void *id_out /* RH_COMM_ID_BYTES */);
+int rh_comm_create(rh_cloud *c, int32_t rank, int32_t world, const void *unique_id, rh_comm **out);
+int rh_comm_destroy(rh_comm *m);
+int rh_score_batch_allreduce_dev(rh_cloud *c, rh_comm *m, const rh_shape *d_shapes, int32_t b, int32_t offset, int32_t b_total,
+                                 const rh_params *p, int32_t *d_counts_total);
+int rh_comm_fence(rh_comm *m, rh_cloud *c);
+int rh_comm_sync(rh_comm *m);
+
 /* wall time of the rh_cloud_create call that made the cloud, ms: [0] total, [1] the host-side k-d leaf order of subset 1
  * (what gives the culled score kernel its compact 64-point groups; single-threaded), [2] before it (allocations,
  * uploads, AoS -> SoA, Morton order of the cloud on the device), [3] after it (subset gather, group boxes, enabled bits) */

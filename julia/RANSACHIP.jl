@@ -273,7 +273,7 @@ function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_strea
     cp = Ref(toC(params; sampling_streams = sampling_streams))
     rng = Ref(RhRng((0, 0, 0, 0), C_NULL, 0, 0, 0))
     ccall((:rh_rng_seed, LIB), Cvoid, (Ptr{RhRng}, UInt64), rng, UInt64(seed))
-    res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, C_NULL))
+    res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, C_NULL))
     if mp == C_NULL
         GC.@preserve pc check(ccall((:rh_ransac, LIB), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
@@ -302,5 +302,45 @@ function mp_open(name::AbstractString, rank::Integer, world::Integer; slot_bytes
     return h[]
 end
 mp_close(mp::Ptr{Cvoid}) = ccall((:rh_mp_close, LIB), Cint, (Ptr{Cvoid},), mp)
+
+# ---- scoring one batch on all GPUs of a node: candidates are independent (src/fitting.jl:181-190), every rank (one
+# Julia process per GPU, each with the same cloud) scores the slice lo:hi of the batch and the library's own RCCL
+# all-reduce (sum of the zero-padded Int32 counts over xGMI) gives every rank every count.
+#   rank 0:      id = comm_unique_id()      ... send the 128 bytes to the other ranks (MPI.Bcast!, a file, a socket) ...
+#   every rank:  comm = comm_create(h, rank, world, id)
+#   per batch:   counts = scorecounts_sharded(h, comm, candidates, lo, hi, params)      # length(candidates) counts
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:rh_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function comm_create(h::HIPCloud, rank::Integer, world::Integer, id::Vector{UInt8})
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rh_comm_create, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ptr{Ptr{Cvoid}}), h.handle, rank, world, id, c))
+    return c[]
+end
+comm_destroy(comm::Ptr{Cvoid}) = ccall((:rh_comm_destroy, LIB), Cint, (Ptr{Cvoid},), comm)
+
+function scorecounts_sharded(h::HIPCloud, comm::Ptr{Cvoid}, candidates::Vector{<:FittedShape}, lo::Integer, hi::Integer, params)
+    btotal = length(candidates)
+    mine = RhShape[toC(c) for c in candidates[lo:hi]]
+    cp = Ref(toC(params))
+    dsh = Ref{Ptr{Cvoid}}(C_NULL); dcn = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rh_dev_alloc, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), h.handle, max(1, length(mine)) * sizeof(RhShape), dsh))
+    check(ccall((:rh_dev_alloc, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), h.handle, 4 * max(1, btotal), dcn))
+    counts = zeros(Int32, btotal)
+    try
+        check(ccall((:rh_dev_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{RhShape}, Int64), h.handle, dsh[], mine, length(mine) * sizeof(RhShape)))
+        check(ccall((:rh_score_batch_allreduce_dev, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32, Ptr{RhParams}, Ptr{Cvoid}),
+            h.handle, comm, dsh[], length(mine), lo - 1, btotal, cp, dcn[]))
+        check(ccall((:rh_comm_sync, LIB), Cint, (Ptr{Cvoid},), comm))
+        check(ccall((:rh_dev_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Cvoid}, Int64), h.handle, counts, dcn[], 4 * btotal))
+    finally
+        ccall((:rh_dev_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.handle, dsh[])
+        ccall((:rh_dev_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.handle, dcn[])
+    end
+    return counts
+end
 
 end # module

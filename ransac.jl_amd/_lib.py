@@ -108,6 +108,12 @@ SIGNATURES = {
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
     "rh_cloud_create_ms": (C.c_int, [_vp, _dp]),
+    "rh_comm_unique_id": (C.c_int, [_vp]),
+    "rh_comm_create": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
+    "rh_comm_destroy": (C.c_int, [_vp]),
+    "rh_score_batch_allreduce_dev": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _pp, _vp]),
+    "rh_comm_fence": (C.c_int, [_vp, _vp]),
+    "rh_comm_sync": (C.c_int, [_vp]),
 }
 
 _lib = None

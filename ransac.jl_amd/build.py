@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libransac_hip.so")
-SOURCES = ["kernels.hip", "score4.hip", "f32.hip", "cloud.hip", "korder.hip", "driver.hip", "sampler.hip", "lsq.hip", "cc.hip", "fit.cpp"]
+SOURCES = ["kernels.hip", "score4.hip", "f32.hip", "cloud.hip", "korder.hip", "driver.hip", "sampler.hip", "lsq.hip", "cc.hip", "comm.hip", "fit.cpp"]
 # -ffp-contract=off: never fuse a*b+c -- inlier sets must match the CPU path bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     for s in SOURCES:
         cmd += ["-x", "hip", os.path.join(CSRC, s)]
-    cmd += ["-o", SO]
+    cmd += ["-ldl", "-o", SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -172,3 +172,53 @@ def gpu_local_score(pc, batch, cparams, wait=True):
         if wait:
             check(lib().rh_cloud_sync(pc._h))
     return fn
+
+
+class LibComm:
+    """The multi-GPU step inside the C ABI (rh_comm_*, include/ransac_hip.h): librccl is reached by the library itself,
+    the host program only carries the 128-byte id from rank 0 to the others (here: through torch.distributed's
+    default group if one is up, else `exchange`, a callable bytes -> bytes that broadcasts rank 0's value)."""
+
+    def __init__(self, pc, rank, world, exchange=None):
+        self.pc, self.rank, self.world = pc, rank, world
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            check(lib().rh_comm_unique_id(ident))
+        raw = bytes(ident)
+        if world > 1:
+            if exchange is not None:
+                raw = exchange(raw)
+            else:
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor(list(raw), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0)
+                raw = bytes(t.cpu().tolist())
+        ident = (C.c_ubyte * 128).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        check(lib().rh_comm_create(pc._h, rank, world, ident, C.byref(self._h)))
+
+    def score_allreduce(self, d_shapes_ptr, b, offset, b_total, cparams, d_counts_total_ptr):
+        """enqueue: zero the b_total counts, score this rank's b candidates into [offset, offset + b), all-reduce (sum)"""
+        sp = d_shapes_ptr if isinstance(d_shapes_ptr, C.c_void_p) else C.c_void_p(d_shapes_ptr)
+        check(lib().rh_score_batch_allreduce_dev(self.pc._h, self._h, sp, b, offset, b_total, C.byref(cparams),
+                                                 C.c_void_p(d_counts_total_ptr)))
+
+    def fence(self):
+        check(lib().rh_comm_fence(self._h, self.pc._h))
+
+    def sync(self):
+        check(lib().rh_comm_sync(self._h))
+
+    def close(self):
+        if self._h:
+            lib().rh_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass

@@ -1,0 +1,58 @@
+"""The multi-GPU step behind the C ABI (rh_comm_create / rh_score_batch_allreduce_dev, include/ransac_hip.h): the
+library reaches RCCL itself.  On the one GPU of the test box: a ONE-rank communicator (a real ncclCommInitRank and a
+real ncclAllReduce on the communicator's stream) must give exactly what rh_score_batch_dev gives, for a slice with an
+offset into a larger zero-padded count buffer as well; two ranks cannot share one GPU under RCCL (it refuses duplicate
+devices), so N > 1 stays with the driver's multi-GPU run (bench.py --collective lib)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ransac_jl_amd as R
+from ransac_jl_amd import _lib as L
+from ransac_jl_amd import dist as rdist, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_library_collective_equals_plain_scoring():
+    import torch
+    prim = ["plane", "plane", "sphere", "cylinder", "cone"]
+    xyz, nrm, truth = synth.make_cloud(120_000, prim, 0.2, seed=21)
+    subs = synth.make_subsets(120_000, 4, seed=21)
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder, R.FittedCone]))
+    import bench
+    cands = synth.jittered_candidates(truth, 700, seed=4)
+    arr = bench.shapes_to_c(R, L, cands)
+    batch = rdist.DeviceBatch(pc, arr, 700)
+    lib = R.lib()
+    ref = torch.zeros(700, dtype=torch.int32, device="cuda")
+    L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), 700, C.byref(cp), C.c_void_p(ref.data_ptr()), None))
+    L.check(lib.rh_cloud_sync(pc._h))
+    ref = ref.cpu().numpy()
+    assert ref.sum() > 10000
+    comm = rdist.LibComm(pc, 0, 1)
+    # the whole batch
+    out = torch.full((700,), 77, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()      # (the fill runs on torch's stream, the library on the cloud's)
+    comm.score_allreduce(batch.slice_ptr(0), 700, 0, 700, cp, out.data_ptr())
+    comm.sync()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # a slice at an offset inside a larger buffer (what rank r of N does): the rest stays zero; twice in a row with two
+    # buffers in flight and a stream-ordered fence instead of a host wait
+    bufs = [torch.full((1000,), 5, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for i, (lo, hi) in enumerate([(100, 350), (350, 700)]):
+        comm.score_allreduce(batch.slice_ptr(lo), hi - lo, 200 + lo, 1000, cp, bufs[i].data_ptr())
+    comm.fence()
+    L.check(lib.rh_cloud_sync(pc._h))
+    for i, (lo, hi) in enumerate([(100, 350), (350, 700)]):
+        got = bufs[i].cpu().numpy()
+        exp = np.zeros(1000, dtype=np.int32)
+        exp[200 + lo:200 + hi] = ref[lo:hi]
+        assert np.array_equal(got, exp)
+    # bad arguments fail loudly
+    with pytest.raises(R.RansacHipError):
+        comm.score_allreduce(batch.slice_ptr(0), 700, 400, 1000, cp, bufs[0].data_ptr())    # slice beyond the buffer
+    comm.close()
