@@ -487,7 +487,7 @@ def main():
             kname = ("score4_kernel" if v4 else "score_groups_all_kernel") + " (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
-            pmc_key = "score4_kernel<8, false>" if v4 else "score_groups_all_kernel<false, false, true"   # counts only, Float64: the timed step's launch
+            pmc_key = "score4_kernel<8, false, false>" if v4 else "score_groups_all_kernel<false, false, true"   # counts only, Float64: the timed step's launch
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom

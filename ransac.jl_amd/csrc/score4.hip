@@ -52,6 +52,7 @@ struct S4Shared {
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
     rh_f32x2 pb[S4_TG][S4_ROW];          // (ny, nz)
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
+    rh_f32x4 gbox[S4_TG][2];             // the groups' binary32 boxes (cx cy cz hx | hy hz hr 0): stage 1 reads them as broadcasts
     uint16_t plist[R * 64 * S4_TG];      // the block's surviving pairs: candidate of the row << 2 | group
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
     unsigned long long maskb[S4_W][64];  // cone, masks wanted: per-wave inlier words of the batch's pairs
@@ -252,7 +253,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 // pairs from the list until it is empty.
 template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
-score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG], const int64_t bstride, const int lo, const int hi,
+score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
                int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride)
 {
@@ -280,7 +281,14 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG],
         }
         unsigned surv = 0;
 #pragma unroll
-        for (int g = 0; g < S4_TG; g++) surv |= box_skip32<KIND>(B[h & 1], G[g]) ? 0u : (1u << g);
+        for (int g = 0; g < S4_TG; g++) {
+            // (the boxes come from LDS, wave-uniform addresses: kept in scalar registers across the four per-kind bodies
+            // of the kernel they were spilled lane by lane into vector registers -- 30 spilled registers, 217 lane moves)
+            const rh_f32x4 g0v = sh.gbox[g][0], g1v = sh.gbox[g][1];
+            rh_box32 G;
+            G.cx = g0v.x; G.cy = g0v.y; G.cz = g0v.z; G.hx = g0v.w; G.hy = g1v.x; G.hz = g1v.y; G.hr = g1v.z;
+            surv |= box_skip32<KIND>(B[h & 1], G) ? 0u : (1u << g);
+        }
         if (dbg == 2) surv = 15u;
         surv &= live;
         if (ci >= nk || dbg == 1) surv = 0;
@@ -317,7 +325,8 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const rh_box32 (&G)[S4_TG],
 // the tile as binary32 with the enabled words of one kind applied (one point per thread)
 template <int R>
 static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
-                                                const uint64_t *__restrict__ enabled_words, const int64_t p0)
+                                                const uint64_t *__restrict__ enabled_words, const int64_t p0, const float *__restrict__ gb32,
+                                                const int64_t ngroups)
 {
     static_assert(S4_W == S4_TG, "one wave per group");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,6 +351,10 @@ static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *_
     const uint64_t wb = WB(bad);
     if (lane == 0) { sh.weirdw[wv] = wb != 0 ? 1 : 0; sh.len[wv] = v; }   // wave w stages group w: v is its word
     if (tid == 0) { sh.npairs = 0; sh.next_batch = 0; }
+    if (tid < 2 * S4_TG) {   // the four boxes, 32 bytes each
+        const int64_t g = p0 / 64 + (tid >> 1);
+        sh.gbox[tid >> 1][tid & 1] = ((const rh_f32x4 *)gb32)[(g < ngroups ? g : ngroups - 1) * 2 + (tid & 1)];
+    }
 }
 
 // grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
@@ -360,17 +373,6 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
     const int lo = (int)blockIdx.y * R, hi = min(total, lo + R);
     if (lo >= hi) return;
-    // the boxes of the tile's groups: wave-uniform, in scalar registers for the whole block
-    rh_box32 G[S4_TG];
-    {
-        const RH4_CONST_AS float *gq = (const RH4_CONST_AS float *)(uintptr_t)A.gb32;
-#pragma unroll
-        for (int g = 0; g < S4_TG; g++) {
-            const int64_t gg = g0 + g < A.ngroups ? g0 + g : A.ngroups - 1;
-            const RH4_CONST_AS float *q = gq + gg * 8;
-            G[g].cx = q[0]; G[g].cy = q[1]; G[g].cz = q[2]; G[g].hx = q[3]; G[g].hy = q[4]; G[g].hz = q[5]; G[g].hr = q[6];
-        }
-    }
     int base = 0;
     bool ran = false, weird = false;
     unsigned live = 0;
@@ -379,13 +381,13 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
         const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
         if (slo < shi) {                                                                                               \
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile and the list */        \
-            s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64);                                                          \
+            s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64, A.gb32, A.ngroups);                                       \
             __syncthreads();                                                                                           \
             live = 0;                                                                                                  \
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
-            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], G, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
+            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -401,7 +403,8 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
 // a32 / b32 are what the score kernel computes (the very same functions); a64 / b64 the same scaled quantities from
 // the reference's binary64 arithmetic.  |x32 - x64| has to stay below 1/2 for the classification to be sound; by
 // construction (RH_CLS_SAFETY) it should stay below ~1/8.  out[kind * 2 + {0, 1}] = max over the batch of |a32 - a64|,
-// |b32 - b64| (b only where the distance half is not surely outside: a64 > -1.5); out[8 + kind] = pairs looked at.
+// |b32 - b64| (sphere / cylinder: only where the distance half is not far outside, a64 > -2 -- the norm's error is relative
+// to the norm); out[8 + kind] = pairs looked at.
 struct S4AuditCand { rh_prep P; rh_cls C; double cNhi, wN, eDlo, wD; int kind, usable; };
 
 __global__ void __launch_bounds__(256)
@@ -446,8 +449,9 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             const double dt = ((inv * qx) * nx + (inv * qy) * ny) + (inv * qz) * nz;
             a64 = (Q.eDlo - fabs(nr - R)) / Q.wD;
             b64 = (sgn * dt - Q.cNhi) / Q.wN;
-            ea = fabs((double)a32 - a64);
-            if (a64 > -1.5) eb = fabs((double)b32 - b64);
+            // the norm's error is relative (4.5 u nr): far outside the band it exceeds any fixed margin and cannot matter
+            // (a is a few thousand widths below -1 there); what has to hold is the bound NEAR the band
+            if (a64 > -2.0) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
             counted = true;
         }
         if (!(ea == ea)) ea = 1e30;   // a NaN on one side only is a failure

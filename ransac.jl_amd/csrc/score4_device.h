@@ -18,19 +18,21 @@
 // |d| <= u.  With M = max |coordinate| of the point set, Nm = max |normal component|, T = M + max |centre coordinate|:
 //   plane     dn = n . np - c             |.32 - .|   <= u (5.05 |n|_1 Nm + 4.1 |c|)      (c = cos alpha, added first)
 //             d  = oz . p - oz . P0       |d32 - d|   <= 6.1 u (|oz|_1 M + |oz . P0|)
-//   sphere    dx = p - o (per component e = 2.01 u T);  nr = |dx|:  |nr32 - nr| <= sqrt(3) e + 4 u nr
+//   sphere    dx = p - o (per component e = 2.01 u T);  nr = |dx| = n2 rsq(n2):  |nr32 - nr| <= sqrt(3) e + 4.5 u nr
 //             L = sgn dx . np - c nr  (c = cos alpha; the test is L > 0):
 //                                         |L32 - L| <= Nm (3 e + 8.7 u nr) + |c| (sqrt(3) e + 6 u nr)
 //   cylinder  q = t - a (a . t), t = p - c0: per component e_q = u T (3.01 + 8.04 |a|_inf |a|_1);  then as the sphere
 //             with e_q for e
 //   cone      closed form rho^2 = |t|^2 - (t . a^)^2 against (k h -+ e)^2 (prefilter only: survivors take the exact test)
-// Every margin is the first-order bound x RH_CLS_SAFETY (4) plus the conversion error of the threshold itself; the
+// Every margin is the first-order bound x RH_CLS_SAFETY (2) plus the conversion error of the threshold itself; the
 // binary64 side's own rounding (~1e-15 relative) disappears in that factor.  rh_dbg_cls_audit (score4.hip) evaluates
-// max |q32 - q64| / (width of the ambiguity band, >= 2 m) over real batches with these very functions: sound below 1/2,
-// by construction below 1/8; tests/test_parity_gpu.py and tools/cls_audit.py hold it below 0.25.
+// max |q32 - q64| / (width of the ambiguity band = 2 m) over real batches with these very functions: sound below 1/2,
+// by construction below 1/4 (measured worst 0.21 = 0.84 of the first-order bound); tests/test_parity_gpu.py and
+// tools/cls_audit.py hold it below 0.3.  (Round 3 started with a safety factor of 4 and widths rounded up to powers of
+// two: 8.6 % of the cylinder pairs of the cfg3 batch were redone in binary64 then.)
 //
-// The plane record is SCALED: with wN, wD = powers of two >= 2 x margin, the kernel computes a = (dn - cN_hi) / wN and
-// b = (eD_lo - |d|) / wD directly (the scaling is folded into the coefficients, exactly), so that with t = min(a, b)
+// The records are SCALED: with wN, wD = 2 x margin, the kernel computes a = (dn - cN_hi) / wN and b = (eD_lo - |d|) / wD
+// directly (the scaling is folded into the coefficients before they are rounded to binary32), so that with t = min(a, b)
 //     sure <=> t > 0,   maybe <=> t > -1                       (two compares for both sides of both tests).
 //
 // Guards.  Non-finite or huge inputs would make binary32 overflow where binary64 does not, so a candidate is marked
@@ -45,7 +47,7 @@
 namespace rh4 {
 
 constexpr double RH_CLS_U = 5.9604644775390625e-08;   // 2^-24
-constexpr double RH_CLS_SAFETY = 4.0;
+constexpr double RH_CLS_SAFETY = 2.0;
 constexpr double RH_CLS_BIG = 1048576.0;               // 2^20
 
 // 64-byte record, gathered per lane (lane = (candidate, group) pair or (candidate, point) pair)
@@ -125,8 +127,8 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         const double mD = S * u * (6.1 * (z1 * M + fabs(zp)) + 4.0 * fabs(eps)) + 1e-30;
         ok = ok && cls_fin(mN) && cls_fin(mD) && cls_fin(zp) && mN < 1e30 && mD < 1e30;
         if (ok) {
-            const double wN = cls_pow2ceil(2.0 * mN), wD = cls_pow2ceil(2.0 * mD);
-            const double iN = cls_pow2recip(wN), iD = cls_pow2recip(wD);   // (multiplying by them scales exactly)
+            const double wN = 2.0 * mN, wD = 2.0 * mD;
+            const double iN = 1.0 / wN, iD = 1.0 / wD;
             const double cNhi = cosa + 0.5 * wN, eDlo = eps - 0.5 * wD;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
             o.f[0] = (float)(P.f[3] * iN); o.f[1] = (float)(P.f[4] * iN); o.f[2] = (float)(P.f[5] * iN);
@@ -165,7 +167,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             lipk = fmax(1.0, fabs(P.f[9] - 1.0));   // |1 - |a|^2| = |k - 1| (prep_derived)
         }
         const double s3 = 1.7320508075688774;
-        const double mD = S * (s3 * e + 5.0 * u * (fabs(R) + fabs(eps))) + 1e-30;
+        const double mD = S * (s3 * e + 7.0 * u * (fabs(R) + fabs(eps))) + 1e-30;   // (nr = n2 * rsq(n2): 4.5 u; R, eps and the scaled constant: 2 u)
         // a point the distance half may accept (|nr32 - R| < eps + wD / 2, wD < 4 mD) lies at least this far from the
         // centre / axis
         const double nrmin = R - eps - 3.0 * mD;
@@ -182,10 +184,10 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         else { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)P.f[3]; o.f[4] = (float)P.f[4]; o.f[5] = (float)P.f[5]; o.f[6] = (float)R; }
         if (ok) {
             const double mN2 = mN + 8.0 * u * Nm;   // + the rsq / multiply in place of the comparison against c * nr
-            const double wD = cls_pow2ceil(2.0 * mD), wN = cls_pow2ceil(2.0 * mN2);
+            const double wD = 2.0 * mD, wN = 2.0 * mN2;
             const double eDlo = eps - 0.5 * wD, cNhi = cosa + 0.5 * wN;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
-            const double iN = cls_pow2recip(wN), iD = cls_pow2recip(wD);
+            const double iN = 1.0 / wN, iD = 1.0 / wD;
             const float s0 = (float)iD, s1 = (float)(eDlo * iD), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN);
             if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             if (sph) { o.f[4] = s0; o.f[5] = s1; o.f[6] = s2; o.f[7] = s3f; }

@@ -93,7 +93,7 @@ def test_binary32_classifier_stays_inside_its_margins(small_scene):
     threshold to the binary64 test (csrc/score4_device.h).  The audit evaluates every (candidate, point) pair of
     the batch with the kernel's own binary32 functions against the reference's binary64 arithmetic: the error has
     to stay below 1/2 of the ambiguity band's width for the classification to be sound; the margins are built
-    with a safety factor of 4, so it stays below ~1/8."""
+    with a safety factor of 2, so it stays below 1/4."""
     pc, oc, truth = small_scene
     rng = np.random.default_rng(3)
     for eps, alpha_deg in [(0.3, 5.0), (0.01, 1.0), (5.0, 60.0)]:
@@ -107,7 +107,7 @@ def test_binary32_classifier_stays_inside_its_margins(small_scene):
         out = np.zeros(12)
         L.check(R.lib().rh_dbg_cls_audit(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_double))))
         assert out[8:11].min() > 1e5, out          # planes, spheres and cylinders were all looked at
-        assert out[:6].max() < 0.25, out           # sound below 0.5
+        assert out[:6].max() < 0.3, out            # sound below 0.5
 
 
 @pytest.mark.parametrize("eps,alpha_deg,seed", [(0.3, 5.0, 0), (0.01, 1.0, 1), (5.0, 60.0, 2), (40.0, 89.0, 3)])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Worst binary32 error of the score kernel's classifier in units of its margin width (rh_dbg_cls_audit), on synthetic
-scenes at several coordinate scales with jittered-truth and arbitrary candidates.  Sound below 0.5; expected below ~0.13
-(the margins carry a safety factor of 4).  python tools/cls_audit.py [cases] [seed]"""
+scenes at several coordinate scales with jittered-truth and arbitrary candidates.  Sound below 0.5; expected below 0.25
+(the margins carry a safety factor of 2).  python tools/cls_audit.py [cases] [seed]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

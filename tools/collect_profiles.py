@@ -40,32 +40,39 @@ def main(rnd):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    for name in ("bench_default_unprofiled.json", "bench_score_only_under_rocprof.json", "bench_under_rocprof.json"):
+    for name in ("bench_default_unprofiled.json", "bench_score_only_under_rocprof.json", "bench_under_rocprof.json",
+                 "bench_score_only_under_rocprof_cfg5.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
-    for sub, out in (("score_only", "kernel_stats_bench_score_only.csv"), ("with_e2e", "kernel_stats_bench_with_e2e.csv")):
+    for sub, out in (("score_only", "kernel_stats_bench_score_only.csv"), ("with_e2e", "kernel_stats_bench_with_e2e.csv"),
+                     ("score_only_cfg5", "kernel_stats_bench_score_only_cfg5.csv")):
         f = newest(os.path.join(src, sub, "**", "*kernel_stats.csv"))
         if f:
             shutil.copy(max(f, key=os.path.getmtime), os.path.join(dst, out))
-    acc = counters([os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write")])
-    rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean_KB": sum(v) / len(v), "max_KB": max(v)} for (k, c), v in acc.items()]
-    rows.sort(key=lambda r: (r["counter"], r["kernel"]))
-    json.dump(rows, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
-    acc = counters([os.path.join(src, "pmc_sq1"), os.path.join(src, "pmc_sq2")])
-    rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for (k, c), v in acc.items()]
-    rows.sort(key=lambda r: (r["kernel"], r["counter"]))
-    json.dump(rows, open(os.path.join(dst, "pmc_sq_counters.json"), "w"), indent=1)
+    rows = []
+    for sfx in ("", "_cfg5"):     # the default workload's passes and the ones taken with --workload cfg5
+        acc = counters([os.path.join(src, "pmc_fetch" + sfx), os.path.join(src, "pmc_write" + sfx)])
+        if acc:
+            rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean_KB": sum(v) / len(v), "max_KB": max(v)} for (k, c), v in acc.items()]
+            rows.sort(key=lambda r: (r["counter"], r["kernel"]))
+            json.dump(rows, open(os.path.join(dst, "pmc_hbm_traffic%s.json" % sfx), "w"), indent=1)
+        acc = counters([os.path.join(src, "pmc_sq1" + sfx), os.path.join(src, "pmc_sq2" + sfx)])
+        if acc:
+            rows = [{"kernel": k, "counter": c, "dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for (k, c), v in acc.items()]
+            rows.sort(key=lambda r: (r["kernel"], r["counter"]))
+            json.dump(rows, open(os.path.join(dst, "pmc_sq_counters%s.json" % sfx), "w"), indent=1)
+            for r in rows:
+                if "score4_kernel" in r["kernel"] and r["counter"] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"):
+                    print(sfx or "default", r["kernel"][:60], r["counter"], r["mean"])
     import importlib.util
     spec = importlib.util.spec_from_file_location("_b", os.path.join(ROOT, "ransac.jl_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    json.dump({"lib_source_hash": b.source_hash(), "command": "tools/profile_round.sh " + rnd,
-               "passes": "bench.py --no-cpu --no-cfg5 --no-cfg2 --no-e2e --steps 3 --warmup 1 --prewarm-ms 0, one rocprofv3 --pmc run per counter group"},
+    json.dump({"lib_source_hash": b.source_hash(), "command": "tools/profile_round.sh %s default; tools/profile_round.sh %s cfg5" % (rnd, rnd),
+               "passes": "bench.py [--workload cfg5] --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-e2e --steps 3 --warmup 1 --prewarm-ms 0, one rocprofv3 --pmc "
+                         "run per counter group, the program itself after `--`"},
               open(os.path.join(dst, "pmc_meta.json"), "w"), indent=1)
-    for r in rows:
-        if "score_groups_all" in r["kernel"] and r["counter"] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"):
-            print(r["counter"], r["mean"])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r2")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r3")

@@ -1,31 +1,46 @@
 #!/bin/bash
-# Collects a round's profiles on a GPU box (run through gpurun from the repo root): tools/profile_round.sh r2
-#   1. the default bench line, un-profiled;
-#   2. rocprofv3 --kernel-trace --stats of the bench (score only, and with the end-to-end legs);
-#   3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, and two SQ passes of 8 counters.
-# Output: gpurun_out/prof_<round>/ (copy what is to be judged into profiles/<round>/, tools/collect_profiles.py does it).
+# Collects a round's profiles on a GPU box (run through gpurun from the repo root):
+#     tools/profile_round.sh r3 [default|cfg5]
+#   default: 1. the default bench line, un-profiled;
+#            2. rocprofv3 --kernel-trace --stats of the bench (score + masks legs only, and with the end-to-end legs);
+#            3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, two SQ passes of 8 counters.
+#   cfg5:    the same stats + PMC passes for `--workload cfg5` (50M points, cones; the 50M-point refit scan).
+# The program itself follows `--` (no env / bash -c hop: the profiler's library has initialised the GPU by then).
+# Output: gpurun_out/prof_<round>/ (tools/collect_profiles.py copies what is to be judged into profiles/<round>/).
 set -e
 ROOT=$(pwd)
-RND=${1:-r2}
+RND=${1:-r3}
+WHAT=${2:-default}
 OUT=$ROOT/gpurun_out/prof_$RND
-rm -rf "$OUT"; mkdir -p "$OUT"
-python bench.py > "$OUT/bench_default_unprofiled.json" 2> "$OUT/bench_default.err"
-echo "bench done"
-cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
-echo "stats 1 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
-echo "stats 2 done"
+mkdir -p "$OUT"
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"
+SQ2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+if [ "$WHAT" = "default" ]; then
+    python bench.py > "$OUT/bench_default_unprofiled.json" 2> "$OUT/bench_default.err"
+    echo "bench done"
+    cd /tmp && export TMPDIR=/tmp
+    B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32"
+    SFX=""
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
+    echo "stats 1 done"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
+    echo "stats 2 done"
+else
+    cd /tmp && export TMPDIR=/tmp
+    B="$ROOT/bench.py --workload cfg5 --no-cpu --no-cfg5 --no-cfg2 --no-f32"
+    SFX="_cfg5"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only$SFX" -- python3 $B --no-e2e --steps 60 --warmup 10 > "$OUT/bench_score_only_under_rocprof$SFX.json" 2> "$OUT/score_only$SFX.err"
+    echo "stats cfg5 done"
+fi
 S="$B --no-e2e --steps 3 --warmup 1 --prewarm-ms 0"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $S > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $S > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch$SFX" -- python3 $S > "$OUT/pmc_fetch$SFX.json" 2> "$OUT/pmc_fetch$SFX.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write$SFX" -- python3 $S > "$OUT/pmc_write$SFX.json" 2> "$OUT/pmc_write$SFX.err"
 echo "pmc hbm done"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_sq1" -- python3 $S > "$OUT/pmc_sq1.json" 2> "$OUT/pmc_sq1.err"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq2" -- python3 $S > "$OUT/pmc_sq2.json" 2> "$OUT/pmc_sq2.err"
+rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d "$OUT/pmc_sq1$SFX" -- python3 $S > "$OUT/pmc_sq1$SFX.json" 2> "$OUT/pmc_sq1$SFX.err"
+rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d "$OUT/pmc_sq2$SFX" -- python3 $S > "$OUT/pmc_sq2$SFX.json" 2> "$OUT/pmc_sq2$SFX.err"
 echo "pmc sq done"
 # the traces are large: keep the stats and the counter tables only
 find "$OUT" -name '*kernel_trace.csv' -delete
 cd "$ROOT"
 echo "now run: python3 tools/collect_profiles.py $RND (in the build container, after gpurun merged gpurun_out/)"
-ls "$OUT" | head -40
+ls "$OUT" | head -60

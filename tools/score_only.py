@@ -23,15 +23,19 @@ f32 = bool(os.environ.get("F32"))   # a Float32 cloud (binary32 exact tests; sha
 pc = R.RANSACCloud(xyz.astype(np.float32), nrm.astype(np.float32), subs, force_eltype=np.float32) if f32 else R.RANSACCloud(xyz, nrm, subs)
 cp = R.params_to_c(R.ransacparameters(types), score_mode=L.SCORE_F64)
 cands = synth.jittered_candidates(truth, 4096, seed=0)
+if os.environ.get("KINDS"):   # e.g. KINDS=plane or KINDS=sphere,cylinder: the other candidates of the batch are dropped (per-region counters)
+    keep = set(os.environ["KINDS"].split(","))
+    cands = [c for c in cands if c[0] in keep]
+NB = len(cands)
 arr = bench.shapes_to_c(R, L, cands)
 if f32:
-    for i in range(4096):
+    for i in range(NB):
         R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
-batch = rdist.DeviceBatch(pc, arr, 4096)
-counts = torch.zeros(4096, dtype=torch.int32, device="cuda")
+batch = rdist.DeviceBatch(pc, arr, NB)
+counts = torch.zeros(NB, dtype=torch.int32, device="cuda")
 lib = R.lib()
 def step():
-    L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), 4096, C.byref(cp), C.c_void_p(counts.data_ptr()), None))
+    L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), NB, C.byref(cp), C.c_void_p(counts.data_ptr()), None))
 for _ in range(int(os.environ.get("PRE", "200"))): step()
 L.check(lib.rh_cloud_sync(pc._h))
 steps = int(os.environ.get("STEPS", "100"))
