@@ -307,7 +307,10 @@ class RANSACCloud:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().rh_cloud_destroy(h)
+            try:
+                lib().rh_cloud_destroy(h)
+            except (AttributeError, TypeError):
+                pass   # interpreter shutdown: the module globals are gone, the process frees the device memory
             self._h = None
 
     @property

@@ -49,7 +49,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd = [hipcc()] + FLAGS + os.environ.get("RH_EXTRA_FLAGS", "").split() + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     for s in SOURCES:
         cmd += ["-x", "hip", os.path.join(CSRC, s)]
     cmd += ["-ldl", "-o", SO]

@@ -181,7 +181,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
     (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_surv); (void)hipFree(c->d_occ);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
-    (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P);
+    (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab);
     (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
     (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
@@ -281,6 +281,7 @@ int rh_octree_ensure(rh_cloud *c, const double *xyz, int max_depth)
     }
     c->oct_depth = depth;
     c->oct_max_depth = max_depth;
+    RH_TRY(rhk_oct_build_tab(c));
     c->oct_built = true;
     return rhk_oct_sync_enabled(c);
 }

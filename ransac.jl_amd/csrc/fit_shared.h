@@ -5,6 +5,9 @@
 // Paths in comments are under /root/reference/src.
 #pragma once
 
+#if defined(RH_OCT_TIMING)
+#include <hip/hip_runtime.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 
@@ -454,6 +457,66 @@ struct OctView {
     const int32_t *prefix;    // exclusive popcount prefix per word of men; [nwords] = total
     int64_t n, nwords;
     int depth;
+    // Optional (device sampler): tab[k] = lower_bound(k << tab_shift), k = 0 .. 8^(tab_level - 1) -- the first Morton
+    // position of every level-tab_level cell.  A level-l cell, l <= tab_level, is a run of such cells, so its bounds are
+    // two table entries; a deeper cell is searched for inside its level-tab_level ancestor.  The results are those of the
+    // plain binary searches (a lower bound is unique), found in 2-4 dependent loads instead of ~50.
+    const int32_t *tab = nullptr;
+    int tab_level = 0;
+
+    // lower_bound(key) on [lo, hi]: the answer is known to lie in that range.  8-ary rounds (seven independent loads)
+    RH_HD int64_t lower_bound_in(uint64_t key, int64_t lo, int64_t hi) const
+    {
+        while (hi - lo > 7) {
+            const int64_t step = (hi - lo + 7) >> 3;   // pivots lo + i * step - 1, i = 1..7: code[pv] < key  <=>  answer > pv
+            // (the seven loads are unconditional, on clamped addresses, so that they are in flight together)
+            uint64_t cv[7];
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                const int64_t pv = lo + i * step - 1;
+                cv[i - 1] = code[pv < hi ? pv : hi - 1];
+            }
+            int k = 0;   // codes ascend: the pivots below the answer come first
+#pragma unroll
+            for (int i = 1; i < 8; i++) k += ((lo + i * step - 1 < hi) & (cv[i - 1] < key)) ? 1 : 0;
+            const int64_t nlo = lo + k * step;
+            hi = (k < 7 && nlo + step - 1 < hi) ? nlo + step - 1 : hi;
+            lo = nlo < hi ? nlo : hi;
+        }
+        // at most seven candidates left: the answer is lo + the number of them below the key
+        uint64_t cv[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) cv[i] = code[lo + i < hi ? lo + i : (hi > 0 ? hi - 1 : 0)];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) k += ((lo + i < hi) & (cv[i] < key)) ? 1 : 0;
+        return lo + k;
+    }
+    // [lo, hi) of the level-`level` cell that holds Morton position q0
+    RH_HD void cell_bounds(int level, int64_t q0, int64_t *lo_out, int64_t *hi_out) const
+    {
+        const int shift = 3 * (21 - (level - 1));
+        if (shift >= 63) { *lo_out = 0; *hi_out = n; return; }
+        const uint64_t key = code[q0] >> shift;
+        const bool last = (((key + 1) << shift) >> shift) != key + 1;   // the cell reaches the end of the code space
+        if (tab == nullptr) {
+            *lo_out = lower_bound(key << shift);
+            *hi_out = last ? n : lower_bound((key + 1) << shift);
+            return;
+        }
+        const int tshift = 3 * (21 - (tab_level - 1));
+        if (level <= tab_level) {
+            const int up = shift - tshift;
+            *lo_out = tab[key << up];
+            *hi_out = last ? n : tab[(key + 1) << up];
+            return;
+        }
+        // deeper than the table: inside the ancestor cell [a, b); the cell starts at or before q0 and ends after it
+        const uint64_t anc = code[q0] >> tshift;
+        const int64_t a = tab[anc], b = tab[anc + 1];
+        *lo_out = lower_bound_in(key << shift, a, q0);
+        *hi_out = last ? n : lower_bound_in((key + 1) << shift, q0 + 1, b);
+    }
 
     RH_HD int64_t lower_bound(uint64_t key) const
     {
@@ -485,8 +548,56 @@ struct OctView {
         while (!((m >> b) & 1ULL)) b++;
         return lo * 64 + b;
     }
+    // select(r) when the r-th enabled point is known to lie in the words [wlo, whi] and prefix[wlo] < r: the same word
+    // (the last one whose exclusive prefix is below r), found by 8-ary rounds inside the bracket
+    RH_HD int64_t select_in(int64_t r, int64_t wlo, int64_t whi) const
+    {
+        int64_t lo = wlo, hi = whi;   // answer in [lo, hi]
+        while (hi - lo >= 8) {
+            const int64_t step = (hi - lo + 8) >> 3;
+            int32_t pv7[7];
+#pragma unroll
+            for (int i = 1; i < 8; i++) {
+                const int64_t pv = lo + i * step;
+                pv7[i - 1] = prefix[pv <= hi ? pv : hi];
+            }
+            int k = 0;   // prefix is non-decreasing: the pivots with prefix < r are the first k
+#pragma unroll
+            for (int i = 1; i < 8; i++) k += ((lo + i * step <= hi) & ((int64_t)pv7[i - 1] < r)) ? 1 : 0;
+            lo += k * step;
+            hi = hi < lo + step - 1 ? hi : lo + step - 1;
+        }
+        {
+            int32_t pv7[7];
+#pragma unroll
+            for (int i = 1; i < 8; i++) pv7[i - 1] = prefix[lo + i <= hi ? lo + i : hi];
+            int k = 0;
+#pragma unroll
+            for (int i = 1; i < 8; i++) k += ((lo + i <= hi) & ((int64_t)pv7[i - 1] < r)) ? 1 : 0;
+            lo += k;
+        }
+        uint64_t m = men[lo];
+        for (int64_t t = 1; t < r - prefix[lo]; t++) m &= m - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return lo * 64 + __builtin_ctzll(m);
+#else
+        int b = 0;
+        while (!((m >> b) & 1ULL)) b++;
+        return lo * 64 + b;
+#endif
+    }
 };
 
+#if defined(RH_OCT_TIMING)
+static __device__ unsigned long long rh_oct_t[16];
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RH_OCT_TIMING)
+#define RH_OCT_T(i) do { const unsigned long long t_ = wall_clock64(); atomicAdd(&rhfit::rh_oct_t[i], t_ - t0_); t0_ = t_; } while (0)
+#define RH_OCT_T0 unsigned long long t0_ = wall_clock64()
+#else
+#define RH_OCT_T(i) do { } while (0)
+#define RH_OCT_T0 do { } while (0)
+#endif
 template <int DN, class En>
 RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P, int64_t n, int64_t n_enabled,
                                      int drawN_rt, uint64_t *x, int64_t *sd, uint32_t *ndraws, bool *gave_up, int *level_out)
@@ -494,12 +605,14 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
     const int drawN = DN > 0 ? DN : drawN_rt;
     *level_out = 1;
     if (n_enabled <= 0) return false;
+    RH_OCT_T0;
     int64_t r1 = set_stream_range(x, n);
     uint32_t nd = 1;
     while (!en.test(r1 - 1)) {
         r1 = set_stream_range(x, n);
         if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
     }
+    RH_OCT_T(0);
     const double u = (double)(set_stream_next(x) >> 11) * (1.0 / 9007199254740992.0);
     *ndraws += nd + 1;
     int level = oc.depth;
@@ -509,26 +622,52 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
         if (u < acc) { level = l + 1; break; }
     }
     *level_out = level;
-    const int shift = 3 * (21 - (level - 1));
     int64_t lo, hi;
-    if (shift >= 63) { lo = 0; hi = oc.n; }
-    else {
-        const uint64_t key = oc.code[oc.pos[r1 - 1]] >> shift;
-        lo = oc.lower_bound(key << shift);
-        hi = (((key + 1) << shift) >> shift != key + 1) ? oc.n : oc.lower_bound((key + 1) << shift);
-    }
+    oc.cell_bounds(level, (int64_t)oc.pos[r1 - 1], &lo, &hi);
+    RH_OCT_T(1);
     const int64_t base = oc.rank(lo), ne = oc.rank(hi) - base;
+    RH_OCT_T(2);
     if (ne < drawN) return false;
     sd[0] = r1;
+    if (oc.tab != nullptr) {
+        // Device form.  The ranks of all the other points are drawn first, as if no redraw happened, and looked up
+        // together (independent searches, bracketed by the cell's words); a pick that hits the first point -- the one
+        // case that changes the stream (fitting.jl:416-419) -- sends the set through the one-at-a-time loop below.
+        const uint64_t xs = *x;
+        const int64_t wlo = lo >> 6, whi = (hi - 1) >> 6;
+        bool redo = false;
 #pragma unroll
-    for (int q = 1; q < drawN; q++) {
-        int64_t pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
-        ++*ndraws;
-        if (pick == sd[0]) {
-            pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
-            ++*ndraws;
+        for (int q = 1; q < drawN; q++) sd[q] = base + set_stream_range(x, ne);
+#pragma unroll
+        for (int q = 1; q < drawN; q++) sd[q] = oc.select_in(sd[q], wlo, whi);
+        RH_OCT_T(3);
+#pragma unroll
+        for (int q = 1; q < drawN; q++) { sd[q] = (int64_t)oc.perm[sd[q]] + 1; redo = redo || sd[q] == sd[0]; }
+        RH_OCT_T(4);
+        if (!redo) *ndraws += (uint32_t)(drawN - 1);
+        else {
+            *x = xs;
+            for (int q = 1; q < drawN; q++) {
+                int64_t pick = (int64_t)oc.perm[oc.select_in(base + set_stream_range(x, ne), wlo, whi)] + 1;
+                ++*ndraws;
+                if (pick == sd[0]) {
+                    pick = (int64_t)oc.perm[oc.select_in(base + set_stream_range(x, ne), wlo, whi)] + 1;
+                    ++*ndraws;
+                }
+                sd[q] = pick;
+            }
         }
-        sd[q] = pick;
+    } else {
+#pragma unroll
+        for (int q = 1; q < drawN; q++) {
+            int64_t pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
+            ++*ndraws;
+            if (pick == sd[0]) {
+                pick = (int64_t)oc.perm[oc.select(base + set_stream_range(x, ne))] + 1;
+                ++*ndraws;
+            }
+            sd[q] = pick;
+        }
     }
     bool distinct = true;
 #pragma unroll

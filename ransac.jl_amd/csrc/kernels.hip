@@ -1667,6 +1667,41 @@ int rhk_word_prefix(rh_cloud *c, const uint64_t *words, int64_t nwords, int32_t 
     return RH_OK;
 }
 
+// tab[k] = first Morton position whose code is >= k << shift (k = entries - 1: n): the cell directory of the octree
+// sampler (fit_shared.h, OctView::cell_bounds)
+__global__ void __launch_bounds__(256)
+oct_tab_kernel(const uint64_t *__restrict__ code, int64_t n, int shift, int64_t entries, int32_t *__restrict__ tab)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= entries) return;
+    int64_t lo = 0, hi = n;
+    if (k == entries - 1) lo = n;
+    else {
+        const uint64_t key = (uint64_t)k << shift;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (code[mid] < key) lo = mid + 1; else hi = mid;
+        }
+    }
+    tab[k] = (int32_t)lo;
+}
+
+int rhk_oct_build_tab(rh_cloud *c)
+{
+    (void)hipFree(c->oct_tab);
+    c->oct_tab = nullptr;
+    c->oct_tab_level = 0;
+    if (c->n == 0) return RH_OK;
+    const int level = c->oct_depth < 8 ? c->oct_depth : 8;   // 8^7 + 1 entries at most (8 MB)
+    const int64_t entries = ((int64_t)1 << (3 * (level - 1))) + 1;
+    RH_HIP(hipMalloc((void **)&c->oct_tab, sizeof(int32_t) * (size_t)entries));
+    hipLaunchKernelGGL(oct_tab_kernel, dim3(cdiv(entries, 256)), dim3(256), 0, c->stream, c->oct_code, c->n, 3 * (21 - (level - 1)),
+                       entries, c->oct_tab);
+    RH_HIP(hipGetLastError());
+    c->oct_tab_level = level;
+    return RH_OK;
+}
+
 int rhk_oct_gather_enabled(rh_cloud *c)
 {
     if (c->n == 0) return RH_OK;

@@ -119,6 +119,8 @@ struct rh_cloud {
     int32_t *oct_pos = nullptr;        // [n] original index0 -> Morton position
     uint64_t *oct_men = nullptr;       // [nwords] enabled bits in Morton order
     int32_t *oct_prefix = nullptr;     // [nwords + 1]
+    int32_t *oct_tab = nullptr;        // first Morton position of every level-oct_tab_level cell (+ n at the end)
+    int oct_tab_level = 0;
     double *oct_P = nullptr;           // level distributions of a speculation window
     int64_t oct_P_cap = 0;
     std::vector<uint64_t> h_oct_code;  // host twins (host-side sampling, enabled mirror)
@@ -257,6 +259,7 @@ bool rhk_refit_is_culled(const rh_cloud *c);
 int rhk_refitk_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double cosa, bool apply);
 int rhk_refitk_mask_f32(rh_cloud *c, const void *prepf, const rh_prep &P, int kind, double eps, double cosa, bool apply);
 int rhk_group_bounds_of(rh_cloud *c, const double *pts, int64_t stride, int64_t count, int64_t ngroups, double *gb, int64_t gstride);
+int rhk_oct_build_tab(rh_cloud *c);                                     // the sampler's cell directory (needs oct_depth)
 int rhk_oct_gather_enabled(rh_cloud *c);                                // oct_men = enabled in Morton order
 int rhk_compact_mask(rh_cloud *c, const uint64_t *mask, int64_t nwords, int64_t *idx_out, int64_t cap,
                      int32_t *d_total);

@@ -182,6 +182,10 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
     }
     if (gave_up) atomicExch(gave_up_flag, 1);
     set_level[t] = ok ? level : 0;
+#ifdef RH_OCT_TIMING
+    unsigned long long t0_ = wall_clock64();
+    if (Pwin != nullptr) atomicAdd(&rhfit::rh_oct_t[8], 1ULL);
+#endif
     if (!ok) return;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -192,7 +196,12 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
         w[0] = a.x; w[total] = a.y; w[2 * total] = b.x;
         w[3 * total] = b.y; w[4 * total] = c.x; w[5 * total] = c.y;
     }
+#ifdef RH_OCT_TIMING
+    if (Pwin != nullptr) { RH_OCT_T(5); }
+#endif
 }
+
+
 
 template <int DN, bool CONE>
 __global__ void __launch_bounds__(128)
@@ -379,6 +388,14 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
 
 }  // namespace
 
+#ifdef RH_OCT_TIMING
+extern "C" int rh_dbg_oct_timing(unsigned long long *out)
+{
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rhfit::rh_oct_t), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
                     int32_t head_cap, void *h_status, void *h_entries, int32_t *h_counts)
 {
@@ -462,6 +479,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     rhfit::OctView oc;
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
+    if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; }
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
     if (d_P == nullptr && n_enabled > 0 && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));

@@ -371,9 +371,6 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     int nch[4], total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
-    const int lo = (int)blockIdx.y * R, hi = min(total, lo + R);
-    if (lo >= hi) return;
-    int base = 0;
     bool ran = false, weird = false;
     unsigned live = 0;
 #define RH_S4_BODY(K)                                                                                                  \
@@ -392,10 +389,16 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
         }                                                                                                              \
         base += nch[K];                                                                                                \
     }
-    RH_S4_BODY(RH_CONE)
-    RH_S4_BODY(RH_CYLINDER)
-    RH_S4_BODY(RH_SPHERE)
-    RH_S4_BODY(RH_PLANE)
+    // (the grid's rows cover the launch's bound on the number of candidates; the bins on the device may hold more -- a
+    // window of the candidate loop is launched before its list length is known -- so the rows are walked grid-stride)
+    for (int lo = (int)blockIdx.y * R; lo < total; lo += (int)gridDim.y * R) {
+        const int hi = min(total, lo + R);
+        int base = 0;
+        RH_S4_BODY(RH_CONE)
+        RH_S4_BODY(RH_CYLINDER)
+        RH_S4_BODY(RH_SPHERE)
+        RH_S4_BODY(RH_PLANE)
+    }
 #undef RH_S4_BODY
 }
 

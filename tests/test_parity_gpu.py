@@ -452,6 +452,29 @@ def test_ransac_octree_sampling(prims, kinds, seed, host, monkeypatch):
         R.ransac(pc2, R.params_to_c(params, octree_sampling=True), seed=seed)
 
 
+def test_ransac_octree_window_longer_than_its_launch_bound():
+    """A window of the candidate loop is put on the stream before the length of its candidate list is known: the score
+    launch is sized from the previous windows' lengths.  Thousands of minimal sets per iteration with octree sampling
+    give a first window with more candidates than that bound covers (1024 at the start) -- every one of them has to
+    be scored all the same (the kernel walks its rows grid-stride).  Regression: the culled kernel once left the
+    candidates beyond the bound at count 0, and WHICH ones depended on the order the fits were appended in."""
+    prims = ["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"]
+    xyz, nrm, truth = synth.make_cloud(60_000, prims, 0.2, seed=701)
+    subs = synth.make_subsets(60_000, 6, seed=7)
+    types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+    params = R.ransacparameters(types, iteration={"minsubsetN": 6000, "τ": 300, "itermax": 10, "prob_det": 0.9})
+    kw = dict(score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
+    pc, oc, got, exp, stats = run_both(xyz, nrm, subs, params, seed=5, octree_sampling=True, **kw)
+    assert stats["candidates_scored"] > 1024 * 1.5 * stats["iterations"]   # the first window alone is beyond the bound
+    assert_same_run(pc, oc, got, exp, stats)
+    # and the same run again on the same cloud gives the same thing (the defect was a race on list positions)
+    pc.enable_all()
+    got2, _, stats2 = R.ransac(pc, R.params_to_c(params, octree_sampling=True, **kw), seed=5, return_stats=True)
+    assert stats2["draws"] == stats["draws"] and len(got2) == len(got)
+    for a, b in zip(got, got2):
+        assert np.array_equal(a.inpoints, b.inpoints)
+
+
 @pytest.mark.parametrize("cache", [True, False])
 def test_ransac_calls_in_a_row_on_one_cloud(cache, monkeypatch):
     """rh_ransac parks its windows, device store and pinned scratch on the cloud for the next call
