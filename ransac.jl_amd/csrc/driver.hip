@@ -424,12 +424,21 @@ namespace {
 #define RUNH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rh_set_error("%s: %s", #x, hipGetErrorString(e_)); return RH_E_NODEVICE; } } while (0)
 
 // a sampled window in flight: device list + status, pinned landing zones, completion event
+constexpr int RH_CHAIN_MAX = 64;   // iterations per chained octree window, at most
 struct Window {
     rh_cand_entry *d_entries = nullptr, *h_entries = nullptr;   // h_entries: pinned, head of the list
     int32_t entries_cap = 0;
     char *d_status = nullptr, *h_status = nullptr;              // int32 count, int32 gave_up, u64 draws[W]
     int32_t *d_counts = nullptr, *h_counts = nullptr;           // inlier counts per list entry (h: pinned head)
     bool scored = false;                                        // the counts were computed with the window
+    // chained octree windows (run_streams_device): pinned state as uploaded, per-iteration headers + events, and pinned
+    // twins of the whole list and its counts (every iteration's slice lands at its list positions)
+    rh_oct_state *h_ost = nullptr;
+    rh_oct_iter_hdr *h_hdr = nullptr;
+    rh_cand_entry *h_list = nullptr;
+    int32_t *h_list_counts = nullptr;
+    int32_t h_list_cap = 0;
+    hipEvent_t ev_it[RH_CHAIN_MAX] = {};
     hipEvent_t ev = nullptr;
     int64_t k = 0;
     int32_t W = 0;
@@ -440,6 +449,8 @@ void window_free(Window &w)
 {
     (void)hipFree(w.d_entries); (void)hipFree(w.d_status); (void)hipFree(w.d_counts);
     (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
+    (void)hipHostFree(w.h_ost); (void)hipHostFree(w.h_hdr); (void)hipHostFree(w.h_list); (void)hipHostFree(w.h_list_counts);
+    for (hipEvent_t e : w.ev_it) if (e) (void)hipEventDestroy(e);
     if (w.ev) (void)hipEventDestroy(w.ev);
     w = Window();
 }
@@ -1030,7 +1041,7 @@ struct Driver {
         const int64_t K = Kmax;  // longest window
         // window length in use: slow start (an extraction within the first iterations would throw a long first
         // window away), doubled by every window that is used to its end, halved by one that is cut short
-        int64_t Kcur = octree ? 1 : std::min<int64_t>(Kmax, 2);
+        int64_t Kcur = octree ? 1 : std::min<int64_t>(Kmax, 2);   // (chained octree windows: Kchain, below)
         // (sized for the longest window whatever this run's parameters: the windows outlive the run on the cloud)
         const size_t status_bytes = (8 + sizeof(unsigned long long) * (size_t)512 + 63) / 64 * 64;
         for (Window &w : win) {
@@ -1060,6 +1071,160 @@ struct Driver {
         std::vector<int32_t> counts, levels, wcounts, order;
         std::vector<int64_t> slots;
         const int T = p->n_shape_types;
+        // Octree windows, one process: CHAINED.  Every iteration's scores change the level distribution the next
+        // one samples from (fitting.jl:184, octree.jl:198-205), so nothing can be sampled ahead.  Instead the whole
+        // iteration -- sampling, fits, scoring, the level update and the copy of its candidates to the host
+        // (rhk_oct_advance) -- is queued W times back to back, with an event behind each, and the host replays iteration
+        // i while the device runs i + 1, ...: recordscore!, the extraction test, updatelevelweight, checking the
+        // device's level distribution against its own bit for bit.  The device ends the window (stop flag: the remaining
+        // launches return at once) at the first iteration whose extraction test passes in its arithmetic; the decision
+        // is the host's.
+        const bool chain = octree && fused_score && mp == nullptr && rh_score_v4_enabled(c) && !getenv("RH_NO_OCT_CHAIN");
+        if (chain) {
+            int64_t Kchain = 8;
+            if (const char *e = getenv("RH_OCT_CHAIN_W")) Kchain = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
+            if (c->oct_state == nullptr) RUNH(hipMalloc((void **)&c->oct_state, sizeof(rh_oct_state)));
+            auto ensure_pinned = [&](Window &w) -> int {
+                if (w.h_ost == nullptr) {
+                    RUNH(hipHostMalloc((void **)&w.h_ost, sizeof(rh_oct_state)));
+                    RUNH(hipHostMalloc((void **)&w.h_hdr, sizeof(rh_oct_iter_hdr) * RH_CHAIN_MAX));
+                    for (hipEvent_t &e : w.ev_it) RUNH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
+                if (w.h_list_cap < w.entries_cap) {
+                    (void)hipHostFree(w.h_list); (void)hipHostFree(w.h_list_counts);
+                    w.h_list = nullptr; w.h_list_counts = nullptr; w.h_list_cap = 0;
+                    RUNH(hipHostMalloc((void **)&w.h_list, sizeof(rh_cand_entry) * (size_t)w.entries_cap));
+                    RUNH(hipHostMalloc((void **)&w.h_list_counts, sizeof(int32_t) * (size_t)w.entries_cap));
+                    w.h_list_cap = w.entries_cap;
+                }
+                return RH_OK;
+            };
+            const int32_t per_it = (int32_t)std::min<int64_t>((int64_t)p->minsubsetN * T, (int64_t)INT32_MAX / 2);
+            int cur = 0;
+            int64_t k = 1;
+            while (k <= p->itermax) {
+                if (en.count < p->tau) break;
+                Window &w = win[cur];
+                cur = 1 - cur;
+                const double t0 = now_s();
+                // one iteration's candidates must fit the list (a longer list is only a matter of how far a window gets)
+                if (w.entries_cap < per_it + per_it / 4) {
+                    RUNH(hipStreamSynchronize(c->stream));
+                    (void)hipFree(w.d_entries); (void)hipFree(w.d_counts);
+                    w.d_entries = nullptr; w.d_counts = nullptr;
+                    w.entries_cap = per_it + per_it / 4;
+                    RUNH(hipMalloc((void **)&w.d_entries, sizeof(rh_cand_entry) * (size_t)w.entries_cap));
+                    RUNH(hipMalloc((void **)&w.d_counts, sizeof(int32_t) * (size_t)w.entries_cap));
+                }
+                RUN(ensure_pinned(w));
+                bool certain = false;
+                if (!store.empty()) {
+                    int64_t lb[4] = { 0, (int64_t)store.size(), cc[2], k * p->minsubsetN };
+                    certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
+                }
+                const int32_t W = (int32_t)std::min<int64_t>(certain ? 1 : Kchain, p->itermax - k + 1);
+                // ---- queue the window
+                rh_oct_state &h = *w.h_ost;
+                memset(&h, 0, sizeof h);
+                for (int i = 0; i < od; i++) { h.S[i] = oS[i]; h.P[i] = oP[i]; }
+                h.has_best = store.empty() ? 0 : 1;
+                h.best_E = store.empty() ? 0.0 : store[(size_t)best].E;
+                h.store_n = (long long)store.size();
+                h.cc2 = cc[2];
+                RUNH(hipMemcpyAsync(c->oct_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+                RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));
+                RUN(rh_ensure_batch(c, w.entries_cap));
+                const uint64_t *enw[4];
+                const rh_prep *pr[4];
+                const int32_t *og[4], *nkp[4];
+                const void *clsw[4];
+                const float *boxw[4];
+                for (int q = 0; q < 4; q++) {
+                    enw[q] = (q == RH_SPHERE && !p->sphere_uses_enabled) ? nullptr : c->sub_enabled;
+                    pr[q] = c->d_prep + (int64_t)q * c->batch_cap;
+                    og[q] = c->d_orig + (int64_t)q * c->batch_cap;
+                    nkp[q] = c->d_nk + q;
+                    clsw[q] = (const char *)c->d_qpre + (size_t)q * (size_t)c->batch_cap * 64;
+                    boxw[q] = c->d_box + (int64_t)q * c->batch_cap;
+                }
+                c->s4_stop = &c->oct_state->stop;
+                c->s4_open_count = true;
+                int rc = RH_OK;
+                for (int32_t it = 0; it < W && rc == RH_OK; it++) {
+                    rc = rhk_sample_fit(c, p, rng->s[0], k + it, 1, (int32_t)en.count, c->oct_state->P, w.d_entries, w.entries_cap, w.d_status, 1,
+                                        c->d_nk, it, c->oct_state);
+                    if (rc == RH_OK) rc = rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, per_it, w.d_counts, 1, p->eps,
+                                                           p->cos_alpha, c->oct_state);
+                    if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>(2 * cnt_est, 1024)), p->eps,
+                                                               p->cos_alpha, w.d_counts, nullptr, nullptr, clsw, boxw, 4 * c->batch_cap);
+                    if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k + it, w.h_list,
+                                                          w.h_list_counts, w.h_hdr);
+                    if (rc == RH_OK && hipEventRecord(w.ev_it[it], c->stream) != hipSuccess) { rh_set_error("hipEventRecord failed"); rc = RH_E_NODEVICE; }
+                }
+                c->s4_stop = nullptr;
+                c->s4_open_count = false;
+                if (rc != RH_OK) return rc;
+                nwin++;
+                const double tw0 = now_s();
+                tw[0] += tw0 - t0;
+                t_sample += tw0 - t0;
+                // ---- replay it, iteration by iteration, as the results arrive
+                bool stop = false, did = false, regrow = false;
+                int32_t it = 0;
+                for (; it < W; it++) {
+                    const double ta = now_s();
+                    RUNH(hipEventSynchronize(w.ev_it[it]));
+                    const double tb = now_s();
+                    tw[1] += tb - ta;
+                    const rh_oct_iter_hdr &H = w.h_hdr[it];
+                    if (H.skipped) break;                       // the device saw an extraction coming that the host did not take: go on from here
+                    if (H.gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
+                    if (H.overflow) { regrow = true; break; }   // the list is full: this iteration is drawn again in a longer one
+                    if (en.count < p->tau) { stop = true; break; }
+                    const int32_t cnt = H.end - H.start;
+                    order.resize((size_t)cnt);
+                    for (int32_t i = 0; i < cnt; i++) order[(size_t)i] = H.start + i;
+                    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return w.h_list[a].slot < w.h_list[b].slot; });
+                    cands.resize((size_t)cnt);
+                    levels.resize((size_t)cnt);
+                    counts.resize((size_t)cnt);
+                    for (int32_t i = 0; i < cnt; i++) {
+                        const rh_cand_entry &e = w.h_list[order[(size_t)i]];
+                        cands[(size_t)i] = e.shape; levels[(size_t)i] = e.level;
+                        counts[(size_t)i] = w.h_list_counts[order[(size_t)i]];
+                    }
+                    cnt_est = cnt;
+                    rng->draws += (int64_t)H.draws;
+                    const double tc = now_s();
+                    tw[2] += tc - tb;
+                    t_sample += tc - ta;
+                    RUN(finish_iteration(k + it, cands.data(), levels.data(), cnt, counts.data(), &did, &stop));
+                    if (memcmp(oP, H.P, sizeof(double) * (size_t)od) != 0) {
+                        // (the device advanced the level distribution with the operations of update_level_probs on the sums
+                        // it built in candidate order: any difference is a defect, never a rounding matter)
+                        rh_set_error("rh_ransac: the device's level distribution left the host's at iteration %lld", (long long)(k + it));
+                        return RH_E_INTERNAL;
+                    }
+                    if (stop || did) { it++; break; }
+                }
+                k += it;
+                if (regrow) {
+                    RUNH(hipStreamSynchronize(c->stream));
+                    for (Window &g : win) {
+                        (void)hipFree(g.d_entries); (void)hipFree(g.d_counts);
+                        g.d_entries = nullptr; g.d_counts = nullptr;
+                        g.entries_cap *= 2;
+                        RUNH(hipMalloc((void **)&g.d_entries, sizeof(rh_cand_entry) * (size_t)g.entries_cap));
+                        RUNH(hipMalloc((void **)&g.d_counts, sizeof(int32_t) * (size_t)g.entries_cap));
+                    }
+                }
+                if (stop) break;
+            }
+            // the tail of a window that was cut short may still be in the queue; the status blocks go back zeroed
+            for (Window &w : win) RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));
+            RUNH(hipStreamSynchronize(c->stream));
+            return RH_OK;
+        }
         auto issue = [&](Window &w, int64_t k0, int32_t W) -> int {
             const double *d_P = nullptr;
             if (octree) {
@@ -1106,8 +1271,11 @@ struct Driver {
                     clsw[q] = (const char *)c->d_qpre + (size_t)q * (size_t)c->batch_cap * 64;
                     boxw[q] = c->d_box + (int64_t)q * c->batch_cap;
                 }
-                RUN(rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr, nullptr,
-                                         c->qpre_v4 ? clsw : nullptr, c->qpre_v4 ? boxw : nullptr, 4 * c->batch_cap));
+                c->s4_open_count = true;   // (bound is a guess: the kernel's tail launch covers a longer list)
+                const int rcs = rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr, nullptr,
+                                                     c->qpre_v4 ? clsw : nullptr, c->qpre_v4 ? boxw : nullptr, 4 * c->batch_cap);
+                c->s4_open_count = false;
+                if (rcs != RH_OK) return rcs;
                 w.scored = true;
             }
             // status + head of the list (+ counts) land in pinned host memory through one small kernel

@@ -679,7 +679,7 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
 
 // level distribution update (src/octree.jl:198-205, x = 9/10) with the initialisation the docs
 // describe; left unchanged while no score has been collected or if the formula leaves the simplex
-inline void update_level_probs(double *P, const double *sigma, int d)
+RH_HD void update_level_probs(double *P, const double *sigma, int d)
 {
     double w = 0, Pn[32];
     for (int i = 0; i < d; i++) w += sigma[i] / P[i];

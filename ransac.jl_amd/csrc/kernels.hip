@@ -142,9 +142,11 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
 __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
                                     int32_t cap_entries, rh_prep *__restrict__ prep, int32_t *__restrict__ orig,
                                     int32_t *__restrict__ nk, int64_t cap, int32_t *__restrict__ counts,
-                                    rh_pre *__restrict__ qpre, const PreArgs QA)
+                                    rh_pre *__restrict__ qpre, const PreArgs QA, const rh_oct_state *__restrict__ ost)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (an iteration of a chained octree window takes the entries from its start in the list on; nothing after a stop)
+    if (ost != nullptr && ost->stop != 0) return;
+    const int i = (ost != nullptr ? ost->start : 0) + blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int b = min(*count_ptr, cap_entries);
     rh_shape s;
@@ -1212,14 +1214,15 @@ static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa)
 }
 
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
-                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps, const double *cosa)
+                     int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps, const double *cosa,
+                     const rh_oct_state *ost)
 {
     if (!nk_is_zero) RH_HIP(hipMemsetAsync(c->d_nk, 0, 4 * sizeof(int32_t), c->stream));
     const PreArgs QA = pre_args(c, eps, cosa);
     if (launch_bound <= 0) return RH_OK;
     hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
                        cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts,
-                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA);
+                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA, ost);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -53,6 +53,7 @@ constexpr int64_t RH_G2_MIN_POINTS = 8192;               // below this the brute
 constexpr int64_t RH_KREFIT_MIN = 1 << 21;               // clouds from this size on take the culled refit scan (korder.hip): 1M points 17 us culled against 13 us streaming, 10M 24 against 80
 
 // ---- the cloud --------------------------------------------------------------
+struct rh_oct_state;
 struct rh_cloud {
     int device = -1;
     hipStream_t stream = nullptr;      // the stream every launch / copy of this cloud goes to
@@ -119,6 +120,14 @@ struct rh_cloud {
     int32_t *oct_pos = nullptr;        // [n] original index0 -> Morton position
     uint64_t *oct_men = nullptr;       // [nwords] enabled bits in Morton order
     int32_t *oct_prefix = nullptr;     // [nwords + 1]
+    rh_oct_state *oct_state = nullptr; // chained octree windows: the window's state,
+    const int32_t *s4_stop = nullptr;  //   its stop flag as the score kernel sees it (null outside such windows),
+    bool s4_open_count = false;        // the candidate count of the score launches being queued is a guess (windows of the candidate loop)
+    int32_t *oct_adv_tab = nullptr;    //   the (level, slot) table of rhk_oct_advance, its bitmap (kept zero) and the sorted scores
+    unsigned long long *oct_adv_bits = nullptr;
+    int64_t oct_adv_cells = 0;
+    double *oct_adv_E = nullptr;
+    int64_t oct_adv_E_cap = 0;
     int32_t *oct_tab = nullptr;        // first Morton position of every level-oct_tab_level cell (+ n at the end)
     int oct_tab_level = 0;
     double *oct_P = nullptr;           // level distributions of a speculation window
@@ -206,9 +215,10 @@ int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int6
 int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep,
                     int32_t *d_counts_to_zero = nullptr, const double *eps = nullptr, const double *cosa = nullptr);
 struct rh_cand_entry;
+struct rh_oct_state;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
                      int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps = nullptr,
-                     const double *cosa = nullptr);   // eps: also fill d_qpre; cosa too: with the v4 kernel's classifier records
+                     const double *cosa = nullptr, const rh_oct_state *ost = nullptr);   // eps: also fill d_qpre; cosa too: with the v4 kernel's classifier records
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
                     const double *eps = nullptr, const double *cosa = nullptr);   // eps (+ cosa): also fill d_qpre (bins in c->d_prep only)
@@ -285,10 +295,42 @@ struct rh_cand_entry {
     int32_t pad;
     rh_shape shape;
 };
-// d_P: null (root-cell sampling) or n_iters x oct_depth level distributions
+// State of a CHAINED octree window on the device (driver.hip, run_streams_device): the iterations of the window are
+// queued back to back -- sample, fit, prepare, score, rhk_oct_advance -- and the level scores / level distribution
+// the next iteration samples from are advanced on the device, so the host is not in the loop between iterations.
+struct rh_oct_state {
+    double S[32], P[32];          // pc.levelscore, pc.levelweight: as the NEXT iteration of the window finds them
+    double best_E;                // the best stored score (findhighestscore), has_best != 0
+    long long store_n, cc2;       // stored candidates / candidates scored so far
+    int32_t has_best;
+    int32_t stop;                 // an iteration's extraction test passed (approximately: the host decides): the rest of the window is skipped
+    int32_t start;                // list position where the entries of the next iteration begin
+    int32_t it_done;              // iterations of the window that ran
+};
+// d_P: null (root-cell sampling) or n_iters x oct_depth level distributions.  Chained octree windows launch one
+// iteration at a time: n_iters = 1, it0 = its index in the window (slots, draw counters), ost = the window's state
+// (d_P = ost->P; a set stop flag skips the launch).
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
                    const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status, int status_is_zero,
-                   int32_t *d_nk_zero);
+                   int32_t *d_nk_zero, int32_t it0 = 0, const rh_oct_state *ost = nullptr);
+// What the host gets per iteration of a chained window (pinned memory, written by rhk_oct_advance's kernel)
+struct rh_oct_iter_hdr {
+    int32_t skipped;              // the window had ended before this iteration: nothing else is valid
+    int32_t overflow;             // the candidate list is full: the iteration is incomplete (the window ends here)
+    int32_t gave_up;              // sampling found no enabled point
+    int32_t start, end;           // the iteration's entries in the list (and in the pinned copies of the list and the counts)
+    int32_t stop_after;           // the device expects an extraction after this iteration (it skips the rest of the window)
+    int32_t pad[2];
+    unsigned long long draws;     // random numbers the iteration consumed
+    double P[32];                 // the level distribution after the iteration
+};
+// end of an iteration of a chained octree window: levelscore[level] += E(candidate) in candidate order (fitting.jl:184),
+// updatelevelweight (octree.jl:198-205), the running best score and the (approximate) extraction test; the iteration's
+// entries and counts are copied to h_entries / h_counts (same positions as in the list) and h_hdr[it] is filled.
+// it = index of the iteration in the window, k = its number.
+int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const rh_cand_entry *d_entries, const void *d_status,
+                    int32_t cap, const int32_t *d_counts, int32_t it, int64_t k, rh_cand_entry *h_entries, int32_t *h_counts,
+                    rh_oct_iter_hdr *h_hdr);
 // status block, head of the list and of its counts -> pinned host memory; zeroes the status block
 int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
                     int32_t head_cap, void *h_status, void *h_entries, int32_t *h_counts);

@@ -140,8 +140,12 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
                    const rhfit::OctView oc, const double *__restrict__ Pwin, int32_t drawN_rt, int32_t minsubsetN,
                    uint64_t seed, int64_t k0, int32_t n_iters, double *__restrict__ ws, int32_t *__restrict__ set_level,
                    unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag,
-                   const double *__restrict__ crec, SetShard sh)
+                   const double *__restrict__ crec, SetShard sh, const rh_oct_state *__restrict__ ost)
 {
+    if (ost != nullptr) {   // an iteration of a chained octree window (n_iters = 1; draws_per_iter already points at its counter)
+        if (ost->stop != 0) return;
+        Pwin = ost->P;
+    }
     // thread t = (iteration, local set): this rank's sets of an iteration are j = lo + jl * step (one process: 0, 1)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)n_iters * sh.m_local;
@@ -207,10 +211,11 @@ template <int DN, bool CONE>
 __global__ void __launch_bounds__(128)
 fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_level, int64_t total, const rh_params prm,
                 rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count, int32_t *__restrict__ nk_zero,
-                SetShard sh)
+                SetShard sh, int32_t it0, const rh_oct_state *__restrict__ ost)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;   // the kind bins prep_entries_kernel fills next
+    if (ost != nullptr && ost->stop != 0) return;
     if (t >= total) return;
     const int level = set_level[t];
     if (level == 0) return;
@@ -244,7 +249,7 @@ fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_l
         if (pos < cap) {
             // the slot is GLOBAL (iteration, set, type): the same whatever the number of processes sharing the window
             const int64_t it = t / sh.m_local;
-            const int64_t tg = it * prm.minsubsetN + sh.lo + (t - it * sh.m_local) * sh.step;
+            const int64_t tg = (it0 + it) * prm.minsubsetN + sh.lo + (t - it * sh.m_local) * sh.step;
             out[pos].slot = tg * prm.n_shape_types + ti;
             out[pos].level = level;
             out[pos].pad = 0;
@@ -386,6 +391,181 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
     }
 }
 
+
+// ---- chained octree windows: the end of an iteration on the device (rh_internal.h, rh_oct_state) -------------------------
+// E of estimatescore (confidenceintervals.jl:71-74, 53-59): the operations of rh_estimatescore (fit.cpp), one for one;
+// (lo + hi) / 2 = (a + b) / 2 whichever of the two is the smaller.
+__device__ __forceinline__ double oct_estimate_E(int64_t S1length, int64_t Plength, int64_t sigma, int32_t score_mode)
+{
+    const int64_t N = -2 - S1length, x = -2 - Plength, n = -1 - sigma;
+    double sq_, xn;
+    if (score_mode == RH_SCORE_INT64_WRAP) {
+        const uint64_t xn_u = (uint64_t)x * (uint64_t)n;
+        const uint64_t prod = xn_u * (uint64_t)(N - x) * (uint64_t)(N - n);
+        sq_ = (double)(int64_t)prod / (double)(N - 1);
+        xn = (double)(int64_t)xn_u;
+    } else {
+        const double xd = (double)x, nd = (double)n, Nd = (double)N;
+        sq_ = (xd * nd * (Nd - xd) * (Nd - nd)) / (Nd - 1);
+        xn = xd * nd;
+    }
+    const double sq = sq_ < 0 ? 0.0 : sqrt(sq_);
+    const double a = -1 - (xn + sq) / (double)N, b = -1 - (xn - sq) / (double)N;
+    return (a + b) / 2;
+}
+
+// One block.  The candidates of the iteration sit in the list at [ost->start, count) in the order the fits were
+// appended (atomics); the reference adds their scores to the level scores in CANDIDATE order, and a sum of doubles
+// depends on its order.  So: every candidate sets its bit in a zeroed (level, slot) bitmap and drops its list position
+// into the table cell of the same key; an ordered compaction of the bitmap (a popcount scan over the block) yields the
+// scores sorted by (level, slot); lane l of the first wave then adds level l's run to S[l] one by one, in order -- od
+// independent serial chains.  Thread 0 finishes the iteration: updatelevelweight, the counters, the extraction test.
+constexpr int OA_THREADS = 1024, OA_WAVES = OA_THREADS / 64;
+
+__global__ void __launch_bounds__(OA_THREADS)
+oct_advance_kernel(rh_oct_state *__restrict__ ost, const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
+                   int32_t cap, const int32_t *__restrict__ counts, int32_t it, int64_t k, int64_t per_it, int32_t od, int64_t S1length,
+                   int64_t Plength, int32_t score_mode, int32_t extract_s, int32_t minsubsetN, int32_t drawN, double prob_det,
+                   int32_t *__restrict__ tab, unsigned long long *__restrict__ bits, double *__restrict__ Esort,
+                   const unsigned long long *__restrict__ status, rh_cand_entry *__restrict__ h_entries, int32_t *__restrict__ h_counts,
+                   rh_oct_iter_hdr *__restrict__ h_hdr)
+{
+    if (ost->stop != 0) {
+        if (threadIdx.x == 0) h_hdr[it].skipped = 1;
+        return;
+    }
+    __shared__ int32_t hist[33], seg[33], wave_tot[OA_WAVES], wave_base[OA_WAVES];
+    __shared__ double bestw[OA_WAVES];
+    __shared__ int32_t anyw[OA_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t count = *count_ptr;
+    const int32_t start = ost->start, end = max(start, min(count, cap)), m = end - start;
+    if (tid < 33) hist[tid] = 0;
+    // 0. the iteration's slice of the list and of the counts -> pinned host memory (posted writes: they drain while the
+    // rest of the kernel runs)
+    {
+        constexpr int EW = (int)(sizeof(rh_cand_entry) / 8);
+        const unsigned long long *src = (const unsigned long long *)(entries + start);
+        unsigned long long *dst = (unsigned long long *)(h_entries + start);
+        for (int64_t i = tid; i < (int64_t)m * EW; i += OA_THREADS) dst[i] = src[i];
+        for (int32_t i = start + tid; i < end; i += OA_THREADS) h_counts[i] = counts[i];
+    }
+    __syncthreads();
+    // 1. bits + positions, level histogram
+    double bE = 0.0;
+    bool any = false;
+    for (int32_t e = start + tid; e < end; e += OA_THREADS) {
+        const int64_t ls = entries[e].slot - (int64_t)it * per_it;
+        const int32_t lv = entries[e].level;
+        if (ls >= 0 && ls < per_it && lv >= 1 && lv <= od) {
+            const int64_t key = (int64_t)(lv - 1) * per_it + ls;
+            tab[key] = e;
+            atomicOr(&bits[key >> 6], 1ULL << (key & 63));
+            atomicAdd(&hist[lv - 1], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t a = 0;
+        for (int l = 0; l < od; l++) { seg[l] = a; a += hist[l]; }
+        seg[od] = a;
+    }
+    // 2. ordered compaction: thread t owns the bitmap words [t * wpt, (t + 1) * wpt)
+    const int64_t nw = ((int64_t)od * per_it + 63) >> 6;
+    const int64_t wpt = (nw + OA_THREADS - 1) / OA_THREADS;
+    const int64_t w0 = min(nw, (int64_t)tid * wpt), w1 = min(nw, w0 + wpt);
+    int32_t mine = 0;
+    for (int64_t w = w0; w < w1; w++) mine += __popcll(bits[w]);
+    int32_t incl = mine;   // inclusive scan over the wave, then over the waves
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t a = 0;
+        for (int w = 0; w < OA_WAVES; w++) { wave_base[w] = a; a += wave_tot[w]; }
+    }
+    __syncthreads();
+    int32_t pos = wave_base[wv] + incl - mine;
+    for (int64_t w = w0; w < w1; w++) {
+        unsigned long long bm = bits[w];
+        if (bm == 0) continue;
+        bits[w] = 0;                             // the bitmap is zero again for the next iteration
+        while (bm != 0) {
+            const int bit = __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const int32_t e = tab[(w << 6) + bit];
+            const double E = oct_estimate_E(S1length, Plength, (int64_t)counts[e], score_mode);
+            Esort[pos++] = E;
+            if (!any || E > bE) bE = E;
+            any = true;
+        }
+    }
+    // best score of the iteration (a maximum: any order)
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(bE, off);
+        const int oa = __shfl_xor((int)any, off);
+        if (oa && (!any || o > bE)) bE = o;
+        any = any || oa;
+    }
+    if (lane == 0) { bestw[wv] = bE; anyw[wv] = any ? 1 : 0; }
+    __syncthreads();
+    // 3. level scores, in candidate order
+    if (tid < od) {
+        double acc = ost->S[tid];
+        const int32_t a = seg[tid], b = seg[tid + 1];
+        int32_t j = a;
+        for (; j + 8 <= b; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = Esort[j + q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc += v[q];
+        }
+        for (; j < b; j++) acc += Esort[j];
+        ost->S[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int32_t scored = seg[od];           // (= m unless an entry was malformed)
+        double best = ost->best_E;
+        int32_t has = ost->has_best;
+        for (int w = 0; w < OA_WAVES; w++)
+            if (anyw[w] && (!has || bestw[w] > best)) { best = bestw[w]; has = 1; }
+        ost->best_E = best;
+        ost->has_best = has;
+        const long long store_n = ost->store_n + scored, cc2 = ost->cc2 + scored;
+        ost->store_n = store_n;
+        ost->cc2 = cc2;
+        // the extraction test of iterations.jl:114-123 -- with the device's pow, which may differ from the host's in
+        // the last place: this only ends the window (the host replays the iterations and decides)
+        if (has) {
+            const long long sl[4] = { 0, store_n, cc2, (long long)k * minsubsetN };
+            const double ppp = 1 - pow(1 - pow(best / (double)Plength, (double)drawN), (double)sl[extract_s & 3]);
+            if (ppp > prob_det) ost->stop = 1;
+        }
+        // updatelevelweight (octree.jl:198-205), as the host does it (fit_shared.h, update_level_probs)
+        double P[32], S[32];
+        for (int i = 0; i < 32; i++) { P[i] = ost->P[i]; S[i] = ost->S[i]; }
+        rhfit::update_level_probs(P, S, od);
+        rh_oct_iter_hdr &H = h_hdr[it];
+        for (int i = 0; i < 32; i++) { ost->P[i] = P[i]; H.P[i] = P[i]; }
+        ost->start = end;
+        ost->it_done = it + 1;
+        const int32_t over = count > cap ? 1 : 0;
+        if (over) ost->stop = 1;
+        H.skipped = 0;
+        H.overflow = over;
+        H.gave_up = (int32_t)(status[0] >> 32);          // status block: int32 count, int32 gave_up, u64 draws[]
+        H.start = start;
+        H.end = end;
+        H.stop_after = ost->stop;
+        H.draws = status[1 + it];
+    }
+}
+
 }  // namespace
 
 #ifdef RH_OCT_TIMING
@@ -409,11 +589,12 @@ int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_
 
 int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0, int32_t n_iters, int32_t n_enabled,
                    const double *d_P, rh_cand_entry *d_out, int32_t cap, void *d_status, int status_is_zero,
-                   int32_t *d_nk_zero)
+                   int32_t *d_nk_zero, int32_t it0, const rh_oct_state *ost)
 {
+    if (ost != nullptr && (n_iters != 1 || d_P == nullptr)) { rh_set_error("rhk_sample_fit: a chained window samples one octree iteration per launch"); return RH_E_INTERNAL; }
     // status block: int32 count, int32 gave_up, u64 draws[n_iters]
     int32_t *d_count = (int32_t *)d_status, *d_gave_up = d_count + 1;
-    unsigned long long *d_draws = (unsigned long long *)((char *)d_status + 8);
+    unsigned long long *d_draws = (unsigned long long *)((char *)d_status + 8) + it0;
     if (prm->drawN > RH_MAX_DRAWN) { rh_set_error("device sampler supports drawN <= %d", RH_MAX_DRAWN); return RH_E_INVALID; }
     if (!c->select_valid) RH_TRY(rhk_build_select(c));
     // (the block is a multiple of 64 bytes: one aligned fill; the driver's windows keep it zero themselves)
@@ -494,10 +675,10 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
 #define RH_SAMPLE(DN)                                                                                                  \
     hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
-                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec, sh)
+                       prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec, sh, ost)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
-                       d_out, cap, d_count, d_nk_zero, sh)
+                       d_out, cap, d_count, d_nk_zero, sh, it0, ost)
     if (prm->drawN == 3) {   // the reference's default: fully unrolled, no scratch
         RH_SAMPLE(3);
         if (cone) RH_FIT(3, true); else RH_FIT(3, false);
@@ -507,6 +688,39 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
 #undef RH_SAMPLE
 #undef RH_FIT
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const rh_cand_entry *d_entries, const void *d_status,
+                    int32_t cap, const int32_t *d_counts, int32_t it, int64_t k, rh_cand_entry *h_entries, int32_t *h_counts,
+                    rh_oct_iter_hdr *h_hdr)
+{
+    const int64_t per_it = (int64_t)prm->minsubsetN * prm->n_shape_types;
+    const int od = c->oct_depth;
+    if (od < 1 || od > 32) { rh_set_error("rhk_oct_advance: octree depth %d", od); return RH_E_INTERNAL; }
+    const int64_t cells = (int64_t)od * per_it;
+    if (c->oct_adv_cells < cells) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->oct_adv_tab);
+        c->oct_adv_tab = nullptr; c->oct_adv_cells = 0;
+        (void)hipFree(c->oct_adv_bits);
+        c->oct_adv_bits = nullptr;
+        RH_HIP(hipMalloc((void **)&c->oct_adv_tab, sizeof(int32_t) * (size_t)cells));
+        RH_HIP(hipMalloc((void **)&c->oct_adv_bits, sizeof(unsigned long long) * (size_t)((cells + 63) / 64)));
+        RH_HIP(hipMemsetAsync(c->oct_adv_bits, 0, sizeof(unsigned long long) * (size_t)((cells + 63) / 64), c->stream));   // the kernel leaves it zero
+        c->oct_adv_cells = cells;
+    }
+    if (c->oct_adv_E_cap < per_it) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->oct_adv_E);
+        c->oct_adv_E = nullptr; c->oct_adv_E_cap = 0;
+        RH_HIP(hipMalloc((void **)&c->oct_adv_E, sizeof(double) * (size_t)per_it));
+        c->oct_adv_E_cap = per_it;
+    }
+    hipLaunchKernelGGL(oct_advance_kernel, dim3(1), dim3(OA_THREADS), 0, c->stream, ost, d_entries, (const int32_t *)d_status, cap, d_counts,
+                       it, k, per_it, (int32_t)od, c->s, c->n, prm->score_mode, prm->extract_s, prm->minsubsetN, prm->drawN, prm->prob_det,
+                       c->oct_adv_tab, c->oct_adv_bits, c->oct_adv_E, (const unsigned long long *)d_status, h_entries, h_counts, h_hdr);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -84,6 +84,8 @@ struct S4KindArgs {
     double eps, cosa;
 };
 struct S4AllArgs {
+    const int32_t *stop;   // chained octree windows: non-zero = the window has ended, nothing to score (else null)
+    int row0;              // TAIL launch: first row that the sized launch did not cover
     S4KindArgs k[4];
     int64_t ntiles, bstride, ngroups;
     const float *gb32;      // binary32 boxes of the groups, 8 floats each
@@ -360,13 +362,17 @@ static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *_
 // grid: (tiles padded to a multiple of 8, rows).  The 64-candidate chunks of the four kind bins are laid end to end,
 // the expensive kinds first (cone, cylinder, sphere, plane), and cut into rows of R; a block runs the per-kind
 // segment(s) of its row (almost always one) on its tile.
-template <int R, bool MASK, bool F32>
+// TAIL: the launch that picks up what a sized-before-the-count-was-known launch leaves over (rhk_score4_all, `open`):
+// its blocks walk the rows from A.row0 on grid-stride.  A separate instantiation -- the loop around the four per-kind
+// bodies costs the register allocation dearly (96 scalar + 40 vector registers spilled), the one-row form none.
+template <int R, bool MASK, bool F32, bool TAIL = false>
 __global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
     __shared__ S4Shared<R> sh;
     const int64_t tile = blockIdx.x;
     if (tile >= A.ntiles) return;
+    if (A.stop != nullptr && *A.stop != 0) return;
     const int64_t g0 = tile * S4_TG;
     int nch[4], total = 0;
 #pragma unroll
@@ -389,15 +395,23 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
         }                                                                                                              \
         base += nch[K];                                                                                                \
     }
-    // (the grid's rows cover the launch's bound on the number of candidates; the bins on the device may hold more -- a
-    // window of the candidate loop is launched before its list length is known -- so the rows are walked grid-stride)
-    for (int lo = (int)blockIdx.y * R; lo < total; lo += (int)gridDim.y * R) {
-        const int hi = min(total, lo + R);
+    if (!TAIL) {
+        const int lo = (int)blockIdx.y * R, hi = min(total, lo + R);
+        if (lo >= hi) return;
         int base = 0;
         RH_S4_BODY(RH_CONE)
         RH_S4_BODY(RH_CYLINDER)
         RH_S4_BODY(RH_SPHERE)
         RH_S4_BODY(RH_PLANE)
+    } else {
+        for (int lo = (A.row0 + (int)blockIdx.y) * R; lo < total; lo += (int)gridDim.y * R) {
+            const int hi = min(total, lo + R);
+            int base = 0;
+            RH_S4_BODY(RH_CONE)
+            RH_S4_BODY(RH_CYLINDER)
+            RH_S4_BODY(RH_SPHERE)
+            RH_S4_BODY(RH_PLANE)
+        }
     }
 #undef RH_S4_BODY
 }
@@ -580,6 +594,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
                    int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
                    uint8_t *d_occ, int64_t mstride, const void *const prep32[4])
 {
+    const bool open_count = c->s4_open_count;
     const int64_t ntiles = (c->ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
     if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
@@ -590,6 +605,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     for (int k = 0; k < 4; k++)
         A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, f32_round_up(eps[k]),
                    f32_round_down(cosa[k]), orig[k], nk[k], en[k], eps[k], cosa[k] };
+    A.stop = c->s4_stop;
     A.ntiles = ntiles;
     A.bstride = bstride;
     A.ngroups = c->ngroups;
@@ -604,6 +620,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
+    A.row0 = 0;
 #define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
     if (prep32 != nullptr) {   // Float32 cloud: c->sub holds the exactly converted values
         if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
@@ -611,6 +628,21 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     } else if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, false); else RH_S4_LAUNCH(8, true, false); }
     else { if (R == 4) RH_S4_LAUNCH(4, false, false); else RH_S4_LAUNCH(8, false, false); }
 #undef RH_S4_LAUNCH
+    if (open_count) {
+        // nk_total_bound was a guess (a window of the candidate loop is queued before its list length is known): whatever
+        // lies beyond the rows above is scored by a second, small launch that walks the remaining rows grid-stride --
+        // its blocks return at once when there is nothing (the usual case)
+        if (d_masks_int != nullptr) { rh_set_error("rhk_score4_all: masks need an exact candidate count"); return RH_E_INTERNAL; }
+        A.row0 = (int)rows;
+        dim3 gt(grid.x, 2);
+        if (prep32 != nullptr) {
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+        } else {
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+        }
+    }
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -31,7 +31,7 @@ for r in range(int(os.environ.get("RUNS", "3"))):
     h = hashlib.sha256()
     for g in got:
         h.update(np.asarray(g.inpoints, dtype=np.int64).tobytes())
-    print("   result digest", h.hexdigest()[:16], [(g.iteration, len(g.inpoints)) for g in got][:6], "rng draws", st.get("draws"), flush=True)
+    print("   result digest", h.hexdigest()[:16], [(g.iteration, len(g.inpoints)) for g in got][:6], "rng draws", st.get("draws"), "scored_left", st.get("scored_left"), flush=True)
 if os.environ.get("OCT_TIMING"):
     import ctypes as C
     t = (C.c_ulonglong * 16)()
