@@ -436,7 +436,7 @@ struct Window {
     rh_oct_state *h_ost = nullptr;
     rh_oct_iter_hdr *h_hdr = nullptr;
     rh_cand_entry *h_list = nullptr;
-    int32_t *h_list_counts = nullptr;
+    int32_t *h_list_counts = nullptr, *h_list_rank = nullptr, *h_list_slot = nullptr;
     int32_t h_list_cap = 0;
     hipEvent_t ev_it[RH_CHAIN_MAX] = {};
     hipEvent_t ev = nullptr;
@@ -450,6 +450,7 @@ void window_free(Window &w)
     (void)hipFree(w.d_entries); (void)hipFree(w.d_status); (void)hipFree(w.d_counts);
     (void)hipHostFree(w.h_status); (void)hipHostFree(w.h_entries); (void)hipHostFree(w.h_counts);
     (void)hipHostFree(w.h_ost); (void)hipHostFree(w.h_hdr); (void)hipHostFree(w.h_list); (void)hipHostFree(w.h_list_counts);
+    (void)hipHostFree(w.h_list_rank); (void)hipHostFree(w.h_list_slot);
     for (hipEvent_t e : w.ev_it) if (e) (void)hipEventDestroy(e);
     if (w.ev) (void)hipEventDestroy(w.ev);
     w = Window();
@@ -517,6 +518,10 @@ struct Driver {
     double t_last_extraction = 0;           // wall clock at the end of the latest extraction
     double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
     double tw[4] = { 0, 0, 0, 0 };           // windows: enqueue, wait, host list handling, record()
+#ifdef RH_OCT_TIMING
+    double oa_t[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long oa_n = 0;
+#endif
     int64_t nwin = 0;
     int64_t iterations = 0;
     bool terminated = false;
@@ -735,9 +740,32 @@ struct Driver {
     }
 
     // recordscore! (fitting.jl:114-119) in candidate order + prepared records into the device store
-    int record(const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts)
+    // dev_slots (chained octree windows): the device has appended the candidates' records to the store itself
+    // (rhk_oct_advance) -- dev_slots[i] is candidate i's slot in the store of its kind
+    int record(const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts, const int32_t *dev_slots = nullptr)
     {
         if (ncand == 0) return RH_OK;
+        if (dev_slots != nullptr) {
+            int32_t nk[4] = { 0, 0, 0, 0 };
+            for (int32_t i = 0; i < ncand; i++) {
+                double lo, hi, E;
+                RUN(rh_estimatescore(c->s, c->n, counts[i], p->score_mode, &lo, &hi, &E));
+                Stored rec;
+                rec.shape = (int32_t)shapes.size();
+                shapes.push_back(cands[i]);
+                rec.kind = cands[i].kind;
+                rec.E = E;
+                rec.slot = dev_slots[i];
+                rec.sigma = counts[i];
+                store.push_back(rec);
+                nk[rec.kind]++;
+                oS[levels[i] - 1] += E;   // pc.levelscore[level] += E(sc): fitting.jl:184
+                if (best < 0) best = (int64_t)store.size() - 1;
+                else if (E > store[(size_t)best].E) best = (int64_t)store.size() - 1;
+            }
+            for (int q = 0; q < 4; q++) st.n[q] += nk[q];
+            return RH_OK;
+        }
         // the prepared records are made here (rh_prep_host is the host twin of the device's prep_one) and go
         // straight behind the store of their kind: one small copy per kind present, no launch
         int32_t nk[4] = { 0, 0, 0, 0 };
@@ -996,11 +1024,11 @@ struct Driver {
     // everything of iteration k after the candidates exist: iterations.jl:98-156.
     // Returns through *stop whether the loop ends after this iteration.
     int finish_iteration(int64_t k, const rh_shape *cands, const int32_t *levels, int32_t ncand, const int32_t *counts,
-                         bool *did_extract, bool *stop)
+                         bool *did_extract, bool *stop, const int32_t *dev_slots = nullptr)
     {
         cc[2] += ncand;
         const double tr0 = now_s();
-        RUN(record(cands, levels, ncand, counts));
+        RUN(record(cands, levels, ncand, counts, dev_slots));
         tw[3] += now_s() - tr0;
         cc[3] = k * p->minsubsetN;
         cc[1] = (int64_t)store.size();
@@ -1068,7 +1096,7 @@ struct Driver {
         const bool pipeline = !octree && !getenv("RH_NO_PIPELINE");
         std::vector<rh_cand_entry> entries;
         std::vector<rh_shape> cands;
-        std::vector<int32_t> counts, levels, wcounts, order;
+        std::vector<int32_t> counts, levels, wcounts, order, wslots;
         std::vector<int64_t> slots;
         const int T = p->n_shape_types;
         // Octree windows, one process: CHAINED.  Every iteration's scores change the level distribution the next
@@ -1091,10 +1119,12 @@ struct Driver {
                     for (hipEvent_t &e : w.ev_it) RUNH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 }
                 if (w.h_list_cap < w.entries_cap) {
-                    (void)hipHostFree(w.h_list); (void)hipHostFree(w.h_list_counts);
-                    w.h_list = nullptr; w.h_list_counts = nullptr; w.h_list_cap = 0;
+                    (void)hipHostFree(w.h_list); (void)hipHostFree(w.h_list_counts); (void)hipHostFree(w.h_list_rank); (void)hipHostFree(w.h_list_slot);
+                    w.h_list = nullptr; w.h_list_counts = w.h_list_rank = w.h_list_slot = nullptr; w.h_list_cap = 0;
                     RUNH(hipHostMalloc((void **)&w.h_list, sizeof(rh_cand_entry) * (size_t)w.entries_cap));
                     RUNH(hipHostMalloc((void **)&w.h_list_counts, sizeof(int32_t) * (size_t)w.entries_cap));
+                    RUNH(hipHostMalloc((void **)&w.h_list_rank, sizeof(int32_t) * (size_t)w.entries_cap));
+                    RUNH(hipHostMalloc((void **)&w.h_list_slot, sizeof(int32_t) * (size_t)w.entries_cap));
                     w.h_list_cap = w.entries_cap;
                 }
                 return RH_OK;
@@ -1129,8 +1159,17 @@ struct Driver {
                 for (int i = 0; i < od; i++) { h.S[i] = oS[i]; h.P[i] = oP[i]; }
                 h.has_best = store.empty() ? 0 : 1;
                 h.best_E = store.empty() ? 0.0 : store[(size_t)best].E;
-                h.store_n = (long long)store.size();
+                h.store_count = (long long)store.size();
                 h.cc2 = cc[2];
+                // the iterations append their candidates' records to the device store: room for a whole window
+                for (int q = 0; q < 4; q++) {
+                    bool has_kind = false;
+                    for (int ti = 0; ti < T; ti++) has_kind |= p->shape_types[ti] == q;
+                    if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + (int64_t)W * p->minsubsetN * T));
+                    h.store_prep[q] = st.prep[q];
+                    h.store_cap[q] = st.cap[q];
+                    h.store_n[q] = st.n[q];
+                }
                 RUNH(hipMemcpyAsync(c->oct_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
                 RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));
                 RUN(rh_ensure_batch(c, w.entries_cap));
@@ -1158,7 +1197,7 @@ struct Driver {
                     if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>(2 * cnt_est, 1024)), p->eps,
                                                                p->cos_alpha, w.d_counts, nullptr, nullptr, clsw, boxw, 4 * c->batch_cap);
                     if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k + it, w.h_list,
-                                                          w.h_list_counts, w.h_hdr);
+                                                          w.h_list_counts, w.h_list_rank, w.h_list_slot, w.h_hdr);
                     if (rc == RH_OK && hipEventRecord(w.ev_it[it], c->stream) != hipSuccess) { rh_set_error("hipEventRecord failed"); rc = RH_E_NODEVICE; }
                 }
                 c->s4_stop = nullptr;
@@ -1177,28 +1216,33 @@ struct Driver {
                     const double tb = now_s();
                     tw[1] += tb - ta;
                     const rh_oct_iter_hdr &H = w.h_hdr[it];
+#ifdef RH_OCT_TIMING
+                    if (!H.skipped) { for (int i = 0; i < 7; i++) oa_t[i] += (double)H.t[i] / 100.0; oa_n++; }
+#endif
                     if (H.skipped) break;                       // the device saw an extraction coming that the host did not take: go on from here
                     if (H.gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
                     if (H.overflow) { regrow = true; break; }   // the list is full: this iteration is drawn again in a longer one
                     if (en.count < p->tau) { stop = true; break; }
                     const int32_t cnt = H.end - H.start;
-                    order.resize((size_t)cnt);
-                    for (int32_t i = 0; i < cnt; i++) order[(size_t)i] = H.start + i;
-                    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return w.h_list[a].slot < w.h_list[b].slot; });
+                    // candidate order = slot order: the device ranked the entries (no sort here)
                     cands.resize((size_t)cnt);
                     levels.resize((size_t)cnt);
                     counts.resize((size_t)cnt);
+                    wslots.resize((size_t)cnt);
                     for (int32_t i = 0; i < cnt; i++) {
-                        const rh_cand_entry &e = w.h_list[order[(size_t)i]];
-                        cands[(size_t)i] = e.shape; levels[(size_t)i] = e.level;
-                        counts[(size_t)i] = w.h_list_counts[order[(size_t)i]];
+                        const int32_t r = w.h_list_rank[H.start + i];
+                        if (r < 0 || r >= cnt) { rh_set_error("rh_ransac: bad candidate rank from the device (%d of %d)", r, cnt); return RH_E_INTERNAL; }
+                        const rh_cand_entry &e = w.h_list[H.start + i];
+                        cands[(size_t)r] = e.shape; levels[(size_t)r] = e.level;
+                        counts[(size_t)r] = w.h_list_counts[H.start + i];
+                        wslots[(size_t)r] = w.h_list_slot[H.start + i];
                     }
                     cnt_est = cnt;
                     rng->draws += (int64_t)H.draws;
                     const double tc = now_s();
                     tw[2] += tc - tb;
                     t_sample += tc - ta;
-                    RUN(finish_iteration(k + it, cands.data(), levels.data(), cnt, counts.data(), &did, &stop));
+                    RUN(finish_iteration(k + it, cands.data(), levels.data(), cnt, counts.data(), &did, &stop, wslots.data()));
                     if (memcmp(oP, H.P, sizeof(double) * (size_t)od) != 0) {
                         // (the device advanced the level distribution with the operations of update_level_probs on the sums
                         // it built in candidate order: any difference is a defect, never a rounding matter)
@@ -1576,6 +1620,10 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
     out->seconds_score = d.t_score;
     out->seconds_extract = d.t_extract;
     out->seconds_host = d.t_sample;
+#ifdef RH_OCT_TIMING
+    if (d.oa_n > 0) fprintf(stderr, "[rh_ransac] oct_advance phases (us, mean of %lld): copy %.2f scatter %.2f hist %.2f scan %.2f emit %.2f sums+ranks %.2f sync %.2f final %.2f\n", d.oa_n,
+                            d.oa_t[0] / d.oa_n, d.oa_t[1] / d.oa_n, d.oa_t[2] / d.oa_n, d.oa_t[3] / d.oa_n, d.oa_t[4] / d.oa_n, d.oa_t[5] / d.oa_n, d.oa_t[6] / d.oa_n, 0.0);
+#endif
     if (getenv("RH_DRIVER_PROF")) {
         fprintf(stderr, "[rh_ransac] init %.4f loop %.4f tail %.4f s\n", t_init, t_loop, out->seconds - t_init - t_loop);
         fprintf(stderr, "[rh_ransac] %lld windows: enqueue %.4f wait %.4f lists %.4f record %.4f s; total %.4f\n", (long long)d.nwin,

@@ -127,7 +127,6 @@ struct rh_cloud {
     unsigned long long *oct_adv_bits = nullptr;
     int64_t oct_adv_cells = 0;
     double *oct_adv_E = nullptr;
-    int64_t oct_adv_E_cap = 0;
     int32_t *oct_tab = nullptr;        // first Morton position of every level-oct_tab_level cell (+ n at the end)
     int oct_tab_level = 0;
     double *oct_P = nullptr;           // level distributions of a speculation window
@@ -301,7 +300,10 @@ struct rh_cand_entry {
 struct rh_oct_state {
     double S[32], P[32];          // pc.levelscore, pc.levelweight: as the NEXT iteration of the window finds them
     double best_E;                // the best stored score (findhighestscore), has_best != 0
-    long long store_n, cc2;       // stored candidates / candidates scored so far
+    long long store_count, cc2;   // stored candidates / candidates scored so far
+    rh_prep *store_prep[4];       // the device store of prepared candidates (driver.hip): arrays per kind, their capacities and
+    long long store_cap[4];       //   fill -- every iteration appends its candidates' records
+    int32_t store_n[4];
     int32_t has_best;
     int32_t stop;                 // an iteration's extraction test passed (approximately: the host decides): the rest of the window is skipped
     int32_t start;                // list position where the entries of the next iteration begin
@@ -323,14 +325,19 @@ struct rh_oct_iter_hdr {
     int32_t pad[2];
     unsigned long long draws;     // random numbers the iteration consumed
     double P[32];                 // the level distribution after the iteration
+#ifdef RH_OCT_TIMING
+    unsigned long long t[8];      // phase times of the kernel (100 MHz ticks)
+#endif
 };
 // end of an iteration of a chained octree window: levelscore[level] += E(candidate) in candidate order (fitting.jl:184),
 // updatelevelweight (octree.jl:198-205), the running best score and the (approximate) extraction test; the iteration's
-// entries and counts are copied to h_entries / h_counts (same positions as in the list) and h_hdr[it] is filled.
+// entries and counts are copied to h_entries / h_counts (same positions as in the list), h_rank gets every entry's rank
+// in candidate order within the iteration, the prepared records go behind the device store (ost->store_*) with h_slot
+// saying where, and h_hdr[it] is filled.
 // it = index of the iteration in the window, k = its number.
 int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const rh_cand_entry *d_entries, const void *d_status,
                     int32_t cap, const int32_t *d_counts, int32_t it, int64_t k, rh_cand_entry *h_entries, int32_t *h_counts,
-                    rh_oct_iter_hdr *h_hdr);
+                    int32_t *h_rank, int32_t *h_slot, rh_oct_iter_hdr *h_hdr);
 // status block, head of the list and of its counts -> pinned host memory; zeroes the status block
 int rhk_pack_window(rh_cloud *c, void *d_status, int32_t n_iters, const rh_cand_entry *d_entries, const int32_t *d_counts,
                     int32_t head_cap, void *h_status, void *h_entries, int32_t *h_counts);

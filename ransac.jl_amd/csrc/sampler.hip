@@ -419,92 +419,99 @@ __device__ __forceinline__ double oct_estimate_E(int64_t S1length, int64_t Pleng
 // depends on its order.  So: every candidate sets its bit in a zeroed (level, slot) bitmap and drops its list position
 // into the table cell of the same key; an ordered compaction of the bitmap (a popcount scan over the block) yields the
 // scores sorted by (level, slot); lane l of the first wave then adds level l's run to S[l] one by one, in order -- od
-// independent serial chains.  Thread 0 finishes the iteration: updatelevelweight, the counters, the extraction test.
-constexpr int OA_THREADS = 1024, OA_WAVES = OA_THREADS / 64;
+// independent serial chains.  A second bitmap over the slots alone gives every candidate its rank in candidate order
+// (the host replays the iteration in that order without sorting).  The kernel also ships the iteration to the host
+// (its slice of the list and of the counts, pinned memory) and appends the prepared records of its candidates to the
+// device store (driver.hip), telling the host the store slot of each.  Thread 0 finishes the iteration:
+// updatelevelweight, the counters, the extraction test.
+constexpr int OA_THREADS = 1024, OA_WAVES = OA_THREADS / 64, OA_ES = 6144;
+
+struct OctAdvArgs {
+    rh_oct_state *ost;
+    const rh_cand_entry *entries;
+    const unsigned long long *status;    // int32 count, int32 gave_up, u64 draws[]
+    const int32_t *counts;
+    int32_t cap, it, od, score_mode, extract_s, minsubsetN, drawN;
+    int64_t k, per_it, S1length, Plength;
+    double prob_det;
+    double *Etab;                        // [od * per_it] score per (level, slot); stale outside the set bits
+    unsigned long long *bits, *sbits;    // (level, slot) bitmap, slot bitmap: zero on entry and on exit
+    int32_t *spref;                      // [words of sbits] scratch
+    double *Esort;                       // [per_it] scratch
+    const rh_prep *bin_prep;             // the iteration's candidates as prep_entries_kernel binned them: records,
+    const int32_t *bin_orig, *bin_nk;    //   list positions, numbers per kind; bins bin_cap apart
+    int64_t bin_cap;
+    rh_cand_entry *h_entries;            // pinned: the list, its counts, every entry's rank in candidate order within its
+    int32_t *h_counts, *h_rank, *h_slot; //   iteration and its slot in the device store of its kind
+    rh_oct_iter_hdr *h_hdr;
+};
+
+// copies n words, the block's threads t0 .. t0 + nt - 1 taking eight each per round (eight loads in flight)
+typedef unsigned int oa_u32x4 __attribute__((ext_vector_type(4)));
+template <class W>
+static __device__ __forceinline__ void oa_copy(W *__restrict__ dst, const W *__restrict__ src, int64_t n, int t, int nt)
+{
+    for (int64_t i0 = (int64_t)t; i0 < n; i0 += (int64_t)nt * 8) {
+        W v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int64_t i = i0 + (int64_t)q * nt; if (i < n) v[q] = src[i]; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int64_t i = i0 + (int64_t)q * nt; if (i < n) dst[i] = v[q]; }
+    }
+}
 
 __global__ void __launch_bounds__(OA_THREADS)
-oct_advance_kernel(rh_oct_state *__restrict__ ost, const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
-                   int32_t cap, const int32_t *__restrict__ counts, int32_t it, int64_t k, int64_t per_it, int32_t od, int64_t S1length,
-                   int64_t Plength, int32_t score_mode, int32_t extract_s, int32_t minsubsetN, int32_t drawN, double prob_det,
-                   int32_t *__restrict__ tab, unsigned long long *__restrict__ bits, double *__restrict__ Esort,
-                   const unsigned long long *__restrict__ status, rh_cand_entry *__restrict__ h_entries, int32_t *__restrict__ h_counts,
-                   rh_oct_iter_hdr *__restrict__ h_hdr)
+oct_advance_kernel(const OctAdvArgs A)
 {
+    rh_oct_state *__restrict__ ost = A.ost;
+    const int it = A.it;
     if (ost->stop != 0) {
-        if (threadIdx.x == 0) h_hdr[it].skipped = 1;
+        if (threadIdx.x == 0) A.h_hdr[it].skipped = 1;
         return;
     }
-    __shared__ int32_t hist[33], seg[33], wave_tot[OA_WAVES], wave_base[OA_WAVES];
-    __shared__ double bestw[OA_WAVES];
-    __shared__ int32_t anyw[OA_WAVES];
+    __shared__ int32_t hist[33], seg[33], wave_tot[2][OA_WAVES], wave_base[2][OA_WAVES];
+    __shared__ double bestw[OA_WAVES], lP[32], lS[32], lr[32], lw;
+    __shared__ int32_t anyw[OA_WAVES], store_over, lstop, lkeep;
+    __shared__ double Es[OA_ES];          // the sorted scores of an iteration of up to OA_ES candidates (else: A.Esort)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int32_t count = *count_ptr;
-    const int32_t start = ost->start, end = max(start, min(count, cap)), m = end - start;
+    const rh_cand_entry *__restrict__ entries = A.entries;
+    const int64_t per_it = A.per_it;
+    const int od = A.od;
+    const int32_t count = (int32_t)(A.status[0] & 0xffffffffULL);
+    const int32_t start = ost->start, end = max(start, min(count, A.cap)), m = end - start;
+    int32_t nkq[4], sbase[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { nkq[q] = A.bin_nk[q]; sbase[q] = ost->store_n[q]; }
     if (tid < 33) hist[tid] = 0;
-    // 0. the iteration's slice of the list and of the counts -> pinned host memory (posted writes: they drain while the
-    // rest of the kernel runs)
-    {
-        constexpr int EW = (int)(sizeof(rh_cand_entry) / 8);
-        const unsigned long long *src = (const unsigned long long *)(entries + start);
-        unsigned long long *dst = (unsigned long long *)(h_entries + start);
-        for (int64_t i = tid; i < (int64_t)m * EW; i += OA_THREADS) dst[i] = src[i];
-        for (int32_t i = start + tid; i < end; i += OA_THREADS) h_counts[i] = counts[i];
-    }
+    if (tid < 32) { lP[tid] = ost->P[tid]; lS[tid] = ost->S[tid]; }
+    if (tid == 0) { store_over = 0; lstop = 0; lkeep = 0; }
+#ifdef RH_OCT_TIMING
+    unsigned long long tq[8];
+    int tqi = 0;
+#define OA_T() do { if (tid == 0) tq[tqi] = wall_clock64(); tqi++; } while (0)
+#else
+#define OA_T() do { } while (0)
+#endif
+    OA_T();
     __syncthreads();
-    // 1. bits + positions, level histogram
+    // 1. every candidate: its score into the (level, slot) table, its bits, the level histogram, the best score
     double bE = 0.0;
     bool any = false;
     for (int32_t e = start + tid; e < end; e += OA_THREADS) {
         const int64_t ls = entries[e].slot - (int64_t)it * per_it;
         const int32_t lv = entries[e].level;
         if (ls >= 0 && ls < per_it && lv >= 1 && lv <= od) {
+            const double E = oct_estimate_E(A.S1length, A.Plength, (int64_t)A.counts[e], A.score_mode);
             const int64_t key = (int64_t)(lv - 1) * per_it + ls;
-            tab[key] = e;
-            atomicOr(&bits[key >> 6], 1ULL << (key & 63));
+            A.Etab[key] = E;
+            atomicOr(&A.bits[key >> 6], 1ULL << (key & 63));
+            atomicOr(&A.sbits[ls >> 6], 1ULL << (ls & 63));
             atomicAdd(&hist[lv - 1], 1);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int32_t a = 0;
-        for (int l = 0; l < od; l++) { seg[l] = a; a += hist[l]; }
-        seg[od] = a;
-    }
-    // 2. ordered compaction: thread t owns the bitmap words [t * wpt, (t + 1) * wpt)
-    const int64_t nw = ((int64_t)od * per_it + 63) >> 6;
-    const int64_t wpt = (nw + OA_THREADS - 1) / OA_THREADS;
-    const int64_t w0 = min(nw, (int64_t)tid * wpt), w1 = min(nw, w0 + wpt);
-    int32_t mine = 0;
-    for (int64_t w = w0; w < w1; w++) mine += __popcll(bits[w]);
-    int32_t incl = mine;   // inclusive scan over the wave, then over the waves
-    for (int off = 1; off < 64; off <<= 1) {
-        const int32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        int32_t a = 0;
-        for (int w = 0; w < OA_WAVES; w++) { wave_base[w] = a; a += wave_tot[w]; }
-    }
-    __syncthreads();
-    int32_t pos = wave_base[wv] + incl - mine;
-    for (int64_t w = w0; w < w1; w++) {
-        unsigned long long bm = bits[w];
-        if (bm == 0) continue;
-        bits[w] = 0;                             // the bitmap is zero again for the next iteration
-        while (bm != 0) {
-            const int bit = __builtin_ctzll(bm);
-            bm &= bm - 1;
-            const int32_t e = tab[(w << 6) + bit];
-            const double E = oct_estimate_E(S1length, Plength, (int64_t)counts[e], score_mode);
-            Esort[pos++] = E;
             if (!any || E > bE) bE = E;
             any = true;
         }
     }
-    // best score of the iteration (a maximum: any order)
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 32; off > 0; off >>= 1) {   // (a maximum: any order)
         const double o = __shfl_xor(bE, off);
         const int oa = __shfl_xor((int)any, off);
         if (oa && (!any || o > bE)) bE = o;
@@ -512,57 +519,179 @@ oct_advance_kernel(rh_oct_state *__restrict__ ost, const rh_cand_entry *__restri
     }
     if (lane == 0) { bestw[wv] = bE; anyw[wv] = any ? 1 : 0; }
     __syncthreads();
-    // 3. level scores, in candidate order
-    if (tid < od) {
-        double acc = ost->S[tid];
-        const int32_t a = seg[tid], b = seg[tid + 1];
-        int32_t j = a;
-        for (; j + 8 <= b; j += 8) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = Esort[j + q];
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc += v[q];
-        }
-        for (; j < b; j++) acc += Esort[j];
-        ost->S[tid] = acc;
+    OA_T();
+    if (tid == 0) {
+        int32_t a = 0;
+        for (int l = 0; l < od; l++) { seg[l] = a; a += hist[l]; }
+        seg[od] = a;
+    }
+    // 2. ordered compaction: thread t owns the words [t * wpt, (t + 1) * wpt) of either bitmap
+    const int64_t nw = ((int64_t)od * per_it + 63) >> 6, nws = (per_it + 63) >> 6;
+    const int64_t wpt = (nw + OA_THREADS - 1) / OA_THREADS, wpts = (nws + OA_THREADS - 1) / OA_THREADS;
+    const int64_t w0 = min(nw, (int64_t)tid * wpt), w1 = min(nw, w0 + wpt);
+    const int64_t v0 = min(nws, (int64_t)tid * wpts), v1 = min(nws, v0 + wpts);
+    int32_t mine = 0, mines = 0;
+    for (int64_t w = w0; w < w1; w++) mine += __popcll(A.bits[w]);
+    for (int64_t w = v0; w < v1; w++) mines += __popcll(A.sbits[w]);
+    int32_t incl = mine, incls = mines;   // inclusive scans over the wave, then over the waves
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t o = __shfl_up(incl, off), os = __shfl_up(incls, off);
+        if (lane >= off) { incl += o; incls += os; }
+    }
+    if (lane == 63) { wave_tot[0][wv] = incl; wave_tot[1][wv] = incls; }
+    __syncthreads();
+    if (tid < 2) {
+        int32_t a = 0;
+        for (int w = 0; w < OA_WAVES; w++) { wave_base[tid][w] = a; a += wave_tot[tid][w]; }
     }
     __syncthreads();
-    if (tid == 0) {
-        const int32_t scored = seg[od];           // (= m unless an entry was malformed)
-        double best = ost->best_E;
-        int32_t has = ost->has_best;
-        for (int w = 0; w < OA_WAVES; w++)
-            if (anyw[w] && (!has || bestw[w] > best)) { best = bestw[w]; has = 1; }
-        ost->best_E = best;
-        ost->has_best = has;
-        const long long store_n = ost->store_n + scored, cc2 = ost->cc2 + scored;
-        ost->store_n = store_n;
-        ost->cc2 = cc2;
-        // the extraction test of iterations.jl:114-123 -- with the device's pow, which may differ from the host's in
-        // the last place: this only ends the window (the host replays the iterations and decides)
-        if (has) {
-            const long long sl[4] = { 0, store_n, cc2, (long long)k * minsubsetN };
-            const double ppp = 1 - pow(1 - pow(best / (double)Plength, (double)drawN), (double)sl[extract_s & 3]);
-            if (ppp > prob_det) ost->stop = 1;
+    OA_T();
+    {
+        int32_t ps = wave_base[1][wv] + incls - mines;
+        for (int64_t w = v0; w < v1; w++) { A.spref[w] = ps; ps += __popcll(A.sbits[w]); }
+    }
+    const bool lds = m <= OA_ES;
+    int32_t pos = wave_base[0][wv] + incl - mine;
+    for (int64_t w = w0; w < w1; w++) {
+        unsigned long long bm = A.bits[w];
+        if (bm == 0) continue;
+        A.bits[w] = 0;                           // the bitmap is zero again for the next iteration
+        while (bm != 0) {
+            const int bit = __builtin_ctzll(bm);
+            bm &= bm - 1;
+            const double E = A.Etab[(w << 6) + bit];
+            if (lds) Es[pos++] = E; else A.Esort[pos++] = E;
         }
-        // updatelevelweight (octree.jl:198-205), as the host does it (fit_shared.h, update_level_probs)
-        double P[32], S[32];
-        for (int i = 0; i < 32; i++) { P[i] = ost->P[i]; S[i] = ost->S[i]; }
-        rhfit::update_level_probs(P, S, od);
-        rh_oct_iter_hdr &H = h_hdr[it];
-        for (int i = 0; i < 32; i++) { ost->P[i] = P[i]; H.P[i] = P[i]; }
+    }
+    __syncthreads();
+    OA_T();
+    // 3. first wave: the level scores in candidate order, then updatelevelweight; second wave: the extraction test;
+    // the others: the iteration -> the host, its prepared records -> the device store
+    if (wv == 0) {
+        if (lane < od) {
+            // (the chain of additions is the critical path: the next eight scores are fetched while the current eight are added)
+            double acc = lS[lane];
+            const int32_t a = seg[lane], b = seg[lane + 1];
+            auto at = [&](int32_t j) { return lds ? Es[j] : A.Esort[j]; };
+            int32_t j = a;
+            if (j + 8 <= b) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = at(j + q);
+                for (; j + 16 <= b; j += 8) {
+                    double nx[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) nx[q] = at(j + 8 + q);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc += v[q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = nx[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc += v[q];
+                j += 8;
+            }
+            for (; j < b; j++) acc += at(j);
+            lS[lane] = acc;
+            ost->S[lane] = acc;
+        }
+        // updatelevelweight (octree.jl:198-205): the operations of update_level_probs (fit_shared.h) -- the quotients
+        // and the new weights lane-parallel, the two sums one term after the other in level order
+        if (od <= 32) {
+            if (lane < od) lr[lane] = lS[lane] / lP[lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double w = 0;
+                for (int i = 0; i < od; i++) w += lr[i];
+                lw = w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double w = lw;
+            double pn = 0.0;
+            if (lane < od) { pn = 0.9 * lS[lane] / (w * lP[lane]) + (1 - 0.9) / od; lr[lane] = pn; }
+            const bool bad = lane < od && !(pn >= 0);
+            const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double sum = 0;
+                for (int i = 0; i < od; i++) sum += lr[i];
+                lkeep = ((w > 0) && !any_bad && (sum > 0)) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lkeep && lane < od) lP[lane] = pn;
+        }
+    } else if (wv == 1) {
+        if (lane == 0) {
+            double best = ost->best_E;
+            int32_t has = ost->has_best;
+            for (int w = 0; w < OA_WAVES; w++)
+                if (anyw[w] && (!has || bestw[w] > best)) { best = bestw[w]; has = 1; }
+            ost->best_E = best;
+            ost->has_best = has;
+            const int32_t scored = seg[od];           // (= m unless an entry was malformed)
+            const long long store_n = ost->store_count + scored, cc2 = ost->cc2 + scored;
+            ost->store_count = store_n;
+            ost->cc2 = cc2;
+            // the extraction test of iterations.jl:114-123 -- with the device's pow, which may differ from the host's in
+            // the last place: this only ends the window (the host replays the iterations and decides)
+            if (has) {
+                const long long sl[4] = { 0, store_n, cc2, (long long)A.k * A.minsubsetN };
+                const double ppp = 1 - pow(1 - pow(best / (double)A.Plength, (double)A.drawN), (double)sl[A.extract_s & 3]);
+                if (ppp > A.prob_det) lstop = 1;
+            }
+        }
+    } else {
+        const int t = tid - 128, nt = OA_THREADS - 128;
+        static_assert(sizeof(rh_cand_entry) % 8 == 0 && sizeof(rh_prep) % 16 == 0, "copied as 8- / 16-byte words");
+        oa_copy((unsigned long long *)(A.h_entries + start), (const unsigned long long *)(entries + start),
+                (int64_t)m * (int64_t)(sizeof(rh_cand_entry) / 8), t, nt);
+        for (int32_t i = start + t; i < end; i += nt) {
+            A.h_counts[i] = A.counts[i];
+            const int64_t ls = entries[i].slot - (int64_t)it * per_it;
+            int32_t r = -1;
+            if (ls >= 0 && ls < per_it) r = A.spref[ls >> 6] + __popcll(A.sbits[ls >> 6] & ((1ULL << (ls & 63)) - 1ULL));
+            A.h_rank[i] = r;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (nkq[q] == 0) continue;
+            if ((int64_t)sbase[q] + nkq[q] > ost->store_cap[q]) { if (t == 0) store_over = 1; continue; }
+            oa_copy((oa_u32x4 *)(ost->store_prep[q] + sbase[q]), (const oa_u32x4 *)(A.bin_prep + (int64_t)q * A.bin_cap),
+                      (int64_t)nkq[q] * (int64_t)(sizeof(rh_prep) / 16), t, nt);
+            for (int32_t j = t; j < nkq[q]; j += nt) {
+                const int32_t e = A.bin_orig[(int64_t)q * A.bin_cap + j];
+                if (e >= start && e < end) A.h_slot[e] = sbase[q] + j;
+            }
+        }
+    }
+    OA_T();
+    __syncthreads();
+    OA_T();
+    for (int64_t w = v0; w < v1; w++) A.sbits[w] = 0;
+    if (tid < 32) {
+        ost->P[tid] = lP[tid];
+        A.h_hdr[it].P[tid] = lP[tid];
+    }
+    if (tid == 0) {
         ost->start = end;
         ost->it_done = it + 1;
-        const int32_t over = count > cap ? 1 : 0;
-        if (over) ost->stop = 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) ost->store_n[q] = sbase[q] + nkq[q];
+        const int32_t over = (count > A.cap || store_over != 0) ? 1 : 0;
+        const int32_t stop = (over || lstop) ? 1 : 0;
+        if (stop) ost->stop = 1;
+        rh_oct_iter_hdr &H = A.h_hdr[it];
         H.skipped = 0;
         H.overflow = over;
-        H.gave_up = (int32_t)(status[0] >> 32);          // status block: int32 count, int32 gave_up, u64 draws[]
+        H.gave_up = (int32_t)(A.status[0] >> 32);
         H.start = start;
         H.end = end;
-        H.stop_after = ost->stop;
-        H.draws = status[1 + it];
+        H.stop_after = stop;
+        H.draws = A.status[1 + it];
+#ifdef RH_OCT_TIMING
+        tq[7] = wall_clock64();
+        for (int i = 0; i < 7; i++) H.t[i] = tq[i + 1] - tq[i];
+#endif
     }
 }
 
@@ -694,33 +823,31 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
 
 int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const rh_cand_entry *d_entries, const void *d_status,
                     int32_t cap, const int32_t *d_counts, int32_t it, int64_t k, rh_cand_entry *h_entries, int32_t *h_counts,
-                    rh_oct_iter_hdr *h_hdr)
+                    int32_t *h_rank, int32_t *h_slot, rh_oct_iter_hdr *h_hdr)
 {
     const int64_t per_it = (int64_t)prm->minsubsetN * prm->n_shape_types;
     const int od = c->oct_depth;
     if (od < 1 || od > 32) { rh_set_error("rhk_oct_advance: octree depth %d", od); return RH_E_INTERNAL; }
     const int64_t cells = (int64_t)od * per_it;
+    const int64_t nw = (cells + 63) / 64, nws = (per_it + 63) / 64;
     if (c->oct_adv_cells < cells) {
         RH_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->oct_adv_tab);
-        c->oct_adv_tab = nullptr; c->oct_adv_cells = 0;
-        (void)hipFree(c->oct_adv_bits);
-        c->oct_adv_bits = nullptr;
-        RH_HIP(hipMalloc((void **)&c->oct_adv_tab, sizeof(int32_t) * (size_t)cells));
-        RH_HIP(hipMalloc((void **)&c->oct_adv_bits, sizeof(unsigned long long) * (size_t)((cells + 63) / 64)));
-        RH_HIP(hipMemsetAsync(c->oct_adv_bits, 0, sizeof(unsigned long long) * (size_t)((cells + 63) / 64), c->stream));   // the kernel leaves it zero
+        (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);
+        c->oct_adv_tab = nullptr; c->oct_adv_bits = nullptr; c->oct_adv_E = nullptr; c->oct_adv_cells = 0;
+        RH_HIP(hipMalloc((void **)&c->oct_adv_tab, sizeof(double) * (size_t)cells + sizeof(int32_t) * (size_t)nws));   // score table, then the slot prefixes
+        RH_HIP(hipMalloc((void **)&c->oct_adv_bits, sizeof(unsigned long long) * (size_t)(nw + nws)));   // both bitmaps
+        RH_HIP(hipMemsetAsync(c->oct_adv_bits, 0, sizeof(unsigned long long) * (size_t)(nw + nws), c->stream));   // the kernel leaves them zero
+        RH_HIP(hipMalloc((void **)&c->oct_adv_E, sizeof(double) * (size_t)per_it));
         c->oct_adv_cells = cells;
     }
-    if (c->oct_adv_E_cap < per_it) {
-        RH_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->oct_adv_E);
-        c->oct_adv_E = nullptr; c->oct_adv_E_cap = 0;
-        RH_HIP(hipMalloc((void **)&c->oct_adv_E, sizeof(double) * (size_t)per_it));
-        c->oct_adv_E_cap = per_it;
-    }
-    hipLaunchKernelGGL(oct_advance_kernel, dim3(1), dim3(OA_THREADS), 0, c->stream, ost, d_entries, (const int32_t *)d_status, cap, d_counts,
-                       it, k, per_it, (int32_t)od, c->s, c->n, prm->score_mode, prm->extract_s, prm->minsubsetN, prm->drawN, prm->prob_det,
-                       c->oct_adv_tab, c->oct_adv_bits, c->oct_adv_E, (const unsigned long long *)d_status, h_entries, h_counts, h_hdr);
+    OctAdvArgs A;
+    A.ost = ost; A.entries = d_entries; A.status = (const unsigned long long *)d_status; A.counts = d_counts;
+    A.cap = cap; A.it = it; A.od = od; A.score_mode = prm->score_mode; A.extract_s = prm->extract_s; A.minsubsetN = prm->minsubsetN;
+    A.drawN = prm->drawN; A.k = k; A.per_it = per_it; A.S1length = c->s; A.Plength = c->n; A.prob_det = prm->prob_det;
+    A.Etab = (double *)c->oct_adv_tab; A.spref = (int32_t *)((double *)c->oct_adv_tab + cells); A.bits = c->oct_adv_bits; A.sbits = c->oct_adv_bits + nw; A.Esort = c->oct_adv_E;
+    A.bin_prep = c->d_prep; A.bin_orig = c->d_orig; A.bin_nk = c->d_nk; A.bin_cap = c->batch_cap;
+    A.h_entries = h_entries; A.h_counts = h_counts; A.h_rank = h_rank; A.h_slot = h_slot; A.h_hdr = h_hdr;
+    hipLaunchKernelGGL(oct_advance_kernel, dim3(1), dim3(OA_THREADS), 0, c->stream, A);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

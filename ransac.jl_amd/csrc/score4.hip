@@ -379,12 +379,17 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
     bool ran = false, weird = false;
     unsigned live = 0;
+    const uint64_t *staged_en = nullptr;
+    (void)staged_en;
 #define RH_S4_BODY(K)                                                                                                  \
     {                                                                                                                  \
         const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
         if (slo < shi) {                                                                                               \
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile and the list */        \
-            s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64, A.gb32, A.ngroups);                                       \
+            if (!TAIL || !ran || A.k[K].en != staged_en) {                                                             \
+                s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64, A.gb32, A.ngroups);                                   \
+                staged_en = A.k[K].en;                                                                                 \
+            } else if (threadIdx.x == 0) { sh.npairs = 0; sh.next_batch = 0; }   /* same tile, same enabled words */   \
             __syncthreads();                                                                                           \
             live = 0;                                                                                                  \
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
@@ -621,6 +626,25 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
     A.row0 = 0;
+    static int env_loop = -2;
+    if (env_loop < -1) { const char *e = getenv("RH_S4_LOOP"); env_loop = e ? atoi(e) : -1; }
+    // the candidate loop's windows with few candidates (octree sampling: ~1000 local shapes per iteration, few pairs
+    // survive the boxes): one block per tile walks ALL the rows -- the tile is staged once instead of once per row
+    // (measured on the cfg3 octree leg, 18 chunks: 27 us against 39 + 7 for rows + tail).  RH_S4_LOOP=n: for every
+    // unmasked launch of up to n chunks, 0: never.
+    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? 64 : 0);
+    if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
+        dim3 gt(grid.x, 1);
+        if (prep32 != nullptr) {
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+        } else {
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+        }
+        RH_HIP(hipGetLastError());
+        return RH_OK;
+    }
 #define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
     if (prep32 != nullptr) {   // Float32 cloud: c->sub holds the exactly converted values
         if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
