@@ -314,6 +314,12 @@ struct DeviceStore {
     rh_prep *prep[4] = { nullptr, nullptr, nullptr, nullptr };
     rh_prep *spare[4] = { nullptr, nullptr, nullptr, nullptr };   // compaction target, same capacity
     int64_t spare_cap[4] = { 0, 0, 0, 0 };
+    // device-managed mode (chained octree windows): the host's candidate number of every entry, the spare twin, and the
+    // scratch of rhk_store_compact
+    int32_t *id[4] = { nullptr, nullptr, nullptr, nullptr };
+    int32_t *spare_id[4] = { nullptr, nullptr, nullptr, nullptr };
+    int32_t *d_work = nullptr;
+    int64_t work_cap = 0;
     int64_t cap[4] = { 0, 0, 0, 0 };
     int32_t n[4] = { 0, 0, 0, 0 };
     int32_t *iota = nullptr;      // 0..iota_cap-1
@@ -327,7 +333,8 @@ struct DeviceStore {
 int store_free(rh_cloud *c, DeviceStore &st)
 {
     (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); }
+    for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); (void)hipFree(st.id[k]); (void)hipFree(st.spare_id[k]); }
+    (void)hipFree(st.d_work);
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
     (void)hipFree(st.live);
     return RH_OK;
@@ -335,15 +342,26 @@ int store_free(rh_cloud *c, DeviceStore &st)
 
 int store_reserve(rh_cloud *c, DeviceStore &st, int kind, int64_t need)
 {
-    if (need <= st.cap[kind]) return RH_OK;
+    if (need <= st.cap[kind]) {
+        if (st.id[kind] == nullptr && st.cap[kind] > 0)   // (a store parked by a run that kept no ids)
+            RH_HIP(hipMalloc((void **)&st.id[kind], sizeof(int32_t) * (size_t)st.cap[kind]));
+        return RH_OK;
+    }
     const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(4096, st.cap[kind] * 2));
     rh_prep *np = nullptr;
+    int32_t *ni = nullptr;
     RH_HIP(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)cap));
-    if (st.n[kind] > 0)
+    RH_HIP(hipMalloc((void **)&ni, sizeof(int32_t) * (size_t)cap));
+    if (st.n[kind] > 0) {
         RH_HIP(hipMemcpyAsync(np, st.prep[kind], sizeof(rh_prep) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
+        if (st.id[kind] != nullptr)
+            RH_HIP(hipMemcpyAsync(ni, st.id[kind], sizeof(int32_t) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
+    }
     RH_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(st.prep[kind]);
+    (void)hipFree(st.id[kind]);
     st.prep[kind] = np;
+    st.id[kind] = ni;
     st.cap[kind] = cap;
     return RH_OK;
 }
@@ -514,6 +532,36 @@ struct Driver {
     std::vector<rh_extracted> extracted;
     int64_t cc[4] = { 0, 0, 0, 0 };         // countcandidates (1-based like the reference)
     int64_t best = -1;                      // index into store of the running first maximum
+    // Device-managed store (chained octree windows: hundreds of thousands of stored candidates).  `store` is append-only
+    // then -- a dead candidate stays as a tombstone (kind -1), its index is the id the device keeps beside its record --
+    // and the first maximum is kept per block of 256 entries, so that an extraction costs the host O(dead + blocks)
+    // instead of several passes over the whole store.
+    bool managed = false;
+    int64_t live_count = 0;
+    struct BlockMax { double E; int64_t idx; };   // idx < 0: no live entry
+    std::vector<BlockMax> bmax;
+    int64_t store_count() const { return managed ? live_count : (int64_t)store.size(); }
+    void bmax_append(int64_t i, double E)
+    {
+        const size_t b = (size_t)(i >> 8);
+        if (b >= bmax.size()) bmax.push_back(BlockMax{ 0.0, -1 });
+        if (bmax[b].idx < 0 || E > bmax[b].E) bmax[b] = BlockMax{ E, i };
+    }
+    void bmax_rescan(size_t b)
+    {
+        BlockMax m{ 0.0, -1 };
+        const size_t lo = b << 8, hi = std::min(store.size(), lo + 256);
+        for (size_t i = lo; i < hi; i++)
+            if (store[i].kind >= 0 && (m.idx < 0 || store[i].E > m.E)) m = BlockMax{ store[i].E, (int64_t)i };
+        bmax[b] = m;
+    }
+    void bmax_best()   // findhighestscore over the live entries: first maximum, strict >
+    {
+        best = -1;
+        double bE = 0;
+        for (const BlockMax &m : bmax)
+            if (m.idx >= 0 && (best < 0 || m.E > bE)) { best = m.idx; bE = m.E; }
+    }
     double t_score = 0, t_extract = 0, t_sample = 0;
     double t_last_extraction = 0;           // wall clock at the end of the latest extraction
     double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
@@ -755,9 +803,11 @@ struct Driver {
                 shapes.push_back(cands[i]);
                 rec.kind = cands[i].kind;
                 rec.E = E;
-                rec.slot = dev_slots[i];
+                rec.slot = dev_slots[i];   // (where the device put it; stale after the first compaction -- the id rules)
                 rec.sigma = counts[i];
                 store.push_back(rec);
+                live_count++;
+                bmax_append((int64_t)store.size() - 1, E);
                 nk[rec.kind]++;
                 oS[levels[i] - 1] += E;   // pc.levelscore[level] += E(sc): fitting.jl:184
                 if (best < 0) best = (int64_t)store.size() - 1;
@@ -835,7 +885,7 @@ struct Driver {
     int maybe_extract(int64_t k, bool *did)
     {
         *did = false;
-        if (store.empty()) return RH_OK;
+        if (store_count() == 0) return RH_OK;
         const double scr = store[(size_t)best].E;
         const double ppp = rh_prob(scr, cc[p->extract_s], c->n, drawN);
         if (!(ppp > p->prob_det)) return RH_OK;   // iterations.jl:123
@@ -857,8 +907,11 @@ struct Driver {
             const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
             live_work += (int64_t)st.n[q] * ((all_disabled ? c->n_dis : 0) + store[(size_t)best].sigma);
         }
-        const bool fast = sum_n <= LIVE_MAX && live_work <= ((int64_t)1 << 24) && !getenv("RH_NO_FAST_EXTRACT");
-        RUN(store_reserve_aux(c, st, sum_n));
+        const bool fast = !managed && sum_n <= LIVE_MAX && live_work <= ((int64_t)1 << 24) && !getenv("RH_NO_FAST_EXTRACT");
+        // (device-managed store: the kinds laid end to end, each padded to a multiple of RH_STORE_PAD)
+        int32_t pbase[5] = { 0, 0, 0, 0, 0 };
+        for (int q = 0; q < 4; q++) pbase[q + 1] = pbase[q] + (st.n[q] + RH_STORE_PAD - 1) / RH_STORE_PAD * RH_STORE_PAD;
+        RUN(store_reserve_aux(c, st, managed ? std::max<int64_t>(sum_n, pbase[4]) : sum_n));
         RUN(ensure_scratch(32 + 2 * sum_n));   // (may wait for the stream: before anything lands in the scratch)
         int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
         const int64_t ndis_old = c->n_dis;
@@ -934,6 +987,88 @@ struct Driver {
         c->n_dis = ndis_new;
 
         tp[1] += now_s() - tq; tq = now_s();
+        if (managed) {
+            // removeinvalidshapes! (fitting.jl:209-221) with the store managed on the device: liveness counts per entry,
+            // then rhk_store_compact moves the survivors to the spare arrays and hands the dead candidates' numbers
+            // over -- one wait, and the host touches only the dead
+            const int64_t extracted_id = (int64_t)extracted_pos;
+            int32_t *h_out = h_scr + 24, *h_dead = h_counts;
+            for (int i = 0; i < 5; i++) h_out[i] = 0;
+            if (sum_n > 0) {
+                const int64_t nblocks = pbase[4] / RH_STORE_PAD;
+                if (st.work_cap < 2 * nblocks + 16) {
+                    RUNH(hipStreamSynchronize(c->stream));
+                    (void)hipFree(st.d_work);
+                    st.d_work = nullptr; st.work_cap = 0;
+                    const int64_t cap = std::max<int64_t>(4 * nblocks + 64, 4096);
+                    RUNH(hipMalloc((void **)&st.d_work, sizeof(int32_t) * (size_t)cap));
+                    st.work_cap = cap;
+                }
+                for (int q = 0; q < 4; q++) {
+                    if (st.n[q] == 0 || (st.spare_cap[q] >= st.cap[q] && st.spare_id[q] != nullptr)) continue;
+                    RUNH(hipStreamSynchronize(c->stream));
+                    (void)hipFree(st.spare[q]); (void)hipFree(st.spare_id[q]);
+                    st.spare[q] = nullptr; st.spare_id[q] = nullptr; st.spare_cap[q] = 0;
+                    RUNH(hipMalloc((void **)&st.spare[q], sizeof(rh_prep) * (size_t)st.cap[q]));
+                    RUNH(hipMalloc((void **)&st.spare_id[q], sizeof(int32_t) * (size_t)st.cap[q]));
+                    st.spare_cap[q] = st.cap[q];
+                }
+                RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)pbase[4], c->stream));
+                for (int q = 0; q < 4; q++) h_nk[q] = st.n[q];
+                RUNH(hipMemcpyAsync(st.d_nk + 4, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                for (int q = 0; q < 4; q++) {
+                    if (st.n[q] == 0) continue;
+                    const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                    const int64_t first = all_disabled ? 0 : ndis_old;
+                    const int64_t cnt = (int64_t)ndis_new - first;
+                    if (cnt <= 0) continue;
+                    RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota + pbase[q], st.d_nk + 4 + q, st.n[q], p->eps[q],
+                                           p->cos_alpha[q], st.counts));
+                }
+                rh_store_plan SP;
+                for (int q = 0; q < 4; q++) {
+                    SP.prep[q] = st.prep[q]; SP.spare[q] = st.spare[q]; SP.id[q] = st.id[q]; SP.spare_id[q] = st.spare_id[q];
+                    SP.n[q] = st.n[q];
+                }
+                for (int q = 0; q < 5; q++) SP.pbase[q] = pbase[q];
+                SP.counts = st.counts;
+                SP.extracted_id = (int32_t)extracted_id;
+                RUN(rhk_store_compact(c, SP, st.d_work, h_out, h_dead));
+                RUNH(hipStreamSynchronize(c->stream));
+            }
+            tp[2] += now_s() - tq; tq = now_s();
+            const int32_t ndead = h_out[4];
+            if (ndead < 1 || ndead > sum_n) { rh_set_error("rh_ransac: store compaction reported %d dead of %lld", ndead, (long long)sum_n); return RH_E_INTERNAL; }
+            bool saw_extracted = false;
+            for (int32_t i = 0; i < ndead; i++) {
+                const int64_t id = h_dead[i];
+                if (id < 0 || id >= (int64_t)store.size() || store[(size_t)id].kind < 0) {
+                    rh_set_error("rh_ransac: the device store names candidate %lld, which is not alive", (long long)id);
+                    return RH_E_INTERNAL;
+                }
+                saw_extracted |= id == extracted_id;
+                store[(size_t)id].kind = -1;
+                live_count--;
+            }
+            for (int32_t i = 0; i < ndead; i++) {   // a block whose first maximum died is searched again, once
+                const size_t b = (size_t)(h_dead[i] >> 8);
+                if (bmax[b].idx >= 0 && store[(size_t)bmax[b].idx].kind < 0) bmax_rescan(b);
+            }
+            if (!saw_extracted) { rh_set_error("rh_ransac: the extracted candidate is missing from the dead list"); return RH_E_INTERNAL; }
+            for (int q = 0; q < 4; q++) {
+                if (st.n[q] == 0) continue;
+                std::swap(st.prep[q], st.spare[q]);
+                std::swap(st.id[q], st.spare_id[q]);
+                std::swap(st.cap[q], st.spare_cap[q]);
+                st.n[q] = h_out[q];
+            }
+            tp[3] += now_s() - tq; tq = now_s();
+            bmax_best();
+            tp[4] += now_s() - tq;
+            t_extract += now_s() - t0;
+            *did = true;
+            return RH_OK;
+        }
         // removeinvalidshapes!: fitting.jl:209-221, recomputed on the device (see header)
         std::vector<char> dead_slot[4];
         for (int q = 0; q < 4; q++) dead_slot[q].assign((size_t)st.n[q], 0);   // every slot is referenced by `store`
@@ -1031,7 +1166,7 @@ struct Driver {
         RUN(record(cands, levels, ncand, counts, dev_slots));
         tw[3] += now_s() - tr0;
         cc[3] = k * p->minsubsetN;
-        cc[1] = (int64_t)store.size();
+        cc[1] = store_count();
         RUN(maybe_extract(k, did_extract));
         // updatelevelweight (octree.jl:198-205): in the reference it only ever produces NaN weights (header)
         if (octree) rhfit::update_level_probs(oP, oS, od);
@@ -1112,6 +1247,7 @@ struct Driver {
             int64_t Kchain = 8;
             if (const char *e = getenv("RH_OCT_CHAIN_W")) Kchain = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
             if (c->oct_state == nullptr) RUNH(hipMalloc((void **)&c->oct_state, sizeof(rh_oct_state)));
+            managed = !getenv("RH_NO_MANAGED_STORE");   // (the store is empty here: run_streams_device is where a run starts)
             auto ensure_pinned = [&](Window &w) -> int {
                 if (w.h_ost == nullptr) {
                     RUNH(hipHostMalloc((void **)&w.h_ost, sizeof(rh_oct_state)));
@@ -1148,8 +1284,8 @@ struct Driver {
                 }
                 RUN(ensure_pinned(w));
                 bool certain = false;
-                if (!store.empty()) {
-                    int64_t lb[4] = { 0, (int64_t)store.size(), cc[2], k * p->minsubsetN };
+                if (store_count() > 0) {
+                    int64_t lb[4] = { 0, store_count(), cc[2], k * p->minsubsetN };
                     certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
                 }
                 const int32_t W = (int32_t)std::min<int64_t>(certain ? 1 : Kchain, p->itermax - k + 1);
@@ -1157,9 +1293,10 @@ struct Driver {
                 rh_oct_state &h = *w.h_ost;
                 memset(&h, 0, sizeof h);
                 for (int i = 0; i < od; i++) { h.S[i] = oS[i]; h.P[i] = oP[i]; }
-                h.has_best = store.empty() ? 0 : 1;
-                h.best_E = store.empty() ? 0.0 : store[(size_t)best].E;
-                h.store_count = (long long)store.size();
+                h.has_best = store_count() == 0 ? 0 : 1;
+                h.best_E = store_count() == 0 ? 0.0 : store[(size_t)best].E;
+                h.store_count = (long long)store_count();
+                h.appended = (long long)store.size();
                 h.cc2 = cc[2];
                 // the iterations append their candidates' records to the device store: room for a whole window
                 for (int q = 0; q < 4; q++) {
@@ -1167,6 +1304,7 @@ struct Driver {
                     for (int ti = 0; ti < T; ti++) has_kind |= p->shape_types[ti] == q;
                     if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + (int64_t)W * p->minsubsetN * T));
                     h.store_prep[q] = st.prep[q];
+                    h.store_id[q] = st.id[q];
                     h.store_cap[q] = st.cap[q];
                     h.store_n[q] = st.n[q];
                 }
@@ -1605,7 +1743,7 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
 
     out->iterations = d.iterations;
     out->candidates_scored = d.cc[2];
-    out->scored_left = (int64_t)d.store.size();
+    out->scored_left = d.store_count();
     out->n_shapes = (int64_t)d.extracted.size();
     out->shapes = (rh_extracted *)malloc(sizeof(rh_extracted) * std::max<size_t>(d.extracted.size(), 1));
     if (!out->shapes) { rh_set_error("out of host memory"); return RH_E_NOMEM; }

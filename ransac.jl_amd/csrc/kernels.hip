@@ -1440,6 +1440,121 @@ int rhk_iota(rh_cloud *c, int32_t *d, int32_t n, int32_t base)
     return RH_OK;
 }
 
+
+// ---- device-managed candidate store: compaction after an extraction (rh_internal.h, rh_store_plan) ----------------------
+namespace {
+__device__ __forceinline__ bool store_alive(const rh_store_plan &P, int64_t g, int &q_out, int32_t &slot_out, bool &valid)
+{
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++) q += g >= P.pbase[k] ? 1 : 0;
+    const int32_t slot = (int32_t)(g - P.pbase[q]);
+    q_out = q; slot_out = slot;
+    valid = slot < P.n[q];
+    return valid && P.counts[g] == 0 && P.id[q][slot] != P.extracted_id;
+}
+
+__global__ void __launch_bounds__(RH_STORE_PAD)
+store_count_kernel(const rh_store_plan P, int32_t *__restrict__ blk_cnt)
+{
+    __shared__ int32_t wc[RH_STORE_PAD / 64];
+    const int64_t g = (int64_t)blockIdx.x * RH_STORE_PAD + threadIdx.x;
+    int q; int32_t slot; bool valid;
+    const bool alive = store_alive(P, g, q, slot, valid);
+    const uint64_t bm = __builtin_amdgcn_ballot_w64(alive);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t a = 0;
+        for (int w = 0; w < RH_STORE_PAD / 64; w++) a += wc[w];
+        blk_cnt[blockIdx.x] = a;
+    }
+}
+
+// one block: exclusive scan of the block counts; the kinds' offsets and new lengths; the dead-list counter back to zero
+__global__ void __launch_bounds__(1024)
+store_scan_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_cnt, int32_t nblocks, int32_t *__restrict__ blk_off,
+                  int32_t *__restrict__ kind_off, int32_t *__restrict__ dead_counter, int32_t *__restrict__ h_out)
+{
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int32_t per = (nblocks + 1023) / 1024;
+    const int32_t b0 = min(nblocks, tid * per), b1 = min(nblocks, b0 + per);
+    int32_t a = 0;
+    for (int32_t b = b0; b < b1; b++) a += blk_cnt[b];
+    part[tid] = a;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int t = 0; t < 1024; t++) { const int32_t v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    int32_t run = part[tid];
+    for (int32_t b = b0; b < b1; b++) { blk_off[b] = run; run += blk_cnt[b]; }
+    if (tid == 1023) blk_off[nblocks] = run;   // (the last thread's range ends the array: the total)
+    __syncthreads();
+    if (tid == 0) {
+        *dead_counter = 0;
+        int32_t total_old = 0, total_new = 0;
+        for (int q = 0; q < 4; q++) {
+            const int32_t lo = blk_off[P.pbase[q] / RH_STORE_PAD], hi = blk_off[P.pbase[q + 1] / RH_STORE_PAD];
+            kind_off[q] = lo;
+            h_out[q] = hi - lo;
+            total_old += P.n[q];
+            total_new += hi - lo;
+        }
+        h_out[4] = total_old - total_new;
+    }
+}
+
+__global__ void __launch_bounds__(RH_STORE_PAD)
+store_move_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_off, const int32_t *__restrict__ kind_off,
+                  int32_t *__restrict__ dead_counter, int32_t *__restrict__ h_dead)
+{
+    __shared__ int32_t wc[RH_STORE_PAD / 64];
+    const int64_t g = (int64_t)blockIdx.x * RH_STORE_PAD + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int q; int32_t slot; bool valid;
+    const bool alive = store_alive(P, g, q, slot, valid);
+    const uint64_t bm = __builtin_amdgcn_ballot_w64(alive);
+    if (lane == 0) wc[wv] = __popcll(bm);
+    __syncthreads();
+    if (alive) {
+        int32_t pos = blk_off[blockIdx.x] - kind_off[q] + __popcll(bm & ((1ULL << lane) - 1ULL));
+        for (int w = 0; w < wv; w++) pos += wc[w];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = (const u32x4 *)(P.prep[q] + slot);
+        u32x4 *dst = (u32x4 *)(P.spare[q] + pos);
+        u32x4 v[sizeof(rh_prep) / 16];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(rh_prep) / 16); i++) v[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(rh_prep) / 16); i++) dst[i] = v[i];
+        P.spare_id[q][pos] = P.id[q][slot];
+    } else if (valid) {
+        // dead: its id goes to the host (one atomic per wave)
+        const uint64_t dm = __builtin_amdgcn_ballot_w64(true);
+        const int leader = __builtin_ctzll(dm);
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(dead_counter, __popcll(dm));
+        base = __shfl(base, leader);
+        h_dead[base + __popcll(dm & ((1ULL << lane) - 1ULL))] = P.id[q][slot];
+    }
+}
+}  // namespace
+
+int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead)
+{
+    const int32_t nblocks = P.pbase[4] / RH_STORE_PAD;
+    if (nblocks <= 0) { for (int i = 0; i < 5; i++) h_out[i] = 0; return RH_OK; }
+    int32_t *blk_cnt = d_work, *blk_off = d_work + nblocks, *kind_off = d_work + 2 * nblocks + 1, *counter = d_work + 2 * nblocks + 8;
+    hipLaunchKernelGGL(store_count_kernel, dim3((unsigned)nblocks), dim3(RH_STORE_PAD), 0, c->stream, P, blk_cnt);
+    hipLaunchKernelGGL(store_scan_kernel, dim3(1), dim3(1024), 0, c->stream, P, blk_cnt, nblocks, blk_off, kind_off, counter, h_out);
+    hipLaunchKernelGGL(store_move_kernel, dim3((unsigned)nblocks), dim3(RH_STORE_PAD), 0, c->stream, P, blk_off, kind_off, counter, h_dead);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
 int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32_t n, rh_prep *dst)
 {
     if (n == 0) return RH_OK;

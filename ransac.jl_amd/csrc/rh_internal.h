@@ -283,6 +283,23 @@ int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out);
 int rhk_count_enabled(rh_cloud *c, int64_t *out);
 int rhk_iota(rh_cloud *c, int32_t *d, int32_t n, int32_t base);
 int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32_t n, rh_prep *dst);
+// removeinvalidshapes! (fitting.jl:209-221) on a device-managed store (driver.hip, chained octree windows): the store's
+// entries carry the host's candidate number (id); an entry dies when its liveness count is non-zero or it is the
+// extracted candidate.  The survivors move to the spare arrays in order, the ids of the dead ones go to the host.
+// Index space: the kinds laid end to end, each padded to a multiple of RH_STORE_PAD (pbase[q]; pbase[4] = the end).
+constexpr int RH_STORE_PAD = 1024;
+struct rh_store_plan {
+    const rh_prep *prep[4];
+    rh_prep *spare[4];
+    const int32_t *id[4];
+    int32_t *spare_id[4];
+    int32_t n[4], pbase[5];
+    const int32_t *counts;       // liveness counts at pbase[q] + slot
+    int32_t extracted_id;
+};
+// d_work: 2 * (pbase[4] / RH_STORE_PAD) + 16 ints of scratch; h_out (pinned): [0..3] the kinds' new lengths, [4] the number
+// of dead entries; h_dead (pinned): their ids, in no particular order
+int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead);
 
 int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
                         int64_t *idx_out, int64_t cap, int32_t *d_total);
@@ -302,7 +319,9 @@ struct rh_oct_state {
     double best_E;                // the best stored score (findhighestscore), has_best != 0
     long long store_count, cc2;   // stored candidates / candidates scored so far
     rh_prep *store_prep[4];       // the device store of prepared candidates (driver.hip): arrays per kind, their capacities and
-    long long store_cap[4];       //   fill -- every iteration appends its candidates' records
+    int32_t *store_id[4];         //   fill -- every iteration appends its candidates' records and their numbers on the host
+    long long store_cap[4];       //   (appended + the candidate's rank in candidate order)
+    long long appended;
     int32_t store_n[4];
     int32_t has_best;
     int32_t stop;                 // an iteration's extraction test passed (approximately: the host decides): the rest of the window is skipped

@@ -660,7 +660,14 @@ oct_advance_kernel(const OctAdvArgs A)
                       (int64_t)nkq[q] * (int64_t)(sizeof(rh_prep) / 16), t, nt);
             for (int32_t j = t; j < nkq[q]; j += nt) {
                 const int32_t e = A.bin_orig[(int64_t)q * A.bin_cap + j];
-                if (e >= start && e < end) A.h_slot[e] = sbase[q] + j;
+                int32_t id = -1;
+                if (e >= start && e < end) {
+                    A.h_slot[e] = sbase[q] + j;
+                    const int64_t ls = entries[e].slot - (int64_t)it * per_it;
+                    if (ls >= 0 && ls < per_it)
+                        id = (int32_t)ost->appended + A.spref[ls >> 6] + __popcll(A.sbits[ls >> 6] & ((1ULL << (ls & 63)) - 1ULL));
+                }
+                ost->store_id[q][sbase[q] + j] = id;
             }
         }
     }
@@ -677,6 +684,7 @@ oct_advance_kernel(const OctAdvArgs A)
         ost->it_done = it + 1;
 #pragma unroll
         for (int q = 0; q < 4; q++) ost->store_n[q] = sbase[q] + nkq[q];
+        ost->appended += seg[od];
         const int32_t over = (count > A.cap || store_over != 0) ? 1 : 0;
         const int32_t stop = (over || lstop) ? 1 : 0;
         if (stop) ost->stop = 1;
