@@ -184,7 +184,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab);
     (void)hipFree(c->oct_state); (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);
     (void)hipFree(c->fullk); (void)hipFree(c->fullk32); (void)hipFree(c->kgb); (void)hipFree(c->klist); (void)hipFree(c->kctr); (void)hipFree(c->kflag);
-    (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb);
+    (void)hipFree(c->en_block_sums); (void)hipFree(c->dis_gb); (void)hipFree(c->dis_gb32);
     (void)hipFree(c->d_ndis); (void)hipFree(c->refit_mask); (void)hipFree(c->block_sums);
     (void)hipFree(c->word_prefix); (void)hipFree(c->idx_out); (void)hipFree(c->d_total);
     (void)hipFree(c->d_shapes); (void)hipFree(c->d_prep); (void)hipFree(c->d_orig); (void)hipFree(c->d_nk); (void)hipFree(c->d_nk2);
@@ -362,6 +362,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->gb, 7 * c->ng_pad));
     CK(dev_alloc(&c->gb32, 8 * c->ng_pad));
     CK(dev_alloc(&c->dis_gb, 7 * c->ng_pad));
+    CK(dev_alloc(&c->dis_gb32, 8 * c->ng_pad));
     CKH(hipMemsetAsync(c->dis_gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     CKH(hipMemsetAsync(c->gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     {

@@ -320,6 +320,9 @@ struct DeviceStore {
     int32_t *spare_id[4] = { nullptr, nullptr, nullptr, nullptr };
     int32_t *d_work = nullptr;
     int64_t work_cap = 0;
+    void *d_cls = nullptr;        // classifier + culling records of the whole store for a liveness pass of the v4 kernel
+    float *d_box = nullptr;       //   (made on the fly by rhk_store_cls), cls_cap entries
+    int64_t cls_cap = 0;
     int64_t cap[4] = { 0, 0, 0, 0 };
     int32_t n[4] = { 0, 0, 0, 0 };
     int32_t *iota = nullptr;      // 0..iota_cap-1
@@ -334,7 +337,7 @@ int store_free(rh_cloud *c, DeviceStore &st)
 {
     (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); (void)hipFree(st.id[k]); (void)hipFree(st.spare_id[k]); }
-    (void)hipFree(st.d_work);
+    (void)hipFree(st.d_work); (void)hipFree(st.d_cls); (void)hipFree(st.d_box);
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
     (void)hipFree(st.live);
     return RH_OK;
@@ -540,19 +543,23 @@ struct Driver {
     int64_t live_count = 0;
     struct BlockMax { double E; int64_t idx; };   // idx < 0: no live entry
     std::vector<BlockMax> bmax;
+    std::vector<uint8_t> alive;                   // per entry of `store` (the dead list arrives in no order: a byte array stays in cache)
+    std::vector<double> Ev;                       // the scores again, densely (block rescans)
     int64_t store_count() const { return managed ? live_count : (int64_t)store.size(); }
     void bmax_append(int64_t i, double E)
     {
         const size_t b = (size_t)(i >> 8);
         if (b >= bmax.size()) bmax.push_back(BlockMax{ 0.0, -1 });
         if (bmax[b].idx < 0 || E > bmax[b].E) bmax[b] = BlockMax{ E, i };
+        alive.push_back(1);
+        Ev.push_back(E);
     }
     void bmax_rescan(size_t b)
     {
         BlockMax m{ 0.0, -1 };
         const size_t lo = b << 8, hi = std::min(store.size(), lo + 256);
         for (size_t i = lo; i < hi; i++)
-            if (store[i].kind >= 0 && (m.idx < 0 || store[i].E > m.E)) m = BlockMax{ store[i].E, (int64_t)i };
+            if (alive[i] && (m.idx < 0 || Ev[i] > m.E)) m = BlockMax{ Ev[i], (int64_t)i };
         bmax[b] = m;
     }
     void bmax_best()   // findhighestscore over the live entries: first maximum, strict >
@@ -998,7 +1005,7 @@ struct Driver {
                 const int64_t nblocks = pbase[4] / RH_STORE_PAD;
                 if (st.work_cap < 2 * nblocks + 16) {
                     RUNH(hipStreamSynchronize(c->stream));
-                    (void)hipFree(st.d_work);
+                    (void)hipFree(st.d_work); (void)hipFree(st.d_cls); (void)hipFree(st.d_box);
                     st.d_work = nullptr; st.work_cap = 0;
                     const int64_t cap = std::max<int64_t>(4 * nblocks + 64, 4096);
                     RUNH(hipMalloc((void **)&st.d_work, sizeof(int32_t) * (size_t)cap));
@@ -1014,16 +1021,55 @@ struct Driver {
                     st.spare_cap[q] = st.cap[q];
                 }
                 RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)pbase[4], c->stream));
-                for (int q = 0; q < 4; q++) h_nk[q] = st.n[q];
-                RUNH(hipMemcpyAsync(st.d_nk + 4, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-                for (int q = 0; q < 4; q++) {
-                    if (st.n[q] == 0) continue;
-                    const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
-                    const int64_t first = all_disabled ? 0 : ndis_old;
-                    const int64_t cnt = (int64_t)ndis_new - first;
-                    if (cnt <= 0) continue;
-                    RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota + pbase[q], st.d_nk + 4 + q, st.n[q], p->eps[q],
-                                           p->cos_alpha[q], st.counts));
+                // h_nk[0..3]: the kinds' lengths; [4..7]: zeros (a kind left out of a pass)
+                for (int q = 0; q < 4; q++) { h_nk[q] = st.n[q]; h_nk[4 + q] = 0; }
+                const bool v4 = rh_score_v4_enabled(c) && !getenv("RH_NO_V4_LIVENESS");
+                if (v4) {
+                    // the culled binary32-classified kernel of the batch path, over the new entries of the disabled list:
+                    // its records are made from the stored prepared candidates on the fly
+                    if (st.cls_cap < pbase[4]) {
+                        RUNH(hipStreamSynchronize(c->stream));
+                        (void)hipFree(st.d_cls); (void)hipFree(st.d_box);
+                        st.d_cls = nullptr; st.d_box = nullptr; st.cls_cap = 0;
+                        const int64_t cap = std::max<int64_t>(2 * (int64_t)pbase[4], 1 << 16);
+                        RUNH(hipMalloc(&st.d_cls, 64 * (size_t)cap));
+                        RUNH(hipMalloc((void **)&st.d_box, sizeof(float) * 11 * (size_t)cap));
+                        st.cls_cap = cap;
+                    }
+                    RUNH(hipMemcpyAsync(st.d_nk, h_nk, 8 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                    RUN(rhk_store_cls(c, st.prep, st.n, pbase, p->eps, p->cos_alpha, st.d_cls, st.d_box, st.cls_cap));
+                    // kinds that look at the same stretch of the list go in one launch (faithful-mode spheres look at all of it)
+                    for (int pass = 0; pass < 2; pass++) {
+                        const rh_prep *pr[4];
+                        const void *cl[4];
+                        const float *bx[4];
+                        const int32_t *og[4], *nkp[4];
+                        int64_t first = -1;
+                        int32_t bound = 0;
+                        for (int q = 0; q < 4; q++) {
+                            const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                            const bool in = st.n[q] > 0 && (pass == 0 ? !all_disabled : all_disabled);
+                            pr[q] = st.prep[q];
+                            cl[q] = (const char *)st.d_cls + 64 * (size_t)pbase[q];
+                            bx[q] = st.d_box + pbase[q];
+                            og[q] = st.iota + pbase[q];
+                            nkp[q] = st.d_nk + (in ? q : 4 + q);
+                            if (in) { first = all_disabled ? 0 : ndis_old; bound += st.n[q]; }
+                        }
+                        if (first < 0 || (int64_t)ndis_new - first <= 0) continue;
+                        RUN(rhk_score4_dis(c, first, (int64_t)ndis_new - first, pr, cl, bx, st.cls_cap, og, nkp, bound, p->eps, p->cos_alpha, st.counts));
+                    }
+                } else {
+                    RUNH(hipMemcpyAsync(st.d_nk + 4, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                    for (int q = 0; q < 4; q++) {
+                        if (st.n[q] == 0) continue;
+                        const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
+                        const int64_t first = all_disabled ? 0 : ndis_old;
+                        const int64_t cnt = (int64_t)ndis_new - first;
+                        if (cnt <= 0) continue;
+                        RUN(rhk_score_kind_dis(c, q, first, cnt, st.prep[q], st.iota + pbase[q], st.d_nk + 4 + q, st.n[q], p->eps[q],
+                                               p->cos_alpha[q], st.counts));
+                    }
                 }
                 rh_store_plan SP;
                 for (int q = 0; q < 4; q++) {
@@ -1042,17 +1088,17 @@ struct Driver {
             bool saw_extracted = false;
             for (int32_t i = 0; i < ndead; i++) {
                 const int64_t id = h_dead[i];
-                if (id < 0 || id >= (int64_t)store.size() || store[(size_t)id].kind < 0) {
+                if (id < 0 || id >= (int64_t)store.size() || !alive[(size_t)id]) {
                     rh_set_error("rh_ransac: the device store names candidate %lld, which is not alive", (long long)id);
                     return RH_E_INTERNAL;
                 }
                 saw_extracted |= id == extracted_id;
-                store[(size_t)id].kind = -1;
+                alive[(size_t)id] = 0;
                 live_count--;
             }
             for (int32_t i = 0; i < ndead; i++) {   // a block whose first maximum died is searched again, once
                 const size_t b = (size_t)(h_dead[i] >> 8);
-                if (bmax[b].idx >= 0 && store[(size_t)bmax[b].idx].kind < 0) bmax_rescan(b);
+                if (bmax[b].idx >= 0 && !alive[(size_t)bmax[b].idx]) bmax_rescan(b);
             }
             if (!saw_extracted) { rh_set_error("rh_ransac: the extracted candidate is missing from the dead list"); return RH_E_INTERNAL; }
             for (int q = 0; q < 4; q++) {

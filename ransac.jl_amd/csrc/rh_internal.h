@@ -54,6 +54,11 @@ constexpr int64_t RH_KREFIT_MIN = 1 << 21;               // clouds from this siz
 
 // ---- the cloud --------------------------------------------------------------
 struct rh_oct_state;
+struct rh_s4_points {   // what the v4 score kernel runs over (score4.hip): points as six planes `stride` apart, 64-point groups + their boxes
+    const double *pts;
+    int64_t stride, s, ngroups;
+    const float *gb32;
+};
 struct rh_cloud {
     int device = -1;
     hipStream_t stream = nullptr;      // the stream every launch / copy of this cloud goes to
@@ -122,6 +127,8 @@ struct rh_cloud {
     int32_t *oct_prefix = nullptr;     // [nwords + 1]
     rh_oct_state *oct_state = nullptr; // chained octree windows: the window's state,
     const int32_t *s4_stop = nullptr;  //   its stop flag as the score kernel sees it (null outside such windows),
+    const rh_s4_points *s4_points = nullptr;   // the launches being queued run over this set instead of subset 1 (rhk_score4_dis)
+    float *dis_gb32 = nullptr;         // binary32 twins of dis_gb
     bool s4_open_count = false;        // the candidate count of the score launches being queued is a guess (windows of the candidate loop)
     int32_t *oct_adv_tab = nullptr;    //   the (level, slot) table of rhk_oct_advance, its bitmap (kept zero) and the sorted scores
     unsigned long long *oct_adv_bits = nullptr;
@@ -244,7 +251,13 @@ int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep
                          const void *const prep32[4] = nullptr,    // prep32: Float32 cloud, float records of the same bins
                          const void *const cls[4] = nullptr,       // cls / box: classifier and culling records (score4_device.h) of the
                          const float *const box[4] = nullptr, int64_t bstride = 0);   // same bins and thresholds -> v4 kernel
-int rhk_gb32_build(rh_cloud *c);   // score4.hip: gb32 from gb
+int rhk_gb32_build(rh_cloud *c);
+int rhk_store_cls(rh_cloud *c, const rh_prep *const prep[4], const int32_t n[4], const int32_t pbase[5], const double eps[4],
+                  const double cosa[4], void *d_cls, float *d_box, int64_t bstride);
+int rhk_score4_dis(rh_cloud *c, int64_t first, int64_t cnt, const rh_prep *const prep[4], const void *const cls[4], const float *const box[4],
+                   int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound, const double eps[4],
+                   const double cosa[4], int32_t *d_counts);
+// (score4.hip: gb32 from gb)
 int rhk_prep_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const int32_t *d_orig, const int64_t off[4],
                  const int32_t *d_nk, int32_t nmax);               // fills c->d_prep32 (f32.hip)
 // Float32 clouds (f32.hip)

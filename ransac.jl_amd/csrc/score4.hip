@@ -600,7 +600,10 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
                    uint8_t *d_occ, int64_t mstride, const void *const prep32[4])
 {
     const bool open_count = c->s4_open_count;
-    const int64_t ntiles = (c->ngroups + S4_TG - 1) / S4_TG;
+    // the points: subset 1 in internal order, or the set rhk_score4_dis put in place (a segment of the disabled list)
+    rh_s4_points PS = { c->sub, c->s_pad, c->s, c->ngroups, c->gb32 };
+    if (c->s4_points != nullptr) PS = *c->s4_points;
+    const int64_t ntiles = (PS.ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
     if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
     static int dbg = -1, env_swz = -1;
@@ -613,8 +616,8 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.stop = c->s4_stop;
     A.ntiles = ntiles;
     A.bstride = bstride;
-    A.ngroups = c->ngroups;
-    A.gb32 = c->gb32;
+    A.ngroups = PS.ngroups;
+    A.gb32 = PS.gb32;
     A.masks = d_masks_int;
     A.occ = d_occ;
     A.mstride = mstride;
@@ -636,16 +639,16 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
         dim3 gt(grid.x, 1);
         if (prep32 != nullptr) {
-            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         } else {
-            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         }
         RH_HIP(hipGetLastError());
         return RH_OK;
     }
-#define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg)
+#define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg)
     if (prep32 != nullptr) {   // Float32 cloud: c->sub holds the exactly converted values
         if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
         else { if (R == 4) RH_S4_LAUNCH(4, false, true); else RH_S4_LAUNCH(8, false, true); }
@@ -660,15 +663,66 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         A.row0 = (int)rows;
         dim3 gt(grid.x, 2);
         if (prep32 != nullptr) {
-            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         } else {
-            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
-            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, c->sub, c->s_pad, c->s, A, d_counts, dbg);
+            if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
+            else hipLaunchKernelGGL((score4_kernel<8, false, false, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         }
     }
     RH_HIP(hipGetLastError());
     return RH_OK;
+}
+
+// the prepared candidates of a device store (driver.hip) -> classifier + culling records for the v4 kernel, made on the
+// fly for a liveness pass: index space = the kinds laid end to end from pbase[q] on, fields of the culling records bstride apart
+namespace {
+__global__ void __launch_bounds__(256)
+store_cls_kernel(const rh_prep *p0, const rh_prep *p1, const rh_prep *p2, const rh_prep *p3, int32_t n0, int32_t n1, int32_t n2, int32_t n3,
+                 int32_t b1, int32_t b2, int32_t b3, int32_t total, double e0, double e1, double e2, double e3, double c0, double c1, double c2,
+                 double c3, double M, double Nm, rh_cls *__restrict__ cls, float *__restrict__ box, int64_t bstride)
+{
+    const int32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int q = (g >= b1 ? 1 : 0) + (g >= b2 ? 1 : 0) + (g >= b3 ? 1 : 0);
+    const int32_t slot = g - (q == 0 ? 0 : (q == 1 ? b1 : (q == 2 ? b2 : b3)));
+    const int32_t n = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
+    if (slot >= n) return;
+    const rh_prep *pp = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
+    const double eps = q == 0 ? e0 : (q == 1 ? e1 : (q == 2 ? e2 : e3)), cosa = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    const rh_prep P = pp[slot];
+    cls_make(P, q, eps, cosa, M, Nm, cls[g], box + g, bstride);
+}
+}  // namespace
+
+int rhk_store_cls(rh_cloud *c, const rh_prep *const prep[4], const int32_t n[4], const int32_t pbase[5], const double eps[4],
+                  const double cosa[4], void *d_cls, float *d_box, int64_t bstride)
+{
+    if (pbase[4] <= 0) return RH_OK;
+    hipLaunchKernelGGL(store_cls_kernel, dim3((unsigned)cdiv4(pbase[4], 256)), dim3(256), 0, c->stream, prep[0], prep[1], prep[2], prep[3], n[0], n[1],
+                       n[2], n[3], pbase[1], pbase[2], pbase[3], pbase[4], eps[0], eps[1], eps[2], eps[3], cosa[0], cosa[1], cosa[2], cosa[3],
+                       c->coord_mag, c->nrm_mag, (rh_cls *)d_cls, d_box, bstride);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// the v4 kernel on cnt points of the disabled list from `first` on (every one counts: no enabled words)
+int rhk_score4_dis(rh_cloud *c, int64_t first, int64_t cnt, const rh_prep *const prep[4], const void *const cls[4], const float *const box[4],
+                   int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound, const double eps[4],
+                   const double cosa[4], int32_t *d_counts)
+{
+    if (cnt <= 0 || nk_total_bound <= 0) return RH_OK;
+    const int64_t ng = (cnt + 63) / 64;
+    if (ng > c->ng_pad) { rh_set_error("rhk_score4_dis: %lld groups", (long long)ng); return RH_E_INTERNAL; }
+    RH_TRY(rhk_group_bounds_of(c, c->dis + first, c->dis_stride, cnt, ng, c->dis_gb, c->ng_pad));
+    hipLaunchKernelGGL(gb32_kernel, dim3(cdiv4(ng, 256)), dim3(256), 0, c->stream, c->dis_gb, c->ng_pad, ng, c->dis_gb32);
+    RH_HIP(hipGetLastError());
+    const rh_s4_points PS = { c->dis + first, c->dis_stride, cnt, ng, c->dis_gb32 };
+    const uint64_t *en[4] = { nullptr, nullptr, nullptr, nullptr };
+    c->s4_points = &PS;
+    const int rc = rhk_score4_all(c, en, prep, cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts, nullptr, nullptr, 0, nullptr);
+    c->s4_points = nullptr;
+    return rc;
 }
 
 // diagnostics (tests): the classifier's worst binary32 error on a batch, in units of its margin widths (see
