@@ -318,6 +318,8 @@ struct DeviceStore {
     // scratch of rhk_store_compact
     int32_t *id[4] = { nullptr, nullptr, nullptr, nullptr };
     int32_t *spare_id[4] = { nullptr, nullptr, nullptr, nullptr };
+    double *Eb[4] = { nullptr, nullptr, nullptr, nullptr };        // the entries' scores (the compaction finds the best survivor)
+    double *spare_E[4] = { nullptr, nullptr, nullptr, nullptr };
     int32_t *d_work = nullptr;
     int64_t work_cap = 0;
     void *d_cls = nullptr;        // classifier + culling records of the whole store for a liveness pass of the v4 kernel
@@ -336,7 +338,8 @@ struct DeviceStore {
 int store_free(rh_cloud *c, DeviceStore &st)
 {
     (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); (void)hipFree(st.id[k]); (void)hipFree(st.spare_id[k]); }
+    for (int k = 0; k < 4; k++) { (void)hipFree(st.prep[k]); (void)hipFree(st.spare[k]); (void)hipFree(st.id[k]); (void)hipFree(st.spare_id[k]);
+                                  (void)hipFree(st.Eb[k]); (void)hipFree(st.spare_E[k]); }
     (void)hipFree(st.d_work); (void)hipFree(st.d_cls); (void)hipFree(st.d_box);
     (void)hipFree(st.iota); (void)hipFree(st.counts); (void)hipFree(st.d_idx); (void)hipFree(st.d_nk);
     (void)hipFree(st.live);
@@ -346,25 +349,33 @@ int store_free(rh_cloud *c, DeviceStore &st)
 int store_reserve(rh_cloud *c, DeviceStore &st, int kind, int64_t need)
 {
     if (need <= st.cap[kind]) {
-        if (st.id[kind] == nullptr && st.cap[kind] > 0)   // (a store parked by a run that kept no ids)
+        if (st.id[kind] == nullptr && st.cap[kind] > 0) {   // (a store parked by a run that kept no ids)
             RH_HIP(hipMalloc((void **)&st.id[kind], sizeof(int32_t) * (size_t)st.cap[kind]));
+            RH_HIP(hipMalloc((void **)&st.Eb[kind], sizeof(double) * (size_t)st.cap[kind]));
+        }
         return RH_OK;
     }
     const int64_t cap = std::max<int64_t>(need, std::max<int64_t>(4096, st.cap[kind] * 2));
     rh_prep *np = nullptr;
     int32_t *ni = nullptr;
     RH_HIP(hipMalloc((void **)&np, sizeof(rh_prep) * (size_t)cap));
+    double *ne = nullptr;
     RH_HIP(hipMalloc((void **)&ni, sizeof(int32_t) * (size_t)cap));
+    RH_HIP(hipMalloc((void **)&ne, sizeof(double) * (size_t)cap));
     if (st.n[kind] > 0) {
         RH_HIP(hipMemcpyAsync(np, st.prep[kind], sizeof(rh_prep) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
-        if (st.id[kind] != nullptr)
+        if (st.id[kind] != nullptr) {
             RH_HIP(hipMemcpyAsync(ni, st.id[kind], sizeof(int32_t) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
+            RH_HIP(hipMemcpyAsync(ne, st.Eb[kind], sizeof(double) * (size_t)st.n[kind], hipMemcpyDeviceToDevice, c->stream));
+        }
     }
     RH_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(st.prep[kind]);
     (void)hipFree(st.id[kind]);
+    (void)hipFree(st.Eb[kind]);
     st.prep[kind] = np;
     st.id[kind] = ni;
+    st.Eb[kind] = ne;
     st.cap[kind] = cap;
     return RH_OK;
 }
@@ -537,38 +548,12 @@ struct Driver {
     int64_t best = -1;                      // index into store of the running first maximum
     // Device-managed store (chained octree windows: hundreds of thousands of stored candidates).  `store` is append-only
     // then -- a dead candidate stays as a tombstone (kind -1), its index is the id the device keeps beside its record --
-    // and the first maximum is kept per block of 256 entries, so that an extraction costs the host O(dead + blocks)
+    // and the compaction on the device names the best survivor, so that an extraction costs the host O(dead + blocks)
     // instead of several passes over the whole store.
     bool managed = false;
     int64_t live_count = 0;
-    struct BlockMax { double E; int64_t idx; };   // idx < 0: no live entry
-    std::vector<BlockMax> bmax;
     std::vector<uint8_t> alive;                   // per entry of `store` (the dead list arrives in no order: a byte array stays in cache)
-    std::vector<double> Ev;                       // the scores again, densely (block rescans)
     int64_t store_count() const { return managed ? live_count : (int64_t)store.size(); }
-    void bmax_append(int64_t i, double E)
-    {
-        const size_t b = (size_t)(i >> 8);
-        if (b >= bmax.size()) bmax.push_back(BlockMax{ 0.0, -1 });
-        if (bmax[b].idx < 0 || E > bmax[b].E) bmax[b] = BlockMax{ E, i };
-        alive.push_back(1);
-        Ev.push_back(E);
-    }
-    void bmax_rescan(size_t b)
-    {
-        BlockMax m{ 0.0, -1 };
-        const size_t lo = b << 8, hi = std::min(store.size(), lo + 256);
-        for (size_t i = lo; i < hi; i++)
-            if (alive[i] && (m.idx < 0 || Ev[i] > m.E)) m = BlockMax{ Ev[i], (int64_t)i };
-        bmax[b] = m;
-    }
-    void bmax_best()   // findhighestscore over the live entries: first maximum, strict >
-    {
-        best = -1;
-        double bE = 0;
-        for (const BlockMax &m : bmax)
-            if (m.idx >= 0 && (best < 0 || m.E > bE)) { best = m.idx; bE = m.E; }
-    }
     double t_score = 0, t_extract = 0, t_sample = 0;
     double t_last_extraction = 0;           // wall clock at the end of the latest extraction
     double tp[6] = { 0, 0, 0, 0, 0, 0 };     // extraction breakdown (RH_DRIVER_PROF=1 prints it)
@@ -814,7 +799,7 @@ struct Driver {
                 rec.sigma = counts[i];
                 store.push_back(rec);
                 live_count++;
-                bmax_append((int64_t)store.size() - 1, E);
+                alive.push_back(1);
                 nk[rec.kind]++;
                 oS[levels[i] - 1] += E;   // pc.levelscore[level] += E(sc): fitting.jl:184
                 if (best < 0) best = (int64_t)store.size() - 1;
@@ -919,7 +904,8 @@ struct Driver {
         int32_t pbase[5] = { 0, 0, 0, 0, 0 };
         for (int q = 0; q < 4; q++) pbase[q + 1] = pbase[q] + (st.n[q] + RH_STORE_PAD - 1) / RH_STORE_PAD * RH_STORE_PAD;
         RUN(store_reserve_aux(c, st, managed ? std::max<int64_t>(sum_n, pbase[4]) : sum_n));
-        RUN(ensure_scratch(32 + 2 * sum_n));   // (may wait for the stream: before anything lands in the scratch)
+        // (may wait for the stream: before anything lands in the scratch; managed: + one rh_store_best per block of the store)
+        RUN(ensure_scratch(32 + 2 * sum_n + (managed ? 4 * (int64_t)(pbase[4] / RH_STORE_PAD) + 8 : 0)));
         int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
         const int64_t ndis_old = c->n_dis;
         RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind], true));
@@ -1000,6 +986,7 @@ struct Driver {
             // over -- one wait, and the host touches only the dead
             const int64_t extracted_id = (int64_t)extracted_pos;
             int32_t *h_out = h_scr + 24, *h_dead = h_counts;
+            rh_store_best *h_best = (rh_store_best *)(h_scr + 32 + 2 * ((sum_n + 1) / 2 * 2));   // (8-byte aligned: the scratch is, the offset is even)
             for (int i = 0; i < 5; i++) h_out[i] = 0;
             if (sum_n > 0) {
                 const int64_t nblocks = pbase[4] / RH_STORE_PAD;
@@ -1014,10 +1001,11 @@ struct Driver {
                 for (int q = 0; q < 4; q++) {
                     if (st.n[q] == 0 || (st.spare_cap[q] >= st.cap[q] && st.spare_id[q] != nullptr)) continue;
                     RUNH(hipStreamSynchronize(c->stream));
-                    (void)hipFree(st.spare[q]); (void)hipFree(st.spare_id[q]);
-                    st.spare[q] = nullptr; st.spare_id[q] = nullptr; st.spare_cap[q] = 0;
+                    (void)hipFree(st.spare[q]); (void)hipFree(st.spare_id[q]); (void)hipFree(st.spare_E[q]);
+                    st.spare[q] = nullptr; st.spare_id[q] = nullptr; st.spare_E[q] = nullptr; st.spare_cap[q] = 0;
                     RUNH(hipMalloc((void **)&st.spare[q], sizeof(rh_prep) * (size_t)st.cap[q]));
                     RUNH(hipMalloc((void **)&st.spare_id[q], sizeof(int32_t) * (size_t)st.cap[q]));
+                    RUNH(hipMalloc((void **)&st.spare_E[q], sizeof(double) * (size_t)st.cap[q]));
                     st.spare_cap[q] = st.cap[q];
                 }
                 RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)pbase[4], c->stream));
@@ -1074,12 +1062,13 @@ struct Driver {
                 rh_store_plan SP;
                 for (int q = 0; q < 4; q++) {
                     SP.prep[q] = st.prep[q]; SP.spare[q] = st.spare[q]; SP.id[q] = st.id[q]; SP.spare_id[q] = st.spare_id[q];
+                    SP.E[q] = st.Eb[q]; SP.spare_E[q] = st.spare_E[q];
                     SP.n[q] = st.n[q];
                 }
                 for (int q = 0; q < 5; q++) SP.pbase[q] = pbase[q];
                 SP.counts = st.counts;
                 SP.extracted_id = (int32_t)extracted_id;
-                RUN(rhk_store_compact(c, SP, st.d_work, h_out, h_dead));
+                RUN(rhk_store_compact(c, SP, st.d_work, h_out, h_dead, h_best));
                 RUNH(hipStreamSynchronize(c->stream));
             }
             tp[2] += now_s() - tq; tq = now_s();
@@ -1096,20 +1085,28 @@ struct Driver {
                 alive[(size_t)id] = 0;
                 live_count--;
             }
-            for (int32_t i = 0; i < ndead; i++) {   // a block whose first maximum died is searched again, once
-                const size_t b = (size_t)(h_dead[i] >> 8);
-                if (bmax[b].idx >= 0 && !alive[(size_t)bmax[b].idx]) bmax_rescan(b);
-            }
+
             if (!saw_extracted) { rh_set_error("rh_ransac: the extracted candidate is missing from the dead list"); return RH_E_INTERNAL; }
             for (int q = 0; q < 4; q++) {
                 if (st.n[q] == 0) continue;
                 std::swap(st.prep[q], st.spare[q]);
                 std::swap(st.id[q], st.spare_id[q]);
+                std::swap(st.Eb[q], st.spare_E[q]);
                 std::swap(st.cap[q], st.spare_cap[q]);
                 st.n[q] = h_out[q];
             }
             tp[3] += now_s() - tq; tq = now_s();
-            bmax_best();
+            // findhighestscore over the survivors: the blocks' best entries, first maximum = greatest score, smallest number
+            best = -1;
+            double bE = 0;
+            for (int64_t b = 0; b < (int64_t)(pbase[4] / RH_STORE_PAD); b++) {
+                const rh_store_best &m = h_best[b];
+                if (m.id < 0) continue;
+                if (m.id >= (int64_t)store.size() || !alive[(size_t)m.id]) { rh_set_error("rh_ransac: bad best survivor %lld", m.id); return RH_E_INTERNAL; }
+                if (best < 0 || m.E > bE || (m.E == bE && m.id < best)) { best = m.id; bE = m.E; }
+            }
+            if ((best < 0) != (live_count == 0)) { rh_set_error("rh_ransac: %lld live candidates but no best survivor", (long long)live_count); return RH_E_INTERNAL; }
+            if (best >= 0 && store[(size_t)best].E != bE) { rh_set_error("rh_ransac: the device store's score of candidate %lld differs from the host's", (long long)best); return RH_E_INTERNAL; }
             tp[4] += now_s() - tq;
             t_extract += now_s() - t0;
             *did = true;
@@ -1351,6 +1348,7 @@ struct Driver {
                     if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + (int64_t)W * p->minsubsetN * T));
                     h.store_prep[q] = st.prep[q];
                     h.store_id[q] = st.id[q];
+                    h.store_E[q] = st.Eb[q];
                     h.store_cap[q] = st.cap[q];
                     h.store_n[q] = st.n[q];
                 }

@@ -463,6 +463,7 @@ struct OctView {
     // plain binary searches (a lower bound is unique), found in 2-4 dependent loads instead of ~50.
     const int32_t *tab = nullptr;
     int tab_level = 0;
+    const uint64_t *code_o = nullptr;   // optional (device sampler): the codes again, in ORIGINAL point order (code[pos[i]] in one load)
 
     // lower_bound(key) on [lo, hi]: the answer is known to lie in that range.  8-ary rounds (seven independent loads)
     RH_HD int64_t lower_bound_in(uint64_t key, int64_t lo, int64_t hi) const
@@ -491,6 +492,27 @@ struct OctView {
 #pragma unroll
         for (int i = 0; i < 7; i++) k += ((lo + i < hi) & (cv[i] < key)) ? 1 : 0;
         return lo + k;
+    }
+    // [lo, hi) of the level-`level` cell of the point with code cd (needs the directory): a cell deeper than the
+    // directory's level is looked for inside its ancestor there, both ends at once
+    RH_HD void cell_bounds_code(int level, uint64_t cd, int64_t *lo_out, int64_t *hi_out) const
+    {
+        const int shift = 3 * (21 - (level - 1));
+        if (shift >= 63) { *lo_out = 0; *hi_out = n; return; }
+        const uint64_t key = cd >> shift;
+        const bool last = (((key + 1) << shift) >> shift) != key + 1;
+        const int tshift = 3 * (21 - (tab_level - 1));
+        if (level <= tab_level) {
+            const int up = shift - tshift;
+            const int32_t a = tab[key << up], b = tab[last ? (key << up) : ((key + 1) << up)];
+            *lo_out = a;
+            *hi_out = last ? n : b;
+            return;
+        }
+        const uint64_t anc = cd >> tshift;
+        const int64_t a = tab[anc], b = tab[anc + 1];
+        *lo_out = lower_bound_in(key << shift, a, b);
+        *hi_out = last ? n : lower_bound_in((key + 1) << shift, *lo_out, b);
     }
     // [lo, hi) of the level-`level` cell that holds Morton position q0
     RH_HD void cell_bounds(int level, int64_t q0, int64_t *lo_out, int64_t *hi_out) const
@@ -586,6 +608,64 @@ struct OctView {
         return lo * 64 + b;
 #endif
     }
+    // position of the (k + 1)-th set bit of m (k < popcount): five halving steps instead of k clearings
+    static RH_HD int select_bit(uint64_t m, int k)
+    {
+        int pos = 0;
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) {
+            const uint64_t lowmask = w == 32 ? 0xffffffffULL : ((1ULL << w) - 1ULL);
+            const uint64_t lowpart = (m >> pos) & lowmask;
+            int c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            c = __builtin_popcountll(lowpart);
+#else
+            for (uint64_t t = lowpart; t; t &= t - 1) c++;
+#endif
+            if (k >= c) { k -= c; pos += w; }
+        }
+        return pos;
+    }
+    // select_in for K ranks at once, in lockstep: the K searches' loads are in flight together (a round is the same
+    // 8-ary step whatever the width of the bracket, down to a single word)
+    template <int K>
+    RH_HD void select_in_many(int64_t (&r)[K], int64_t wlo, int64_t whi) const
+    {
+        int64_t lo[K], hi[K];
+#pragma unroll
+        for (int q = 0; q < K; q++) { lo[q] = wlo; hi[q] = whi; }
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int q = 0; q < K; q++) more = more || hi[q] > lo[q];
+            if (!more) break;
+            int32_t pv[K][7];
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                const int64_t step = (hi[q] - lo[q] + 8) >> 3;
+#pragma unroll
+                for (int i = 1; i < 8; i++) {
+                    const int64_t p = lo[q] + i * step;
+                    pv[q][i - 1] = prefix[p <= hi[q] ? p : hi[q]];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                const int64_t step = (hi[q] - lo[q] + 8) >> 3;
+                int k = 0;
+#pragma unroll
+                for (int i = 1; i < 8; i++) k += ((lo[q] + i * step <= hi[q]) & ((int64_t)pv[q][i - 1] < r[q])) ? 1 : 0;
+                lo[q] += k * step;
+                hi[q] = hi[q] < lo[q] + step - 1 ? hi[q] : lo[q] + step - 1;
+            }
+        }
+        uint64_t m[K];
+        int32_t pf[K];
+#pragma unroll
+        for (int q = 0; q < K; q++) { m[q] = men[lo[q]]; pf[q] = prefix[lo[q]]; }
+#pragma unroll
+        for (int q = 0; q < K; q++) r[q] = lo[q] * 64 + select_bit(m[q], (int)(r[q] - 1 - pf[q]));
+    }
 };
 
 #if defined(RH_OCT_TIMING)
@@ -606,11 +686,44 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
     *level_out = 1;
     if (n_enabled <= 0) return false;
     RH_OCT_T0;
-    int64_t r1 = set_stream_range(x, n);
-    uint32_t nd = 1;
-    while (!en.test(r1 - 1)) {
+    int64_t r1 = 0;
+    uint32_t nd = 0;
+    uint64_t cd = 0;
+    if (oc.code_o != nullptr) {
+        // Device form of the loop below: the stream advances by a constant per draw, so draw k is a pure function of
+        // (x0, k) -- four draws are tested per round, each with its Morton code fetched alongside (independent loads
+        // instead of a chain); the accepted index and the draws consumed are those of the one-at-a-time loop.
+        const uint64_t G = 0x9E3779B97F4A7C15ULL, x0 = *x;
+        for (;;) {
+            int64_t r[4];
+            bool e[4];
+            uint64_t c4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                r[i] = 1 + (int64_t)mulhi64(mix64(x0 + (uint64_t)(nd + 1 + i) * G), (uint64_t)n);
+                e[i] = en.test(r[i] - 1);
+                c4[i] = oc.code_o[r[i] - 1];
+            }
+            int hit = -1;
+#pragma unroll
+            for (int i = 3; i >= 0; i--) hit = e[i] ? i : hit;
+            if (hit >= 0) {
+                nd += (uint32_t)hit + 1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (i == hit) { r1 = r[i]; cd = c4[i]; }
+                break;
+            }
+            nd += 4;
+            if (nd > (1u << 24)) { *gave_up = true; *x = x0 + (uint64_t)nd * G; *ndraws += nd; return false; }
+        }
+        *x = x0 + (uint64_t)nd * G;
+    } else {
         r1 = set_stream_range(x, n);
-        if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+        nd = 1;
+        while (!en.test(r1 - 1)) {
+            r1 = set_stream_range(x, n);
+            if (++nd > (1u << 24)) { *gave_up = true; *ndraws += nd; return false; }
+        }
     }
     RH_OCT_T(0);
     const double u = (double)(set_stream_next(x) >> 11) * (1.0 / 9007199254740992.0);
@@ -623,7 +736,8 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
     }
     *level_out = level;
     int64_t lo, hi;
-    oc.cell_bounds(level, (int64_t)oc.pos[r1 - 1], &lo, &hi);
+    if (oc.code_o != nullptr && oc.tab != nullptr) oc.cell_bounds_code(level, cd, &lo, &hi);
+    else oc.cell_bounds(level, (int64_t)oc.pos[r1 - 1], &lo, &hi);
     RH_OCT_T(1);
     const int64_t base = oc.rank(lo), ne = oc.rank(hi) - base;
     RH_OCT_T(2);
@@ -638,8 +752,16 @@ RH_HD bool sample_minimal_set_octree(En &en, const OctView &oc, const double *P,
         bool redo = false;
 #pragma unroll
         for (int q = 1; q < drawN; q++) sd[q] = base + set_stream_range(x, ne);
+        if (DN > 1) {
+            int64_t rk[DN > 1 ? DN - 1 : 1];
 #pragma unroll
-        for (int q = 1; q < drawN; q++) sd[q] = oc.select_in(sd[q], wlo, whi);
+            for (int q = 1; q < DN; q++) rk[q - 1] = sd[q];
+            oc.template select_in_many<(DN > 1 ? DN - 1 : 1)>(rk, wlo, whi);
+#pragma unroll
+            for (int q = 1; q < DN; q++) sd[q] = rk[q - 1];
+        } else {
+            for (int q = 1; q < drawN; q++) sd[q] = oc.select_in(sd[q], wlo, whi);
+        }
         RH_OCT_T(3);
 #pragma unroll
         for (int q = 1; q < drawN; q++) { sd[q] = (int64_t)oc.perm[sd[q]] + 1; redo = redo || sd[q] == sd[0]; }

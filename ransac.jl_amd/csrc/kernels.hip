@@ -1482,14 +1482,21 @@ store_scan_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_cnt, in
     const int32_t b0 = min(nblocks, tid * per), b1 = min(nblocks, b0 + per);
     int32_t a = 0;
     for (int32_t b = b0; b < b1; b++) a += blk_cnt[b];
-    part[tid] = a;
+    // exclusive scan of the 1024 partial sums: shuffles inside the waves, then over the 16 wave totals
+    const int lane = tid & 63, wv = tid >> 6;
+    int32_t incl = a;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) part[wv] = incl;
     __syncthreads();
     if (tid == 0) {
         int32_t run = 0;
-        for (int t = 0; t < 1024; t++) { const int32_t v = part[t]; part[t] = run; run += v; }
+        for (int w = 0; w < 16; w++) { const int32_t v = part[w]; part[w] = run; run += v; }
     }
     __syncthreads();
-    int32_t run = part[tid];
+    int32_t run = part[wv] + incl - a;
     for (int32_t b = b0; b < b1; b++) { blk_off[b] = run; run += blk_cnt[b]; }
     if (tid == 1023) blk_off[nblocks] = run;   // (the last thread's range ends the array: the total)
     __syncthreads();
@@ -1509,9 +1516,11 @@ store_scan_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_cnt, in
 
 __global__ void __launch_bounds__(RH_STORE_PAD)
 store_move_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_off, const int32_t *__restrict__ kind_off,
-                  int32_t *__restrict__ dead_counter, int32_t *__restrict__ h_dead)
+                  int32_t *__restrict__ dead_counter, int32_t *__restrict__ h_dead, rh_store_best *__restrict__ h_best)
 {
     __shared__ int32_t wc[RH_STORE_PAD / 64];
+    __shared__ double wE[RH_STORE_PAD / 64];
+    __shared__ long long wI[RH_STORE_PAD / 64];
     const int64_t g = (int64_t)blockIdx.x * RH_STORE_PAD + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int q; int32_t slot; bool valid;
@@ -1531,6 +1540,7 @@ store_move_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_off, co
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(rh_prep) / 16); i++) dst[i] = v[i];
         P.spare_id[q][pos] = P.id[q][slot];
+        P.spare_E[q][pos] = P.E[q][slot];
     } else if (valid) {
         // dead: its id goes to the host (one atomic per wave)
         const uint64_t dm = __builtin_amdgcn_ballot_w64(true);
@@ -1540,17 +1550,35 @@ store_move_kernel(const rh_store_plan P, const int32_t *__restrict__ blk_off, co
         base = __shfl(base, leader);
         h_dead[base + __popcll(dm & ((1ULL << lane) - 1ULL))] = P.id[q][slot];
     }
+    // the block's best survivor: greatest score, smallest id among equals
+    double bE = 0.0;
+    long long bI = -1;
+    if (alive) { bE = P.E[q][slot]; bI = P.id[q][slot]; }
+    auto better = [](double e1, long long i1, double e2, long long i2) { return i1 >= 0 && (i2 < 0 || e1 > e2 || (e1 == e2 && i1 < i2)); };
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oE = __shfl_xor(bE, off);
+        const long long oI = __shfl_xor(bI, off);
+        if (better(oE, oI, bE, bI)) { bE = oE; bI = oI; }
+    }
+    if (lane == 0) { wE[wv] = bE; wI[wv] = bI; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RH_STORE_PAD / 64; w++)
+            if (better(wE[w], wI[w], bE, bI)) { bE = wE[w]; bI = wI[w]; }
+        h_best[blockIdx.x].E = bE;
+        h_best[blockIdx.x].id = bI;
+    }
 }
 }  // namespace
 
-int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead)
+int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead, rh_store_best *h_best)
 {
     const int32_t nblocks = P.pbase[4] / RH_STORE_PAD;
     if (nblocks <= 0) { for (int i = 0; i < 5; i++) h_out[i] = 0; return RH_OK; }
     int32_t *blk_cnt = d_work, *blk_off = d_work + nblocks, *kind_off = d_work + 2 * nblocks + 1, *counter = d_work + 2 * nblocks + 8;
     hipLaunchKernelGGL(store_count_kernel, dim3((unsigned)nblocks), dim3(RH_STORE_PAD), 0, c->stream, P, blk_cnt);
     hipLaunchKernelGGL(store_scan_kernel, dim3(1), dim3(1024), 0, c->stream, P, blk_cnt, nblocks, blk_off, kind_off, counter, h_out);
-    hipLaunchKernelGGL(store_move_kernel, dim3((unsigned)nblocks), dim3(RH_STORE_PAD), 0, c->stream, P, blk_off, kind_off, counter, h_dead);
+    hipLaunchKernelGGL(store_move_kernel, dim3((unsigned)nblocks), dim3(RH_STORE_PAD), 0, c->stream, P, blk_off, kind_off, counter, h_dead, h_best);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1804,12 +1832,23 @@ oct_tab_kernel(const uint64_t *__restrict__ code, int64_t n, int shift, int64_t 
     tab[k] = (int32_t)lo;
 }
 
+__global__ void __launch_bounds__(256)
+oct_code_o_kernel(const uint64_t *__restrict__ code, const int32_t *__restrict__ perm, int64_t n, uint64_t *__restrict__ code_o)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) code_o[perm[q]] = code[q];
+}
+
 int rhk_oct_build_tab(rh_cloud *c)
 {
     (void)hipFree(c->oct_tab);
+    (void)hipFree(c->oct_code_o);
     c->oct_tab = nullptr;
+    c->oct_code_o = nullptr;
     c->oct_tab_level = 0;
     if (c->n == 0) return RH_OK;
+    RH_HIP(hipMalloc((void **)&c->oct_code_o, sizeof(uint64_t) * (size_t)c->n));
+    hipLaunchKernelGGL(oct_code_o_kernel, dim3(cdiv(c->n, 256)), dim3(256), 0, c->stream, c->oct_code, c->oct_perm, c->n, c->oct_code_o);
     const int level = c->oct_depth < 8 ? c->oct_depth : 8;   // 8^7 + 1 entries at most (8 MB)
     const int64_t entries = ((int64_t)1 << (3 * (level - 1))) + 1;
     RH_HIP(hipMalloc((void **)&c->oct_tab, sizeof(int32_t) * (size_t)entries));

@@ -134,6 +134,7 @@ struct rh_cloud {
     unsigned long long *oct_adv_bits = nullptr;
     int64_t oct_adv_cells = 0;
     double *oct_adv_E = nullptr;
+    uint64_t *oct_code_o = nullptr;    // [n] the Morton codes in original point order (built with oct_tab)
     int32_t *oct_tab = nullptr;        // first Morton position of every level-oct_tab_level cell (+ n at the end)
     int oct_tab_level = 0;
     double *oct_P = nullptr;           // level distributions of a speculation window
@@ -300,19 +301,23 @@ int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32
 // entries carry the host's candidate number (id); an entry dies when its liveness count is non-zero or it is the
 // extracted candidate.  The survivors move to the spare arrays in order, the ids of the dead ones go to the host.
 // Index space: the kinds laid end to end, each padded to a multiple of RH_STORE_PAD (pbase[q]; pbase[4] = the end).
-constexpr int RH_STORE_PAD = 1024;
+constexpr int RH_STORE_PAD = 256;
 struct rh_store_plan {
     const rh_prep *prep[4];
     rh_prep *spare[4];
     const int32_t *id[4];
     int32_t *spare_id[4];
+    const double *E[4];          // the entries' scores: the first maximum over the survivors is found on the way
+    double *spare_E[4];
     int32_t n[4], pbase[5];
     const int32_t *counts;       // liveness counts at pbase[q] + slot
     int32_t extracted_id;
 };
 // d_work: 2 * (pbase[4] / RH_STORE_PAD) + 16 ints of scratch; h_out (pinned): [0..3] the kinds' new lengths, [4] the number
-// of dead entries; h_dead (pinned): their ids, in no particular order
-int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead);
+// of dead entries; h_dead (pinned): their ids, in no particular order; h_best (pinned, one per block of RH_STORE_PAD
+// entries): the block's best survivor -- greatest score, smallest id among equals; id < 0: none
+struct rh_store_best { double E; long long id; };
+int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead, rh_store_best *h_best);
 
 int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
                         int64_t *idx_out, int64_t cap, int32_t *d_total);
@@ -332,6 +337,7 @@ struct rh_oct_state {
     double best_E;                // the best stored score (findhighestscore), has_best != 0
     long long store_count, cc2;   // stored candidates / candidates scored so far
     rh_prep *store_prep[4];       // the device store of prepared candidates (driver.hip): arrays per kind, their capacities and
+    double *store_E[4];           //   (with the candidates' scores)
     int32_t *store_id[4];         //   fill -- every iteration appends its candidates' records and their numbers on the host
     long long store_cap[4];       //   (appended + the candidate's rank in candidate order)
     long long appended;

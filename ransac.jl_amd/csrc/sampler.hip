@@ -668,6 +668,7 @@ oct_advance_kernel(const OctAdvArgs A)
                         id = (int32_t)ost->appended + A.spref[ls >> 6] + __popcll(A.sbits[ls >> 6] & ((1ULL << (ls & 63)) - 1ULL));
                 }
                 ost->store_id[q][sbase[q] + j] = id;
+                ost->store_E[q][sbase[q] + j] = (e >= start && e < end) ? oct_estimate_E(A.S1length, A.Plength, (int64_t)A.counts[e], A.score_mode) : 0.0;
             }
         }
     }
@@ -797,7 +798,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     rhfit::OctView oc;
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
-    if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; }
+    if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; oc.code_o = c->oct_code_o; }
     const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
     if (d_P == nullptr && n_enabled > 0 && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));
