@@ -799,7 +799,12 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
     if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; oc.code_o = c->oct_code_o; }
-    const dim3 gs((unsigned)((total + 255) / 256)), gf((unsigned)((total + 127) / 128));
+    // (octree sampling is a chain of dependent random reads per set: one wave per block spreads a window of a few thousand
+    // sets over four times as many compute units -- each with its own address translation -- as 256-thread blocks would)
+    static int env_sb = -1;
+    if (env_sb < 0) { const char *e = getenv("RH_SAMPLE_BLOCK"); env_sb = e ? atoi(e) : 0; }
+    const int sblock = (env_sb == 64 || env_sb == 128 || env_sb == 256) ? env_sb : (d_P != nullptr ? 64 : 256);
+    const dim3 gs((unsigned)((total + sblock - 1) / sblock)), gf((unsigned)((total + 127) / 128));
     if (d_P == nullptr && n_enabled > 0 && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));
         if (prm->drawN == 3)
@@ -812,7 +817,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
         return RH_OK;
     }
 #define RH_SAMPLE(DN)                                                                                                  \
-    hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3(256), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
+    hipLaunchKernelGGL(sample_sets_kernel<DN>, gs, dim3((unsigned)sblock), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P,      \
                        prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec, sh, ost)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \

@@ -635,7 +635,9 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     // survive the boxes): one block per tile walks ALL the rows -- the tile is staged once instead of once per row
     // (measured on the cfg3 octree leg, 18 chunks: 27 us against 39 + 7 for rows + tail).  RH_S4_LOOP=n: for every
     // unmasked launch of up to n chunks, 0: never.
-    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? 64 : 0);
+    static int env_loop_open = -2;
+    if (env_loop_open < -1) { const char *e = getenv("RH_S4_LOOP_OPEN"); env_loop_open = e ? atoi(e) : -1; }
+    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 64) : 0);
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
         dim3 gt(grid.x, 1);
         if (prep32 != nullptr) {
