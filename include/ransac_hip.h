@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 105
+#define RH_VERSION 106
 
 enum {
     RH_OK = 0,
@@ -316,6 +316,12 @@ int rh_cloud_create_ms(const rh_cloud *c, double *out4);
  * the margin width: out[2k], out[2k+1] = max |a32 - a64|, |b32 - b64| for kind k (plane, sphere, cylinder;
  * sound below 1/2), out[8+k] = pairs looked at.  Host shapes, synchronous. */
 int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, double *out /* [12] */);
+/* The device's octree sampler finds a point's cell and the r-th enabled point of a cell with a cell directory and
+ * bracketed 8-ary searches (csrc/fit_shared.h: cell_bounds_code, lower_bound_in, select_in, select_in_many, select_bit)
+ * where the host form uses plain binary searches.  Host-only self-check of those routines against the plain ones on a
+ * synthetic Morton order of n points (duplicate codes, random enabled bits, every level): *mismatches = the number of
+ * disagreements over `queries` random queries.  Needs no GPU. */
+int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t queries, int64_t *mismatches);
 
 #ifdef __cplusplus
 }

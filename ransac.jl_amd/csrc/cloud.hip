@@ -179,7 +179,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
-    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_surv); (void)hipFree(c->d_occ);
+    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab); (void)hipFree(c->oct_code_o);
     (void)hipFree(c->oct_state); (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);

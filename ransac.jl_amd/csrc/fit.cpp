@@ -5,6 +5,9 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "fit_shared.h"
 #include "rh_internal.h"
 
@@ -145,4 +148,81 @@ static uint64_t rng_next(rh_rng *r)
 extern "C" int64_t rh_rng_range(rh_rng *r, int64_t n)
 {
     return 1 + (int64_t)(((unsigned __int128)rng_next(r) * (unsigned __int128)(uint64_t)n) >> 64);
+}
+
+// ---- self-check of the device sampler's search routines (ransac_hip.h), on the host --------------------------------
+extern "C" int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t queries, int64_t *mismatches)
+{
+    if (n < 1 || queries < 0 || !mismatches) { rh_set_error("rh_dbg_oct_search_selftest: bad arguments"); return RH_E_INVALID; }
+    uint64_t x = seed;
+    auto rnd = [&]() { return splitmix(&x); };
+    // a Morton order with clusters: a few thousand distinct deep cells, many points per cell, some exact duplicates
+    std::vector<uint64_t> code((size_t)n);
+    const int ncell = (int)std::min<int64_t>(n, 1 + (int64_t)(rnd() % 4096));
+    std::vector<uint64_t> cell((size_t)ncell);
+    for (uint64_t &c : cell) c = rnd() >> 1;   // 63 bits
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t c = cell[(size_t)(rnd() % (uint64_t)ncell)];
+        const int keep = 3 * (int)(rnd() % 22);   // low bits to redraw: 0 (a duplicate of the cell's code) .. 63
+        const uint64_t mask = keep >= 63 ? ~0ULL >> 1 : ((1ULL << keep) - 1ULL);
+        code[(size_t)i] = (c & ~mask) | (rnd() & mask);
+    }
+    std::sort(code.begin(), code.end());
+    const int64_t nwords = (n + 63) / 64;
+    std::vector<uint64_t> men((size_t)nwords, 0);
+    std::vector<int32_t> prefix((size_t)nwords + 1, 0);
+    const uint64_t density = rnd() % 5;   // 0: every bit, else about 1/2, 1/4, 1/8, 1/16 of them, in runs
+    for (int64_t i = 0; i < n; i++) {
+        bool on = true;
+        if (density) on = (rnd() & ((1ULL << density) - 1ULL)) == 0 || ((i >> 7) % 5 == 0);
+        if (on) men[(size_t)(i >> 6)] |= 1ULL << (i & 63);
+    }
+    for (int64_t w = 0; w < nwords; w++) prefix[(size_t)w + 1] = prefix[(size_t)w] + (int32_t)__builtin_popcountll(men[(size_t)w]);
+    const int64_t total = prefix[(size_t)nwords];
+    std::vector<int32_t> perm((size_t)n), pos((size_t)n);
+    for (int64_t i = 0; i < n; i++) { perm[(size_t)i] = (int32_t)i; pos[(size_t)i] = (int32_t)i; }
+    rhfit::OctView plain;
+    plain.code = code.data(); plain.perm = perm.data(); plain.pos = pos.data(); plain.men = men.data(); plain.prefix = prefix.data();
+    plain.n = n; plain.nwords = nwords; plain.depth = 22;
+    int64_t bad = 0;
+    for (int tab_level = 1; tab_level <= 6; tab_level++) {
+        const int64_t entries = ((int64_t)1 << (3 * (tab_level - 1))) + 1;
+        const int tshift = 3 * (21 - (tab_level - 1));
+        std::vector<int32_t> tab((size_t)entries);
+        for (int64_t k = 0; k < entries; k++)
+            tab[(size_t)k] = k == entries - 1 ? (int32_t)n : (int32_t)plain.lower_bound((uint64_t)k << tshift);
+        rhfit::OctView fast = plain;
+        fast.tab = tab.data(); fast.tab_level = tab_level; fast.code_o = code.data();   // (identity permutation: code_o = code)
+        for (int64_t qi = 0; qi < queries; qi++) {
+            const int64_t q0 = (int64_t)(rnd() % (uint64_t)n);
+            const int level = 1 + (int)(rnd() % 22);
+            int64_t lo0, hi0, lo1, hi1, lo2, hi2;
+            plain.cell_bounds(level, q0, &lo0, &hi0);
+            fast.cell_bounds(level, q0, &lo1, &hi1);
+            fast.cell_bounds_code(level, code[(size_t)q0], &lo2, &hi2);
+            bad += (lo0 != lo1) + (hi0 != hi1) + (lo0 != lo2) + (hi0 != hi2);
+            if (!(lo0 <= q0 && q0 < hi0)) bad++;
+            const int64_t base = plain.rank(lo0), ne = plain.rank(hi0) - base;
+            if (ne < 1) continue;
+            const int64_t wlo = lo0 >> 6, whi = (hi0 - 1) >> 6;
+            int64_t r2[2] = { base + 1 + (int64_t)(rnd() % (uint64_t)ne), base + 1 + (int64_t)(rnd() % (uint64_t)ne) };
+            const int64_t s0 = plain.select(r2[0]), s1 = plain.select(r2[1]);
+            bad += (fast.select_in(r2[0], wlo, whi) != s0) + (fast.select_in(r2[1], wlo, whi) != s1);
+            bad += (fast.select_in(r2[0], 0, nwords - 1) != s0);
+            fast.select_in_many<2>(r2, wlo, whi);
+            bad += (r2[0] != s0) + (r2[1] != s1);
+            if (!(s0 >= lo0 && s0 < hi0)) bad++;
+        }
+    }
+    for (int64_t qi = 0; qi < queries; qi++) {   // select_bit against clearing bits one by one
+        const uint64_t m = rnd() | (1ULL << (rnd() % 64));
+        const int pc = __builtin_popcountll(m);
+        const int k = (int)(rnd() % (uint64_t)pc);
+        uint64_t t = m;
+        for (int i = 0; i < k; i++) t &= t - 1;
+        bad += rhfit::OctView::select_bit(m, k) != __builtin_ctzll(t);
+    }
+    (void)total;
+    *mismatches = bad;
+    return RH_OK;
 }

@@ -180,8 +180,6 @@ struct rh_cloud {
     float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
     void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
     void *d_qpre = nullptr;            // [4 * batch_cap] band constants of the prefilter (rhdev::rh_pre) of the bins in d_prep
-    uint64_t *d_surv = nullptr;        // survivor matrix of the v4 score kernel's cull pass (grown on demand)
-    int64_t surv_cap = 0;              // in words
     float *d_box = nullptr;            // [RH_BOX_FIELDS][4 * batch_cap] culling records of the same bins (v4 score kernel), structure of arrays
     bool qpre_valid = false;           // ... made by the last prep kernel, for the thresholds qpre_eps
     double qpre_eps[4] = { 0, 0, 0, 0 };

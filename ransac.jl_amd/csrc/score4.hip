@@ -78,7 +78,6 @@ struct S4KindArgs {
     const float *box;       // culling records of the bin: field f of slot i at box[f * bstride + i]
     const rh_prep *prep;    // binary64 records of the bin
     const rh_prepf *prep32; // Float32 cloud: the binary32 records of the bin (score_device32.h) for its exact test, else null
-    float eps_up, cosa_dn;  // (unused)
     const int32_t *orig, *nk;
     const uint64_t *en;
     double eps, cosa;
@@ -119,7 +118,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
              uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0,
-             const rh_prepf *__restrict__ prep32, const float eps_up, const float cosa_dn)
+             const rh_prepf *__restrict__ prep32)
 {
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
@@ -320,7 +319,7 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, cons
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
         score4_batch<KIND, R, MASK, F32>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
-                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, K.prep32, K.eps_up, K.cosa_dn);
+                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, K.prep32);
     }
 }
 
@@ -611,8 +610,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
-        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, f32_round_up(eps[k]),
-                   f32_round_down(cosa[k]), orig[k], nk[k], en[k], eps[k], cosa[k] };
+        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
     A.stop = c->s4_stop;
     A.ntiles = ntiles;
     A.bstride = bstride;

@@ -75,25 +75,6 @@ __host__ __device__ inline bool cls_fin(double v) { return v - v == 0.0; }
 __host__ __device__ inline float cls_dn(double v) { return (float)(v - fabs(v) * (2.0 * RH_CLS_U) - 1e-37); }
 __host__ __device__ inline float cls_up(double v) { return (float)(v + fabs(v) * (2.0 * RH_CLS_U) + 1e-37); }
 
-// the smallest power of two >= v (v > 0, finite, normal), by exponent arithmetic
-__host__ __device__ inline double cls_pow2ceil(double v)
-{
-    union { double d; uint64_t u; } c;
-    c.d = v;
-    const uint64_t mant = c.u & 0x000FFFFFFFFFFFFFull;
-    c.u &= 0x7FF0000000000000ull;
-    return mant != 0 ? c.d * 2.0 : c.d;
-}
-
-// 1 / p for a power of two p (normal, and 1 / p normal): exact, by exponent arithmetic
-__host__ __device__ inline double cls_pow2recip(double p)
-{
-    union { double d; uint64_t u; } c;
-    c.d = p;
-    c.u = (uint64_t)(2046 - (c.u >> 52)) << 52;
-    return c.d;
-}
-
 // the old kernel's slack of the conservative stages: covers the exact test's own binary64 rounding (score_device.h)
 __host__ __device__ inline double cls_slack64(const rh_prep &P, double M) { return 1e-9 * ((1.0 + M) + P.f[11]); }
 

@@ -120,91 +120,6 @@ static __device__ __forceinline__ uint64_t test_point32(const rh_prepf &P, float
 }
 
 
-// ---- the same four tests for ONE point per lane without wave-level early-outs (the v4 score kernel: lane = (candidate,
-// group) pair walking its group's points): the same binary32 operations in the same order, so the same bits.  The
-// thresholds arrive as floats chosen so that comparing floats reproduces Julia's Float32-against-Float64 comparison:
-// for a float x and a double t,  (double)x > t  <=>  x > rd(t)  and  (double)x < t  <=>  x < ru(t)  (rd / ru = t
-// rounded down / up to binary32: no float lies strictly between them).
-static __host__ __device__ inline float f32_round_down(double t)
-{
-    float f = (float)t;
-    if ((double)f > t) f = __builtin_nextafterf(f, -__builtin_inff());
-    return f;
-}
-static __host__ __device__ inline float f32_round_up(double t)
-{
-    float f = (float)t;
-    if ((double)f < t) f = __builtin_nextafterf(f, __builtin_inff());
-    return f;
-}
-
-template <int KIND>
-static __device__ __forceinline__ bool test_lane32(const rh_prepf &P, float px, float py, float pz, float nx, float ny, float nz,
-                                            float eps_up, float cosa_dn)
-{
-    if (KIND == RH_PLANE) {
-        const float dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
-        const float vx = px - P.f[0], vy = py - P.f[1], vz = pz - P.f[2];
-        const float d = (P.f[6] * vx + P.f[7] * vy) + P.f[8] * vz;
-        return (dn > cosa_dn) & (fabsf(d) < eps_up);
-    }
-    if (KIND == RH_SPHERE) {
-        const float dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
-        const float nr = sqrtf((dx * dx + dy * dy) + dz * dz);
-        const float inv = 1.0f / nr;
-        const float ux = inv * dx, uy = inv * dy, uz = inv * dz;
-        const float dt = (ux * nx + uy * ny) + uz * nz;
-        return (fabsf(nr - P.f[3]) < eps_up) & (P.f[4] * dt > cosa_dn);
-    }
-    if (KIND == RH_CYLINDER) {
-        const float ax = P.f[0], ay = P.f[1], az = P.f[2];
-        const float cx = P.f[3], cy = P.f[4], cz = P.f[5];
-        const float tx = px - cx, ty = py - cy, tz = pz - cz;
-        const float sd = (ax * tx + ay * ty) + az * tz;
-        const float qx = (px - ax * sd) - cx, qy = (py - ay * sd) - cy, qz = (pz - az * sd) - cz;
-        const float nr = sqrtf((qx * qx + qy * qy) + qz * qz);
-        const float inv = 1.0f / nr;
-        const float ux = inv * qx, uy = inv * qy, uz = inv * qz;
-        const float dt = (ux * nx + uy * ny) + uz * nz;
-        return (fabsf(nr - P.f[6]) < eps_up) & (P.f[7] * dt > cosa_dn);
-    }
-    // cone: the wave form's ballots are plain comparisons per lane; reuse it on a one-hot basis
-    const float ax = P.f[3], ay = P.f[4], az = P.f[5];
-    const float c = P.f[6], s = P.f[7];
-    const float tx = P.f[0] - px, ty = P.f[1] - py, tz = P.f[2] - pz;
-    float inv = 1.0f / sqrtf((tx * tx + ty * ty) + tz * tz);
-    const float tnx = inv * tx, tny = inv * ty, tnz = inv * tz;
-    float kx = ay * tnz - az * tny, ky = az * tnx - ax * tnz, kz = ax * tny - ay * tnx;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float rx = inv * kx, ry = inv * ky, rz = inv * kz;
-    kx = ay * rz - az * ry; ky = az * rx - ax * rz; kz = ax * ry - ay * rx;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float mx = inv * kx, my = inv * ky, mz = inv * kz;
-    inv = 1.0f / sqrtf((rx * rx + ry * ry) + rz * rz);
-    const float vx = inv * rx, vy = inv * ry, vz = inv * rz;
-    const float nxx = vx * vx, nxy = vx * vy, nxz = vx * vz, nyy = vy * vy, nyz = vy * vz, nzz = vz * vz;
-    const float R00 = nxx + c * (1.0f - nxx);
-    float R01 = nxy + c * (0.0f - nxy);
-    float R02 = nxz + c * (0.0f - nxz);
-    float R10 = R01;
-    const float R11 = nyy + c * (1.0f - nyy);
-    float R12 = nyz + c * (0.0f - nyz);
-    float R20 = R02;
-    float R21 = R12;
-    const float R22 = nzz + c * (1.0f - nzz);
-    R01 -= s * vz; R02 += s * vy;
-    R10 += s * vz; R12 -= s * vx;
-    R20 -= s * vy; R21 += s * vx;
-    kx = (R00 * mx + R01 * my) + R02 * mz;
-    ky = (R10 * mx + R11 * my) + R12 * mz;
-    kz = (R20 * mx + R21 * my) + R22 * mz;
-    inv = 1.0f / sqrtf((kx * kx + ky * ky) + kz * kz);
-    const float gx = inv * kx, gy = inv * ky, gz = inv * kz;
-    const float dist = ((-gx) * (-tx) + (-gy) * (-ty)) + (-gz) * (-tz);
-    const float dt = (gx * nx + gy * ny) + gz * nz;
-    return (P.f[8] * dt > cosa_dn) & (fabsf(dist) < eps_up);
-}
-
 static __device__ __forceinline__ uint64_t valid_mask32(int64_t base, int64_t s)
 {
     const int64_t left = s - base;
