@@ -990,14 +990,18 @@ struct Driver {
             for (int i = 0; i < 5; i++) h_out[i] = 0;
             if (sum_n > 0) {
                 const int64_t nblocks = pbase[4] / RH_STORE_PAD;
-                if (st.work_cap < 2 * nblocks + 16) {
+                // scratch of the compaction: block counts + offsets, then (16-byte aligned) the blocks' best entries; the dead
+                // list is staged in st.d_idx (as long as the store)
+                const int64_t best_at = ((2 * nblocks + 16 + 3) / 4) * 4, work_ints = best_at + 4 * nblocks;
+                if (st.work_cap < work_ints) {
                     RUNH(hipStreamSynchronize(c->stream));
-                    (void)hipFree(st.d_work); (void)hipFree(st.d_cls); (void)hipFree(st.d_box);
+                    (void)hipFree(st.d_work);
                     st.d_work = nullptr; st.work_cap = 0;
-                    const int64_t cap = std::max<int64_t>(4 * nblocks + 64, 4096);
+                    const int64_t cap = std::max<int64_t>(2 * work_ints, 4096);
                     RUNH(hipMalloc((void **)&st.d_work, sizeof(int32_t) * (size_t)cap));
                     st.work_cap = cap;
                 }
+                rh_store_best *d_best = (rh_store_best *)(st.d_work + best_at);
                 for (int q = 0; q < 4; q++) {
                     if (st.n[q] == 0 || (st.spare_cap[q] >= st.cap[q] && st.spare_id[q] != nullptr)) continue;
                     RUNH(hipStreamSynchronize(c->stream));
@@ -1068,7 +1072,7 @@ struct Driver {
                 for (int q = 0; q < 5; q++) SP.pbase[q] = pbase[q];
                 SP.counts = st.counts;
                 SP.extracted_id = (int32_t)extracted_id;
-                RUN(rhk_store_compact(c, SP, st.d_work, h_out, h_dead, h_best));
+                RUN(rhk_store_compact(c, SP, st.d_work, h_out, h_dead, h_best, st.d_idx, d_best));
                 RUNH(hipStreamSynchronize(c->stream));
             }
             tp[2] += now_s() - tq; tq = now_s();

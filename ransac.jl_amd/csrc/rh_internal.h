@@ -315,7 +315,9 @@ struct rh_store_plan {
 // of dead entries; h_dead (pinned): their ids, in no particular order; h_best (pinned, one per block of RH_STORE_PAD
 // entries): the block's best survivor -- greatest score, smallest id among equals; id < 0: none
 struct rh_store_best { double E; long long id; };
-int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead, rh_store_best *h_best);
+// d_dead (>= the store's entries), d_best (one per block): device staging of the two lists (flushed to the pinned ones by a last small kernel)
+int rhk_store_compact(rh_cloud *c, const rh_store_plan &P, int32_t *d_work, int32_t *h_out, int32_t *h_dead, rh_store_best *h_best,
+                      int32_t *d_dead, rh_store_best *d_best);
 
 int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords, int32_t *ws_block_sums,
                         int64_t *idx_out, int64_t cap, int32_t *d_total);
