@@ -1313,6 +1313,10 @@ struct Driver {
                 return RH_OK;
             };
             const int32_t per_it = (int32_t)std::min<int64_t>((int64_t)p->minsubsetN * T, (int64_t)INT32_MAX / 2);
+            // the score launch of an iteration is sized for this share of the previous iteration's candidates (the tail
+            // launch covers the rest)
+            int64_t bound_pct = 200;
+            if (const char *e = getenv("RH_OCT_BOUND_PCT")) bound_pct = std::max<int64_t>(100, std::min<int64_t>(atoll(e), 1000));
             int cur = 0;
             int64_t k = 1;
             while (k <= p->itermax) {
@@ -1380,7 +1384,7 @@ struct Driver {
                                         c->d_nk, it, c->oct_state);
                     if (rc == RH_OK) rc = rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, per_it, w.d_counts, 1, p->eps,
                                                            p->cos_alpha, c->oct_state);
-                    if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>(2 * cnt_est, 1024)), p->eps,
+                    if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>((int32_t)((int64_t)cnt_est * bound_pct / 100) + 64, 1024)), p->eps,
                                                                p->cos_alpha, w.d_counts, nullptr, nullptr, clsw, boxw, 4 * c->batch_cap);
                     if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k + it, w.h_list,
                                                           w.h_list_counts, w.h_list_rank, w.h_list_slot, w.h_hdr);

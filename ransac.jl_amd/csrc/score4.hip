@@ -631,11 +631,12 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (env_loop < -1) { const char *e = getenv("RH_S4_LOOP"); env_loop = e ? atoi(e) : -1; }
     // the candidate loop's windows with few candidates (octree sampling: ~1000 local shapes per iteration, few pairs
     // survive the boxes): one block per tile walks ALL the rows -- the tile is staged once instead of once per row
-    // (measured on the cfg3 octree leg, 18 chunks: 27 us against 39 + 7 for rows + tail).  RH_S4_LOOP=n: for every
-    // unmasked launch of up to n chunks, 0: never.
+    // (measured on the cfg3 octree leg, 18 chunks: 27 us against 39 + 7 for rows + tail; from ~40 chunks on the rows win:
+    // sweep of the threshold 32 / 40 / 48 / 64 -> 0.0491 / 0.0498 / 0.0498 / 0.0499 s for the leg).  RH_S4_LOOP=n: for every
+    // unmasked launch of up to n chunks, 0: never; RH_S4_LOOP_OPEN=n: the threshold for open-ended windows (32).
     static int env_loop_open = -2;
     if (env_loop_open < -1) { const char *e = getenv("RH_S4_LOOP_OPEN"); env_loop_open = e ? atoi(e) : -1; }
-    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 64) : 0);
+    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 32) : 0);
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
         dim3 gt(grid.x, 1);
         if (prep32 != nullptr) {
