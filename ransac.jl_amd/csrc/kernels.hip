@@ -116,15 +116,21 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
         s = shapes[i];
         if (s.kind >= 0 && s.kind <= 3) kind = s.kind;   // anything else: counts[i] stays 0
     }
+    // slot in the kind's bin: the first lane of every kind present in the wave reserves the wave's share -- ONE atomic
+    // instruction (up to four lanes, four counters), one round trip
     int slot = 0;
+    {
+        uint64_t mk = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint64_t m = WB(kind == k);
-        if (m == 0) continue;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t m = WB(kind == k);
+            if (kind == k) mk = m;
+        }
+        const int leader = mk != 0 ? __builtin_ctzll(mk) : lane;
         int base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&nk[k], __popcll(m));
-        base = __shfl(base, __builtin_ctzll(m));
-        if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        if (kind >= 0 && lane == leader) base = atomicAdd(&nk[kind], __popcll(mk));
+        base = __shfl(base, leader);
+        slot = base + __popcll(mk & ((1ULL << lane) - 1ULL));
     }
     if (kind < 0) return;
     rh_prep P;
@@ -156,15 +162,21 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
         counts[i] = 0;
         if (s.kind >= 0 && s.kind <= 3) kind = s.kind;
     }
+    // slot in the kind's bin: the first lane of every kind present in the wave reserves the wave's share -- ONE atomic
+    // instruction (up to four lanes, four counters), one round trip
     int slot = 0;
+    {
+        uint64_t mk = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint64_t m = WB(kind == k);
-        if (m == 0) continue;
+        for (int k = 0; k < 4; k++) {
+            const uint64_t m = WB(kind == k);
+            if (kind == k) mk = m;
+        }
+        const int leader = mk != 0 ? __builtin_ctzll(mk) : lane;
         int base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&nk[k], __popcll(m));
-        base = __shfl(base, __builtin_ctzll(m));
-        if (kind == k) slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+        if (kind >= 0 && lane == leader) base = atomicAdd(&nk[kind], __popcll(mk));
+        base = __shfl(base, leader);
+        slot = base + __popcll(mk & ((1ULL << lane) - 1ULL));
     }
     if (kind < 0) return;
     rh_prep P;
