@@ -134,7 +134,8 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 #pragma unroll
         for (int f = 0; f < NF; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
-        int cs = 0, cm = 0;
+        int cs = 0;
+        float tmin = 2.0f;           // min |t| over the group's points: <= 1/2 <=> some point is undecided
         uint32_t wlo = 0, whi = 0;   // MASK: the pair's inlier word as far as it is sure
 #pragma unroll 8
         for (int j = 0; j < 64; j++) {
@@ -143,14 +144,16 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const float t = KIND == RH_PLANE ? cls_plane_t(C, a.x, a.y, a.z, a.w, b.x, b.y)
                                              : cls_round_t<KIND == RH_PLANE ? RH_SPHERE : KIND>(C, a.x, a.y, a.z, a.w, b.x, b.y);
             if (MASK) {
-                if (j < 32) wlo |= t > 0.0f ? (1u << j) : 0u; else whi |= t > 0.0f ? (1u << (j - 32)) : 0u;
+                if (j < 32) wlo |= t > 0.5f ? (1u << j) : 0u; else whi |= t > 0.5f ? (1u << (j - 32)) : 0u;
             } else {
-                cs += t > 0.0f ? 1 : 0;
+                cs += t > 0.5f ? 1 : 0;
             }
-            cm += t > -1.0f ? 1 : 0;
+            tmin = fminf(tmin, __builtin_fabsf(t));
         }
         if (MASK) cs = __popc(wlo) + __popc(whi);
-        const bool amb = act && (cs != cm || exact_only);
+        // (t = -1/2 exactly -- surely outside by the margins -- counts as undecided too: the redo is exact either way;
+        // a NaN t can only come from a non-finite record or point, and those never get here: exact_only, weird)
+        const bool amb = act && (!(tmin > 0.5f) || exact_only);
         total = (act && !amb) ? cs : 0;
         word = (act && !amb) ? (((uint64_t)whi << 32) | wlo) : 0ULL;
         // pairs the classifier could not decide: the exact test on the whole group, lane = point
@@ -448,8 +451,8 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             cls_plane_ab(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32);
             const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
             const double d = (P.f[6] * (x - P.f[0]) + P.f[7] * (y - P.f[1])) + P.f[8] * (z - P.f[2]);
-            a64 = (dn - Q.cNhi) / Q.wN;
-            b64 = (Q.eDlo - fabs(d)) / Q.wD;
+            a64 = (dn - Q.cNhi) / Q.wN + RH_CLS_SHIFT;
+            b64 = (Q.eDlo - fabs(d)) / Q.wD + RH_CLS_SHIFT;
             ea = fabs((double)a32 - a64);
             eb = fabs((double)b32 - b64);
             counted = true;
@@ -468,11 +471,11 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             const double nr = sqrt((qx * qx + qy * qy) + qz * qz);
             const double inv = 1.0 / nr;
             const double dt = ((inv * qx) * nx + (inv * qy) * ny) + (inv * qz) * nz;
-            a64 = (Q.eDlo - fabs(nr - R)) / Q.wD;
-            b64 = (sgn * dt - Q.cNhi) / Q.wN;
+            a64 = (Q.eDlo - fabs(nr - R)) / Q.wD + RH_CLS_SHIFT;
+            b64 = (sgn * dt - Q.cNhi) / Q.wN + RH_CLS_SHIFT;
             // the norm's error is relative (4.5 u nr): far outside the band it exceeds any fixed margin and cannot matter
             // (a is a few thousand widths below -1 there); what has to hold is the bound NEAR the band
-            if (a64 > -2.0) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
+            if (a64 > -2.0 + RH_CLS_SHIFT) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
             counted = true;
         }
         if (!(ea == ea)) ea = 1e30;   // a NaN on one side only is a failure

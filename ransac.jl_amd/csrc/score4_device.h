@@ -37,6 +37,7 @@
 //
 // Guards.  Non-finite or huge inputs would make binary32 overflow where binary64 does not, so a candidate is marked
 // EXACT-ONLY (field RH_CLS_FLAG = NaN) unless all its parameters are finite and below 2^20 (cylinder axis components
+constexpr double RH_CLS_SHIFT = 0.5;   // added to both scaled quantities of a record: see cls_plane_ab
 // below 16) and M, Nm <= 2^20; a tile with an infinite or NaN value in an enabled point treats every candidate as
 // exact-only.  Exact-only means: every enabled point is ambiguous.  Disabled points are staged as zeros and masked out
 // (plane: their zero normal fails the angle test by itself, which needs cos(alpha) - margin > 0, else exact-only).
@@ -113,10 +114,10 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             const double cNhi = cosa + 0.5 * wN, eDlo = eps - 0.5 * wD;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
             o.f[0] = (float)(P.f[3] * iN); o.f[1] = (float)(P.f[4] * iN); o.f[2] = (float)(P.f[5] * iN);
-            o.f[3] = (float)(-cNhi * iN);
+            o.f[3] = (float)(-cNhi * iN + RH_CLS_SHIFT);
             o.f[4] = (float)(P.f[6] * iD); o.f[5] = (float)(P.f[7] * iD); o.f[6] = (float)(P.f[8] * iD);
             o.f[7] = (float)(-zp * iD);
-            o.f[8] = (float)(eDlo * iD);
+            o.f[8] = (float)(eDlo * iD + RH_CLS_SHIFT);
             if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             for (int i = 0; i < 9; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
@@ -169,7 +170,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             const double eDlo = eps - 0.5 * wD, cNhi = cosa + 0.5 * wN;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
             const double iN = 1.0 / wN, iD = 1.0 / wD;
-            const float s0 = (float)iD, s1 = (float)(eDlo * iD), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN);
+            const float s0 = (float)iD, s1 = (float)(eDlo * iD + RH_CLS_SHIFT), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN + RH_CLS_SHIFT);
             if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             if (sph) { o.f[4] = s0; o.f[5] = s1; o.f[6] = s2; o.f[7] = s3f; }
             else { o.f[7] = s0; o.f[8] = s1; o.f[9] = s2; o.f[10] = s3f; }
@@ -299,7 +300,9 @@ static __device__ __forceinline__ bool box_skip32(const float (&B)[RH_BOX_FIELDS
     return (rho2 > s2) & ((hi <= 0.0f) | (rho2 > hi2) | ((lo > 0.0f) & (rho2 < lo2)));
 }
 
-// ---- plane: t = min(a, b) of the scaled record: sure <=> t > 0, maybe <=> t > -1
+// ---- plane: t = min(a, b) of the scaled record, SHIFTED by RH_CLS_SHIFT = 1/2 (the record's two additive constants carry
+// it): sure <=> t > 1/2, maybe <=> |t| <= 1/2, surely not <=> t < -1/2.  The shift makes "a maybe among the 64 points" a
+// running minimum of |t| -- one instruction per point where a second counter took a compare and an add
 static __device__ __forceinline__ void cls_plane_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &b)
 {
     a = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
@@ -313,7 +316,7 @@ static __device__ __forceinline__ float cls_plane_t(const rh_cls &C, float x, fl
     return fminf(a, b);
 }
 
-// ---- sphere / cylinder: the same t = min(a, b) from the scaled record (sure <=> t > 0, maybe <=> t > -1)
+// ---- sphere / cylinder: the same shifted t = min(a, b) from the scaled record
 template <int KIND>
 static __device__ __forceinline__ void cls_round_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &bb)
 {
