@@ -137,20 +137,27 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         int cs = 0;
         float tmin = 2.0f;           // min |t| over the group's points: <= 1/2 <=> some point is undecided
         uint32_t wlo = 0, whi = 0;   // MASK: the pair's inlier word as far as it is sure
-#pragma unroll 8
-        for (int j = 0; j < 64; j++) {
+        auto point_t = [&](int j) {
             const rh_f32x4 a = rowa[j];
             const rh_f32x2 b = rowb[j];
             const float t = KIND == RH_PLANE ? cls_plane_t(C, a.x, a.y, a.z, a.w, b.x, b.y)
                                              : cls_round_t<KIND == RH_PLANE ? RH_SPHERE : KIND>(C, a.x, a.y, a.z, a.w, b.x, b.y);
-            if (MASK) {
-                if (j < 32) wlo |= t > 0.5f ? (1u << j) : 0u; else whi |= t > 0.5f ? (1u << (j - 32)) : 0u;
-            } else {
-                cs += t > 0.5f ? 1 : 0;
-            }
             tmin = fminf(tmin, __builtin_fabsf(t));
+            return t > 0.5f ? 1u : 0u;
+        };
+        if (MASK) {
+            // (two loops of 32: one loop with `j < 32 ? lo : hi` inside is not unrolled and pays a scalar compare and
+            // branch per point; the bits are shifted in from the right and un-reversed afterwards -- `|= 1u << j` needs
+            // a 32-bit literal per point, a scalar move each on this ISA)
+#pragma unroll 8
+            for (int j = 0; j < 32; j++) wlo = wlo + wlo + point_t(j);
+#pragma unroll 8
+            for (int j = 32; j < 64; j++) whi = whi + whi + point_t(j);
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < 64; j++) cs += (int)point_t(j);
         }
-        if (MASK) cs = __popc(wlo) + __popc(whi);
+        if (MASK) { wlo = __brev(wlo); whi = __brev(whi); cs = __popc(wlo) + __popc(whi); }
         // (t = -1/2 exactly -- surely outside by the margins -- counts as undecided too: the redo is exact either way;
         // a NaN t can only come from a non-finite record or point, and those never get here: exact_only, weird)
         const bool amb = act && (!(tmin > 0.5f) || exact_only);
@@ -186,13 +193,14 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 #pragma unroll 8
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[j];
-            mlo |= cls_pre_cone(C, a.x, a.y, a.z) ? (1u << j) : 0u;
+            mlo = mlo + mlo + (cls_pre_cone(C, a.x, a.y, a.z) ? 1u : 0u);
         }
 #pragma unroll 8
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[32 + j];
-            mhi |= cls_pre_cone(C, a.x, a.y, a.z) ? (1u << j) : 0u;
+            mhi = mhi + mhi + (cls_pre_cone(C, a.x, a.y, a.z) ? 1u : 0u);
         }
+        mlo = __brev(mlo); mhi = __brev(mhi);   // (bits shifted in from the right: no 32-bit literal per point)
         const uint64_t lg = sh.len[g];
         uint64_t mask = exact_only ? lg : ((((uint64_t)mhi << 32) | mlo) & lg);
         if (!act) mask = 0;
