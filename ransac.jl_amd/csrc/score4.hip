@@ -276,10 +276,13 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, cons
     // (the culling records of the wave's chunks are requested together, before the first box test)
     constexpr int CPW = R / S4_W;
     float B[2][RH_BOX_FIELDS];
+    // (unconditional loads from a clamped slot: a lane without a candidate reads slot 0 and is masked out below -- a
+    // guarded load per field costs a scalar exec-mask save / branch / restore each, ~20 scalar instructions per chunk)
     {
         const int ci = ((lo + wv) << 6) + lane;
+        const int cil = (lo + wv < hi && ci < nk) ? ci : 0;
 #pragma unroll
-        for (int f = 0; f < NB; f++) B[0][f] = (lo + wv < hi && ci < nk) ? K.box[(int64_t)f * bstride + ci] : 0.0f;
+        for (int f = 0; f < NB; f++) B[0][f] = K.box[(int64_t)f * bstride + cil];
     }
 #pragma unroll
     for (int h = 0; h < CPW; h++) {
@@ -288,8 +291,9 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, cons
         const int ci = (c << 6) + lane;
         if (h + 1 < CPW) {   // the next chunk's records: in flight during this chunk's tests
             const int cin = ((c + S4_W) << 6) + lane;
+            const int cinl = (c + S4_W < hi && cin < nk) ? cin : 0;
 #pragma unroll
-            for (int f = 0; f < NB; f++) B[(h + 1) & 1][f] = (c + S4_W < hi && cin < nk) ? K.box[(int64_t)f * bstride + cin] : 0.0f;
+            for (int f = 0; f < NB; f++) B[(h + 1) & 1][f] = K.box[(int64_t)f * bstride + cinl];
         }
         unsigned surv = 0;
 #pragma unroll
