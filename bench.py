@@ -852,6 +852,7 @@ def main():
                 R.ransac(pc, ocp, seed=99)                      # builds + caches the linear octree (setup)
                 pc.enable_all()
                 ocp.itermax = args.e2e_octree_iters
+                R.ransac(pc, ocp, seed=99)                      # warm-up: a whole run of the same length, like the root-cell leg's
                 oruns = []
                 for _ in range(max(1, args.e2e_runs)):
                     pc.enable_all()
@@ -867,7 +868,7 @@ def main():
                     "last_extraction_iteration": max([g.iteration for g in goto_], default=0),
                     "seconds_to_last_extraction": sto.get("seconds_to_last_extraction"),
                     "breakdown_s": {"sample_fit": sto["seconds_host"], "score": sto["seconds_score"], "extract": sto["seconds_extract"]},
-                    "note": "median of %d runs; same cloud, octree_sampling=1 (level-weighted cells of a linear Morton octree; not what the "
+                    "note": "median of %d runs after a warm-up run of the same length; same cloud, octree_sampling=1 (level-weighted cells of a linear Morton octree; not what the "
                             "reference executes, SURVEY.md 0.5), minsubsetN=4096, itermax=%d.  Every iteration's scores move the level "
                             "distribution the next one samples from, so the iterations run as CHAINED windows: sampling, fits, scoring, "
                             "the level update and the extraction test of up to 8 iterations are queued back to back on the device, the "
