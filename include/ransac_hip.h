@@ -291,7 +291,8 @@ int rh_dev_download(rh_cloud *c, void *h_dst, const void *d_src, int64_t bytes);
  *   every rank:  rh_comm_create(cloud, rank, world, id, &comm)
  *   per batch:   rh_score_batch_allreduce_dev(cloud, comm, d_my_shapes, b, offset, b_total, &params, d_counts_total)
  *                (enqueues: zero, score into [offset, offset + b), all-reduce on the communicator's own stream -- so the
- *                next batch's scoring overlaps it when the caller alternates two count buffers)
+ *                next batch's scoring overlaps it when the caller alternates two count buffers: a buffer may come back two
+ *                calls later, the library orders that call behind the collective that read it)
  *   then:        rh_comm_fence(comm, cloud)  (the cloud's stream waits, no host sync)  or  rh_comm_sync(comm)  (host waits) */
 #define RH_COMM_ID_BYTES 128
 typedef struct rh_comm rh_comm;

@@ -52,6 +52,8 @@ struct rh_comm {
     hipStream_t stream = nullptr;     // the collectives' stream
     hipEvent_t scored = nullptr;      // cloud stream -> collective stream
     hipEvent_t reduced = nullptr;     // collective stream -> whoever waits (rh_comm_fence / rh_comm_sync)
+    hipEvent_t done[2] = { nullptr, nullptr };   // the last two collectives, alternately: call k waits for call k - 2 before it
+    unsigned long long calls = 0;                //   touches its count buffer (two batches in flight, buffers reused two calls later)
 };
 
 #define RH_NCCL(call)                                                                                      \
@@ -90,7 +92,9 @@ extern "C" int rh_comm_create(rh_cloud *c, int32_t rank, int32_t world, const vo
     if (r != ncclSuccess) { rh_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, R->GetErrorString(r)); delete m; return RH_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->scored, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->reduced, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&m->reduced, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->done[1], hipEventDisableTiming) != hipSuccess) {
         rh_set_error("rh_comm_create: stream / event creation failed");
         (void)R->CommDestroy(m->comm);
         delete m;
@@ -109,6 +113,7 @@ extern "C" int rh_comm_destroy(rh_comm *m)
     if (R && m->comm) (void)R->CommDestroy(m->comm);
     if (m->scored) (void)hipEventDestroy(m->scored);
     if (m->reduced) (void)hipEventDestroy(m->reduced);
+    for (hipEvent_t e : m->done) if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return RH_OK;
@@ -130,12 +135,33 @@ extern "C" int rh_score_batch_allreduce_dev(rh_cloud *c, rh_comm *m, const rh_sh
     if (!R) { rh_set_error("librccl is not loaded"); return RH_E_NODEVICE; }
     RH_HIP(hipSetDevice(c->device));
     if (b_total == 0) return RH_OK;
-    RH_HIP(hipMemsetAsync(d_counts_total, 0, sizeof(int32_t) * (size_t)b_total, c->stream));
-    if (b > 0) RH_TRY(rh_score_batch_dev(c, d_shapes, b, p, d_counts_total + offset, nullptr));
+    // a caller that keeps two batches in flight alternates two count buffers: this call's buffer was last read by the
+    // collective of two calls ago, which the cloud's stream lets finish first (stream order, no host wait)
+    // (asked on the host first: it is nearly always long finished, and a wait packet on the stream costs ~9 us of gap)
+    if (m->calls >= 2 && hipEventQuery(m->done[m->calls & 1]) != hipSuccess) RH_HIP(hipStreamWaitEvent(c->stream, m->done[m->calls & 1], 0));
+    // the whole total is zeroed by the batch's prepare launch (no fill launch of its own); a rank without candidates, or a
+    // batch that does not go through that launch (<= 32 candidates travel staged), fills it the plain way
+    bool zeroed = false;
+    if (b > 32) {
+        c->zero_extra = d_counts_total;
+        c->zero_extra_n = b_total;
+    } else {
+        RH_HIP(hipMemsetAsync(d_counts_total, 0, sizeof(int32_t) * (size_t)b_total, c->stream));
+        zeroed = true;
+    }
+    if (b > 0) {
+        const int rc = rh_score_batch_dev(c, d_shapes, b, p, d_counts_total + offset, nullptr);
+        const bool consumed = c->zero_extra == nullptr;
+        c->zero_extra = nullptr; c->zero_extra_n = 0;
+        if (rc != RH_OK) return rc;
+        if (!zeroed && !consumed) { rh_set_error("rh_score_batch_allreduce_dev: the batch did not pass the prepare launch"); return RH_E_INTERNAL; }
+    }
     RH_HIP(hipEventRecord(m->scored, c->stream));
     RH_HIP(hipStreamWaitEvent(m->stream, m->scored, 0));
     RH_NCCL(R->AllReduce(d_counts_total, d_counts_total, (size_t)b_total, ncclInt32, ncclSum, m->comm, m->stream));
     RH_HIP(hipEventRecord(m->reduced, m->stream));
+    RH_HIP(hipEventRecord(m->done[m->calls & 1], m->stream));
+    m->calls++;
     return RH_OK;
 }
 

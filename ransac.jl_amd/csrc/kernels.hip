@@ -103,9 +103,11 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap,
                                    int32_t *__restrict__ counts_zero, int32_t *__restrict__ nk_other, int32_t spread,
-                                   rh_pre *__restrict__ qpre, const PreArgs QA)
+                                   rh_pre *__restrict__ qpre, const PreArgs QA, int32_t *__restrict__ zero_extra, int32_t zero_extra_n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // (a wider range of counts to zero: the other ranks' slices of a sharded batch, rh_score_batch_allreduce_dev)
+    for (int i = t; i < zero_extra_n; i += gridDim.x * blockDim.x) zero_extra[i] = 0;
     const int lane = threadIdx.x & 63;
     rh_shape s;
     int kind = -1;
@@ -1259,9 +1261,13 @@ int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d
     if (b == 0) return RH_OK;
     static int no_spread = -1;
     if (no_spread < 0) no_spread = getenv("RH_NO_SPREAD") ? 1 : 0;
+    // (consumed by this launch: set by rh_score_batch_allreduce_dev around its score call)
+    int32_t *zx = c->zero_extra;
+    const int32_t zxn = c->zero_extra_n;
+    c->zero_extra = nullptr; c->zero_extra_n = 0;
     hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
                        d_nk, cap, d_counts_to_zero, d_nk_other, no_spread ? 1 : rh_spread_multiplier(b),
-                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA);
+                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA, zx, zxn);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -129,6 +129,8 @@ struct rh_cloud {
     const int32_t *s4_stop = nullptr;  //   its stop flag as the score kernel sees it (null outside such windows),
     const rh_s4_points *s4_points = nullptr;   // the launches being queued run over this set instead of subset 1 (rhk_score4_dis)
     float *dis_gb32 = nullptr;         // binary32 twins of dis_gb
+    int32_t *zero_extra = nullptr;     // the next rhk_prep_binned launch also zeroes zero_extra_n ints from here (then forgets it)
+    int32_t zero_extra_n = 0;
     bool s4_open_count = false;        // the candidate count of the score launches being queued is a guess (windows of the candidate loop)
     int32_t *oct_adv_tab = nullptr;    //   the (level, slot) table of rhk_oct_advance, its bitmap (kept zero) and the sorted scores
     unsigned long long *oct_adv_bits = nullptr;
