@@ -1317,13 +1317,13 @@ struct Driver {
             // launch covers the rest)
             int64_t bound_pct = 200;
             if (const char *e = getenv("RH_OCT_BOUND_PCT")) bound_pct = std::max<int64_t>(100, std::min<int64_t>(atoll(e), 1000));
-            int cur = 0;
-            int64_t k = 1;
-            while (k <= p->itermax) {
-                if (en.count < p->tau) break;
-                Window &w = win[cur];
-                cur = 1 - cur;
-                const double t0 = now_s();
+            // Two windows in flight.  A window that is not the first after an extraction CONTINUES from the state the device
+            // holds (level scores and distribution, best score, counters, store fill): nothing is uploaded, the next
+            // window is queued before the host has replayed the current one, and the device never waits for the host
+            // between windows (it used to idle ~0.2 ms at every window boundary without an extraction).  Whatever ends
+            // a window early -- an extraction, the stop flag, a full list -- empties the pipeline: what is still queued
+            // returns at once (stop flag) or is simply not replayed, and the next window starts from the host's state.
+            auto enqueue = [&](Window &w, int64_t k0, int32_t W, bool upload, int64_t ahead) -> int {
                 // one iteration's candidates must fit the list (a longer list is only a matter of how far a window gets)
                 if (w.entries_cap < per_it + per_it / 4) {
                     RUNH(hipStreamSynchronize(c->stream));
@@ -1334,33 +1334,31 @@ struct Driver {
                     RUNH(hipMalloc((void **)&w.d_counts, sizeof(int32_t) * (size_t)w.entries_cap));
                 }
                 RUN(ensure_pinned(w));
-                bool certain = false;
-                if (store_count() > 0) {
-                    int64_t lb[4] = { 0, store_count(), cc[2], k * p->minsubsetN };
-                    certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
+                if (upload) {
+                    rh_oct_state &h = *w.h_ost;
+                    memset(&h, 0, sizeof h);
+                    for (int i = 0; i < od; i++) { h.S[i] = oS[i]; h.P[i] = oP[i]; }
+                    h.has_best = store_count() == 0 ? 0 : 1;
+                    h.best_E = store_count() == 0 ? 0.0 : store[(size_t)best].E;
+                    h.store_count = (long long)store_count();
+                    h.appended = (long long)store.size();
+                    h.cc2 = cc[2];
+                    // the iterations append their candidates' records to the device store: room for the windows that can be
+                    // in flight before the next upload (the device checks the capacity itself and ends the window otherwise)
+                    for (int q = 0; q < 4; q++) {
+                        bool has_kind = false;
+                        for (int ti = 0; ti < T; ti++) has_kind |= p->shape_types[ti] == q;
+                        if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + ahead * p->minsubsetN * T));
+                        h.store_prep[q] = st.prep[q];
+                        h.store_id[q] = st.id[q];
+                        h.store_E[q] = st.Eb[q];
+                        h.store_cap[q] = st.cap[q];
+                        h.store_n[q] = st.n[q];
+                    }
+                    RUNH(hipMemcpyAsync(c->oct_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+                } else {
+                    RUN(rhk_oct_window_begin(c, c->oct_state));   // the list of this window starts at position 0
                 }
-                const int32_t W = (int32_t)std::min<int64_t>(certain ? 1 : Kchain, p->itermax - k + 1);
-                // ---- queue the window
-                rh_oct_state &h = *w.h_ost;
-                memset(&h, 0, sizeof h);
-                for (int i = 0; i < od; i++) { h.S[i] = oS[i]; h.P[i] = oP[i]; }
-                h.has_best = store_count() == 0 ? 0 : 1;
-                h.best_E = store_count() == 0 ? 0.0 : store[(size_t)best].E;
-                h.store_count = (long long)store_count();
-                h.appended = (long long)store.size();
-                h.cc2 = cc[2];
-                // the iterations append their candidates' records to the device store: room for a whole window
-                for (int q = 0; q < 4; q++) {
-                    bool has_kind = false;
-                    for (int ti = 0; ti < T; ti++) has_kind |= p->shape_types[ti] == q;
-                    if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + (int64_t)W * p->minsubsetN * T));
-                    h.store_prep[q] = st.prep[q];
-                    h.store_id[q] = st.id[q];
-                    h.store_E[q] = st.Eb[q];
-                    h.store_cap[q] = st.cap[q];
-                    h.store_n[q] = st.n[q];
-                }
-                RUNH(hipMemcpyAsync(c->oct_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
                 RUNH(hipMemsetAsync(w.d_status, 0, status_bytes, c->stream));
                 RUN(rh_ensure_batch(c, w.entries_cap));
                 const uint64_t *enw[4];
@@ -1380,13 +1378,13 @@ struct Driver {
                 c->s4_open_count = true;
                 int rc = RH_OK;
                 for (int32_t it = 0; it < W && rc == RH_OK; it++) {
-                    rc = rhk_sample_fit(c, p, rng->s[0], k + it, 1, (int32_t)en.count, c->oct_state->P, w.d_entries, w.entries_cap, w.d_status, 1,
+                    rc = rhk_sample_fit(c, p, rng->s[0], k0 + it, 1, (int32_t)en.count, c->oct_state->P, w.d_entries, w.entries_cap, w.d_status, 1,
                                         c->d_nk, it, c->oct_state);
                     if (rc == RH_OK) rc = rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, per_it, w.d_counts, 1, p->eps,
                                                            p->cos_alpha, c->oct_state);
                     if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>((int32_t)((int64_t)cnt_est * bound_pct / 100) + 64, 1024)), p->eps,
                                                                p->cos_alpha, w.d_counts, nullptr, nullptr, clsw, boxw, 4 * c->batch_cap);
-                    if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k + it, w.h_list,
+                    if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k0 + it, w.h_list,
                                                           w.h_list_counts, w.h_list_rank, w.h_list_slot, w.h_hdr);
                     if (rc == RH_OK && hipEventRecord(w.ev_it[it], c->stream) != hipSuccess) { rh_set_error("hipEventRecord failed"); rc = RH_E_NODEVICE; }
                 }
@@ -1394,9 +1392,47 @@ struct Driver {
                 c->s4_open_count = false;
                 if (rc != RH_OK) return rc;
                 nwin++;
+                return RH_OK;
+            };
+            struct Flight { int wi; int64_t k0; int32_t W; };
+            Flight fl[2];
+            int nfl = 0, next_w = 0;
+            const int max_flight = getenv("RH_OCT_ONE_WINDOW") ? 1 : 2;
+            // (iterations per window: the launches of Kchain iterations are in the queue at most, whatever the number of
+            // windows they are cut into -- a deeper queue makes the launches themselves slow)
+            int64_t Wfl = std::max<int64_t>(1, max_flight == 2 ? (Kchain * 3) / 8 : Kchain);   // (8 -> two windows of 3: swept 2 / 3 / 4 / 6 -> 0.0482 / 0.0474 / 0.0484 / 0.0492 s)
+            if (const char *e = getenv("RH_OCT_WINDOW_ITERS")) Wfl = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
+            bool need_upload = true;
+            int64_t k = 1, k_enq = 1;
+            for (;;) {
+                if (nfl == 0 && (k > p->itermax || en.count < p->tau)) break;
+                const double t0 = now_s();
+                while (nfl < max_flight && k_enq <= p->itermax && !(need_upload && nfl > 0)) {
+                    // Is iteration k_enq certain to extract?  (prob() grows with the counters and the best score can only
+                    // rise: "the stored best already passes with the counters as they are" decides it.)  Then the window is
+                    // that one iteration -- everything behind it would be queued for nothing.
+                    bool certain = false;
+                    if (need_upload && store_count() > 0) {
+                        int64_t lb[4] = { 0, store_count(), cc[2], k_enq * p->minsubsetN };
+                        certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
+                    }
+                    const int32_t W = (int32_t)std::min<int64_t>(certain ? 1 : Wfl, p->itermax - k_enq + 1);
+                    RUN(enqueue(win[next_w], k_enq, W, need_upload, 4 * Kchain));
+                    fl[nfl++] = Flight{ next_w, k_enq, W };
+                    next_w ^= 1;
+                    k_enq += W;
+                    need_upload = false;
+                    if (certain) break;
+                }
                 const double tw0 = now_s();
                 tw[0] += tw0 - t0;
                 t_sample += tw0 - t0;
+                if (nfl == 0) break;
+                const Flight F = fl[0];
+                fl[0] = fl[1];
+                nfl--;
+                Window &w = win[F.wi];
+                const int32_t W = F.W;
                 // ---- replay it, iteration by iteration, as the results arrive
                 bool stop = false, did = false, regrow = false;
                 int32_t it = 0;
@@ -1411,7 +1447,7 @@ struct Driver {
 #endif
                     if (H.skipped) break;                       // the device saw an extraction coming that the host did not take: go on from here
                     if (H.gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
-                    if (H.overflow) { regrow = true; break; }   // the list is full: this iteration is drawn again in a longer one
+                    if (H.overflow) { regrow = true; break; }   // the list (or the store) is full: this iteration is drawn again
                     if (en.count < p->tau) { stop = true; break; }
                     const int32_t cnt = H.end - H.start;
                     // candidate order = slot order: the device ranked the entries (no sort here)
@@ -1432,16 +1468,21 @@ struct Driver {
                     const double tc = now_s();
                     tw[2] += tc - tb;
                     t_sample += tc - ta;
-                    RUN(finish_iteration(k + it, cands.data(), levels.data(), cnt, counts.data(), &did, &stop, wslots.data()));
+                    RUN(finish_iteration(F.k0 + it, cands.data(), levels.data(), cnt, counts.data(), &did, &stop, wslots.data()));
                     if (memcmp(oP, H.P, sizeof(double) * (size_t)od) != 0) {
                         // (the device advanced the level distribution with the operations of update_level_probs on the sums
                         // it built in candidate order: any difference is a defect, never a rounding matter)
-                        rh_set_error("rh_ransac: the device's level distribution left the host's at iteration %lld", (long long)(k + it));
+                        rh_set_error("rh_ransac: the device's level distribution left the host's at iteration %lld", (long long)(F.k0 + it));
                         return RH_E_INTERNAL;
                     }
                     if (stop || did) { it++; break; }
                 }
-                k += it;
+                k = F.k0 + it;
+                if (it < W || did || stop || regrow) {   // the window ended early: whatever is queued behind it is void
+                    nfl = 0;
+                    k_enq = k;
+                    need_upload = true;
+                }
                 if (regrow) {
                     RUNH(hipStreamSynchronize(c->stream));
                     for (Window &g : win) {

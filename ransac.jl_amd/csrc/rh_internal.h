@@ -375,6 +375,7 @@ struct rh_oct_iter_hdr {
 // in candidate order within the iteration, the prepared records go behind the device store (ost->store_*) with h_slot
 // saying where, and h_hdr[it] is filled.
 // it = index of the iteration in the window, k = its number.
+int rhk_oct_window_begin(rh_cloud *c, rh_oct_state *ost);   // a window that continues from the device's state: list position 0
 int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const rh_cand_entry *d_entries, const void *d_status,
                     int32_t cap, const int32_t *d_counts, int32_t it, int64_t k, rh_cand_entry *h_entries, int32_t *h_counts,
                     int32_t *h_rank, int32_t *h_slot, rh_oct_iter_hdr *h_hdr);

@@ -865,3 +865,18 @@ int rhk_oct_advance(rh_cloud *c, const rh_params *prm, rh_oct_state *ost, const 
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
+
+namespace {
+__global__ void oct_window_begin_kernel(rh_oct_state *ost)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ost->start = 0; ost->it_done = 0; }
+}
+}  // namespace
+
+// a chained octree window that continues from the device's state (no upload): its candidate list starts at position 0
+int rhk_oct_window_begin(rh_cloud *c, rh_oct_state *ost)
+{
+    hipLaunchKernelGGL(oct_window_begin_kernel, dim3(1), dim3(64), 0, c->stream, ost);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
