@@ -52,6 +52,30 @@ def test_one_rank_library_collective_equals_plain_scoring():
         exp = np.zeros(1000, dtype=np.int32)
         exp[200 + lo:200 + hi] = ref[lo:hi]
         assert np.array_equal(got, exp)
+    # many batches with two buffers in flight and no wait in between (a buffer comes back two calls later: the library
+    # orders that call behind the collective that read it), slices of every size -- 32 candidates and fewer take the
+    # plain fill, larger ones have their total zeroed by the prepare launch -- and a rank without candidates
+    ring = [torch.full((900,), 9, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    slices = [(0, 5), (5, 37), (37, 38), (38, 300), (300, 300), (300, 699), (699, 700), (0, 700)]
+    for i, (lo, hi) in enumerate(slices):
+        comm.score_allreduce(batch.slice_ptr(lo), hi - lo, 100 + lo, 900, cp, ring[i & 1].data_ptr())
+        if i >= len(slices) - 2:
+            continue
+        # check the one that is two calls old before its buffer is handed out again
+        if i >= 1:
+            comm.fence()
+            L.check(lib.rh_cloud_sync(pc._h))
+            plo, phi = slices[i - 1]
+            exp = np.zeros(900, dtype=np.int32)
+            exp[100 + plo:100 + phi] = ref[plo:phi]
+            assert np.array_equal(ring[(i - 1) & 1].cpu().numpy(), exp), (plo, phi)
+    comm.sync()
+    for i in (len(slices) - 2, len(slices) - 1):
+        plo, phi = slices[i]
+        exp = np.zeros(900, dtype=np.int32)
+        exp[100 + plo:100 + phi] = ref[plo:phi]
+        assert np.array_equal(ring[i & 1].cpu().numpy(), exp), (plo, phi)
     # bad arguments fail loudly
     with pytest.raises(R.RansacHipError):
         comm.score_allreduce(batch.slice_ptr(0), 700, 400, 1000, cp, bufs[0].data_ptr())    # slice beyond the buffer
