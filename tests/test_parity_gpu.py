@@ -475,6 +475,22 @@ def test_ransac_octree_window_longer_than_its_launch_bound():
         assert np.array_equal(a.inpoints, b.inpoints)
 
 
+def test_ransac_octree_iterations_beyond_the_advance_kernels_lds_buffer():
+    """The kernel that ends an iteration of a chained octree window (sampler.hip, oct_advance_kernel) sorts the
+    iteration's scores into candidate order in LDS when there are at most 6144 of them and in global memory beyond:
+    10 000 minimal sets per iteration on a dense cloud give ~7000 candidates per iteration -- the second form, a store of
+    tens of thousands after the first iteration, an extraction in every iteration."""
+    prims = ["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"]
+    xyz, nrm, truth = synth.make_cloud(60_000, prims, 0.1, seed=702)
+    subs = synth.make_subsets(60_000, 6, seed=8)
+    types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+    params = R.ransacparameters(types, iteration={"minsubsetN": 10000, "τ": 300, "itermax": 4, "prob_det": 0.999})
+    kw = dict(score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1)
+    pc, oc, got, exp, stats = run_both(xyz, nrm, subs, params, seed=5, octree_sampling=True, **kw)
+    assert stats["candidates_scored"] > 6144 * stats["iterations"]
+    assert_same_run(pc, oc, got, exp, stats)
+
+
 @pytest.mark.parametrize("cache", [True, False])
 def test_ransac_calls_in_a_row_on_one_cloud(cache, monkeypatch):
     """rh_ransac parks its windows, device store and pinned scratch on the cloud for the next call
