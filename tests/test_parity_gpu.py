@@ -609,6 +609,34 @@ def test_largestconncomp_random_bitmaps(shape, density, seed):
         assert np.array_equal(got, orc.largestconncomp(bm, conn8=conn8))
 
 
+def test_full_size_octree_leg_is_the_same_run_under_every_switch(monkeypatch):
+    """The bench's octree-sampling leg at full size (cfg3: 10M points, minsubsetN = 4096, ~1000 candidates per iteration,
+    a store of ~100 000 candidates at the first extraction) -- too large for the oracle, so the size-independent property:
+    the run is ONE run whichever of its pieces is switched off (chained windows, the device-managed store, the v4
+    liveness pass, the sampler's cell directory, two windows in flight, scoring fused into the window), and the same
+    run twice in a row.  Regression: the v4 score launch once left the candidates beyond its launch bound unscored and the
+    leg's draw counts varied from run to run."""
+    c = synth.config("cfg3")
+    subs = synth.make_subsets(c["xyz"].shape[0], c["r"], c["seed"])
+    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs)
+    types = [R.FittedPlane, R.FittedSphere, R.FittedCylinder]
+    params = R.ransacparameters(types, iteration={"minsubsetN": 4096, "itermax": 128, "τ": 900, "prob_det": 0.9})
+    cp = R.params_to_c(params, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1, octree_sampling=True)
+
+    def run():
+        pc.enable_all()
+        got, _, st = R.ransac(pc, cp, seed=1234, return_stats=True)
+        return (st["draws"], st["candidates_scored"], st["scored_left"], [(g.iteration, bytes(g.c_shape), g.inpoints.tobytes()) for g in got])
+
+    ref = run()
+    assert len(ref[3]) >= 10 and ref[1] > 100_000
+    assert run() == ref
+    for sw in ("RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS", "RH_NO_OCT_TAB", "RH_OCT_ONE_WINDOW", "RH_NO_FUSED_SCORE"):
+        monkeypatch.setenv(sw, "1")
+        assert run() == ref, sw
+        monkeypatch.delenv(sw)
+
+
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
 def test_full_size_properties(cfg):
     """BASELINE configs[1], [2] and [4] at full size (1M / 10M / 50M points, r = 32, B = 4096; cfg5 with cones):
