@@ -786,6 +786,8 @@ struct Driver {
     {
         if (ncand == 0) return RH_OK;
         if (dev_slots != nullptr) {
+            // (the device keeps a candidate's number on the host as an int32 beside its record)
+            if ((int64_t)store.size() + ncand > (int64_t)0x7fff0000) { rh_set_error("rh_ransac: more than 2^31 candidates in one run"); return RH_E_CAPACITY; }
             int32_t nk[4] = { 0, 0, 0, 0 };
             for (int32_t i = 0; i < ncand; i++) {
                 double lo, hi, E;
@@ -1346,9 +1348,9 @@ struct Driver {
                     // the iterations append their candidates' records to the device store: room for the windows that can be
                     // in flight before the next upload (the device checks the capacity itself and ends the window otherwise)
                     for (int q = 0; q < 4; q++) {
-                        bool has_kind = false;
-                        for (int ti = 0; ti < T; ti++) has_kind |= p->shape_types[ti] == q;
-                        if (has_kind) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + ahead * p->minsubsetN * T));
+                        int64_t slots_of_kind = 0;   // a minimal set yields at most one candidate per entry of shape_types
+                        for (int ti = 0; ti < T; ti++) slots_of_kind += p->shape_types[ti] == q ? 1 : 0;
+                        if (slots_of_kind > 0) RUN(store_reserve(c, st, q, (int64_t)st.n[q] + ahead * p->minsubsetN * slots_of_kind));
                         h.store_prep[q] = st.prep[q];
                         h.store_id[q] = st.id[q];
                         h.store_E[q] = st.Eb[q];
@@ -1417,7 +1419,7 @@ struct Driver {
                         certain = rh_prob(store[(size_t)best].E, lb[p->extract_s], c->n, drawN) > p->prob_det;
                     }
                     const int32_t W = (int32_t)std::min<int64_t>(certain ? 1 : Wfl, p->itermax - k_enq + 1);
-                    RUN(enqueue(win[next_w], k_enq, W, need_upload, 4 * Kchain));
+                    RUN(enqueue(win[next_w], k_enq, W, need_upload, 2 * Kchain));
                     fl[nfl++] = Flight{ next_w, k_enq, W };
                     next_w ^= 1;
                     k_enq += W;
@@ -1434,7 +1436,7 @@ struct Driver {
                 Window &w = win[F.wi];
                 const int32_t W = F.W;
                 // ---- replay it, iteration by iteration, as the results arrive
-                bool stop = false, did = false, regrow = false;
+                bool stop = false, did = false, regrow = false, refill = false;
                 int32_t it = 0;
                 for (; it < W; it++) {
                     const double ta = now_s();
@@ -1447,7 +1449,9 @@ struct Driver {
 #endif
                     if (H.skipped) break;                       // the device saw an extraction coming that the host did not take: go on from here
                     if (H.gave_up) { rh_set_error("rh_ransac: sampling did not find an enabled point"); return RH_E_INTERNAL; }
-                    if (H.overflow) { regrow = true; break; }   // the list (or the store) is full: this iteration is drawn again
+                    // the list or the store is full: this iteration is drawn again -- in a longer list (regrow) / behind an upload
+                    // that reserves the store anew
+                    if (H.overflow) { regrow = (H.overflow & 1) != 0; refill = true; break; }
                     if (en.count < p->tau) { stop = true; break; }
                     const int32_t cnt = H.end - H.start;
                     // candidate order = slot order: the device ranked the entries (no sort here)
@@ -1478,7 +1482,7 @@ struct Driver {
                     if (stop || did) { it++; break; }
                 }
                 k = F.k0 + it;
-                if (it < W || did || stop || regrow) {   // the window ended early: whatever is queued behind it is void
+                if (it < W || did || stop || regrow || refill) {   // the window ended early: whatever is queued behind it is void
                     nfl = 0;
                     k_enq = k;
                     need_upload = true;

@@ -358,7 +358,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
 // What the host gets per iteration of a chained window (pinned memory, written by rhk_oct_advance's kernel)
 struct rh_oct_iter_hdr {
     int32_t skipped;              // the window had ended before this iteration: nothing else is valid
-    int32_t overflow;             // the candidate list is full: the iteration is incomplete (the window ends here)
+    int32_t overflow;             // bit 0: the candidate list is full, bit 1: the device store is: the iteration is incomplete (the window ends here)
     int32_t gave_up;              // sampling found no enabled point
     int32_t start, end;           // the iteration's entries in the list (and in the pinned copies of the list and the counts)
     int32_t stop_after;           // the device expects an extraction after this iteration (it skips the rest of the window)

@@ -686,7 +686,7 @@ oct_advance_kernel(const OctAdvArgs A)
 #pragma unroll
         for (int q = 0; q < 4; q++) ost->store_n[q] = sbase[q] + nkq[q];
         ost->appended += seg[od];
-        const int32_t over = (count > A.cap || store_over != 0) ? 1 : 0;
+        const int32_t over = (count > A.cap ? 1 : 0) | (store_over != 0 ? 2 : 0);   // bit 0: the list is full, bit 1: the store
         const int32_t stop = (over || lstop) ? 1 : 0;
         if (stop) ost->stop = 1;
         rh_oct_iter_hdr &H = A.h_hdr[it];
