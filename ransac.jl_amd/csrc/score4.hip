@@ -400,7 +400,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
         const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
         if (slo < shi) {                                                                                               \
             if (ran) __syncthreads();   /* the previous segment's waves are done with the tile and the list */        \
-            if (!TAIL || !ran || A.k[K].en != staged_en) {                                                             \
+            if (!ran || A.k[K].en != staged_en) {                                                                      \
                 s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64, A.gb32, A.ngroups);                                   \
                 staged_en = A.k[K].en;                                                                                 \
             } else if (threadIdx.x == 0) { sh.npairs = 0; sh.next_batch = 0; }   /* same tile, same enabled words */   \
