@@ -32,8 +32,10 @@ for r in range(int(os.environ.get("RUNS", "3"))):
     for g in got:
         h.update(np.asarray(g.inpoints, dtype=np.int64).tobytes())
     print("   result digest", h.hexdigest()[:16], [(g.iteration, len(g.inpoints)) for g in got][:6], "rng draws", st.get("draws"), "scored_left", st.get("scored_left"), flush=True)
-if os.environ.get("OCT_TIMING"):
+if os.environ.get("OCT_TIMING"):   # only with a library built with RH_EXTRA_FLAGS=-DRH_OCT_TIMING (ransac.jl_amd/build.py): phase stamps of the sampler
     import ctypes as C
+    if not hasattr(R.lib(), "rh_dbg_oct_timing"):
+        raise SystemExit("OCT_TIMING needs a library built with RH_EXTRA_FLAGS=-DRH_OCT_TIMING")
     t = (C.c_ulonglong * 16)()
     R.lib().rh_dbg_oct_timing.argtypes = [C.POINTER(C.c_ulonglong)]
     R.lib().rh_dbg_oct_timing(t)
