@@ -931,9 +931,9 @@ def main():
                                     "python bench.py --workload cfg2 --no-cpu --no-e2e --oracle-check 256 (child process): BASELINE "
                                     "configs[1], 1M points = 2 planes + 2 spheres + 2 cylinders without outliers, S = 31 250, B = 4096")
         if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
-            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "96", "--e2e-iters", "4096", "--e2e-runs", "3",
+            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "96", "--e2e-iters", "4096", "--e2e-runs", "5",
                                              "--e2e-cpu-iters", "48", "--no-e2e-octree", "--no-cpu-baseline"],
-                                    "python bench.py --workload cfg5 --steps 60 --warmup 10 --oracle-check 96 --e2e-iters 4096 --e2e-runs 3 "
+                                    "python bench.py --workload cfg5 --steps 60 --warmup 10 --oracle-check 96 --e2e-iters 4096 --e2e-runs 5 "
                                     "--e2e-cpu-iters 48 --no-e2e-octree --no-cpu-baseline (child process): one replica of the 50M-point cloud on "
                                     "this GPU, S = 1 562 500, cones in the batch; 96 candidates of all four kinds checked against the "
                                     "oracle; the refit scan streams 2.4 GB; a bounded end-to-end leg (4096 iterations, the oracle's loop "
