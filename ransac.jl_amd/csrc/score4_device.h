@@ -106,7 +106,13 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         // (the threshold is the first addend of the fused chain: every partial sum is as large as it is, hence the
         // 4.1 |cos alpha| and 4 |eps| beside the products' own 5.05 / 6.1)
         const double mN = S * u * (5.05 * (n1 * Nm) + 4.1 * (fabs(cosa) + 1e-3)) + 1e-30;
-        const double mD = S * u * (6.1 * (z1 * M + fabs(zp)) + 4.0 * fabs(eps)) + 1e-30;
+        // Float32 cloud: the test to be bracketed is the reference's OWN binary32 chain oz32 . (p - p0), whose error does not
+        // shrink when oz . p0 cancels: p - p0 is rounded per component (u |p_i - p0_i|), oz32 = normalize in binary32 is
+        // off by u per component, then three products and two sums -- u (6.2) sum_i |oz_i| (M + |p0_i|) to first order.  A
+        // plane through the cloud given by a point 1e6 away is a legal candidate (test_f32_gpu.py).
+        const double zabs = (fabs(P.f[6] * P.f[0]) + fabs(P.f[7] * P.f[1])) + fabs(P.f[8] * P.f[2]);
+        const double mRef = f32cloud ? RH_CLS_SAFETY * u * 6.2 * (z1 * M + zabs) : 0.0;
+        const double mD = S * u * (6.1 * (z1 * M + fabs(zp)) + 4.0 * fabs(eps)) + mRef + 1e-30;
         ok = ok && cls_fin(mN) && cls_fin(mD) && cls_fin(zp) && mN < 1e30 && mD < 1e30;
         if (ok) {
             const double wN = 2.0 * mN, wD = 2.0 * mD;
@@ -123,7 +129,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         }
         if (fin && cls_fin(zp) && cls_fin(eps) && cls_fin(M)) {
             // box: d(centre) against eps + sum |oz_i| h_i; binary32 error of both sides + the binary64 test's own slack
-            const double sB = S * 10.1 * u * (z1 * M + fabs(zp)) + slack64;
+            const double sB = S * 10.1 * u * (z1 * M + fabs(zp)) + mRef + slack64;
             bx[0] = (float)P.f[6]; bx[1] = (float)P.f[7]; bx[2] = (float)P.f[8];
             bx[3] = (float)(-zp);
             bx[4] = cls_up(eps + sB);

@@ -157,6 +157,44 @@ def test_f32_fuzz_arbitrary_candidates(scene32, eps, alpha_deg, seed):
     assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
 
 
+def test_f32_planes_through_the_cloud_given_by_far_away_points(scene32):
+    """A plane is (point, normal); the point need not be near the cloud.  On a Float32 cloud the reference's distance
+    oz . (p - p0) is a binary32 chain whose rounding grows with |p0| -- 1e6 away, p - p0 is only good to 0.03 -- while
+    oz . p0 itself may cancel to nothing.  The classifier's margins have to bracket THAT chain: planes that cut the cloud
+    at every orientation, defined by points 1e3 ... 1e7 away along directions inside the plane."""
+    pc, oc, truth, x32, n32, subs = scene32
+    pc.enable_all(); oc.enable_all()
+    rng = np.random.default_rng(77)
+    cp = R.params_to_c(R.ransacparameters(plane={"ϵ": 0.3, "α": math.radians(5.0)}))
+    b = 96
+    arr = (L.Shape * b)()
+    planes = [t for t in truth if t["kind"] == "plane"]
+    assert planes
+    for i in range(b):
+        s = arr[i]
+        s.kind = L.PLANE
+        s.outwards = 0
+        t = planes[i % len(planes)]
+        # the scene's own planes (their points have matching normals), slightly tilted and shifted; then the point that
+        # defines the plane is pushed far away INSIDE the plane (two in-plane directions)
+        nrm = np.asarray(t["normal"], dtype=np.float64) + rng.normal(size=3) * 0.01
+        nrm /= np.linalg.norm(nrm)
+        t1 = np.cross(nrm, rng.normal(size=3)); t1 /= np.linalg.norm(t1)
+        t2 = np.cross(nrm, t1)
+        near = np.asarray(t["point"], dtype=np.float64) + nrm * rng.uniform(-0.2, 0.2)
+        far = near + t1 * 10.0 ** rng.uniform(3, 6.5) * rng.choice([-1, 1]) + t2 * 10.0 ** rng.uniform(3, 6.5) * rng.choice([-1, 1])
+        v = np.zeros(10)
+        v[0:3] = far
+        v[3:6] = nrm
+        for j in range(10):
+            s.v[j] = float(v[j])
+        R.lib().rh_shape_finalize_f32(C.byref(s))
+    counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+    ocounts, omasks = oc.score_batch(to_orc(arr, b), orc.Params.from_buffer_copy(bytes(cp)), want_masks=True)
+    assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    assert ocounts.sum() > 1000 and (ocounts > 0).sum() > b // 2   # the planes do cut the cloud
+
+
 def test_f32_device_batch_and_unsupported_calls(scene32):
     pc, oc, truth, x32, n32, subs = scene32
     pc.enable_all(); oc.enable_all()

@@ -25,7 +25,13 @@ def rand_shape(rng, truth, scale):
         j = lambda x: np.asarray(x, dtype=np.float64) * (1 + jit * rng.uniform(-1, 1, size=np.shape(x)))
         k = t["kind"]
         s.kind = KMAP[k]
-        if k == "plane": v = list(j(t["point"])) + list(j(t["normal"]))
+        if k == "plane":
+            pt, nv = j(t["point"]), j(t["normal"])
+            if rng.integers(0, 4) == 0:   # the same plane given by a point far away (inside the plane): oz . p0 cancels, |p0| does not
+                t1 = np.cross(nv, rng.normal(size=3)); t1 /= max(np.linalg.norm(t1), 1e-30)
+                t2 = np.cross(nv / max(np.linalg.norm(nv), 1e-30), t1)
+                pt = pt + t1 * 10.0 ** rng.uniform(2, 6.5) * rng.choice([-1, 1]) + t2 * 10.0 ** rng.uniform(2, 6.5) * rng.choice([-1, 1])
+            v = list(pt) + list(nv)
         elif k == "sphere": v = list(j(t["center"])) + [float(j(t["radius"]))]
         elif k == "cylinder": v = list(j(t["axis"])) + list(j(t["center"])) + [float(j(t["radius"]))]
         else: v = list(j(t["apex"])) + list(j(t["axis"])) + [float(j(t["opang"]))]
@@ -98,7 +104,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
     bad, t0 = 0, time.time()
     for case in range(ncases):
-        ok, desc = one(case, rng)
+        ok, desc = one(case, rng, f32=bool(os.environ.get("F32")))   # F32=1: Float32 clouds against the oracle's binary32 twin
         print("%s case %3d  %s" % ("ok  " if ok else "FAIL", case, desc), flush=True)
         bad += not ok
     print("%d cases, %d failures, %.0f s" % (ncases, bad, time.time() - t0))
