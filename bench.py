@@ -77,6 +77,9 @@ def parse():
                          "library itself (rh_comm_* of the C ABI: librccl directly, the path a Julia / C host uses)")
     ap.add_argument("--no-e2e-octree", action="store_true", help="skip the octree-sampling end-to-end leg")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline legs of the score step (the end-to-end prefix check stays)")
+    ap.add_argument("--detail-out", default=DETAIL_DEFAULT,
+                    help="where rank 0 writes the full result document (notes, per-kind diagnostics, nested cfg2/cfg5 legs, counter "
+                         "provenance); stdout carries only the compact line (< 4 KB)")
     return ap.parse_args()
 
 
@@ -135,6 +138,99 @@ def pmc_replay(kernel_key, enabled, suffix=""):
         except Exception:
             out["stale"] = True
     return out
+
+
+DETAIL_DEFAULT = os.path.join(ROOT, "bench_detail.json")
+LINE_MAX_BYTES = 4096        # the driver keeps a bounded tail of stdout: the line it parses must fit with room to spare
+LINE_MAX_STR = 120
+
+
+def _num(x, digits=6):
+    """a float rounded to `digits` significant digits (None stays None, ints stay ints)"""
+    if x is None or isinstance(x, (bool, int)):
+        return x
+    try:
+        return float("%.*g" % (digits, float(x)))
+    except (TypeError, ValueError):
+        return None
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out, detail_file=None):
+    """The ONE line rank 0 prints: the contract's keys, `roofline` and `cpu_baseline`, and flat scalars for the
+    legs (no prose, no nesting beyond those three objects).  Everything else stays in the detail file.  Pure:
+    tests/test_bench_line.py builds it from a canned result."""
+    rf, cb, cfg = out.get("roofline") or {}, out.get("cpu_baseline") or {}, out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _num(line["value"], 7), _num(line["ms_per_step"], 6)
+    line["config"] = {k: cfg.get(k) for k in ("workload", "points", "subset_points", "candidates_per_step", "score_mode", "parallelism")}
+    line["roofline"] = {"kernel": rf.get("kernel"), "bound": rf.get("bound"), "achieved": _num(rf.get("achieved")),
+                        "peak": _num(rf.get("peak")), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
+                        "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
+                        "counters": rf.get("counters")}
+    line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "sample": cb.get("sample")} if cb else None)
+    line["oracle_checked"] = out.get("oracle_checked")
+    flat = {
+        "rccl_ranks_seen": out.get("rccl_ranks_seen"),
+        "cpu_mt_value": _get(out, "cpu_baseline_mt", "value"), "cpu_mt_cores": _get(out, "cpu_baseline_mt", "cores"),
+        "masks_ms": _get(out, "masks_out", "ms_per_step"),
+        "pcie_ms": _get(out, "pcie_inclusive", "ms_per_step"),
+        "f32_ms": _get(out, "float32", "ms_per_step"),
+        "refit_scan_ms": _get(out, "roofline_refit", "ms_per_launch"), "refit_scan_gbs": _get(out, "roofline_refit", "achieved"),
+        "refit_scan_frac_hbm": _get(out, "roofline_refit", "frac"), "refit_culled_ms": _get(out, "refit_culled", "ms_per_refit_scan"),
+        "e2e_shapes": _get(out, "end_to_end", "shapes"), "e2e_seconds": _get(out, "end_to_end", "seconds"),
+        "e2e_seconds_to_last_extraction": _get(out, "end_to_end", "seconds_to_last_extraction"),
+        "e2e_shapes_per_sec": _get(out, "end_to_end", "shapes_per_sec_to_last_extraction"),
+        "e2e_cpu_sets_per_sec": _get(out, "end_to_end", "cpu_baseline", "minimal_sets_per_sec"),
+        "e2e_sets_per_sec": _get(out, "end_to_end", "minimal_sets_per_sec"),
+        "octree_seconds": _get(out, "end_to_end_octree", "seconds"), "octree_seconds_max": _get(out, "end_to_end_octree", "seconds_max"),
+        "octree_shapes": _get(out, "end_to_end_octree", "shapes"),
+        "e2e_sharded_seconds": _get(out, "end_to_end_sharded", "seconds"), "e2e_sharded_speedup": _get(out, "end_to_end_sharded", "speedup_vs_one_gpu"),
+        "cloud_create_ms": _get(out, "cloud_create", "ms_total"),
+        "cfg2_value": _get(out, "cfg2", "value"), "cfg2_ms": _get(out, "cfg2", "ms_per_step"),
+        "cfg2_oracle_checked": _get(out, "cfg2", "oracle_checked"),
+        "cfg5_value": _get(out, "cfg5", "value"), "cfg5_ms": _get(out, "cfg5", "ms_per_step"),
+        "cfg5_frac": _get(out, "cfg5", "roofline", "frac"),
+        "cfg5_masks_ms": _get(out, "cfg5", "masks_out", "ms_per_step"),
+        "cfg5_refit_scan_ms": _get(out, "cfg5", "roofline_refit", "ms_per_launch"),
+        "cfg5_refit_scan_frac_hbm": _get(out, "cfg5", "roofline_refit", "frac"),
+        "cfg5_oracle_checked": _get(out, "cfg5", "oracle_checked"),
+        "cfg5_e2e_shapes": _get(out, "cfg5", "end_to_end", "shapes"), "cfg5_e2e_seconds": _get(out, "cfg5", "end_to_end", "seconds"),
+        "cfg5_cloud_create_ms": _get(out, "cfg5", "cloud_create", "ms_total"),
+    }
+    for k, v in flat.items():
+        if v is not None:
+            line[k] = _num(v)
+    errs = [k for k in ("masks_out", "float32", "cfg2", "cfg5", "end_to_end_sharded", "hbm_measured") if _get(out, k, "error")]
+    if errs:
+        line["legs_failed"] = errs
+    if detail_file:
+        line["detail"] = os.path.basename(detail_file)
+    def clip(o):
+        if isinstance(o, dict):
+            return {k: clip(v) for k, v in o.items()}
+        return o[:LINE_MAX_STR] if isinstance(o, str) else o
+    text = json.dumps(clip(line), separators=(",", ":"))
+    if len(text) >= LINE_MAX_BYTES:
+        raise RuntimeError("bench line is %d bytes (limit %d)" % (len(text), LINE_MAX_BYTES))
+    return text
+
+
+def write_detail(out, path):
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+    os.replace(tmp, path)
 
 
 def self_launch(args):
@@ -272,7 +368,7 @@ def main():
     if args.workload == "cfg5":
         prim = prim + ["cone"] * 8
         types = types + [R.FittedCone]
-        wseed, wname = 5, "cfg5: 50M-point 48-primitive cloud with cones, scanner-style density, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
+        wseed, wname = 5, "cfg5: 50M-point 48-primitive scanner-style cloud with cones, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step"
         n_default = 50_000_000
     n = args.points or n_default
     t0 = time.time()
@@ -522,6 +618,7 @@ def main():
             "frac_unweighted_x4": None if insts is None else insts * 4 / sec / simd_cycles_per_s,
             "sq_active_inst_valu": sq.get("SQ_ACTIVE_INST_VALU"), "sq_busy_cycles": sq.get("SQ_BUSY_CYCLES"), "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"),
             "traffic": pmc["traffic"],
+            "counters": None if not pmc["replayed_from"] else ("replayed:" + os.path.dirname(pmc["replayed_from"][0]) + (" (stale)" if pmc["stale"] else "")),
             "traffic_frac_of_hbm_peak": None if pmc["traffic"] is None else pmc["traffic"] / sec / 1e9 / HBM_PEAK_GBS,
             "ms_per_launch": sec * 1e3, "ms_source": "HIP events on the library's stream, this run",
             "valu_insts_per_launch": insts, "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"), "fp64_arith_insts_per_launch": arith,
@@ -752,8 +849,7 @@ def main():
             if not np.array_equal(oc_counts, counts_h[:nb]):
                 raise SystemExit("PARITY FAILURE: GPU counts differ from the oracle on the cpu_baseline sample")
             out["cpu_baseline"] = {"value": nb / t_cpu, "unit": "candidates/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d candidates of the same batch on the same subset (S=%d), "
-                                             "%.1f s; counts checked equal to the GPU's" % (nb, S, t_cpu),
+                                   "sample": "first %d candidates of the batch, S=%d, %.1f s, counts equal the GPU's" % (nb, S, t_cpu),
                                    "host_cpus": os.cpu_count()}
             # steelman: the same passes spread over this GPU's share of the host cores (OpenMP over candidates).  A GPU box
             # hands one GPU's job 16 of the host's CPUs; the affinity mask says what this process may really use.
@@ -904,13 +1000,18 @@ def main():
         def child_leg(name, extra, note):
             import subprocess
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cfg5", "--no-cfg2", "--no-f32"] +
+                dpath = os.path.splitext(args.detail_out)[0] + "_%s.json" % name
+                if os.path.exists(dpath):
+                    os.remove(dpath)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cfg5", "--no-cfg2", "--no-f32",
+                                    "--detail-out", dpath] +
                                    ([] if "--e2e-iters" in extra else ["--no-e2e", "--no-cpu"]) + extra, capture_output=True, text=True, timeout=900)
                 if r.returncode != 0:
                     if "PARITY FAILURE" in (r.stderr or ""):   # a wrong result is never just a missing leg
                         raise SystemExit("%s leg: %s" % (name, r.stderr.strip().splitlines()[-1]))
                     return {"error": "exit code %d: %s" % (r.returncode, (r.stderr or "").strip()[-300:])}
-                c5 = json.loads(r.stdout.strip().splitlines()[-1])
+                json.loads(r.stdout.strip().splitlines()[-1])      # the child's own compact line parses
+                c5 = json.load(open(dpath))                         # its full document
                 leg = {"config": c5["config"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
                        "tests_per_sec": c5["tests_per_sec"], "per_kind": c5["per_kind"],
                        "score_kernel_ms": c5["roofline"]["ms_per_launch"],
@@ -938,7 +1039,10 @@ def main():
                                     "this GPU, S = 1 562 500, cones in the batch; 96 candidates of all four kinds checked against the "
                                     "oracle; the refit scan streams 2.4 GB; a bounded end-to-end leg (4096 iterations, the oracle's loop "
                                     "compared on a 48-iteration prefix)")
-        print(json.dumps(out))
+        write_detail(out, args.detail_out)
+        sys.stderr.write("bench.py: full result document -> %s\n" % args.detail_out)
+        sys.stderr.flush()
+        print(compact_line(out, args.detail_out), flush=True)
     batch.free()
     if points_mode:
         sbatch.free()

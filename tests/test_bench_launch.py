@@ -41,17 +41,21 @@ def test_plain_start_with_gpus_2_fails_loudly_without_gpus():
 
 
 @pytest.mark.gpu
-def test_self_launch_on_one_gpu_box():
+def test_self_launch_on_one_gpu_box(tmp_path):
     """One GPU: `--gpus 2` must fail (rank 1 has no GPU); with the two ranks sharing GPU 0 over gloo the script launches
     itself and reports n_gpus = 2 and rccl_ranks_seen = 2."""
     import torch
     if torch.cuda.device_count() >= 2:
         pytest.skip("more than one GPU here")
-    small = ["--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--workload", "cfg2", "--no-cpu", "--no-e2e", "--no-cfg2", "--no-cfg5"]
+    small = ["--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--workload", "cfg2", "--no-cpu", "--no-e2e", "--no-cfg2", "--no-cfg5",
+             "--detail-out", str(tmp_path / "detail.json")]
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + small, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "no fallback" in r.stderr and r.stdout.strip() == ""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + small, env=_env(RH_BENCH_SHARE_GPU0="1", RH_BENCH_BACKEND="gloo"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    line = json.loads(last)
+    assert json.load(open(tmp_path / "detail.json"))["n_gpus"] == 2     # the full document went to the side file
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["config"]["candidates_per_step"] == 8192
