@@ -107,6 +107,7 @@ SIGNATURES = {
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
+    "rh_dbg_cls_soundness": (C.c_int, [_vp, _sp, C.c_int32, _pp, C.POINTER(C.c_uint64)]),
     "rh_dbg_oct_search_selftest": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
     "rh_cloud_create_ms": (C.c_int, [_vp, _dp]),
     "rh_comm_unique_id": (C.c_int, [_vp]),

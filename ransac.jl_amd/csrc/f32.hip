@@ -27,37 +27,6 @@ namespace {
 
 using namespace rhdev32;
 
-// float record of a candidate: the fields of the shape rounded to binary32 (exact for a Float32 shape), per-candidate
-// constants in binary32 with the reference's operations (normalize(plane.normal), plane.jl:85)
-__host__ __device__ inline void prep_one32(const rh_shape &s, rh_prepf &o)
-{
-    for (int i = 0; i < 12; i++) o.f[i] = 0.0f;
-    const float sgn = s.outwards ? 1.0f : -1.0f;
-    switch (s.kind) {
-    case RH_PLANE: {
-        for (int i = 0; i < 6; i++) o.f[i] = (float)s.v[i];
-        const float a = o.f[3], b = o.f[4], c = o.f[5];
-        const float inv = 1.0f / sqrtf((a * a + b * b) + c * c);
-        o.f[6] = inv * a; o.f[7] = inv * b; o.f[8] = inv * c;
-        break;
-    }
-    case RH_SPHERE:
-        for (int i = 0; i < 4; i++) o.f[i] = (float)s.v[i];
-        o.f[4] = sgn;
-        break;
-    case RH_CYLINDER:
-        for (int i = 0; i < 7; i++) o.f[i] = (float)s.v[i];
-        o.f[7] = sgn;
-        break;
-    default:
-        for (int i = 0; i < 6; i++) o.f[i] = (float)s.v[i];
-        o.f[6] = (float)s.v[7];   // cos(-opang/2), a binary32 number on a Float32 shape
-        o.f[7] = (float)s.v[8];
-        o.f[8] = sgn;
-        break;
-    }
-}
-
 // the batch is binned by kind exactly like the Float64 path (bin k at offset off[k] of prep / orig, its size in nk[k]); the
 // float record of slot t of bin k is made from its source shape: shapes[off[k] + t] when the shapes array is sorted like
 // the bins (rh_score_batch), shapes[orig[off[k] + t]] when it is in the caller's order (rh_score_batch_dev)

@@ -187,23 +187,33 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
     } else {
         rh_cls C;
 #pragma unroll
-        for (int f = 0; f < 10; f++) C.f[f] = rec->f[f];
+        for (int f = 0; f < 14; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
-        uint32_t mlo = 0, mhi = 0;
-#pragma unroll 8
+        // two words per pair, bits shifted in from the right (no 32-bit literal per point) and un-reversed afterwards:
+        // s = surely an inlier, m = undecided (|t| <= 1/2, NaN included)
+        uint32_t slo = 0, shi = 0, mlo = 0, mhi = 0;
+#pragma unroll 4
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[j];
-            mlo = mlo + mlo + (cls_pre_cone(C, a.x, a.y, a.z) ? 1u : 0u);
+            const rh_f32x2 b = rowb[j];
+            const float t = cls_cone_t(C, a.x, a.y, a.z, a.w, b.x, b.y);
+            slo = slo + slo + (t > 0.5f ? 1u : 0u);
+            mlo = mlo + mlo + (!(__builtin_fabsf(t) > 0.5f) ? 1u : 0u);
         }
-#pragma unroll 8
+#pragma unroll 4
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[32 + j];
-            mhi = mhi + mhi + (cls_pre_cone(C, a.x, a.y, a.z) ? 1u : 0u);
+            const rh_f32x2 b = rowb[32 + j];
+            const float t = cls_cone_t(C, a.x, a.y, a.z, a.w, b.x, b.y);
+            shi = shi + shi + (t > 0.5f ? 1u : 0u);
+            mhi = mhi + mhi + (!(__builtin_fabsf(t) > 0.5f) ? 1u : 0u);
         }
-        mlo = __brev(mlo); mhi = __brev(mhi);   // (bits shifted in from the right: no 32-bit literal per point)
+        slo = __brev(slo); shi = __brev(shi); mlo = __brev(mlo); mhi = __brev(mhi);
         const uint64_t lg = sh.len[g];
+        // (a disabled point is staged as zeros: whatever the classifier makes of it, its bit is masked out here)
+        uint64_t sure = exact_only ? 0ULL : ((((uint64_t)shi << 32) | slo) & lg);
         uint64_t mask = exact_only ? lg : ((((uint64_t)mhi << 32) | mlo) & lg);
-        if (!act) mask = 0;
+        if (!act) { mask = 0; sure = 0; }
         sh.cntb[wv][lane] = 0;
         if (MASK) sh.maskb[wv][lane] = 0ULL;
         int qbh = 0, qbn = 0;   // ring head / fill (wave-uniform)
@@ -245,8 +255,8 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         }
         if (qbn > 0) drain_b(qbn);
         wave_lds_sync();
-        total = sh.cntb[wv][lane];
-        if (MASK) word = sh.maskb[wv][lane];
+        total = sh.cntb[wv][lane] + __popcll(sure);
+        if (MASK) word = sh.maskb[wv][lane] | sure;
     }
     if (MASK) {
         if (act && word != 0) {
@@ -441,7 +451,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
 // construction (RH_CLS_SAFETY) it should stay below ~1/8.  out[kind * 2 + {0, 1}] = max over the batch of |a32 - a64|,
 // |b32 - b64| (sphere / cylinder: only where the distance half is not far outside, a64 > -2 -- the norm's error is relative
 // to the norm); out[8 + kind] = pairs looked at.
-struct S4AuditCand { rh_prep P; rh_cls C; double cNhi, wN, eDlo, wD; int kind, usable; };
+struct S4AuditCand { rh_prep P; rh_cls C; double cNhi, wN, eDlo, wD, cosa; int kind, usable; };
 
 __global__ void __launch_bounds__(256)
 cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AuditCand *__restrict__ cands, int ncand,
@@ -489,6 +499,26 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             // (a is a few thousand widths below -1 there); what has to hold is the bound NEAR the band
             if (a64 > -2.0 + RH_CLS_SHIFT) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
             counted = true;
+        } else if (Q.kind == RH_CONE) {
+            // a64 / b64 from the reference's own frame (cone_frame: its dist and its normal cosine), the closed form only
+            // supplies rho for the multiplied-through angle test; points the classifier hands to the exact test because
+            // they lie next to the axis are not looked at
+            bool near_axis;
+            cls_cone_ab(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32, near_axis);
+            if (!near_axis) {
+                double dist, dt;
+                cone_frame(P, x, y, z, nx, ny, nz, dist, dt);
+                const double an = sqrt((P.f[3] * P.f[3] + P.f[4] * P.f[4]) + P.f[5] * P.f[5]);
+                const double wx = x - P.f[0], wy = y - P.f[1], wz = z - P.f[2];
+                const double h = ((P.f[3] * wx + P.f[4] * wy) + P.f[5] * wz) / an;
+                const double qx = wx - h * (P.f[3] / an), qy = wy - h * (P.f[4] / an), qz = wz - h * (P.f[5] / an);
+                const double rho = sqrt((qx * qx + qy * qy) + qz * qz);
+                a64 = (Q.eDlo - fabs(dist)) / Q.wD + RH_CLS_SHIFT;
+                b64 = rho * (P.f[8] * dt - Q.cosa) / Q.wN;
+                ea = fabs((double)a32 - a64);
+                eb = fabs((double)b32 - b64);
+                counted = true;
+            }
         }
         if (!(ea == ea)) ea = 1e30;   // a NaN on one side only is a failure
         if (!(eb == eb)) eb = 1e30;
@@ -506,13 +536,88 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
     }
     if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = ua; sb[threadIdx.x >> 6] = ub; sc[threadIdx.x >> 6] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0 && Q.kind >= 0 && Q.kind < 3) {
+    if (threadIdx.x == 0 && Q.kind >= 0 && Q.kind < 4) {
         unsigned long long ma = 0, mb = 0;
         int n = 0;
         for (int w = 0; w < 4; w++) { ma = sa[w] > ma ? sa[w] : ma; mb = sb[w] > mb ? sb[w] : mb; n += sc[w]; }
         atomicMax(&out[Q.kind * 2], ma);
         atomicMax(&out[Q.kind * 2 + 1], mb);
         atomicAdd(&out[8 + Q.kind], (unsigned long long)n);
+    }
+}
+
+// ---- audit of the DECISIONS (tests, tools/fuzz_score.py): what the margin audit above argues, counted.  One wave per
+// (candidate, 64-point group of subset 1), lane = point, with the very records (cls_make) and functions (box_skip32,
+// cls_*_t) the score kernel uses, against the exact test of the cloud's element type:
+//   out[kind * 10 + 0] pairs, 1 pairs the box test skips, 2 VIOLATION: skipped pairs with an exact inlier,
+//   3 points, 4 classified surely-in, 5 surely-out, 6 VIOLATION: surely-in but the exact test rejects,
+//   7 VIOLATION: surely-out but the exact test accepts, 8 exact inliers, 9 VIOLATION: the all-zero point a disabled point
+//   is staged as comes out surely-in (plane / sphere / cylinder count what the classifier says without looking at the
+//   enabled bits; the cone masks them).
+struct S4SoundCand { rh_prep P; rh_prepf Pf; rh_cls C; float box[RH_BOX_FIELDS]; int kind; int pad; };
+struct S4SoundArgs { double eps[4], cosa[4]; int f32; };
+
+template <int KIND>
+static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4SoundArgs &A, double x, double y, double z, double nx, double ny,
+                                                 double nz, const uint64_t valid, const rh_box32 &G, const int lane, unsigned long long *__restrict__ out)
+{
+    const double eps = A.eps[KIND], cosa = A.cosa[KIND];
+    uint64_t ex;
+    if (A.f32) ex = test_point32<KIND>(Q.Pf, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, eps, cosa);
+    else ex = test_point<KIND>(Q.P, x, y, z, nx, ny, nz, eps, cosa);
+    ex &= valid;
+    const bool skip = box_skip32<KIND>(Q.box, G);
+    const bool exact_only = is_nan_bits(Q.C.f[RH_CLS_FLAG]);
+    const float fx = (float)x, fy = (float)y, fz = (float)z, fnx = (float)nx, fny = (float)ny, fnz = (float)nz;
+    float t, t0;
+    if (KIND == RH_PLANE) { t = cls_plane_t(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = cls_plane_t(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
+    else if (KIND == RH_CONE) { t = cls_cone_t(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = 0.0f; }
+    else { t = cls_round_t<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, fx, fy, fz, fnx, fny, fnz);
+           t0 = cls_round_t<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
+    const float sum = (fabsf(fx) + fabsf(fy)) + (fabsf(fz) + fabsf(fnx)) + (fabsf(fny) + fabsf(fnz));
+    const bool weird = WB(!(sum < __builtin_inff()) && ((valid >> lane) & 1ULL)) != 0;   // the kernel: every candidate exact-only on this tile
+    const bool decided = !exact_only && !weird;
+    const uint64_t sin_ = WB(decided && t > 0.5f) & valid;
+    const uint64_t amb = (WB(!decided || !(__builtin_fabsf(t) > 0.5f))) & valid;
+    const uint64_t sout = valid & ~sin_ & ~amb;
+    if (lane == 0) {
+        unsigned long long *o = out + KIND * 10;
+        atomicAdd(&o[0], 1ULL);
+        if (skip) atomicAdd(&o[1], 1ULL);
+        if (skip && ex != 0) atomicAdd(&o[2], 1ULL);
+        atomicAdd(&o[3], (unsigned long long)__popcll(valid));
+        if (sin_) atomicAdd(&o[4], (unsigned long long)__popcll(sin_));
+        if (sout) atomicAdd(&o[5], (unsigned long long)__popcll(sout));
+        if (sin_ & ~ex) atomicAdd(&o[6], (unsigned long long)__popcll(sin_ & ~ex));
+        if (sout & ex) atomicAdd(&o[7], (unsigned long long)__popcll(sout & ex));
+        if (ex) atomicAdd(&o[8], (unsigned long long)__popcll(ex));
+        if (blockIdx.x == 0 && !exact_only && t0 > 0.5f) atomicAdd(&o[9], 1ULL);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const float *__restrict__ gb32, const S4SoundCand *__restrict__ cands,
+                 int ncand, const S4SoundArgs A, unsigned long long *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const int64_t i = g * 64 + lane;
+    const uint64_t valid = valid_mask(g * 64, s);
+    const bool on = (valid >> lane) & 1ULL;
+    const double x = on ? pts[i] : 0.0, y = on ? pts[stride + i] : 0.0, z = on ? pts[2 * stride + i] : 0.0;
+    const double nx = on ? pts[3 * stride + i] : 0.0, ny = on ? pts[4 * stride + i] : 0.0, nz = on ? pts[5 * stride + i] : 0.0;
+    rh_box32 G;
+    G.cx = gb32[g * 8 + 0]; G.cy = gb32[g * 8 + 1]; G.cz = gb32[g * 8 + 2]; G.hx = gb32[g * 8 + 3];
+    G.hy = gb32[g * 8 + 4]; G.hz = gb32[g * 8 + 5]; G.hr = gb32[g * 8 + 6];
+    for (int c = blockIdx.y; c < ncand; c += gridDim.y) {
+        const S4SoundCand &Q = cands[c];
+        switch (Q.kind) {
+        case RH_PLANE: sound_one<RH_PLANE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
+        case RH_SPHERE: sound_one<RH_SPHERE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
+        case RH_CYLINDER: sound_one<RH_CYLINDER>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
+        case RH_CONE: sound_one<RH_CONE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
+        default: break;
+        }
     }
 }
 
@@ -757,9 +862,9 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
         if (Q.kind < 0 || Q.kind > 3) continue;
         rh_prep_host(shapes[i], &Q.P);
         double d4[4] = { 0, 0, 0, 0 };
-        cls_make(Q.P, Q.kind, p->eps[Q.kind], p->cos_alpha[Q.kind], c->coord_mag, c->nrm_mag, Q.C, nullptr, 0, d4);
-        Q.cNhi = d4[0]; Q.wN = d4[1]; Q.eDlo = d4[2]; Q.wD = d4[3];
-        Q.usable = Q.kind != RH_CONE && !(Q.C.f[RH_CLS_FLAG] != Q.C.f[RH_CLS_FLAG]) && Q.wN > 0 && Q.wD > 0;
+        cls_make(Q.P, Q.kind, p->eps[Q.kind], p->cos_alpha[Q.kind], c->coord_mag, c->nrm_mag, Q.C, nullptr, 0, d4, c->f32);
+        Q.cNhi = d4[0]; Q.wN = d4[1]; Q.eDlo = d4[2]; Q.wD = d4[3]; Q.cosa = p->cos_alpha[Q.kind];
+        Q.usable = !(Q.C.f[RH_CLS_FLAG] != Q.C.f[RH_CLS_FLAG]) && Q.wN > 0 && Q.wD > 0;
     }
     S4AuditCand *d_c = nullptr;
     unsigned long long *d_o = nullptr;
@@ -779,6 +884,44 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
     (void)hipFree(d_o);
     for (int i = 0; i < 8; i++) out[i] = __builtin_bit_cast(double, ho[i]);
     for (int i = 8; i < 12; i++) out[i] = (double)ho[i];
+    return RH_OK;
+}
+
+// diagnostics (tests, tools/fuzz_score.py): the decisions of the box test and of the classifier against the exact test
+// on every (candidate, point) of a batch x subset 1 (all points taken as enabled): out[40], layout at cls_sound_kernel
+extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out)
+{
+    if (c == nullptr || out == nullptr || p == nullptr || b < 0 || (b > 0 && shapes == nullptr)) { rh_set_error("rh_dbg_cls_soundness: bad arguments"); return RH_E_INVALID; }
+    for (int i = 0; i < 40; i++) out[i] = 0;
+    if (b == 0 || c->s == 0 || c->ngroups == 0 || c->gb32 == nullptr) return RH_OK;
+    RH_HIP(hipSetDevice(c->device));
+    std::vector<S4SoundCand> h((size_t)b);
+    for (int32_t i = 0; i < b; i++) {
+        S4SoundCand &Q = h[(size_t)i];
+        Q.kind = shapes[i].kind;
+        Q.pad = 0;
+        if (Q.kind < 0 || Q.kind > 3) { Q.kind = -1; continue; }
+        rh_prep_host(shapes[i], &Q.P);
+        prep_one32(shapes[i], Q.Pf);
+        cls_make(Q.P, Q.kind, p->eps[Q.kind], p->cos_alpha[Q.kind], c->coord_mag, c->nrm_mag, Q.C, Q.box, 1, nullptr, c->f32);
+    }
+    S4SoundArgs A;
+    for (int k = 0; k < 4; k++) { A.eps[k] = p->eps[k]; A.cosa[k] = p->cos_alpha[k]; }
+    A.f32 = c->f32 ? 1 : 0;
+    S4SoundCand *d_c = nullptr;
+    unsigned long long *d_o = nullptr;
+    RH_HIP(hipMalloc((void **)&d_c, sizeof(S4SoundCand) * (size_t)b));
+    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 40));
+    RH_HIP(hipMemcpyAsync(d_c, h.data(), sizeof(S4SoundCand) * (size_t)b, hipMemcpyHostToDevice, c->stream));
+    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 40, c->stream));
+    hipLaunchKernelGGL(cls_sound_kernel, dim3((unsigned)c->ngroups, (unsigned)std::min<int32_t>(b, 64)), dim3(64), 0, c->stream, c->sub, c->s_pad, c->s,
+                       c->gb32, d_c, b, A, d_o);
+    unsigned long long ho[40];
+    RH_HIP(hipMemcpyAsync(ho, d_o, sizeof ho, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_c);
+    (void)hipFree(d_o);
+    for (int i = 0; i < 40; i++) out[i] = (uint64_t)ho[i];
     return RH_OK;
 }
 

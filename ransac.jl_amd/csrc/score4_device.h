@@ -23,7 +23,14 @@
 //                                         |L32 - L| <= Nm (3 e + 8.7 u nr) + |c| (sqrt(3) e + 6 u nr)
 //   cylinder  q = t - a (a . t), t = p - c0: per component e_q = u T (3.01 + 8.04 |a|_inf |a|_1);  then as the sphere
 //             with e_q for e
-//   cone      closed form rho^2 = |t|^2 - (t . a^)^2 against (k h -+ e)^2 (prefilter only: survivors take the exact test)
+//   cone      the reference's frame in closed form (cone.jl:68-85 reduces to it, derivation at cls_cone_t): with w = p - apex,
+//             h = w . a^, q = w - h a^, rho = |q| (e_q as the cylinder's with the unit axis a^), c', s' = cos / sin of
+//             -opang/2 normalised:  D = c' rho + s' h  (the test is |D| < eps)
+//                                         |D32 - D|   <= |c'| (sqrt(3) e_q + 5.5 u rho) + |s'| (6 u |a^|_1 T + 2 u |h|) + 4 u eps
+//             L = sgn (c' q . np + s' rho a^ . np) - cos(alpha) rho  (the test is L > 0; no division by rho):
+//                                         |L32 - L|   <= e_q (3 Nm |c'| + sqrt(3) G) + u rho (8.7 Nm |c'| + 6.5 G + 7 |s'| |a^|_1 Nm + 2 |c|)
+//             with G = sqrt(3) Nm (|c'| + |s'|) + |c| + 1/4 and rho, |h| <= sqrt(3) T.  Points next to the axis
+//             (rho^2 <= alpha |w|^2 + beta), where the reference's own frame is ill-conditioned, are always undecided.
 // Every margin is the first-order bound x RH_CLS_SAFETY (2) plus the conversion error of the threshold itself; the
 // binary64 side's own rounding (~1e-15 relative) disappears in that factor.  rh_dbg_cls_audit (score4.hip) evaluates
 // max |q32 - q64| / (width of the ambiguity band = 2 m) over real batches with these very functions: sound below 1/2,
@@ -59,7 +66,7 @@ constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
 // plane:    0-2 n / wN | 3 -cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
 // sphere:   0-2 o | 3 R | 4 1 / wD | 5 eD_lo / wD | 6 sgn / wN | 7 -cN_hi / wN
 // cylinder: 0-2 a | 3-5 c0 | 6 R | 7 1 / wD | 8 eD_lo / wD | 9 sgn / wN | 10 -cN_hi / wN
-// cone:     0-2 apex | 3-5 a^ | 6 kk | 7 e | 8 alpha | 9 beta
+// cone:     0-2 apex | 3-5 a^ | 6 c' / wD | 7 s' / wD | 8 eD_lo / wD | 9 sgn c' / wL | 10 sgn s' / wL | 11 -cos(alpha) / wL | 12 alpha | 13 beta
 
 // culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
 // the box tests of stage 1 read, coalesced, with lane = candidate
@@ -201,38 +208,75 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             }
         }
     } else {
-        // cone (prefilter only): with t = p - apex, h = t . a^, rho^2 = |t|^2 - h^2 the reference's distance is
+        // cone: the two-sided classifier works on the closed form of the reference's frame (cls_cone_t below); the culling
+        // record keeps the band form: with t = p - apex, h = t . a^, rho^2 = |t|^2 - h^2 the reference's distance is
         // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = cos / sin of -opang/2): |dist| < eps <=> rho in (k h - e, k h + e),
         // k = -s / c, e = eps sqrt(c^2 + s^2) / c   (c > 0) -- score_device.h pre_make<RH_CONE>
         for (int i = 0; i < 8; i++) ok = ok && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
-        const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7];
+        const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7], sgn = P.f[8];
         const double an = sqrt((ax * ax + ay * ay) + az * az), cs = sqrt(c * c + sn * sn);
-        ok = ok && (c > 1e-6 * cs) && (an > 1e-300) && cls_fin(an);
+        ok = ok && (an > 1e-300) && cls_fin(an) && (cs > 1e-300) && cls_fin(cs) && (sgn == 1.0 || sgn == -1.0);
+        const bool band_ok = ok && (c > 1e-6 * cs);     // the band form (culling record; Float32 clouds: the point record too)
         const double ia = ok ? 1.0 / an : 0.0;
         const double T = M + fmax(fabs(P.f[0]), fmax(fabs(P.f[1]), fabs(P.f[2])));
-        const double kk = ok ? -sn / c : 0.0;
-        const double cn = ok ? c / cs : 1.0;
+        const double kk = band_ok ? -sn / c : 0.0;
+        const double cn = band_ok ? c / cs : 1.0;
         // band half width: exact form + the f64 prefilter's slack + binary32 error of k h (|t| <= sqrt(3) T)
         // (Float32 cloud: the exact test's frame is a long binary32 chain, ~1e-5 relative near its band: score_device.h F32 margins)
         const double ek = S * 19.1 * fabs(kk) * u * T + 1e-8 * (1.0 + T) * (1.0 + fabs(kk)) + (f32cloud ? 2e-5 * (1.0 + T) * (1.0 + fabs(kk)) : 0.0);
-        const double e = ok ? (eps / cn) * (1.0 + 1e-9) + ek : 0.0;
         const double beta = S * 1.75 * u * T * T + 1e-30;
+        // ---- the point record
+        const double a0 = ax * ia, a1v = ay * ia, a2v = az * ia;          // a^
+        const double cp = ok ? c / cs : 0.0, sp = ok ? sn / cs : 0.0;     // c', s'
+        const double a1 = (fabs(a0) + fabs(a1v)) + fabs(a2v), ai = fmax(fabs(a0), fmax(fabs(a1v), fabs(a2v)));
+        const double s3 = 1.7320508075688774;
+        const double eq = u * T * (3.01 + 8.04 * ai * a1);
+        const double rmax = s3 * T;
+        // (classifier's own binary32 error, first order x RH_CLS_SAFETY -- never the tripled S: a Float32 cloud's exact
+        // chain is bracketed by its own term below)
+        const double mDc = RH_CLS_SAFETY * (fabs(cp) * (s3 * eq + 5.5 * u * rmax) + fabs(sp) * (6.0 * u * a1 * T + 2.0 * u * rmax) + 4.0 * u * fabs(eps));
+        const double G = s3 * Nm * (fabs(cp) + fabs(sp)) + fabs(cosa) + 0.25;
+        const double mLc = RH_CLS_SAFETY * (eq * (3.0 * Nm * fabs(cp) + s3 * G) +
+                                            u * rmax * (8.7 * Nm * fabs(cp) + 6.5 * G + 7.0 * fabs(sp) * a1 * Nm + 2.0 * fabs(cosa)));
+        double mD, mL;
+        if (!f32cloud) {
+            // the binary64 chain of the reference differs from the closed form by ~1e-15 |t| / sin(angle to the axis); the
+            // axis guard (alpha, beta) keeps that sine above ~3e-3: 1e-11 (1 + T) covers it 30 times over
+            mD = mDc + 1e-11 * (1.0 + T) + 1e-30;
+            mL = mLc + 1e-11 * (1.0 + T) * (1.0 + Nm) + 1e-30;
+        } else {
+            // Float32 cloud: the exact test is a ~60-operation binary32 chain.  Its distance is bracketed like round 3's
+            // prefilter did (band form, needs c > 0; 2e-5 relative: in ek); its normal half is never decided here -- every
+            // point inside the widened band goes to the exact test.
+            ok = ok && band_ok;
+            mD = mDc + ek * cn + 1e-9 * fabs(eps) + 1e-30;
+            mL = __builtin_inf();
+        }
         o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2];
-        o.f[3] = (float)(ax * ia); o.f[4] = (float)(ay * ia); o.f[5] = (float)(az * ia);
-        o.f[6] = (float)kk;
-        o.f[7] = cls_up(e);
-        o.f[8] = RH_CONE_ALPHA;     // slack on rho^2 proportional to |t|^2
-        o.f[9] = cls_up(beta);      // absolute slack on rho^2
-        ok = ok && cls_fin(e) && cls_fin(kk) && fabs(kk) <= 1e6 && cls_fin(beta);
+        o.f[3] = (float)a0; o.f[4] = (float)a1v; o.f[5] = (float)a2v;
+        ok = ok && cls_fin(mD) && mD < 1e30 && (f32cloud || (cls_fin(mL) && mL < 1e30)) && cls_fin(beta);
         if (ok) {
+            const double wD = 2.0 * mD, iD = 1.0 / wD, eDlo = eps - 0.5 * wD;
+            const double wL = 2.0 * mL, iL = f32cloud ? 0.0 : 1.0 / wL;
+            o.f[6] = (float)(cp * iD); o.f[7] = (float)(sp * iD);
+            o.f[8] = (float)(eDlo * iD + RH_CLS_SHIFT);
+            o.f[9] = (float)(sgn * cp * iL); o.f[10] = (float)(sgn * sp * iL); o.f[11] = (float)(-cosa * iL);
+            if (dbg4 != nullptr) { dbg4[0] = 0.0; dbg4[1] = wL; dbg4[2] = eDlo; dbg4[3] = wD; }
+            for (int i = 6; i < 12; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
+        }
+        o.f[12] = RH_CONE_ALPHA;    // next to the axis: rho^2 <= alpha |w|^2 + beta -> undecided
+        o.f[13] = cls_up(beta);
+        const double e = band_ok ? (eps / cn) * (1.0 + 1e-9) + ek : 0.0;
+        const bool box_ok = band_ok && cls_fin(e) && cls_fin(kk) && fabs(kk) <= 1e6 && cls_fin(beta);
+        if (box_ok) {
             // box: the same closed form at the centre of the box, the band widened by the radius of the box (the
             // distance is 1-Lipschitz in p): half width (hr + eps + slack) / cn
             bx[0] = o.f[0]; bx[1] = o.f[1]; bx[2] = o.f[2];
             bx[3] = o.f[3]; bx[4] = o.f[4]; bx[5] = o.f[5];
-            bx[6] = o.f[6];
+            bx[6] = (float)kk;
             bx[7] = cls_up(1.0 / cn);
             bx[8] = cls_up((eps + slack64) / cn * (1.0 + 1e-9) + ek);
-            bx[9] = o.f[9];
+            bx[9] = cls_up(beta);
             // Float32 cloud: the exact test's frame degrades as 2^-24 / sin(angle to the axis) -- never skip a box whose
             // centre lies within ~0.03 rad of the axis (rho^2 <= alpha |t|^2)
             bx[10] = f32cloud ? 1e-3f : RH_CONE_ALPHA;
@@ -350,20 +394,36 @@ static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, fl
     return fminf(a, b);
 }
 
-// ---- cone: band prefilter -- may this point pass the distance half?  NaN -> false.
-static __device__ __forceinline__ bool cls_pre_cone(const rh_cls &C, float x, float y, float z)
+// ---- cone: the same shifted t = min(a, b).  The reference builds a frame per point (project2cone, cone.jl:68-85): with
+// w = p - apex = h a^ + rho e_rho (a^ the unit axis, e_rho the unit radial direction, phi^ = a^ x e_rho)
+//     rot_ax = normalize(axis x normalize(-w)) = -phi^,   comp_n = normalize(axis x rot_ax) = e_rho,
+//     current_normal = normalize(R(rot_ax, -opang/2) comp_n) = (c e_rho + s (rot_ax x comp_n)) / |(c, s)| = c' e_rho + s' a^
+// so dist = dot(-current_normal, apex - p) = -(c' rho + s' h) and the normal's cosine is c' (q . n) / rho + s' (a^ . n).
+// a = (eD_lo - |D|) / wD + 1/2 with D = c' rho + s' h;  b = L / wL with L = sgn (c' q . n + s' rho a^ . n) - cos(alpha) rho
+// (the angle test multiplied through by rho > 0: its margin is absolute, nothing is divided by a small rho).  Next to the
+// axis the reference's frame is ill-conditioned (and NaN on it): t = 0, undecided, the exact test answers.
+static __device__ __forceinline__ void cls_cone_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &b,
+                                                   bool &near_axis)
 {
-    const float tx = x - C.f[0], ty = y - C.f[1], tz = z - C.f[2];
-    const float tt = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, tx * tx));
-    const float h = __builtin_fmaf(tz, C.f[5], __builtin_fmaf(ty, C.f[4], tx * C.f[3]));
-    const float rho2 = __builtin_fmaf(-h, h, tt);
-    const float s2 = __builtin_fmaf(C.f[8], tt, C.f[9]);
-    const float uu = C.f[6] * h;
-    const float lo = uu - C.f[7], hi = uu + C.f[7];
-    const float hi2 = __builtin_fmaf(hi, hi, s2), lo2 = __builtin_fmaf(lo, lo, -s2);
-    // next to the axis the reference's frame is ill-conditioned: those points go to the exact test (rho2 <= s2 covers
-    // the f64 prefilter's 1e-10 |t|^2)
-    return (rho2 <= s2) | ((hi > 0.0f) & (rho2 <= hi2) & ((lo <= 0.0f) | (rho2 >= lo2)));
+    const float wx = x - C.f[0], wy = y - C.f[1], wz = z - C.f[2];
+    const float h = __builtin_fmaf(wz, C.f[5], __builtin_fmaf(wy, C.f[4], wx * C.f[3]));
+    const float qx = __builtin_fmaf(-C.f[3], h, wx), qy = __builtin_fmaf(-C.f[4], h, wy), qz = __builtin_fmaf(-C.f[5], h, wz);
+    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    const float rho = n2 * __builtin_amdgcn_rsqf(n2);
+    const float D = __builtin_fmaf(C.f[6], rho, C.f[7] * h);
+    a = C.f[8] - __builtin_fabsf(D);
+    const float qn = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx));
+    const float an = __builtin_fmaf(C.f[5], nz, __builtin_fmaf(C.f[4], ny, C.f[3] * nx));
+    b = __builtin_fmaf(qn, C.f[9], rho * __builtin_fmaf(an, C.f[10], C.f[11]));
+    const float tt = __builtin_fmaf(h, h, n2);
+    near_axis = !(n2 > __builtin_fmaf(C.f[12], tt, C.f[13]));   // (NaN -> near)
+}
+static __device__ __forceinline__ float cls_cone_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+{
+    float a, b;
+    bool near_axis;
+    cls_cone_ab(C, x, y, z, nx, ny, nz, a, b, near_axis);
+    return near_axis ? 0.0f : fminf(a, b);
 }
 #endif   // __HIPCC__
 

@@ -82,8 +82,9 @@ static __device__ __forceinline__ uint64_t test_cylinder(const rh_prep &P, doubl
 
 // cone: compatiblesCone shapes/cone.jl:132-153, project2cone :68-85,
 // rodriguesrad/rodrigues/pluscrossprod! utilities.jl:61-64,19-24,32-43
-static __device__ __forceinline__ uint64_t test_cone(const rh_prep &P, double px, double py, double pz, double nx,
-                                          double ny, double nz, double eps, double cosa)
+// (the frame: dist = dot(-current_normal, -to_point), dt = dot(current_normal, n); the audit kernels read them too)
+static __device__ __forceinline__ void cone_frame(const rh_prep &P, double px, double py, double pz, double nx,
+                                           double ny, double nz, double &dist_out, double &dt_out)
 {
     const double ax = P.f[3], ay = P.f[4], az = P.f[5];
     const double c = P.f[6], s = P.f[7];
@@ -123,8 +124,15 @@ static __device__ __forceinline__ uint64_t test_cone(const rh_prep &P, double px
     inv = 1.0 / sqrt((kx * kx + ky * ky) + kz * kz);
     const double gx = inv * kx, gy = inv * ky, gz = inv * kz;
     // dist = dot(-current_normal, -to_point)
-    const double dist = ((-gx) * (-tx) + (-gy) * (-ty)) + (-gz) * (-tz);
-    const double dt = (gx * nx + gy * ny) + gz * nz;
+    dist_out = ((-gx) * (-tx) + (-gy) * (-ty)) + (-gz) * (-tz);
+    dt_out = (gx * nx + gy * ny) + gz * nz;
+}
+
+static __device__ __forceinline__ uint64_t test_cone(const rh_prep &P, double px, double py, double pz, double nx,
+                                          double ny, double nz, double eps, double cosa)
+{
+    double dist, dt;
+    cone_frame(P, px, py, pz, nx, ny, nz, dist, dt);
     return WB(P.f[8] * dt > cosa) & WB(fabs(dist) < eps);
 }
 

@@ -15,6 +15,38 @@ struct rh_prepf {
     float f[12];
 };
 
+// float record of a candidate: the fields of the shape rounded to binary32 (exact for a Float32 shape), per-candidate
+// constants in binary32 with the reference's operations (normalize(plane.normal), plane.jl:85)
+__host__ __device__ inline void prep_one32(const rh_shape &s, rh_prepf &o)
+{
+    for (int i = 0; i < 12; i++) o.f[i] = 0.0f;
+    const float sgn = s.outwards ? 1.0f : -1.0f;
+    switch (s.kind) {
+    case RH_PLANE: {
+        for (int i = 0; i < 6; i++) o.f[i] = (float)s.v[i];
+        const float a = o.f[3], b = o.f[4], c = o.f[5];
+        const float inv = 1.0f / sqrtf((a * a + b * b) + c * c);
+        o.f[6] = inv * a; o.f[7] = inv * b; o.f[8] = inv * c;
+        break;
+    }
+    case RH_SPHERE:
+        for (int i = 0; i < 4; i++) o.f[i] = (float)s.v[i];
+        o.f[4] = sgn;
+        break;
+    case RH_CYLINDER:
+        for (int i = 0; i < 7; i++) o.f[i] = (float)s.v[i];
+        o.f[7] = sgn;
+        break;
+    default:
+        for (int i = 0; i < 6; i++) o.f[i] = (float)s.v[i];
+        o.f[6] = (float)s.v[7];   // cos(-opang/2), a binary32 number on a Float32 shape
+        o.f[7] = (float)s.v[8];
+        o.f[8] = sgn;
+        break;
+    }
+}
+
+#ifdef __HIPCC__
 #define RH_CONST32 __attribute__((address_space(4)))
 static __device__ __forceinline__ rh_prepf ld_prepf(const rh_prepf *p)
 {
@@ -125,5 +157,7 @@ static __device__ __forceinline__ uint64_t valid_mask32(int64_t base, int64_t s)
     const int64_t left = s - base;
     return left >= 64 ? ~0ULL : (left <= 0 ? 0ULL : ((1ULL << left) - 1ULL));
 }
+
+#endif   // __HIPCC__
 
 }  // namespace rhdev32

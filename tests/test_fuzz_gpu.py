@@ -56,6 +56,30 @@ def test_score_fuzz_slice_float32(seed, ncases):
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("seed,ncases,f32", [(61001, 60, False), (61002, 60, False), (61003, 60, True)])
+def test_classifier_and_box_soundness_slice(seed, ncases, f32):
+    """The bit-exact counts rest on two claims about the v4 score kernel's shortcuts (csrc/score4_device.h): the binary32
+    box test only skips (candidate, group) pairs without an inlier, and the binary32 classifier's "sure" verdicts -- in
+    or out, all four kinds -- agree with the exact test.  rh_dbg_cls_soundness COUNTS the contradictions over every
+    (candidate, point) pair, with the kernel's own records and functions: 0 over random clouds at coordinate scales
+    1 .. 1e6, eps 1e-6 .. 50, alpha 0.5 .. 120 degrees, jittered / arbitrary / degenerate / far-away-point shapes."""
+    import fuzz_sound
+    rng = np.random.default_rng(seed)
+    bad = []
+    tot = np.zeros((4, 10), dtype=np.int64)
+    for case in range(ncases):
+        ok, desc, out = fuzz_sound.one(case + seed % 1000, rng, f32=f32)
+        tot += out
+        if not ok:
+            bad.append(desc)
+    assert not bad, bad[:5]
+    # the audit looked at something: every kind was classified, decided points and skipped pairs exist
+    assert (tot[:, 3] > 1e6).all() and (tot[:, 1] > 0).all(), tot
+    assert (tot[:3, 4] > 0).all() and (tot[:, 5] > 0).all(), tot
+    if not f32:
+        assert tot[3, 4] > 0, tot           # cones are decided in binary32 too (Float32 clouds: distance half only)
+
+
 @pytest.mark.parametrize("seed,ncases,f32", [(5101, 80, False), (5102, 80, False), (5103, 80, True)])
 def test_refit_fuzz_slice(seed, ncases, f32):
     """refit / invalidate_indexes! against the oracle with the culled scan (Morton order + box tests, korder.hip) forced

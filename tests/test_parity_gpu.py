@@ -106,8 +106,8 @@ def test_binary32_classifier_stays_inside_its_margins(small_scene):
         arr = shape_array(cands)
         out = np.zeros(12)
         L.check(R.lib().rh_dbg_cls_audit(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_double))))
-        assert out[8:11].min() > 1e5, out          # planes, spheres and cylinders were all looked at
-        assert out[:6].max() < 0.3, out            # sound below 0.5
+        assert out[8:12].min() > 1e5, out          # planes, spheres, cylinders and cones were all looked at
+        assert out[:8].max() < 0.3, out            # sound below 0.5
 
 
 @pytest.mark.parametrize("eps,alpha_deg,seed", [(0.3, 5.0, 0), (0.01, 1.0, 1), (5.0, 60.0, 2), (40.0, 89.0, 3)])
