@@ -41,23 +41,26 @@ using namespace rhdev32;
 typedef float rh_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int S4_TG = RH_G2_TG;          // groups per tile
+constexpr int S4_TG = 4;                 // groups per tile (8, measured in round 4 -- the per-chunk work of stage 1 paid once per 8 box tests,
+                                         // fuller batches: cfg3 0.0906 -> 0.0959 ms, cfg2 0.078 -> 0.104, cfg5 0.384 -> 0.375; R = 4 with it: worse still)
+constexpr int S4_GB = 2;                 // bits of the group in a pair-list entry
+constexpr unsigned S4_GM = (1u << S4_GB) - 1u;
 constexpr int S4_ROW = 65;               // padded row length of the tile arrays (bank spread of the per-lane rows)
 constexpr int S4_W = 4;                  // waves per block
 // R: 64-candidate chunks per block -- 8 on large subsets (cfg3: 0.108 ms; 4: 0.120, 12: 0.107, 16: 0.116), 4 where the
 // grid would otherwise be a few hundred blocks
 template <int R>
 struct S4Shared {
-    static_assert(S4_TG == 4 && R * 64 * 4 <= 65536 && R % S4_W == 0, "entry encoding: 2 bits of group, the rest of 16 for the candidate");
+    static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && R % S4_W == 0, "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
     rh_f32x2 pb[S4_TG][S4_ROW];          // (ny, nz)
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
     rh_f32x4 gbox[S4_TG][2];             // the groups' binary32 boxes (cx cy cz hx | hy hz hr 0): stage 1 reads them as broadcasts
-    uint16_t plist[R * 64 * S4_TG];      // the block's surviving pairs: candidate of the row << 2 | group
+    uint16_t plist[R * 64 * S4_TG + 2];  // the block's surviving pairs: candidate of the row << S4_GB | group (+ a dump slot)
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
     unsigned long long maskb[S4_W][64];  // cone, masks wanted: per-wave inlier words of the batch's pairs
     uint16_t qb[S4_W][128];              // cone: per-wave ring (slot-in-batch << 6 | point-in-group) for the exact test
-    int weirdw[S4_TG];                   // per staging wave: an enabled point with a non-finite value
+    int weirdw[S4_TG];                   // per group: an enabled point with a non-finite value
     int npairs, next_batch;
 };
 
@@ -85,6 +88,7 @@ struct S4KindArgs {
 struct S4AllArgs {
     const int32_t *stop;   // chained octree windows: non-zero = the window has ended, nothing to score (else null)
     int row0;              // TAIL launch: first row that the sized launch did not cover
+    int rows;              // sized launch: > 0 = a one-dimensional grid of (tiles padded to 8) x rows blocks in XCD order (score4_kernel)
     S4KindArgs k[4];
     int64_t ntiles, bstride, ngroups;
     const float *gb32;      // binary32 boxes of the groups, 8 floats each
@@ -99,14 +103,16 @@ template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLA
 
 #define RH4_CONST_AS __attribute__((address_space(4)))
 
-// segmented sum over runs of equal keys in adjacent lanes (runs of up to 4: the groups of one candidate): the LAST lane
-// of a run gets the run's total, the others 0
+// segmented sum over runs of equal keys in adjacent lanes (runs of up to S4_TG = 8: the groups of one candidate): the
+// LAST lane of a run gets the run's total, the others 0
 static __device__ __forceinline__ int run_total(int v, int key, int lane)
 {
     int u = __shfl_up(v, 1), k1 = __shfl_up(key, 1);
     if (lane >= 1 && k1 == key) v += u;
     u = __shfl_up(v, 2); k1 = __shfl_up(key, 2);
     if (lane >= 2 && k1 == key) v += u;
+    u = __shfl_up(v, 4); k1 = __shfl_up(key, 4);
+    if (lane >= 4 && k1 == key) v += u;
     const int kn = __shfl_down(key, 1);
     return (lane == 63 || kn != key) ? v : 0;
 }
@@ -122,7 +128,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 {
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
-    const int g = (int)(e & 3u), ci = cbase + (int)(e >> 2);
+    const int g = (int)(e & S4_GM), ci = cbase + (int)(e >> S4_GB);
     const rh_f32x4 *__restrict__ rowa = &sh.pa[g][0];
     const rh_f32x2 *__restrict__ rowb = &sh.pb[g][0];
     const rh_cls *__restrict__ rec = &cls[ci];
@@ -169,7 +175,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const int k = __builtin_ctzll(redo);
             redo &= redo - 1;
             const uint32_t ek = __builtin_amdgcn_readlane(e, k);
-            const int g2 = (int)(ek & 3u), ci2 = cbase + (int)(ek >> 2);
+            const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
             const int64_t gi = p0 + g2 * 64 + lane;
             uint64_t mres;
             if (F32) {   // Float32 cloud: the reference's test is the binary32 one (the points are floats, stored exactly)
@@ -224,14 +230,14 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const unsigned e2 = on ? sh.qb[wv][(qbh + lane) & 127] : 0u;
             const int slot = (int)(e2 >> 6);
             const uint32_t pe = sh.plist[head + slot];
-            const int64_t gi = p0 + (int)(pe & 3u) * 64 + (int)(e2 & 63u);
+            const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
             uint64_t r;
             if (F32) {
-                const rh_prepf Pv = prep32[cbase + (int)(pe >> 2)];
+                const rh_prepf Pv = prep32[cbase + (int)(pe >> S4_GB)];
                 r = test_point32<KIND>(Pv, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
                                        (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
             } else {
-                const rh_prep Pv = prep[cbase + (int)(pe >> 2)];
+                const rh_prep Pv = prep[cbase + (int)(pe >> S4_GB)];
                 r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
                                      pts[5 * stride + gi], eps, cosa);
             }
@@ -315,25 +321,26 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, cons
             G.cx = g0v.x; G.cy = g0v.y; G.cz = g0v.z; G.hx = g0v.w; G.hy = g1v.x; G.hz = g1v.y; G.hr = g1v.z;
             surv |= box_skip32<KIND>(B[h & 1], G) ? 0u : (1u << g);
         }
-        if (dbg == 2) surv = 15u;
+        if (dbg == 2) surv = (1u << S4_TG) - 1u;
         surv &= live;
         if (ci >= nk || dbg == 1) surv = 0;
         // positions candidate-major: all lanes before me, then my own lower groups
         const int k = __popc(surv);
-        const uint64_t b0 = WB(k & 1), b1 = WB(k & 2), b2 = WB(k & 4);
-        const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        const uint64_t b0 = WB(k & 1), b1 = WB(k & 2), b2 = WB(k & 4), b3 = WB(k & 8);
+        const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
         if (tot == 0) continue;
         int base = 0;
         if (lane == 0) base = atomicAdd(&sh.npairs, tot);
         base = __builtin_amdgcn_readfirstlane(base);
         auto mb = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
-        int pos = base + mb(b0) + 2 * mb(b1) + 4 * mb(b2);
+        int pos = base + mb(b0) + 2 * mb(b1) + 4 * mb(b2) + 8 * mb(b3);
+        // (branch-free: a group that did not survive writes to the dump slot behind the list -- a predicated store costs a
+        // scalar exec-mask save / branch / restore per group)
 #pragma unroll
         for (int g = 0; g < S4_TG; g++) {
-            if ((surv >> g) & 1u) {
-                sh.plist[pos] = (uint16_t)(((ci - (lo << 6)) << 2) | g);
-                pos++;
-            }
+            const bool on = (surv >> g) & 1u;
+            sh.plist[on ? pos : R * 64 * S4_TG] = (uint16_t)(((ci - (lo << 6)) << S4_GB) | g);
+            pos += on ? 1 : 0;
         }
     }
     __syncthreads();
@@ -354,30 +361,40 @@ static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *_
                                                 const uint64_t *__restrict__ enabled_words, const int64_t p0, const float *__restrict__ gb32,
                                                 const int64_t ngroups)
 {
-    static_assert(S4_W == S4_TG, "one wave per group");
+    static_assert(S4_TG % S4_W == 0, "every wave stages S4_TG / S4_W groups");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t gi = p0 + tid;
-    // (the six loads go out before the enabled word is looked at: one round trip)
-    const double x = pts[gi], y = pts[stride + gi], z = pts[2 * stride + gi];
-    const double nx = pts[3 * stride + gi], ny = pts[4 * stride + gi], nz = pts[5 * stride + gi];
-    uint64_t v = valid_mask((gi >> 6) << 6, s);
-    if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
-    const bool on = (v >> (gi & 63)) & 1ULL;
-    rh_f32x4 a = { 0.f, 0.f, 0.f, 0.f };
-    rh_f32x2 b = { 0.f, 0.f };
-    bool bad = false;
-    if (on) {
-        a.x = (float)x; a.y = (float)y; a.z = (float)z; a.w = (float)nx; b.x = (float)ny; b.y = (float)nz;
-        const float sum = (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w)) + (fabsf(b.x) + fabsf(b.y));
-        bad = !(sum < __builtin_inff());   // an infinite or NaN value (binary32 overflow included)
+    constexpr int GPW = S4_TG / S4_W;
+    // (the loads of all the wave's groups go out before any enabled word is looked at: one round trip)
+    double x[GPW], y[GPW], z[GPW], nx[GPW], ny[GPW], nz[GPW];
+#pragma unroll
+    for (int q = 0; q < GPW; q++) {
+        const int64_t gi = p0 + (int64_t)(wv + q * S4_W) * 64 + lane;
+        x[q] = pts[gi]; y[q] = pts[stride + gi]; z[q] = pts[2 * stride + gi];
+        nx[q] = pts[3 * stride + gi]; ny[q] = pts[4 * stride + gi]; nz[q] = pts[5 * stride + gi];
     }
-    sh.pa[wv][lane] = a;
-    sh.pb[wv][lane] = b;
-    const uint64_t wb = WB(bad);
-    if (lane == 0) { sh.weirdw[wv] = wb != 0 ? 1 : 0; sh.len[wv] = v; }   // wave w stages group w: v is its word
+#pragma unroll
+    for (int q = 0; q < GPW; q++) {
+        const int g = wv + q * S4_W;
+        const int64_t gi = p0 + (int64_t)g * 64 + lane;
+        uint64_t v = valid_mask((gi >> 6) << 6, s);
+        if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
+        const bool on = (v >> (gi & 63)) & 1ULL;
+        rh_f32x4 a = { 0.f, 0.f, 0.f, 0.f };
+        rh_f32x2 b = { 0.f, 0.f };
+        bool bad = false;
+        if (on) {
+            a.x = (float)x[q]; a.y = (float)y[q]; a.z = (float)z[q]; a.w = (float)nx[q]; b.x = (float)ny[q]; b.y = (float)nz[q];
+            const float sum = (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w)) + (fabsf(b.x) + fabsf(b.y));
+            bad = !(sum < __builtin_inff());   // an infinite or NaN value (binary32 overflow included)
+        }
+        sh.pa[g][lane] = a;
+        sh.pb[g][lane] = b;
+        const uint64_t wb = WB(bad);
+        if (lane == 0) { sh.weirdw[g] = wb != 0 ? 1 : 0; sh.len[g] = v; }   // v is the group's word
+    }
     if (tid == 0) { sh.npairs = 0; sh.next_batch = 0; }
-    if (tid < 2 * S4_TG) {   // the four boxes, 32 bytes each
+    if (tid < 2 * S4_TG) {   // the boxes, 32 bytes each
         const int64_t g = p0 / 64 + (tid >> 1);
         sh.gbox[tid >> 1][tid & 1] = ((const rh_f32x4 *)gb32)[(g < ngroups ? g : ngroups - 1) * 2 + (tid & 1)];
     }
@@ -394,7 +411,17 @@ __global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
     __shared__ S4Shared<R> sh;
-    const int64_t tile = blockIdx.x;
+    // Blocks go to the 8 XCDs round-robin by their linear id, each XCD with an L2 of its own.  With rows > 0 the id is
+    // read as ((tile / 8) x rows + row) x 8 + tile % 8: the rows of one tile follow each other on ONE XCD, so the tile is
+    // fetched from HBM once and staged from L2 by the other rows (cfg5, 9 rows over a 75-MB subset: the (tile, row) grid
+    // fetched every tile once per row -- 724 MB per launch, profiles/r3).
+    int64_t tile = blockIdx.x;
+    int rowy = (int)blockIdx.y;
+    if (!TAIL && A.rows > 0) {
+        const int64_t k = blockIdx.x >> 3;
+        rowy = (int)(k % A.rows);
+        tile = ((k / A.rows) << 3) + (blockIdx.x & 7);
+    }
     if (tile >= A.ntiles) return;
     if (A.stop != nullptr && *A.stop != 0) return;
     const int64_t g0 = tile * S4_TG;
@@ -418,14 +445,14 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             live = 0;                                                                                                  \
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
-            weird = __builtin_amdgcn_readfirstlane(sh.weirdw[0] | sh.weirdw[1] | sh.weirdw[2] | sh.weirdw[3]) != 0;    \
+            { int ww = 0; for (int g = 0; g < S4_TG; g++) ww |= sh.weirdw[g]; weird = __builtin_amdgcn_readfirstlane(ww) != 0; }  \
             if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
     }
     if (!TAIL) {
-        const int lo = (int)blockIdx.y * R, hi = min(total, lo + R);
+        const int lo = rowy * R, hi = min(total, lo + R);
         if (lo >= hi) return;
         int base = 0;
         RH_S4_BODY(RH_CONE)
@@ -746,7 +773,18 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
+    const unsigned tiles_x = grid.x;   // the tail / loop launches keep the (tile, row) grid
     A.row0 = 0;
+    A.rows = 0;
+    static int env_xrow = -1;
+    if (env_xrow < 0) { const char *e = getenv("RH_S4_XROW"); env_xrow = e ? atoi(e) : 1; }
+    // (measured, round 4: cfg2 -- 123 tiles x 17 rows -- 0.0753 -> 0.0663 ms; cfg3 -- 1221 x 9 -- 0.0927 -> 0.1041: with every row
+    // in flight at once the record gathers of stage 2 spread over all 4096 candidates instead of a row's 512; cfg5 0.388
+    // either way.  So: small launches only; RH_S4_XROW=0 / 2 = never / always.)
+    if (env_xrow && rows > 1 && (env_xrow == 2 || ((ntiles + 7) / 8) * 8 * rows <= 4096)) {
+        A.rows = (int)rows;
+        grid = dim3((unsigned)(((ntiles + 7) / 8) * 8 * rows), 1);
+    }
     static int env_loop = -2;
     if (env_loop < -1) { const char *e = getenv("RH_S4_LOOP"); env_loop = e ? atoi(e) : -1; }
     // the candidate loop's windows with few candidates (octree sampling: ~1000 local shapes per iteration, few pairs
@@ -758,7 +796,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (env_loop_open < -1) { const char *e = getenv("RH_S4_LOOP_OPEN"); env_loop_open = e ? atoi(e) : -1; }
     const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 32) : 0);
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
-        dim3 gt(grid.x, 1);
+        dim3 gt(tiles_x, 1);
         if (prep32 != nullptr) {
             if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
             else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
@@ -782,7 +820,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         // its blocks return at once when there is nothing (the usual case)
         if (d_masks_int != nullptr) { rh_set_error("rhk_score4_all: masks need an exact candidate count"); return RH_E_INTERNAL; }
         A.row0 = (int)rows;
-        dim3 gt(grid.x, 2);
+        dim3 gt(tiles_x, 2);
         if (prep32 != nullptr) {
             if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
             else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
