@@ -125,7 +125,7 @@ int rh_cloud_create(const double *xyz_aos, const double *nrm_aos, int64_t n,
  * rh_select_enabled and the enabled-bit calls work and every per-point operation is a binary32 operation (the shapes'
  * fields are rounded to binary32 on entry; rh_shape_finalize_f32 prepares a Float32 shape: fields rounded, the cone's
  * cos / sin as binary32); eps and cos_alpha stay doubles and are compared after exact promotion, like Julia compares a
- * Float32 with a Float64.  rh_ransac and rh_refit_lsq are Float64-only. */
+ * Float32 with a Float64.  rh_ransac runs on such a cloud without cones (rh_ransac_f32); rh_refit_lsq is Float64-only. */
 int rh_cloud_create_f32(const float *xyz_aos, const float *nrm_aos, int64_t n,
                         const int64_t *subset1_idx_1based, int64_t s, int device, rh_cloud **out);
 void rh_shape_finalize_f32(rh_shape *s);
@@ -184,6 +184,13 @@ int rh_select_enabled(rh_cloud *c, const int64_t *ranks_1based, int32_t k, int64
  * reference's `nothing`. */
 int rh_fit(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm,
            rh_shape *out, int32_t *fitted);
+/* The same on the points of a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109: p[i], n[i] are
+ * SVector{3,Float32}, so plane.jl:33-57 / sphere.jl:29-114 / cylinder.jl:34-168 run in Float32 and return Float32 shapes;
+ * the parameters stay what the caller made them, utilities.jl:488-503).  p, n carry the Float32 values as doubles.
+ * RH_CONE is refused: cone.jl:40-50 takes rank() and \ of Float32 matrices (LAPACK single precision), which nothing
+ * here can be pinned on. */
+int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm,
+               rh_shape *out, int32_t *fitted);
 
 /* estimatescore / ConfidenceInterval (src/confidenceintervals.jl:71-74, 53-59, 1-6) */
 int rh_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int32_t score_mode,
@@ -229,6 +236,13 @@ typedef struct {
  * pc.isenabled. */
 int rh_ransac(rh_cloud *c, const double *xyz_aos, const double *nrm_aos, const rh_params *p,
               rh_rng *rng, rh_result *out);
+/* ransac(pc, params) on a Float32 cloud (rh_cloud_create_f32; octree.jl:102-109): the minimal-set fits (plane.jl:33-57,
+ * sphere.jl:29-114, cylinder.jl:34-168), scoring, candidate liveness and refit all run in binary32, the thresholds stay
+ * what the caller made them (utilities.jl:488-503); extracted shapes hold binary32 numbers.  FittedCone in shape_types
+ * is refused with RH_E_INVALID (its fit is not restated in binary32).  rh_ransac itself accepts such a cloud when handed
+ * the Float32 values as doubles; this entry takes Julia's Vector{SVector{3,Float32}} memory as is. */
+int rh_ransac_f32(rh_cloud *c, const float *xyz_aos, const float *nrm_aos, const rh_params *p,
+                  rh_rng *rng, rh_result *out);
 void rh_result_free(rh_result *r);
 
 /* ---- one scene on several GPUs of a node (no counterpart in the reference, which is single-threaded:

@@ -150,6 +150,8 @@ def _bind(L):
         "orc32_score_masks_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p, C.c_int32]),
         "orc32_refit": (C.c_int64, [C.c_void_p, sp, pp, i64p, C.c_int64]),
         "orc32_invalidate": (None, [C.c_void_p, i64p, C.c_int64]),
+        "orc32_fit": (C.c_int, [C.c_int, dp, dp, C.c_int, pp, sp]),
+        "orc_cloud_set_f32": (None, [C.c_void_p, C.c_int]),
         "orc_score_masks_mt": (None, [C.c_void_p, sp, C.c_int32, pp, i32p, u64p, C.c_int32]),
         "orc_margin_census_mt": (None, [C.c_void_p, sp, C.c_int32, pp, dp, C.c_int, i64p, C.c_int32]),
         "orc_confidence_interval": (C.c_int, [C.c_double, C.c_double, C.POINTER(CI)]),
@@ -244,10 +246,14 @@ def shapes_array(shapes):
 
 
 class Cloud:
-    """Mirror of the pieces of RANSACCloud (octree.jl:37-59) the path reads."""
+    """Mirror of the pieces of RANSACCloud (octree.jl:37-59) the path reads.  f32: a Float32 cloud (force_eltype = Float32,
+    octree.jl:102-109) -- the values are rounded to binary32 and every per-point test and fit, the whole ransac() loop
+    included, runs in binary32 (orc_f32.c)."""
 
-    def __init__(self, xyz, nrm, subset1_1based, L=None):
+    def __init__(self, xyz, nrm, subset1_1based, L=None, f32=False):
         self.L = L if L is not None else lib()
+        if f32:
+            xyz, nrm = np.asarray(xyz, dtype=np.float32), np.asarray(nrm, dtype=np.float32)
         self.xyz = _f64(xyz).reshape(-1, 3)
         self.nrm = _f64(nrm).reshape(-1, 3)
         self.subset1 = np.ascontiguousarray(subset1_1based, dtype=np.int64)
@@ -255,6 +261,8 @@ class Cloud:
         self.s = self.subset1.shape[0]
         self.h = self.L.orc_cloud_create(_dp(self.xyz), _dp(self.nrm), self.n,
                                         self.subset1.ctypes.data_as(C.POINTER(C.c_int64)), self.s)
+        if f32:
+            self.L.orc_cloud_set_f32(self.h, 1)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -440,6 +448,14 @@ def compatible32(shape, p, n, eps, cos_alpha):
     p, n = np.ascontiguousarray(p, dtype=np.float32), np.ascontiguousarray(n, dtype=np.float32)
     fp = C.POINTER(C.c_float)
     return bool(lib().orc32_compatible(C.byref(shape), p.ctypes.data_as(fp), n.ctypes.data_as(fp), eps, cos_alpha))
+
+
+def fit32(kind, p, n, params):
+    """fit on Float32 points (orc_f32.c); cones never fit"""
+    p, n = _f64(np.asarray(p, dtype=np.float32)).reshape(-1, 3), _f64(np.asarray(n, dtype=np.float32)).reshape(-1, 3)
+    out = Shape()
+    ok = lib().orc32_fit(kind, _dp(p), _dp(n), p.shape[0], C.byref(params), C.byref(out))
+    return out if ok else None
 
 
 def fit(kind, p, n, params):

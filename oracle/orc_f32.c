@@ -252,3 +252,167 @@ void orc32_invalidate(orc_cloud32 *c, const int64_t *idx, int64_t n)
         c->enabled[i0 >> 6] &= ~(1ULL << (i0 & 63));
     }
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Minimal-set fits on a Float32 cloud: plane.jl:33-57, sphere.jl:29-75 + 87-114, cylinder.jl:34-125 + 135-168 with
+ * SVector{3,Float32} points and normals -- every vector operation is a binary32 operation, integer literals of the
+ * source ((v[1]+v[2])/2, -1*crossv) take the vectors' type, and the Float64 parameters only ever appear on one side of
+ * a comparison (collin_threshold, cosd(parallelthrdeg), sphere_par, cos(alpha), eps: the Float32 side is promoted
+ * exactly).  The statements follow ransac_oracle.c's binary64 fits one for one; p / n arrive as doubles holding the
+ * Float32 values.  The cone's fit is NOT restated: cone.jl:40-50 calls rank() and \ on Float32 matrices (LAPACK's
+ * single-precision SVD and LU), which no fixture of the reference pins.
+ */
+static inline f3 fadd(f3 a, f3 b) { f3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return r; }
+static inline f3 fdivs(f3 a, float s) { f3 r = { a.x / s, a.y / s, a.z / s }; return r; }
+static void set_f(double *dst, f3 a) { dst[0] = (double)a.x; dst[1] = (double)a.y; dst[2] = (double)a.z; }
+
+static int fit_plane32(const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
+{
+    if (lp < 3) return 0;
+    f3 p1 = Fd(p), p2 = Fd(p + 3), p3 = Fd(p + 6);
+    f3 crossv = fnormalize(fcross(fsub(p2, p1), fsub(p3, p1)));
+    if ((double)fnorm(crossv) < prm->collin_threshold) return 0;
+    double thr = prm->cos_alpha[ORC_PLANE];
+    int all_ok = 1, all_inv = 1;
+    for (int i = 0; i < lp; i++) {
+        float dotp = fdot(crossv, fnormalize(Fd(n + 3 * i)));
+        if (!((double)dotp > thr)) all_ok = 0;
+        if (!((double)dotp < -thr)) all_inv = 0;
+    }
+    memset(out, 0, sizeof *out);
+    out->kind = ORC_PLANE;
+    if (all_ok) { set_f(&out->v[0], p1); set_f(&out->v[3], crossv); return 1; }
+    if (all_inv) { set_f(&out->v[0], p1); set_f(&out->v[3], fscale(crossv, -1.0f)); return 1; }
+    return 0;
+}
+
+static int fit2pointsphere32(const double *vv, const double *nn, const orc_params *prm, f3 *center_out, float *radius_out)
+{
+    f3 v1 = Fd(vv), v2 = Fd(vv + 3), n1 = Fd(nn), n2v = Fd(nn + 3);
+    f3 n1n = fnormalize(n1), n2n = fnormalize(n2v);
+    f3 center;
+    float radius;
+    if ((double)fabsf(fdot(n1n, n2n)) > prm->cos_parallelthr) {
+        center = fdivs(fadd(v1, v2), 2.0f);
+        radius = fnorm(fsub(center, v1));
+    } else {
+        f3 g = fsub(v2, v1);
+        f3 h = fcross(n2n, g);
+        f3 k = fcross(n2n, n1n);
+        float nk = fnorm(k), nh = fnorm(h);
+        if ((double)nk < prm->sphere_par || (double)nh < prm->sphere_par) {
+            f3 n2 = fcross(n2n, fcross(n1n, n2n));
+            f3 n1_ = fcross(n1n, fcross(n2n, n1n));
+            f3 c1 = fadd(v1, fscale(n1, fdot(fsub(v2, v1), n2) / fdot(n1, n2)));
+            f3 c2 = fadd(v2, fscale(n2v, fdot(fsub(v1, v2), n1_) / fdot(n2v, n1_)));
+            center = fdivs(fadd(c1, c2), 2.0f);
+            radius = (fnorm(fsub(v1, center)) + fnorm(fsub(v1, center))) / 2.0f;
+        } else if (fdot(h, k) > 0.0f) {
+            center = fadd(v1, fscale(n1n, nh / nk));
+            radius = fnorm(fsub(center, v1));
+        } else {
+            center = fsub(v1, fscale(n1n, nh / nk));
+            radius = fnorm(fsub(center, v1));
+        }
+    }
+    *center_out = center;
+    *radius_out = radius;
+    return 1;
+}
+
+static int fit_sphere32(const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
+{
+    if (lp < 3) return 0;
+    f3 center;
+    float radius;
+    if (!fit2pointsphere32(p, n, prm, &center, &radius)) return 0;
+    double thr = prm->cos_alpha[ORC_SPHERE], eps = prm->eps[ORC_SPHERE];
+    int vert = 1, ok = 1, inv = 1;
+    for (int i = 0; i < lp; i++) {
+        f3 pi = Fd(p + 3 * i);
+        if (!((double)fabsf(fnorm(fsub(pi, center)) - radius) < eps)) vert = 0;
+        float dotp = fdot(fnormalize(fsub(pi, center)), fnormalize(Fd(n + 3 * i)));
+        if (!((double)dotp > thr)) ok = 0;
+        if (!((double)dotp < -thr)) inv = 0;
+    }
+    if (!vert) return 0;
+    memset(out, 0, sizeof *out);
+    out->kind = ORC_SPHERE;
+    set_f(&out->v[0], center);
+    out->v[3] = (double)radius;
+    if (ok) { out->outwards = 1; return 1; }
+    if (inv) { out->outwards = 0; return 1; }
+    return 0;
+}
+
+static f3 cyl_project2plane32(f3 n, f3 w) { return fadd(w, fscale(n, fdot(fneg(n), w) / fdot(n, n))); }
+
+static void cyl_projectto2d32(f3 xa, f3 ya, f3 za, f3 p1, float r[2])
+{
+    float xx = xa.x, xy = xa.y, xz = xa.z;
+    float yx = ya.x, yy = ya.y, yz = ya.z;
+    float zx = za.x, zy = za.y, zz = za.z;
+    float px = p1.x, py = p1.y, pz = p1.z;
+    r[0] = -((-(pz * yy * zx) + py * yz * zx + pz * yx * zy - px * yz * zy - py * yx * zz + px * yy * zz) /
+             (xz * yy * zx - xy * yz * zx - xz * yx * zy + xx * yz * zy + xy * yx * zz - xx * yy * zz));
+    r[1] = -((pz * xy * zx - py * xz * zx - pz * xx * zy + px * xz * zy + py * xx * zz - px * xy * zz) /
+             (xz * yy * zx - xy * yz * zx - xz * yx * zy + xx * yz * zy + xy * yx * zz - xx * yy * zz));
+}
+
+static int fit_cylinder32(const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
+{
+    if (lp < 3) return 0;
+    f3 p1 = Fd(p), p2 = Fd(p + 3), n1 = Fd(n), n2 = Fd(n + 3);
+    if ((double)fabsf(fdot(n1, n2)) > prm->cos_parallelthr) return 0;
+    f3 an = fnormalize(fcross(n1, n2));
+    f3 xax = fnormalize(cyl_project2plane32(an, p1));
+    f3 yax = fnormalize(fcross(an, xax));
+    float p11[2], p12[2], p21[2], p22[2];
+    cyl_projectto2d32(xax, yax, an, cyl_project2plane32(an, p1), p11);
+    cyl_projectto2d32(xax, yax, an, cyl_project2plane32(an, fadd(p1, n1)), p12);
+    cyl_projectto2d32(xax, yax, an, cyl_project2plane32(an, p2), p21);
+    cyl_projectto2d32(xax, yax, an, cyl_project2plane32(an, fadd(p2, n2)), p22);
+    float amb[2] = { p11[0] - p12[0], p11[1] - p12[1] };
+    float cmd[2] = { p21[0] - p22[0], p21[1] - p22[1] };
+    float d1 = p11[0] * p12[1] - p11[1] * p12[0];
+    float d2 = p21[0] * p22[1] - p21[1] * p22[0];
+    float d3 = amb[0] * cmd[1] - amb[1] * cmd[0];
+    float interc[2] = { (d1 * cmd[0] - d2 * amb[0]) / d3, (d1 * cmd[1] - d2 * amb[1]) / d3 };
+    f3 c = fadd(fscale(xax, interc[0]), fscale(yax, interc[1]));
+    float nn1 = fnorm(fsub(fsub(p1, c), fscale(an, fdot(an, fsub(p1, c)))));
+    float nn2 = fnorm(fsub(fsub(p2, c), fscale(an, fdot(an, fsub(p2, c)))));
+    float R = (nn1 + nn2) / 2.0f;
+    float outw = (p12[0] - p11[0]) * (p11[0] - interc[0]) + (p12[1] - p11[1]) * (p11[1] - interc[1]);
+    (void)outw;   /* fit() overwrites the outerity (cylinder.jl:165-166) */
+    double thr = prm->cos_alpha[ORC_CYLINDER], eps = prm->eps[ORC_CYLINDER];
+    int vert = 1, ok = 1, inv = 1;
+    for (int i = 0; i < lp; i++) {
+        f3 pi = Fd(p + 3 * i);
+        f3 curr_norm = fsub(fsub(pi, fscale(an, fdot(an, fsub(pi, c)))), c);
+        if (!((double)fabsf(fnorm(curr_norm) - R) < eps)) vert = 0;
+        float dotp = fdot(fnormalize(curr_norm), Fd(n + 3 * i));
+        if (!((double)dotp > thr)) ok = 0;
+        if (!((double)dotp < -thr)) inv = 0;
+    }
+    if (!vert) return 0;
+    memset(out, 0, sizeof *out);
+    out->kind = ORC_CYLINDER;
+    set_f(&out->v[0], an);
+    set_f(&out->v[3], c);
+    out->v[6] = (double)R;
+    if (ok) { out->outwards = 1; return 1; }
+    if (inv) { out->outwards = 0; return 1; }
+    return 0;
+}
+
+/* fit(T, p, n, pc, params) on Float32 points; kind ORC_CONE: never fits (see above; orc_ransac refuses it beforehand) */
+int orc32_fit(int kind, const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
+{
+    switch (kind) {
+    case ORC_PLANE: return fit_plane32(p, n, lp, prm, out);
+    case ORC_SPHERE: return fit_sphere32(p, n, lp, prm, out);
+    case ORC_CYLINDER: return fit_cylinder32(p, n, lp, prm, out);
+    default: return 0;
+    }
+}

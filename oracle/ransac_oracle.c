@@ -390,6 +390,7 @@ struct orc_cloud {
     uint64_t *enabled;   /* BitVector chunks, LSB first */
     int64_t *dir;        /* select directory: enabled count before each 64-chunk block */
     int dir_valid;
+    int f32;             /* the values are Float32 numbers and every per-point test / fit is the binary32 one (orc_f32.c) */
 };
 
 #define DIR_BLOCK 64 /* chunks per directory block (4096 bits) */
@@ -450,6 +451,19 @@ int64_t orc_cloud_count_enabled(const orc_cloud *c)
 
 static inline int is_enabled(const orc_cloud *c, int64_t i0) { return (int)((c->enabled[i0 >> 6] >> (i0 & 63)) & 1); }
 
+void orc_cloud_set_f32(orc_cloud *c, int f32) { c->f32 = f32 ? 1 : 0; }
+
+/* the per-point test of the cloud's element type */
+static inline int compat_pt(const orc_cloud *c, const orc_shape *s, int64_t i0, double eps, double cosa)
+{
+    if (c->f32) {
+        const double *pp = &c->xyz[3 * i0], *nn = &c->nrm[3 * i0];
+        float pf[3] = { (float)pp[0], (float)pp[1], (float)pp[2] }, nf[3] = { (float)nn[0], (float)nn[1], (float)nn[2] };
+        return orc32_compatible(s, pf, nf, eps, cosa);
+    }
+    return compat(s, V(&c->xyz[3 * i0]), V(&c->nrm[3 * i0]), eps, cosa);
+}
+
 /* scorecandidate: plane.jl:61-71, sphere.jl:118-134, cylinder.jl:172-183, cone.jl:155-167.
  * Points are gathered through subsets[1] exactly like the reference's views. */
 int64_t orc_scorecandidate(const orc_cloud *c, const orc_shape *s, const orc_params *p,
@@ -461,7 +475,7 @@ int64_t orc_scorecandidate(const orc_cloud *c, const orc_shape *s, const orc_par
     if (mask) memset(mask, 0, 8 * (size_t)((c->s + 63) / 64));
     for (int64_t j = 0; j < c->s; j++) {
         int64_t i0 = c->subset1[j] - 1;
-        int ok = compat(s, V(&c->xyz[3 * i0]), V(&c->nrm[3 * i0]), eps, cosa);
+        int ok = compat_pt(c, s, i0, eps, cosa);
         if (use_en) ok = ok & is_enabled(c, i0);
         if (ok) {
             if (inpoints) inpoints[cnt] = i0 + 1;
@@ -534,7 +548,7 @@ int64_t orc_refit(const orc_cloud *c, const orc_shape *s, const orc_params *p, i
     int64_t cnt = 0;
     for (int64_t i0 = 0; i0 < c->n; i0++) {
         if (!is_enabled(c, i0)) continue;
-        if (compat(s, V(&c->xyz[3 * i0]), V(&c->nrm[3 * i0]), eps, cosa)) {
+        if (compat_pt(c, s, i0, eps, cosa)) {
             if (cnt < cap) idx_out[cnt] = i0 + 1;
             cnt++;
         }
@@ -1530,6 +1544,9 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
     memset(out, 0, sizeof *out);
     if (octree_depth < 1) octree_depth = 1;
     if (p->drawN < 2 || p->drawN > 16) return -1;
+    if (c->f32)
+        for (int t = 0; t < p->n_shape_types; t++)
+            if (p->shape_types[t] == ORC_CONE) return -3; /* the cone's fit is not restated in binary32 (orc_f32.c) */
     /* nomodRANSACCloud passes (levelscore, levelweight) into (levelweight, levelscore): octree.jl:82-84 */
     double *levelweight = (double *)calloc((size_t)octree_depth, 8);
     double *levelscore = (double *)malloc(8 * (size_t)octree_depth);
@@ -1578,7 +1595,8 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
             }
             for (int t = 0; t < p->n_shape_types; t++) { /* forcefitshapes!: fitting.jl:165-173 */
                 orc_shape fitted;
-                if (!orc_fit(p->shape_types[t], fp, fn, p->drawN, p, &fitted)) continue;
+                if (!(c->f32 ? orc32_fit(p->shape_types[t], fp, fn, p->drawN, p, &fitted)
+                             : orc_fit(p->shape_types[t], fp, fn, p->drawN, p, &fitted))) continue;
                 if (ncand == capcand) {
                     capcand = capcand ? capcand * 2 : 64;
                     cands = (orc_shape *)realloc(cands, sizeof(orc_shape) * (size_t)capcand);

@@ -159,6 +159,12 @@ int64_t orc32_scorecandidate(const orc_cloud32 *c, const orc_shape *s, const orc
 void orc32_score_masks_mt(const orc_cloud32 *c, const orc_shape *s, int32_t b, const orc_params *p, int32_t *counts,
                           uint64_t *masks /* or NULL */, int32_t nthreads);
 int64_t orc32_refit(const orc_cloud32 *c, const orc_shape *s, const orc_params *p, int64_t *idx_out, int64_t cap);
+/* fit on Float32 points (p, n: the Float32 values as doubles); ORC_CONE never fits (not restated in binary32) */
+int orc32_fit(int kind, const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out);
+/* A cloud of Float32 values (given as doubles) whose per-point tests and fits run in binary32: orc_scorecandidate,
+ * orc_refit and orc_ransac then take the orc32 paths -- the whole loop on a Float32 cloud (RANSACCloud(...;
+ * force_eltype = Float32), octree.jl:102-109).  orc_ransac returns -3 when shape_types holds ORC_CONE on such a cloud. */
+void orc_cloud_set_f32(orc_cloud *c, int f32);
 void orc32_invalidate(orc_cloud32 *c, const int64_t *idx_1based, int64_t n);
 
 /* ---- minimal-set fits: p,n are lp x 3 AoS; return 1 = fitted, 0 = nothing ---- */

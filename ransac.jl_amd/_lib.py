@@ -84,11 +84,13 @@ SIGNATURES = {
     "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
     "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),
     "rh_fit": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
+    "rh_fit_f32": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
     "rh_estimatescore": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp, _dp, _dp]),
     "rh_prob": (C.c_double, [C.c_double, C.c_int64, C.c_int64, C.c_int64]),
     "rh_rng_seed": (None, [C.POINTER(Rng), C.c_uint64]),
     "rh_rng_range": (C.c_int64, [C.POINTER(Rng), C.c_int64]),
     "rh_ransac": (C.c_int, [_vp, _dp, _dp, _pp, C.POINTER(Rng), C.POINTER(Result)]),
+    "rh_ransac_f32": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _pp, C.POINTER(Rng), C.POINTER(Result)]),
     "rh_result_free": (None, [C.POINTER(Result)]),
     "rh_largestconncomp": (C.c_int, [_u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int, _i64p, C.c_int64, _i64p]),
     "rh_bitmapparameters": (C.c_int, [_dp, _u8p, _i64p, C.c_int64, C.c_double, _i32p, _i32p, _dp, _dp, _u8p, _i64p]),

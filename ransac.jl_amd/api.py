@@ -272,7 +272,7 @@ class RANSACCloud:
 
     def __init__(self, vertices, normals, subsets, device=0, seed=None, force_eltype=None):
         """force_eltype = numpy.float32: a Float32 cloud (octree.jl:102-109) -- scoring and refit then compute in
-        binary32 like the reference does on such a cloud; rh_ransac / refit_lsq stay Float64-only."""
+        binary32 like the reference does on such a cloud, and so does ransac() (fits included; no cones); refit_lsq stays Float64-only."""
         self.is_f32 = force_eltype is not None and np.dtype(force_eltype) == np.float32
         if force_eltype is not None and not self.is_f32 and np.dtype(force_eltype) != np.float64:
             raise ValueError("force_eltype must be float32 or float64")
@@ -365,14 +365,18 @@ class RANSACCloud:
 
 # ---------------------------------------------------------------- hot path ----
 def fit(T, p, n, pc, params):
-    """fit(::Type{T}, p, n, pc, params) -> T or None (shapes/*.jl `fit`)."""
+    """fit(::Type{T}, p, n, pc, params) -> T or None (shapes/*.jl `fit`).  Float32 points (a Float32 cloud's, or numpy
+    float32 arrays) are fitted in Float32 like Julia fits SVector{3,Float32}s (rh_fit_f32; no cones)."""
+    f32 = bool(getattr(pc, "is_f32", False)) or (getattr(p, "dtype", None) == np.float32 and getattr(n, "dtype", None) == np.float32)
+    if f32:
+        p, n = np.asarray(p, dtype=np.float32), np.asarray(n, dtype=np.float32)
     p, n = _f64(p).reshape(-1, 3), _f64(n).reshape(-1, 3)
     assert p.shape[0] > 2, "At least 3 point is needed."
     assert p.shape == n.shape, "Size must be the same."
     out, ok = L.Shape(), C.c_int32()
     kind = _KIND_OF[T] if T in _KIND_OF else int(T)
-    check(lib().rh_fit(kind, _p(p, C.c_double), _p(n, C.c_double), p.shape[0], C.byref(_cparams(params)),
-                       C.byref(out), C.byref(ok)))
+    check((lib().rh_fit_f32 if f32 else lib().rh_fit)(kind, _p(p, C.c_double), _p(n, C.c_double), p.shape[0], C.byref(_cparams(params)),
+                                                     C.byref(out), C.byref(ok)))
     return shape_from_c(out) if ok.value else None
 
 
@@ -632,6 +636,9 @@ def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=Non
     if mp is not None:
         check(lib().rh_ransac_mp(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
                                  C.byref(rng), mp._h, C.byref(res)))
+    elif getattr(pc, "is_f32", False):   # a Float32 cloud: the loop in binary32 (no cones), from the Float32 arrays as they are
+        check(lib().rh_ransac_f32(pc._h, _p(pc.vertices32, C.c_float), _p(pc.normals32, C.c_float), C.byref(cp),
+                                  C.byref(rng), C.byref(res)))
     else:
         check(lib().rh_ransac(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
                               C.byref(rng), C.byref(res)))

@@ -713,7 +713,8 @@ struct Driver {
         for (int t = 0; t < p->n_shape_types; t++) {
             rh_shape fitted;
             int32_t ok = 0;
-            RUN(rh_fit(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));
+            if (c->f32) RUN(rh_fit_f32(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));   // Float32 cloud: Float32 fits
+            else RUN(rh_fit(p->shape_types[t], fp.data(), fn.data(), drawN, p, &fitted, &ok));
             if (ok) cands.push_back(fitted);
         }
         return RH_OK;
@@ -910,7 +911,8 @@ struct Driver {
         RUN(ensure_scratch(32 + 2 * sum_n + (managed ? 4 * (int64_t)(pbase[4] / RH_STORE_PAD) + 8 : 0)));
         int32_t *h_nk = h_scr + 16, *h_counts = h_scr + 32, *h_lists = h_scr + 32 + sum_n;
         const int64_t ndis_old = c->n_dis;
-        RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind], true));
+        if (c->f32) RUN(rhk_refit_mask_f32(c, bestshape, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind], true));
+        else RUN(rhk_refit_mask(c, P, bestshape.kind, p->eps[bestshape.kind], p->cos_alpha[bestshape.kind], true));
         if (list_copy_pending) {   // the previous list must have left idx_out before it is written again
             RUNH(hipStreamWaitEvent(c->stream, c->ev_copied, 0));
             list_copy_pending = false;
@@ -921,6 +923,7 @@ struct Driver {
         RUN(rhk_rebuild_sub_enabled(c, false));
         if (fast) {
             rh_live_args A;
+            A.f32 = c->f32 ? 1 : 0;
             int64_t lo = c->s;
             for (int q = 0; q < 4; q++) {
                 const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
@@ -1271,7 +1274,8 @@ struct Driver {
         // With the culled score kernel (it takes its candidate counts from device memory) the window's
         // candidates are scored on the device right after they are fitted, in the same stream: the
         // host gets list + counts in one wait instead of a second round trip per window.
-        const bool fused_score = c->use_groups && !getenv("RH_NO_FUSED_SCORE");
+        // (Float32 cloud: the fused launch has no float records to hand to the older culled kernel -- the v4 kernel derives them)
+        const bool fused_score = c->use_groups && !getenv("RH_NO_FUSED_SCORE") && (!c->f32 || rh_score_v4_enabled(c));
         int32_t cnt_est = 64;
         // Without the octree a window's draws depend only on (seed, k, j) and the enabled bits, so the
         // NEXT window is put on the stream before the host waits for this one: it is valid unless this
@@ -1770,6 +1774,18 @@ extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, cons
     return ransac_impl(c, xyz, nrm, p, rng, nullptr, out);
 }
 
+// ransac() on a Float32 cloud from Julia's Vector{SVector{3,Float32}} memory as is (rh_ransac takes the same values as
+// doubles): the host-side fits of sampling_streams = 0 read them
+extern "C" int rh_ransac_f32(rh_cloud *c, const float *xyz, const float *nrm, const rh_params *p, rh_rng *rng, rh_result *out)
+{
+    if (!c) { rh_set_error("rh_ransac_f32: NULL argument"); return RH_E_INVALID; }
+    if (!c->f32) { rh_set_error("rh_ransac_f32: the cloud is not a Float32 cloud (rh_cloud_create_f32)"); return RH_E_INVALID; }
+    if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac_f32: xyz/nrm are NULL"); return RH_E_INVALID; }
+    std::vector<double> x((size_t)(3 * c->n)), n((size_t)(3 * c->n));
+    for (int64_t i = 0; i < 3 * c->n; i++) { x[(size_t)i] = (double)xyz[i]; n[(size_t)i] = (double)nrm[i]; }
+    return ransac_impl(c, x.data(), n.data(), p, rng, nullptr, out);
+}
+
 // ransac() on ONE scene by the `world` processes of `mp` (one per GPU, each with a replica of the cloud in the same
 // state): the minimal sets of every iteration are dealt round-robin to the ranks -- sampling, fits and scoring of
 // a window shrink by the number of ranks -- and the ranks exchange their windows' candidate lists through `mp`
@@ -1799,8 +1815,16 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
 {
     if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
     memset(out, 0, sizeof *out);
-    if (c->f32) { rh_set_error("rh_ransac: Float32 clouds support rh_score_batch / rh_refit / rh_invalidate / rh_select_enabled only"); return RH_E_INVALID; }
     RH_TRY(rh_validate_params(p));
+    if (c->f32) {
+        // Float32 cloud: fits, scoring, liveness and refit in binary32.  Its cone fit would need rank() and \ of Float32
+        // matrices the way LAPACK's single precision does them (cone.jl:40-50): no fixture exists to pin a restatement on
+        for (int t = 0; t < p->n_shape_types && t < 8; t++)
+            if (p->shape_types[t] == RH_CONE) {
+                rh_set_error("rh_ransac: FittedCone is not available in shape_types on a Float32 cloud (its fit is not restated in binary32)");
+                return RH_E_INVALID;
+            }
+    }
     if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
     if (p->drawN < 2 || p->drawN > 16) {   // @assert drawN > 1: src/fitting.jl:386
         rh_set_error("rh_ransac: drawN=%d outside 2..16", p->drawN);

@@ -90,6 +90,29 @@ extern "C" int rh_fit(int kind, const double *p, const double *n, int32_t lp, co
     return RH_OK;
 }
 
+// fit on a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): p / n hold the Float32 values (as
+// doubles, exactly); the fit runs in binary32 (fit_shared.h) and its shape holds binary32 numbers.  Cones: not available
+// (cone.jl:40-50 takes rank() and \ of Float32 matrices -- LAPACK's single-precision SVD / LU, no fixture to restate them on)
+extern "C" int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm, rh_shape *out,
+                          int32_t *fitted)
+{
+    if (!p || !n || !prm || !out || !fitted) { rh_set_error("rh_fit_f32: NULL argument"); return RH_E_INVALID; }
+    if (lp < 3) { rh_set_error("rh_fit_f32: at least 3 points are needed (got %d)", lp); return RH_E_INVALID; }
+    rh_shape s;
+    memset(&s, 0, sizeof s);
+    bool ok;
+    switch (kind) {
+    case RH_PLANE: ok = fit_plane32(p, n, lp, *prm, &s); break;
+    case RH_SPHERE: ok = fit_sphere32(p, n, lp, *prm, &s); break;
+    case RH_CYLINDER: ok = fit_cylinder32(p, n, lp, *prm, &s); break;
+    case RH_CONE: rh_set_error("rh_fit_f32: the cone fit is not available for Float32 clouds"); return RH_E_INVALID;
+    default: rh_set_error("rh_fit_f32: unknown kind %d", kind); return RH_E_INVALID;
+    }
+    *fitted = ok ? 1 : 0;
+    if (ok) *out = s;
+    return RH_OK;
+}
+
 // estimatescore + hypergeomdev + notsoconfident: confidenceintervals.jl:71-74, 53-59, 20-22
 extern "C" int rh_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int32_t score_mode, double *ci_min,
                                 double *ci_max, double *ci_E)

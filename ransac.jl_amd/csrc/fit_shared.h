@@ -22,74 +22,92 @@
 
 namespace rhfit {
 
-// StaticArrays-style 3-vector: dot / norm sum left to right, normalize multiplies by 1/norm
-struct Vec {
-    double x, y, z;
-    RH_HD Vec() : x(0), y(0), z(0) {}
-    RH_HD Vec(double a, double b, double c) : x(a), y(b), z(c) {}
-    RH_HD explicit Vec(const double *p) : x(p[0]), y(p[1]), z(p[2]) {}
-    RH_HD Vec operator+(const Vec &o) const { return Vec(x + o.x, y + o.y, z + o.z); }
-    RH_HD Vec operator-(const Vec &o) const { return Vec(x - o.x, y - o.y, z - o.z); }
-    RH_HD Vec operator-() const { return Vec(-x, -y, -z); }
-    RH_HD Vec operator*(double s) const { return Vec(x * s, y * s, z * s); }
-    RH_HD Vec operator/(double s) const { return Vec(x / s, y / s, z / s); }
-    RH_HD void store(double *p) const { p[0] = x; p[1] = y; p[2] = z; }
-};
-RH_HD Vec operator*(double s, const Vec &v) { return Vec(s * v.x, s * v.y, s * v.z); }
-RH_HD double dot(const Vec &a, const Vec &b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-RH_HD double norm(const Vec &a) { return sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); }
-RH_HD Vec normalize(const Vec &a) { return (1.0 / norm(a)) * a; }
-RH_HD Vec cross(const Vec &a, const Vec &b)
-{
-    return Vec(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
+// StaticArrays-style 3-vector: dot / norm sum left to right, normalize multiplies by 1/norm.
+// T = double, or float for a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109: the points, the
+// normals and everything computed from them are Float32 there; the parameters stay Float64 unless setfloattype,
+// utilities.jl:488-503, converted them, and Julia compares a Float32 with a Float64 after promoting the Float32 exactly
+// -- here the float result is promoted by the comparison with the double threshold).  Integer literals of the Julia
+// source ((v1 + v2) / 2, -1 * crossv) take the vector's type.
+RH_HD double rh_sqrt_t(double x) { return sqrt(x); }
+RH_HD float rh_sqrt_t(float x) { return sqrtf(x); }
+RH_HD double rh_fabs_t(double x) { return fabs(x); }
+RH_HD float rh_fabs_t(float x) { return fabsf(x); }
 
-struct Vec2 {
-    double x, y;
+template <typename T>
+struct VecT {
+    T x, y, z;
+    RH_HD VecT() : x(0), y(0), z(0) {}
+    RH_HD VecT(T a, T b, T c) : x(a), y(b), z(c) {}
+    RH_HD explicit VecT(const double *p) : x((T)p[0]), y((T)p[1]), z((T)p[2]) {}   // (exact: a Float32 cloud's values are binary32 numbers)
+    RH_HD VecT operator+(const VecT &o) const { return VecT(x + o.x, y + o.y, z + o.z); }
+    RH_HD VecT operator-(const VecT &o) const { return VecT(x - o.x, y - o.y, z - o.z); }
+    RH_HD VecT operator-() const { return VecT(-x, -y, -z); }
+    RH_HD VecT operator*(T s) const { return VecT(x * s, y * s, z * s); }
+    RH_HD VecT operator/(T s) const { return VecT(x / s, y / s, z / s); }
+    RH_HD void store(double *p) const { p[0] = (double)x; p[1] = (double)y; p[2] = (double)z; }
 };
+template <typename T> RH_HD VecT<T> operator*(T s, const VecT<T> &v) { return VecT<T>(s * v.x, s * v.y, s * v.z); }
+template <typename T> RH_HD T dot(const VecT<T> &a, const VecT<T> &b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <typename T> RH_HD T norm(const VecT<T> &a) { return rh_sqrt_t((a.x * a.x + a.y * a.y) + a.z * a.z); }
+template <typename T> RH_HD VecT<T> normalize(const VecT<T> &a) { return (T(1) / norm(a)) * a; }
+template <typename T> RH_HD VecT<T> cross(const VecT<T> &a, const VecT<T> &b)
+{
+    return VecT<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+typedef VecT<double> Vec;
+
+template <typename T>
+struct Vec2T {
+    T x, y;
+};
+typedef Vec2T<double> Vec2;
 
 
 // ---- plane.jl:33-57 ----
-RH_HD bool fit_plane(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+template <typename T>
+RH_HD bool fit_plane_t(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
 {
-    const Vec p1(p), p2(p + 3), p3(p + 6);
-    const Vec crossv = normalize(cross(p2 - p1, p3 - p1));
+    typedef VecT<T> V;
+    const V p1(p), p2(p + 3), p3(p + 6);
+    const V crossv = normalize(cross(p2 - p1, p3 - p1));
     if (norm(crossv) < prm.collin_threshold) return false;
     const double thr = prm.cos_alpha[RH_PLANE];
     bool same = true, opposite = true;
     for (int i = 0; i < lp; i++) {
-        const double dotp = dot(crossv, normalize(Vec(n + 3 * i)));
+        const T dotp = dot(crossv, normalize(V(n + 3 * i)));
         same = same && (dotp > thr);
         opposite = opposite && (dotp < -thr);
     }
     if (!same && !opposite) return false;
     out->kind = RH_PLANE;
     p1.store(out->v);
-    (same ? crossv : -1.0 * crossv).store(out->v + 3);
+    (same ? crossv : T(-1) * crossv).store(out->v + 3);
     return true;
 }
 
 // ---- sphere.jl:29-75 ----
-RH_HD void fit2pointsphere(const double *v, const double *n, const rh_params &prm, Vec *center, double *radius)
+template <typename T>
+RH_HD void fit2pointsphere_t(const double *v, const double *n, const rh_params &prm, VecT<T> *center, T *radius)
 {
-    const Vec v1(v), v2(v + 3), n1(n), n2raw(n + 3);
-    const Vec n1n = normalize(n1), n2n = normalize(n2raw);
-    if (fabs(dot(n1n, n2n)) > prm.cos_parallelthr) {
-        *center = (v1 + v2) / 2;
+    typedef VecT<T> V;
+    const V v1(v), v2(v + 3), n1(n), n2raw(n + 3);
+    const V n1n = normalize(n1), n2n = normalize(n2raw);
+    if (rh_fabs_t(dot(n1n, n2n)) > prm.cos_parallelthr) {
+        *center = (v1 + v2) / T(2);
         *radius = norm(*center - v1);
         return;
     }
-    const Vec g = v2 - v1;
-    const Vec h = cross(n2n, g);
-    const Vec k = cross(n2n, n1n);
-    const double nk = norm(k), nh = norm(h);
+    const V g = v2 - v1;
+    const V h = cross(n2n, g);
+    const V k = cross(n2n, n1n);
+    const T nk = norm(k), nh = norm(h);
     if (nk < prm.sphere_par || nh < prm.sphere_par) {
-        const Vec n2 = cross(n2n, cross(n1n, n2n));
-        const Vec n1b = cross(n1n, cross(n2n, n1n));
-        const Vec c1 = v1 + (dot(v2 - v1, n2) / dot(n1, n2)) * n1;
-        const Vec c2 = v2 + (dot(v1 - v2, n1b) / dot(n2raw, n1b)) * n2raw;
-        *center = (c1 + c2) / 2;
-        *radius = (norm(v1 - *center) + norm(v1 - *center)) / 2;
+        const V n2 = cross(n2n, cross(n1n, n2n));
+        const V n1b = cross(n1n, cross(n2n, n1n));
+        const V c1 = v1 + (dot(v2 - v1, n2) / dot(n1, n2)) * n1;
+        const V c2 = v2 + (dot(v1 - v2, n1b) / dot(n2raw, n1b)) * n2raw;
+        *center = (c1 + c2) / T(2);
+        *radius = (norm(v1 - *center) + norm(v1 - *center)) / T(2);
     } else if (dot(h, k) > 0) {
         *center = v1 + (nh / nk) * n1n;
         *radius = norm(*center - v1);
@@ -98,19 +116,25 @@ RH_HD void fit2pointsphere(const double *v, const double *n, const rh_params &pr
         *radius = norm(*center - v1);
     }
 }
+RH_HD void fit2pointsphere(const double *v, const double *n, const rh_params &prm, Vec *center, double *radius)
+{
+    fit2pointsphere_t<double>(v, n, prm, center, radius);
+}
 
 // ---- sphere.jl:87-114 ----
-RH_HD bool fit_sphere(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+template <typename T>
+RH_HD bool fit_sphere_t(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
 {
-    Vec center;
-    double radius;
-    fit2pointsphere(p, n, prm, &center, &radius);
+    typedef VecT<T> V;
+    V center;
+    T radius;
+    fit2pointsphere_t<T>(p, n, prm, &center, &radius);
     const double thr = prm.cos_alpha[RH_SPHERE], eps = prm.eps[RH_SPHERE];
     bool vert = true, same = true, opposite = true;
     for (int i = 0; i < lp; i++) {
-        const Vec pi(p + 3 * i);
-        vert = vert && (fabs(norm(pi - center) - radius) < eps);
-        const double dotp = dot(normalize(pi - center), normalize(Vec(n + 3 * i)));
+        const V pi(p + 3 * i);
+        vert = vert && (rh_fabs_t(norm(pi - center) - radius) < eps);
+        const T dotp = dot(normalize(pi - center), normalize(V(n + 3 * i)));
         same = same && (dotp > thr);
         opposite = opposite && (dotp < -thr);
     }
@@ -118,18 +142,20 @@ RH_HD bool fit_sphere(const double *p, const double *n, int lp, const rh_params 
     out->kind = RH_SPHERE;
     out->outwards = same ? 1 : 0;
     center.store(out->v);
-    out->v[3] = radius;
+    out->v[3] = (double)radius;
     return true;
 }
 
 // ---- cylinder.jl:46-59 (project2plane), :61-85 (projectto2d), :87-101 ----
-RH_HD Vec cyl_project2plane(const Vec &n, const Vec &w) { return w + n * (dot(-n, w) / dot(n, n)); }
+template <typename T>
+RH_HD VecT<T> cyl_project2plane(const VecT<T> &n, const VecT<T> &w) { return w + n * (dot(-n, w) / dot(n, n)); }
 
-RH_HD Vec2 cyl_projectto2d(const Vec &xa, const Vec &ya, const Vec &za, const Vec &p1)
+template <typename T>
+RH_HD Vec2T<T> cyl_projectto2d(const VecT<T> &xa, const VecT<T> &ya, const VecT<T> &za, const VecT<T> &p1)
 {
-    const double xx = xa.x, xy = xa.y, xz = xa.z, yx = ya.x, yy = ya.y, yz = ya.z;
-    const double zx = za.x, zy = za.y, zz = za.z, px = p1.x, py = p1.y, pz = p1.z;
-    Vec2 r;
+    const T xx = xa.x, xy = xa.y, xz = xa.z, yx = ya.x, yy = ya.y, yz = ya.z;
+    const T zx = za.x, zy = za.y, zz = za.z, px = p1.x, py = p1.y, pz = p1.z;
+    Vec2T<T> r;
     r.x = -((-(pz * yy * zx) + py * yz * zx + pz * yx * zy - px * yz * zy - py * yx * zz + px * yy * zz) /
             (xz * yy * zx - xy * yz * zx - xz * yx * zy + xx * yz * zy + xy * yx * zz - xx * yy * zz));
     r.y = -((pz * xy * zx - py * xz * zx - pz * xx * zy + px * xz * zy + py * xx * zz - px * xy * zz) /
@@ -138,47 +164,57 @@ RH_HD Vec2 cyl_projectto2d(const Vec &xa, const Vec &ya, const Vec &za, const Ve
 }
 
 // ---- cylinder.jl:34-125 ----
-RH_HD bool fit2pointcylinder(const double *p, const double *n, const rh_params &prm, Vec *axis, Vec *center, double *radius,
-                       bool *outw)
+template <typename T>
+RH_HD bool fit2pointcylinder_t(const double *p, const double *n, const rh_params &prm, VecT<T> *axis, VecT<T> *center, T *radius,
+                               bool *outw)
 {
-    const Vec p1(p), p2(p + 3), n1(n), n2(n + 3);
-    if (fabs(dot(n1, n2)) > prm.cos_parallelthr) return false;
-    const Vec an = normalize(cross(n1, n2));
-    const Vec xax = normalize(cyl_project2plane(an, p1));
-    const Vec yax = normalize(cross(an, xax));
-    const Vec2 a = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1));
-    const Vec2 b = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1 + n1));
-    const Vec2 c = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2));
-    const Vec2 d = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2 + n2));
-    const Vec2 amb = { a.x - b.x, a.y - b.y }, cmd = { c.x - d.x, c.y - d.y };
-    const double d1 = a.x * b.y - a.y * b.x;       // det([a'; b'])
-    const double d2 = c.x * d.y - c.y * d.x;
-    const double d3 = amb.x * cmd.y - amb.y * cmd.x;
-    const Vec2 ic = { (d1 * cmd.x - d2 * amb.x) / d3, (d1 * cmd.y - d2 * amb.y) / d3 };
-    const Vec cc = ic.x * xax + ic.y * yax;
-    const double r1 = norm((p1 - cc) - an * dot(an, p1 - cc));
-    const double r2 = norm((p2 - cc) - an * dot(an, p2 - cc));
+    typedef VecT<T> V;
+    typedef Vec2T<T> V2;
+    const V p1(p), p2(p + 3), n1(n), n2(n + 3);
+    if (rh_fabs_t(dot(n1, n2)) > prm.cos_parallelthr) return false;
+    const V an = normalize(cross(n1, n2));
+    const V xax = normalize(cyl_project2plane(an, p1));
+    const V yax = normalize(cross(an, xax));
+    const V2 a = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1));
+    const V2 b = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p1 + n1));
+    const V2 c = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2));
+    const V2 d = cyl_projectto2d(xax, yax, an, cyl_project2plane(an, p2 + n2));
+    const V2 amb = { a.x - b.x, a.y - b.y }, cmd = { c.x - d.x, c.y - d.y };
+    const T d1 = a.x * b.y - a.y * b.x;       // det([a'; b'])
+    const T d2 = c.x * d.y - c.y * d.x;
+    const T d3 = amb.x * cmd.y - amb.y * cmd.x;
+    const V2 ic = { (d1 * cmd.x - d2 * amb.x) / d3, (d1 * cmd.y - d2 * amb.y) / d3 };
+    const V cc = ic.x * xax + ic.y * yax;
+    const T r1 = norm((p1 - cc) - an * dot(an, p1 - cc));
+    const T r2 = norm((p2 - cc) - an * dot(an, p2 - cc));
     *axis = an;
     *center = cc;
-    *radius = (r1 + r2) / 2;
+    *radius = (r1 + r2) / T(2);
     *outw = ((b.x - a.x) * (a.x - ic.x) + (b.y - a.y) * (a.y - ic.y)) > 0;
     return true;
 }
+RH_HD bool fit2pointcylinder(const double *p, const double *n, const rh_params &prm, Vec *axis, Vec *center, double *radius,
+                       bool *outw)
+{
+    return fit2pointcylinder_t<double>(p, n, prm, axis, center, radius, outw);
+}
 
 // ---- cylinder.jl:135-168 ----
-RH_HD bool fit_cylinder(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+template <typename T>
+RH_HD bool fit_cylinder_t(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
 {
-    Vec axis, center;
-    double radius;
+    typedef VecT<T> V;
+    V axis, center;
+    T radius;
     bool outw;
-    if (!fit2pointcylinder(p, n, prm, &axis, &center, &radius, &outw)) return false;
+    if (!fit2pointcylinder_t<T>(p, n, prm, &axis, &center, &radius, &outw)) return false;
     const double thr = prm.cos_alpha[RH_CYLINDER], eps = prm.eps[RH_CYLINDER];
     bool vert = true, same = true, opposite = true;
     for (int i = 0; i < lp; i++) {
-        const Vec pi(p + 3 * i);
-        const Vec cn = (pi - axis * dot(axis, pi - center)) - center;
-        vert = vert && (fabs(norm(cn) - radius) < eps);
-        const double dotp = dot(normalize(cn), Vec(n + 3 * i));
+        const V pi(p + 3 * i);
+        const V cn = (pi - axis * dot(axis, pi - center)) - center;
+        vert = vert && (rh_fabs_t(norm(cn) - radius) < eps);
+        const T dotp = dot(normalize(cn), V(n + 3 * i));
         same = same && (dotp > thr);
         opposite = opposite && (dotp < -thr);
     }
@@ -187,9 +223,17 @@ RH_HD bool fit_cylinder(const double *p, const double *n, int lp, const rh_param
     out->outwards = same ? 1 : 0;
     axis.store(out->v);
     center.store(out->v + 3);
-    out->v[6] = radius;
+    out->v[6] = (double)radius;
     return true;
 }
+
+// the binary64 entry points (every caller of rounds 1-3) and the dispatch a cloud's element type makes
+RH_HD bool fit_plane(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_plane_t<double>(p, n, lp, prm, out); }
+RH_HD bool fit_sphere(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_sphere_t<double>(p, n, lp, prm, out); }
+RH_HD bool fit_cylinder(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_cylinder_t<double>(p, n, lp, prm, out); }
+RH_HD bool fit_plane32(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_plane_t<float>(p, n, lp, prm, out); }
+RH_HD bool fit_sphere32(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_sphere_t<float>(p, n, lp, prm, out); }
+RH_HD bool fit_cylinder32(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_cylinder_t<float>(p, n, lp, prm, out); }
 
 
 // cos(-opang/2), sin(-opang/2) of a cone (rodriguesrad(rot_ax, -cone.opang/2): cone.jl:76,

@@ -197,7 +197,9 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
 // RH_SC_WAVE_PTS contiguous points per tile (PPT x 64, PPT points per lane in
 // registers) and walks the block's candidates; per candidate it issues PPT tests per
 // lane, PPT ballots, and one LDS atomic with the wave's popcount.
-template <int KIND, bool MASK>
+// F32: the points are a Float32 cloud's (exactly converted), the test is the binary32 one on the float record that follows
+// from the candidate's binary64 record (prepf_of, score_device32.h) -- rh_ransac's liveness passes and small subsets
+template <int KIND, bool MASK, bool F32 = false>
 __global__ void __launch_bounds__(RH_SC_THREADS)
 score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
              const uint64_t *__restrict__ enabled_words, const rh_prep *__restrict__ prep,
@@ -246,7 +248,9 @@ score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
             int n = 0;
 #pragma unroll
             for (int p = 0; p < RH_SC_PPT; p++) {
-                bw[p] = test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & en[p];
+                if (F32) bw[p] = test_point32<KIND>(prepf_of<KIND>(P), (float)px[p], (float)py[p], (float)pz[p], (float)qx[p], (float)qy[p],
+                                                    (float)qz[p], eps, cosa) & en[p];
+                else bw[p] = test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & en[p];
                 n += __popcll(bw[p]);
             }
             acc += (lane == c) ? n : 0;   // lane c keeps candidate c0+c's count (RH_SC_CT == 64)
@@ -935,9 +939,16 @@ __device__ __forceinline__ void live_kind(const rh_live_args &A, const double (&
     for (int c = c_lo; c < c_hi; c++) {
         const rh_prep P = prep[c];
         uint64_t hit = 0;
+        if (A.f32) {   // Float32 cloud: the binary32 test on the float record the stored one implies
+            const rh_prepf Pf = prepf_of<KIND>(P);
 #pragma unroll
-        for (int p = 0; p < RH_SC_PPT; p++)
-            hit |= test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & vm[p];
+            for (int p = 0; p < RH_SC_PPT; p++)
+                hit |= test_point32<KIND>(Pf, (float)px[p], (float)py[p], (float)pz[p], (float)qx[p], (float)qy[p], (float)qz[p], eps, cosa) & vm[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < RH_SC_PPT; p++)
+                hit |= test_point<KIND>(P, px[p], py[p], pz[p], qx[p], qy[p], qz[p], eps, cosa) & vm[p];
+        }
         if (hit != 0 && lane == 0) flags[A.base[KIND] + c] = 1;
     }
 }
@@ -1083,7 +1094,14 @@ int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, cons
     if (splits < 1) splits = 1;
     if (splits > ntiles) splits = ntiles;
     dim3 grid((unsigned)splits, (unsigned)ctiles);
-    if (masks)
+    if (c->f32) {
+        if (masks)
+            hipLaunchKernelGGL((score_kernel<KIND, true, true>), grid, dim3(RH_SC_THREADS), 0, c->stream, pts, stride, s, en,
+                               prep, orig, nk, eps, cosa, counts, masks, mask_stride);
+        else
+            hipLaunchKernelGGL((score_kernel<KIND, false, true>), grid, dim3(RH_SC_THREADS), 0, c->stream, pts, stride, s, en,
+                               prep, orig, nk, eps, cosa, counts, masks, mask_stride);
+    } else if (masks)
         hipLaunchKernelGGL((score_kernel<KIND, true>), grid, dim3(RH_SC_THREADS), 0, c->stream, pts, stride, s, en,
                            prep, orig, nk, eps, cosa, counts, masks, mask_stride);
     else
@@ -1777,7 +1795,8 @@ int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const 
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts)
 {
     if (cnt <= 0 || nk_bound <= 0) return RH_OK;
-    if (cnt < 512 || nk_bound < 256)   // tiny: the brute-force kernel has less overhead
+    // (Float32 cloud: the older culled kernel wants float records beside the binary64 ones; the brute-force kernel derives them)
+    if (cnt < 512 || nk_bound < 256 || c->f32)   // tiny: the brute-force kernel has less overhead
         return rhk_score_kind(c, kind, c->dis + first, c->dis_stride, cnt, nullptr, d_prep, d_orig, d_nk, nk_bound, eps,
                               cosa, d_counts, nullptr, 0);
     const int64_t ng = (cnt + 63) / 64;

@@ -212,6 +212,7 @@ struct rh_live_args {
     int32_t nk[4], base[4];
     int64_t first[4];
     double eps[4], cosa[4];
+    int32_t f32 = 0;     // Float32 cloud: the binary32 tests
 };
 
 // ---- kernel launchers (kernels.hip) -----------------------------------------

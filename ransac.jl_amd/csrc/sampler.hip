@@ -207,11 +207,25 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
 
 
 
+// fit(T, p, n, pc, params) for one shape type on a gathered minimal set (forcefitshapes!, fitting.jl:165-173).  f32: the cloud
+// is a Float32 cloud -- plane / sphere / cylinder fits in binary32 (fit_shared.h); its cones are refused before a run starts.
+template <bool CONE>
+static __device__ __forceinline__ bool fit_kind(int kind, const double *fp, const double *fn, int drawN, const rh_params &prm, int f32, rh_shape *s)
+{
+    switch (kind) {
+    case RH_PLANE: return f32 ? rhfit::fit_plane32(fp, fn, drawN, prm, s) : rhfit::fit_plane(fp, fn, drawN, prm, s);
+    case RH_SPHERE: return f32 ? rhfit::fit_sphere32(fp, fn, drawN, prm, s) : rhfit::fit_sphere(fp, fn, drawN, prm, s);
+    case RH_CYLINDER: return f32 ? rhfit::fit_cylinder32(fp, fn, drawN, prm, s) : rhfit::fit_cylinder(fp, fn, drawN, prm, s);
+    case RH_CONE: return (CONE && !f32) ? rhfit::fit_cone(fp, fn, drawN, prm, s) : false;
+    default: return false;
+    }
+}
+
 template <int DN, bool CONE>
 __global__ void __launch_bounds__(128)
 fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_level, int64_t total, const rh_params prm,
                 rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count, int32_t *__restrict__ nk_zero,
-                SetShard sh, int32_t it0, const rh_oct_state *__restrict__ ost)
+                SetShard sh, int32_t it0, const rh_oct_state *__restrict__ ost, int f32)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;   // the kind bins prep_entries_kernel fills next
@@ -236,14 +250,7 @@ fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_l
         for (int q = 0; q < 10; q++) s.v[q] = 0.0;
         s.kind = -1;
         s.outwards = 0;
-        bool fitted = false;
-        switch (prm.shape_types[ti]) {
-        case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
-        case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
-        case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
-        case RH_CONE: if (CONE) fitted = rhfit::fit_cone(fp, fn, drawN, prm, &s); break;
-        default: break;
-        }
+        const bool fitted = fit_kind<CONE>(prm.shape_types[ti], fp, fn, drawN, prm, f32, &s);
         if (!fitted) continue;
         const int32_t pos = atomicAdd(out_count, 1);
         if (pos < cap) {
@@ -288,7 +295,7 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
                         int32_t n_enabled, const rh_params prm,
                         uint64_t seed, int64_t k0, int32_t n_iters, rh_cand_entry *__restrict__ out, int32_t cap,
                         int32_t *__restrict__ out_count, unsigned long long *__restrict__ draws_per_iter,
-                        int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero, SetShard sh)
+                        int32_t *__restrict__ gave_up_flag, int32_t *__restrict__ nk_zero, SetShard sh, int f32)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;
@@ -349,13 +356,14 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
         for (int ti = 0; ti < prm.n_shape_types; ti++) {
             switch (prm.shape_types[ti]) {
             case RH_PLANE: {
+                // (Float32 cloud: the fit's dots are binary32, a few 1e-7 from these: 1e-5 below)
                 const double tpl = prm.cos_alpha[RH_PLANE];
                 const double d12 = rhfit::dot(rhfit::normalize(rhfit::Vec(fn)), rhfit::normalize(rhfit::Vec(fn + 3)));
-                maybe = maybe || !(tpl > 0.0 && d12 < 2.0 * tpl * tpl - 1.0 - 1e-9);
+                maybe = maybe || !(tpl > 0.0 && d12 < 2.0 * tpl * tpl - 1.0 - (f32 ? 1e-5 : 1e-9));
                 break;
             }
-            case RH_SPHERE: maybe = maybe || rhfit::fit_sphere(fp, fn, 2, prm, &tmp); break;
-            case RH_CYLINDER: maybe = maybe || rhfit::fit_cylinder(fp, fn, 2, prm, &tmp); break;
+            case RH_SPHERE: maybe = maybe || fit_kind<false>(RH_SPHERE, fp, fn, 2, prm, f32, &tmp); break;
+            case RH_CYLINDER: maybe = maybe || fit_kind<false>(RH_CYLINDER, fp, fn, 2, prm, f32, &tmp); break;
             default: maybe = true; break;
             }
         }
@@ -373,13 +381,7 @@ sample_fit_ranks_kernel(const double *__restrict__ crec, const double *__restric
         for (int q = 0; q < 10; q++) s.v[q] = 0.0;
         s.kind = -1;
         s.outwards = 0;
-        bool fitted = false;
-        switch (prm.shape_types[ti]) {
-        case RH_PLANE: fitted = rhfit::fit_plane(fp, fn, drawN, prm, &s); break;
-        case RH_SPHERE: fitted = rhfit::fit_sphere(fp, fn, drawN, prm, &s); break;
-        case RH_CYLINDER: fitted = rhfit::fit_cylinder(fp, fn, drawN, prm, &s); break;
-        default: break;   // cones take the two-kernel path
-        }
+        const bool fitted = fit_kind<false>(prm.shape_types[ti], fp, fn, drawN, prm, f32, &s);   // (cones take the two-kernel path)
         if (!fitted) continue;
         const int32_t pos = atomicAdd(out_count, 1);
         if (pos < cap) {
@@ -809,10 +811,10 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
         const dim3 gk((unsigned)((total + 127) / 128));
         if (prm->drawN == 3)
             hipLaunchKernelGGL(sample_fit_ranks_kernel<3>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
-                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh);
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh, c->f32 ? 1 : 0);
         else
             hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
-                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh);
+                               seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh, c->f32 ? 1 : 0);
         RH_HIP(hipGetLastError());
         return RH_OK;
     }
@@ -821,7 +823,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
                        prm->drawN, prm->minsubsetN, seed, k0, n_iters, c->set_ws, c->set_level, d_draws, d_gave_up, crec, sh, ost)
 #define RH_FIT(DN, CONE)                                                                                               \
     hipLaunchKernelGGL((fit_sets_kernel<DN, CONE>), gf, dim3(128), 0, c->stream, c->set_ws, c->set_level, total, *prm, \
-                       d_out, cap, d_count, d_nk_zero, sh, it0, ost)
+                       d_out, cap, d_count, d_nk_zero, sh, it0, ost, c->f32 ? 1 : 0)
     if (prm->drawN == 3) {   // the reference's default: fully unrolled, no scratch
         RH_SAMPLE(3);
         if (cone) RH_FIT(3, true); else RH_FIT(3, false);

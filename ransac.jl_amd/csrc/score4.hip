@@ -179,7 +179,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const int64_t gi = p0 + g2 * 64 + lane;
             uint64_t mres;
             if (F32) {   // Float32 cloud: the reference's test is the binary32 one (the points are floats, stored exactly)
-                const rh_prepf Pf = ld_prepf(&prep32[ci2]);
+                const rh_prepf Pf = prepf_of<KIND>(rh_ld_prep_const(&prep[ci2]));   // (the float record follows from the binary64 one: score_device32.h)
                 mres = test_point32<KIND>(Pf, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
                                           (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
             } else {
@@ -233,7 +233,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
             const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
             uint64_t r;
             if (F32) {
-                const rh_prepf Pv = prep32[cbase + (int)(pe >> S4_GB)];
+                const rh_prepf Pv = prepf_of<KIND>(prep[cbase + (int)(pe >> S4_GB)]);
                 r = test_point32<KIND>(Pv, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
                                        (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
             } else {
@@ -746,6 +746,8 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
                    uint8_t *d_occ, int64_t mstride, const void *const prep32[4])
 {
     const bool open_count = c->s4_open_count;
+    const bool f32cloud = c->f32;   // the exact tests in binary32, on float records derived from `prep` (prep32 is no longer read)
+    (void)prep32;
     // the points: subset 1 in internal order, or the set rhk_score4_dis put in place (a segment of the disabled list)
     rh_s4_points PS = { c->sub, c->s_pad, c->s, c->ngroups, c->gb32 };
     if (c->s4_points != nullptr) PS = *c->s4_points;
@@ -797,7 +799,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 32) : 0);
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
         dim3 gt(tiles_x, 1);
-        if (prep32 != nullptr) {
+        if (f32cloud) {
             if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
             else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         } else {
@@ -808,7 +810,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         return RH_OK;
     }
 #define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg)
-    if (prep32 != nullptr) {   // Float32 cloud: c->sub holds the exactly converted values
+    if (f32cloud) {   // Float32 cloud: c->sub (and the disabled list) hold the exactly converted values
         if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
         else { if (R == 4) RH_S4_LAUNCH(4, false, true); else RH_S4_LAUNCH(8, false, true); }
     } else if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, false); else RH_S4_LAUNCH(8, true, false); }
@@ -821,7 +823,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         if (d_masks_int != nullptr) { rh_set_error("rhk_score4_all: masks need an exact candidate count"); return RH_E_INTERNAL; }
         A.row0 = (int)rows;
         dim3 gt(tiles_x, 2);
-        if (prep32 != nullptr) {
+        if (f32cloud) {
             if (R == 4) hipLaunchKernelGGL((score4_kernel<4, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
             else hipLaunchKernelGGL((score4_kernel<8, false, true, true>), gt, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);
         } else {

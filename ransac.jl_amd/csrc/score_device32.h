@@ -46,6 +46,36 @@ __host__ __device__ inline void prep_one32(const rh_shape &s, rh_prepf &o)
     }
 }
 
+// The float record of a candidate from its binary64 record (rh_prep, kernels.hip prep_one): the record's leading fields are the
+// shape's own numbers (+ sgn), so the casts reproduce prep_one32 -- exactly for a Float32 shape, whose fields are binary32
+// numbers, and with the same single rounding for any other; a plane's normalised normal (f[6..8]) is recomputed in
+// binary32 (plane.jl:85 on a Float32 plane).  Lets every kernel that holds only rh_prep records (the candidate store of
+// rh_ransac, the liveness passes) run the binary32 test of a Float32 cloud.
+template <int KIND>
+__host__ __device__ inline rh_prepf prepf_of(const rh_prep &P)
+{
+    rh_prepf o;
+    for (int i = 0; i < 9; i++) o.f[i] = (float)P.f[i];
+    for (int i = 9; i < 12; i++) o.f[i] = 0.0f;
+    if (KIND == RH_PLANE) {
+        const float a = o.f[3], b = o.f[4], c = o.f[5];
+        const float inv = 1.0f / sqrtf((a * a + b * b) + c * c);
+        o.f[6] = inv * a; o.f[7] = inv * b; o.f[8] = inv * c;
+    }
+    if (KIND == RH_SPHERE) { o.f[5] = o.f[6] = o.f[7] = o.f[8] = 0.0f; }
+    if (KIND == RH_CYLINDER) { o.f[8] = 0.0f; }
+    return o;
+}
+__host__ __device__ inline rh_prepf prepf_of_kind(const rh_prep &P, int kind)
+{
+    switch (kind) {
+    case RH_PLANE: return prepf_of<RH_PLANE>(P);
+    case RH_SPHERE: return prepf_of<RH_SPHERE>(P);
+    case RH_CYLINDER: return prepf_of<RH_CYLINDER>(P);
+    default: return prepf_of<RH_CONE>(P);
+    }
+}
+
 #ifdef __HIPCC__
 #define RH_CONST32 __attribute__((address_space(4)))
 static __device__ __forceinline__ rh_prepf ld_prepf(const rh_prepf *p)

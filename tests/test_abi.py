@@ -118,6 +118,43 @@ def test_fit_bit_identical_to_oracle(kind):
     assert nfit > 50
 
 
+@pytest.mark.parametrize("kind", [orc.PLANE, orc.SPHERE, orc.CYLINDER])
+def test_fit_f32_bit_identical_to_oracle(kind):
+    """fit on Float32 points (a Float32 cloud, octree.jl:102-109): rh_fit_f32 -- the binary32 instantiation of
+    fit_shared.h, the same code the device fits of rh_ransac run -- against the oracle's own binary32 restatement
+    (oracle/orc_f32.c), parameter for parameter; the results are Float32 shapes and differ from the Float64 fit of the
+    same (rounded) points."""
+    rng = np.random.default_rng(300 + kind)
+    po = orc.default_params()
+    pp = L.Params.from_buffer_copy(bytes(po))
+    nfit = ndiff = 0
+    for p, n in _minimal_sets(kind, rng, 400):
+        p32, n32 = p.astype(np.float32), n.astype(np.float32)
+        pd, nd = np.ascontiguousarray(p32, dtype=np.float64), np.ascontiguousarray(n32, dtype=np.float64)
+        a = orc.fit32(kind, p32, n32, po)
+        out, ok = L.Shape(), C.c_int32()
+        L.check(R.lib().rh_fit_f32(kind, pd.ctypes.data_as(C.POINTER(C.c_double)), nd.ctypes.data_as(C.POINTER(C.c_double)),
+                                   3, C.byref(pp), C.byref(out), C.byref(ok)))
+        assert bool(ok.value) == (a is not None)
+        if a is not None:
+            nfit += 1
+            assert bytes(a) == bytes(out)
+            assert all(float(np.float32(x)) == x for x in list(out.v)[:7])
+            b = orc.fit(kind, pd, nd, po)
+            ndiff += b is None or bytes(b) != bytes(a)
+    assert nfit > 50 and ndiff > nfit // 2
+    # the mirror: fit() on float32 arrays is the Float32 fit; the cone is refused
+    for p, n in _minimal_sets(kind, rng, 5):
+        m = R.fit({orc.PLANE: R.FittedPlane, orc.SPHERE: R.FittedSphere, orc.CYLINDER: R.FittedCylinder}[kind],
+                  p.astype(np.float32), n.astype(np.float32), None, pp)
+        a = orc.fit32(kind, p, n, po)
+        assert (m is None) == (a is None)
+    out, ok = L.Shape(), C.c_int32()
+    z = np.zeros(9)
+    assert R.lib().rh_fit_f32(orc.CONE, z.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double)), 3,
+                              C.byref(pp), C.byref(out), C.byref(ok)) != 0
+
+
 def test_estimatescore_prob_rng_match_oracle():
     rng = np.random.default_rng(5)
     for mode in (L.SCORE_INT64_WRAP, L.SCORE_F64):

@@ -208,8 +208,8 @@ def test_f32_device_batch_and_unsupported_calls(scene32):
     L.check(R.lib().rh_cloud_sync(pc._h))
     assert np.array_equal(counts.cpu().numpy(), oc.score_batch(to_orc(arr, 300), orc.Params.from_buffer_copy(bytes(cp))))
     batch.free()
-    with pytest.raises(R.RansacHipError):
-        R.ransac(pc, cp, seed=1)
+    with pytest.raises(R.RansacHipError, match="FittedCone"):
+        R.ransac(pc, cp, seed=1)          # the default shape_types hold FittedCone: not available on a Float32 cloud
     with pytest.raises(R.RansacHipError):
         R.refit_lsq(arr[0], pc, cp)
 
@@ -238,3 +238,66 @@ def test_f32_full_size_refit_halves_the_bytes():
     assert a.value < 0.08          # the Float64 scan of the same cloud takes 0.081 ms
     counts = R.score_batch(pc, arr, cp)
     assert np.array_equal(counts, oc.score_batch(to_orc(arr, 80), op, nthreads=16))
+
+
+# ---- ransac() on a Float32 cloud: fits, scoring, candidate liveness and refit in binary32 (octree.jl:102-109,
+# utilities.jl:488-503, plane.jl:33-57, sphere.jl:29-114, cylinder.jl:34-168) against the oracle's binary32 loop
+def _same_run(got, st, exp, pc, oc):
+    assert exp["rc"] == 0
+    assert st["iterations"] == exp["iterations"] and st["candidates_scored"] == exp["candidates_scored"]
+    assert st["scored_left"] == exp["scored_left"] and st["draws"] == exp["draws"]
+    assert len(got) == len(exp["shapes"])
+    for g, e in zip(got, exp["shapes"]):
+        assert bytes(g.c_shape) == bytes(e["shape"])                      # fitted parameters: the same binary32 numbers
+        assert np.array_equal(g.inpoints, e["inpoints"])
+        assert g.score_E == e["score_E"] and g.iteration == e["iteration"]
+        assert all(float(np.float32(x)) == x for x in list(g.c_shape.v)[:7])   # a Float32 shape
+    assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
+
+
+@pytest.mark.parametrize("streams,octree", [(0, False), (1, False), (1, True)])
+def test_f32_ransac_cfg1_end_to_end(streams, octree):
+    c = synth.config("cfg1")
+    subs = synth.make_subsets(50000, c["r"], c["seed"])
+    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs, force_eltype=np.float32)
+    oc = orc.Cloud(c["xyz"], c["nrm"], subs[0], f32=True)
+    params = R.ransacparameters([R.FittedPlane, R.FittedSphere])
+    cp = R.params_to_c(params, sampling_streams=streams, octree_sampling=octree)
+    got, _, st = R.ransac(pc, cp, seed=1234, return_stats=True)
+    exp = oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=1234)
+    assert len(got) == 2 and {R.strt(g.shape) for g in got} == {"plane", "sphere"}
+    _same_run(got, st, exp, pc, oc)
+    # and it is NOT the Float64 run on the same values: the fitted parameters differ in their low bits
+    pc64 = R.RANSACCloud(pc.vertices, pc.normals, subs)
+    got64, _ = R.ransac(pc64, cp, seed=1234)
+    assert any(bytes(a.c_shape) != bytes(b.c_shape) for a, b in zip(got, got64))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("env", [None, "RH_HOST_SAMPLER", "RH_NO_FUSED_SCORE", "RH_NO_FAST_EXTRACT", "RH_NO_PIPELINE", "RH_NO_V4_LIVENESS"])
+def test_f32_ransac_multi_primitive(seed, env, monkeypatch):
+    prim = ["plane", "plane", "sphere", "cylinder", "cylinder", "sphere"]
+    xyz, nrm, truth = synth.make_cloud(60_000, prim, 0.2, seed=40 + seed)
+    subs = synth.make_subsets(60_000, 2, seed=seed)
+    if env:
+        monkeypatch.setenv(env, "1")
+    pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
+    oc = orc.Cloud(xyz, nrm, subs[0], f32=True)
+    params = R.ransacparameters([R.FittedPlane, R.FittedCylinder, R.FittedSphere],
+                                iteration={"minsubsetN": 200, "itermax": 60, "τ": 300, "prob_det": 0.9})
+    cp = R.params_to_c(params, score_mode=L.SCORE_F64, sphere_uses_enabled=bool(seed & 1), sampling_streams=1, octree_sampling=(seed == 3))
+    got, _, st = R.ransac(pc, cp, seed=100 + seed, return_stats=True)
+    exp = oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=100 + seed)
+    assert len(got) >= 3 and len({R.strt(g.shape) for g in got}) >= 2
+    _same_run(got, st, exp, pc, oc)
+
+
+def test_f32_ransac_refuses_cones_on_both_sides():
+    c = synth.config("cfg1")
+    subs = synth.make_subsets(50000, c["r"], c["seed"])
+    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs, force_eltype=np.float32)
+    oc = orc.Cloud(c["xyz"], c["nrm"], subs[0], f32=True)
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedCone]))
+    with pytest.raises(R.RansacHipError, match="FittedCone"):
+        R.ransac(pc, cp, seed=1)
+    assert oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=1)["rc"] == -3

@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 _ENV = ("RH_SCORE_PATH", "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
-        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH")
+        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS",
+        "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS")
 
 
 @pytest.fixture(autouse=True)
@@ -95,13 +96,15 @@ def test_refit_fuzz_slice(seed, ncases, f32):
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("seed,ncases", [(31, 15), (32, 15)])
-def test_e2e_fuzz_slice(seed, ncases):
+@pytest.mark.parametrize("seed,ncases,f32", [(31, 15, False), (32, 15, False), (33, 15, True), (34, 15, True)])
+def test_e2e_fuzz_slice(seed, ncases, f32):
+    """f32: ransac() on Float32 clouds (octree.jl:102-109) -- fits, scoring, liveness and refit in binary32 -- against the
+    oracle's binary32 loop (oracle/orc_f32.c), through the same random modes and driver switches."""
     import fuzz_e2e
     rng = np.random.default_rng(seed)
     bad = []
     for case in range(ncases):
-        ok, desc = fuzz_e2e.one(case + 100 * seed, rng)
+        ok, desc = fuzz_e2e.one(case + 100 * seed, rng, f32=f32)
         if not ok:
             bad.append(desc)
     assert not bad, bad[:3]

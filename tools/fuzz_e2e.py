@@ -12,7 +12,7 @@ from oracle import oracle as orc
 KINDS = {"plane": R.FittedPlane, "sphere": R.FittedSphere, "cylinder": R.FittedCylinder, "cone": R.FittedCone}
 
 
-def one(case, rng):
+def one(case, rng, f32=False):
     n = int(rng.choice([6_000, 20_000, 40_000, 90_000]))
     names = list(rng.choice(list(KINDS), size=int(rng.integers(2, 7))))
     out_frac = float(rng.choice([0.0, 0.1, 0.3]))
@@ -20,6 +20,8 @@ def one(case, rng):
     xyz, nrm, truth = synth.make_cloud(n, names, out_frac, seed=1000 + case)
     subs = synth.make_subsets(n, r, seed=case)
     types = [KINDS[k] for k in sorted(set(names), key=lambda k: rng.random())]
+    if f32:   # a Float32 cloud: the whole loop in binary32; its cone fit is not available (the scene may still hold cone points)
+        types = [t for t in types if t is not R.FittedCone] or [R.FittedPlane]
     it = {"minsubsetN": int(rng.choice([15, 40, 120])), "τ": int(rng.choice([50, 300, 900])),
           "itermax": int(rng.choice([30, 120, 400])), "prob_det": float(rng.choice([0.5, 0.8, 0.9])),
           "drawN": int(rng.choice([3, 3, 3, 4]))}
@@ -52,8 +54,12 @@ def one(case, rng):
         os.environ["RH_NO_FAST_EXTRACT"] = "1"
     # the culled refit scan (korder.hip) on these small clouds in two cases of three, the plain scan in the third
     os.environ["RH_REFIT_PATH"] = str(rng.choice(["culled", "culled", "scan"]))
-    pc = R.RANSACCloud(xyz, nrm, subs)
-    oc = orc.Cloud(xyz, nrm, subs[0])
+    if f32:
+        pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
+        oc = orc.Cloud(xyz, nrm, subs[0], f32=True)
+    else:
+        pc = R.RANSACCloud(xyz, nrm, subs)
+        oc = orc.Cloud(xyz, nrm, subs[0])
     cp = R.params_to_c(params, **kw)
     seed = int(rng.integers(1, 10_000))
     got, secs, st = R.ransac(pc, cp, seed=seed, return_stats=True)
@@ -63,7 +69,7 @@ def one(case, rng):
           and all(bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
                   and g.score_E == e["score_E"] and g.iteration == e["iteration"] for g, e in zip(got, exp["shapes"]))
           and np.array_equal(pc.enabled_chunks(), oc.get_enabled()))
-    desc = "n=%d r=%d prims=%s types=%s it=%s %s env=%s seed=%d -> %d shapes, %d cands, %d its" % (
+    desc = ("f32 " if f32 else "") + "n=%d r=%d prims=%s types=%s it=%s %s env=%s seed=%d -> %d shapes, %d cands, %d its" % (
         n, r, "".join(k[0] for k in names), "".join(R.strt(t)[0] if hasattr(R, "strt") and not isinstance(t, type) else t.__name__[6] for t in types),
         it, {k: int(v) for k, v in kw.items()}, env, seed, len(got), st["candidates_scored"], st["iterations"])
     return ok, desc
@@ -75,7 +81,7 @@ def main():
     bad = 0
     t0 = time.time()
     for case in range(ncases):
-        ok, desc = one(case, rng)
+        ok, desc = one(case, rng, f32=bool(os.environ.get("F32")))   # F32=1: Float32 clouds against the oracle's binary32 loop
         print("%s case %2d  %s" % ("ok  " if ok else "FAIL", case, desc), flush=True)
         bad += not ok
     print("%d cases, %d failures, %.0f s" % (ncases, bad, time.time() - t0))
