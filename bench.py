@@ -335,6 +335,10 @@ def main():
                          "(RH_BENCH_SHARE_GPU0=1 RH_BENCH_BACKEND=gloo rehearses the N > 1 flow on one GPU)"
                          % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    t0 = time.perf_counter()
+    torch.zeros(1, device="cuda")       # the process's first HIP call creates the context (60-300 ms on these boxes): before anything is timed
+    torch.cuda.synchronize()
+    t_hip_context = time.perf_counter() - t0
     # RH_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, pipelined scorer, all-reduce) with
     # one rank -- the RCCL rehearsal a one-GPU box allows
     multi = world > 1 or bool(os.environ.get("RH_BENCH_FORCE_DIST"))
@@ -381,12 +385,12 @@ def main():
     t_setup = time.time() - t0
     cms = (C.c_double * 4)()
     L.check(R.lib().rh_cloud_create_ms(pc._h, cms))
-    cloud_create = {"ms_total": cms[0], "ms_kd_leaf_order_host": cms[1], "ms_before_kd": cms[2], "ms_after_kd": cms[3],
-                    "scene_generation_s": t_scene,
-                    "note": "rh_cloud_create alone (setup_seconds also holds numpy's scene generation): total wall time, of "
-                            "which the single-threaded host k-d leaf order of subset 1 (std::nth_element recursion; what gives the "
-                            "score kernel its compact 64-point groups), the part before it (allocations, H2D, AoS -> SoA, Morton "
-                            "order of the cloud on the device: rocPRIM radix sort) and the part after it"}
+    cloud_create = {"ms_total": cms[0], "ms_subset_order": cms[1], "ms_before_it": cms[2], "ms_after_it": cms[3],
+                    "scene_generation_s": t_scene, "hip_context_ms_before": 1e3 * t_hip_context,
+                    "note": "rh_cloud_create alone, first cloud of the process, HIP context already there (setup_seconds also "
+                            "holds numpy's scene generation): total wall time, of which the k-d leaf order of subset 1 (on the "
+                            "device: one radix sort per level, kdorder.hip; RH_KD_HOST=1: the host's nth_element recursion), the "
+                            "part before it (allocations, uploads, AoS -> SoA, bounding box, Morton order of the cloud) and after it"}
     params = R.ransacparameters(types)
     cp = R.params_to_c(params, score_mode=L.SCORE_F64)   # Int64 score wraps at this size
 

@@ -318,9 +318,11 @@ int rh_score_batch_allreduce_dev(rh_cloud *c, rh_comm *m, const rh_shape *d_shap
 int rh_comm_fence(rh_comm *m, rh_cloud *c);
 int rh_comm_sync(rh_comm *m);
 
-/* wall time of the rh_cloud_create call that made the cloud, ms: [0] total, [1] the host-side k-d leaf order of subset 1
- * (what gives the culled score kernel its compact 64-point groups; single-threaded), [2] before it (allocations,
- * uploads, AoS -> SoA, Morton order of the cloud on the device), [3] after it (subset gather, group boxes, enabled bits) */
+/* wall time of the rh_cloud_create call that made the cloud, ms: [0] total, [1] the k-d leaf order of subset 1 (what
+ * gives the culled score kernel its compact 64-point groups; built on the device, a radix sort per tree level --
+ * RH_KD_HOST=1 keeps the host's nth_element recursion as the A/B), [2] before it (allocations, uploads, AoS -> SoA,
+ * bounding box, Morton order of the cloud on the device), [3] after it (enabled bits).  RH_CREATE_PROF=1 prints the
+ * stages on stderr. */
 int rh_cloud_create_ms(const rh_cloud *c, double *out4);
 
 /* ---- diagnostics (tests) ---- */

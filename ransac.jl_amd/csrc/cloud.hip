@@ -251,6 +251,29 @@ static void cloud_aabb(const double *xyz, int64_t n, double lo[3], double *size_
     *mag_out = mag;
 }
 
+// the same box from the uploaded copy (rhk_cloud_aabb, kdorder.hip).  The host loop's lo / hi start at the first point and
+// move by plain comparisons, so a NaN in the first point stays (every comparison with it is false) and any other NaN is
+// skipped; infinities take part.  Same values, bit for bit: the Morton codes (and the oracle's octree) hang on them.
+static int cloud_aabb_device(rh_cloud *c, const double *d_xyz, const double *xyz, int64_t n)
+{
+    double lo[3], hi[3], mag = 0;
+    bool has[3];
+    RH_TRY(rhk_cloud_aabb(c, d_xyz, n, lo, hi, has, &mag));
+    for (int k = 0; k < 3; k++) {
+        const double first = n > 0 ? xyz[k] : 0.0;
+        if (n > 0 && !(first == first)) { lo[k] = first; hi[k] = first; }   // a NaN first point: nothing ever replaces it
+        else if (!has[k]) { lo[k] = 0; hi[k] = 0; }
+        c->k_lo[k] = lo[k];
+    }
+    double size = 0;
+    for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > size) size = hi[k] - lo[k];
+    size = size * (1 + 1e-9);
+    if (!(size > 0)) size = 1;
+    c->k_size = size;
+    c->k_mag = mag;
+    return RH_OK;
+}
+
 // linear (Morton) octree of the full cloud: codes in the bounding CUBE, sorted by (code, index) -- the Morton order the
 // cloud was given on the device when it was created (korder.hip); here: the host twins and
 // depth = first level whose fullest cell holds <= 8 points (src/octree.jl:163-165), capped.
@@ -319,6 +342,9 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     const auto tc0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double ms_kd = 0, ms_before_kd = 0;
+    // RH_CREATE_PROF=1: wall time of every stage on stderr (each stamp waits for the stream: the stages stop overlapping)
+    const bool prof = getenv("RH_CREATE_PROF") != nullptr;
+    double t_prev = 0;
 
     rh_cloud *c = new (std::nothrow) rh_cloud();
     if (!c) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
@@ -337,6 +363,13 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     int rc = RH_OK;
     double *t_xyz = nullptr, *t_nrm = nullptr;
     int32_t *h_idx = nullptr;
+    auto stamp = [&](const char *what) {
+        if (!prof) return;
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        const double t = ms_since(tc0);
+        fprintf(stderr, "[rh_cloud_create] %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
     auto fail = [&](int code) {
         (void)hipFree(t_xyz); (void)hipFree(t_nrm);
         delete[] h_idx;
@@ -389,16 +422,22 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipMemsetAsync(c->sub, 0, sizeof(double) * 6 * (size_t)c->s_pad, c->stream));
     CKH(hipMemsetAsync(c->dis, 0, sizeof(double) * 6 * (size_t)c->dis_stride, c->stream));
     CKH(hipMemsetAsync(c->d_total, 0, sizeof(int32_t), c->stream));
+    stamp("streams, allocations, memsets");
 
     if (n > 0) {
         CK(dev_alloc(&t_xyz, 3 * n));
         CK(dev_alloc(&t_nrm, 3 * n));
         CKH(hipMemcpyAsync(t_xyz, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
         CKH(hipMemcpyAsync(t_nrm, nrm, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        stamp("upload (xyz, nrm)");
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
         CK(rhk_pack_records(c, t_xyz, t_nrm, n, c->rec));
-        cloud_aabb(xyz, n, c->k_lo, &c->k_size, &c->k_mag);
+        stamp("AoS -> SoA, records");
+        if (getenv("RH_AABB_HOST")) cloud_aabb(xyz, n, c->k_lo, &c->k_size, &c->k_mag);   // (A/B: 25 ms at 10M points, 120 ms at 50M)
+        else CK(cloud_aabb_device(c, t_xyz, xyz, n));
+        stamp("bounding box");
         CK(rhk_korder_build(c, t_xyz, t_nrm, c->k_lo, c->k_size, c->k_mag));
+        stamp("Morton order of the cloud");
         if (s > 0) {
             // internal order of subset 1: 64 consecutive points are spatially compact, which is what the
             // culled score kernel's per-group boxes need (k-d leaves, below)
@@ -406,6 +445,24 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
             if (!h_idx) { rh_set_error("out of host memory"); return fail(RH_E_NOMEM); }
             ms_before_kd = ms_since(tc0);
             const auto tkd0 = std::chrono::steady_clock::now();
+            // Where the order is made: on the device (kdorder.hip: a radix sort per level of the same balanced k-d tree; the
+            // subset's coordinate / normal magnitudes come out of the same pass) unless RH_KD_HOST=1 or RH_SUB_ORDER=morton
+            // ask for the host forms below (A/B; the counts do not depend on the order).
+            const char *ord_env0 = getenv("RH_SUB_ORDER");
+            const bool kd_device = !getenv("RH_KD_HOST") && !(ord_env0 && ord_env0[0] == 'm');
+            if (kd_device) {
+                for (int64_t j = 0; j < s; j++) h_idx[j] = (int32_t)(subset1[j] - 1);
+                int32_t *d_idx_in = nullptr;
+                CK(dev_alloc(&d_idx_in, s));
+                hipError_t ec = hipMemcpyAsync(d_idx_in, h_idx, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream);
+                rc = ec == hipSuccess ? rhk_kd_order(c, t_xyz, t_nrm, d_idx_in) : RH_E_NODEVICE;
+                (void)hipFree(d_idx_in);
+                if (ec != hipSuccess) rh_set_error("hipMemcpyAsync(subset indices): %s", hipGetErrorString(ec));
+                if (rc != RH_OK) return fail(rc);
+                ms_kd = ms_since(tkd0);
+                CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, c->sub_idx0, s, c->sub, c->s_pad));
+                CK(rhk_group_bounds(c));
+            } else {
             double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 }, mag = 0;
             bool first = true;
             for (int64_t j = 0; j < s; j++) {
@@ -531,10 +588,13 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
             CKH(hipMemcpyAsync(c->sub_perm, h_perm, sizeof(int32_t) * (size_t)s, hipMemcpyHostToDevice, c->stream));
             CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, c->sub_idx0, s, c->sub, c->s_pad));
             CK(rhk_group_bounds(c));
+            }   // host forms of the order
         }
     }
+    stamp("subset order, gather, boxes");
     CK(set_all_enabled(c));
     CKH(hipStreamSynchronize(c->stream));
+    stamp("enabled bits");
 #undef CK
 #undef CKH
     (void)hipFree(t_xyz);
@@ -548,9 +608,9 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     return RH_OK;
 }
 
-// wall time of the rh_cloud_create that made this cloud, in ms: total, the host-side k-d leaf order of subset 1
-// (single-threaded), everything before it (allocations, uploads, AoS -> SoA, the Morton order of the cloud on the
-// device), everything after it (subset gather, group boxes, enabled bits)
+// wall time of the rh_cloud_create that made this cloud, in ms: total, the k-d leaf order of subset 1 (device: kdorder.hip;
+// RH_KD_HOST=1: host threads) with the subset gather and the group boxes, everything before it (allocations, uploads,
+// AoS -> SoA, bounding box, the Morton order of the cloud on the device), everything after it (enabled bits)
 extern "C" int rh_cloud_create_ms(const rh_cloud *c, double *out4)
 {
     if (!c || !out4) { rh_set_error("rh_cloud_create_ms: NULL argument"); return RH_E_INVALID; }

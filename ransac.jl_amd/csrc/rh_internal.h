@@ -268,6 +268,8 @@ int rhk_score_all_f32(rh_cloud *c, const rh_shape *d_shapes, int via_orig, const
                       const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], const double eps[4],
                       const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int);
 int rhk_refit_mask_f32(rh_cloud *c, const rh_shape &shape, double eps, double cosa, bool apply = false);
+int rhk_cloud_aabb(rh_cloud *c, const double *d_xyz, int64_t n, double lo[3], double hi[3], bool has[3], double *mag);   // kdorder.hip
+int rhk_kd_order(rh_cloud *c, const double *d_xyz, const double *d_nrm, const int32_t *d_idx0);   // kdorder.hip: subset 1's k-d leaf order on the device
 int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts);
 int rhk_group_bounds(rh_cloud *c);
