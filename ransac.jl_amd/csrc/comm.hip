@@ -5,6 +5,7 @@
 // it), the collective runs on the communicator's own stream behind an event of the cloud's stream, so that batch i's
 // all-reduce overlaps batch i + 1's scoring (the caller alternates two count buffers, like dist.ShardedScorer).
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rccl/rccl.h>
@@ -28,6 +29,13 @@ Rccl *rccl()
     static bool tried = false;
     if (tried) return r.h ? &r : nullptr;
     tried = true;
+    // RH_RCCL_LIB: a library to bind instead (tests/native/fake_rccl.cpp: the same five entry points over host shared
+    // memory, so that the step can meet a second rank on a one-GPU box -- RCCL refuses two ranks on one device)
+    const char *forced = getenv("RH_RCCL_LIB");
+    if (forced && forced[0]) {
+        r.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!r.h) return nullptr;
+    }
     const char *names[] = { "librccl.so.1", "librccl.so" };
     for (const char *n : names)   // one already in the process (PyTorch's) first
         if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

@@ -1,8 +1,12 @@
 """The multi-GPU step behind the C ABI (rh_comm_create / rh_score_batch_allreduce_dev, include/ransac_hip.h): the
 library reaches RCCL itself.  On the one GPU of the test box: a ONE-rank communicator (a real ncclCommInitRank and a
 real ncclAllReduce on the communicator's stream) must give exactly what rh_score_batch_dev gives, for a slice with an
-offset into a larger zero-padded count buffer as well; two ranks cannot share one GPU under RCCL (it refuses duplicate
-devices), so N > 1 stays with the driver's multi-GPU run (bench.py --collective lib)."""
+offset into a larger zero-padded count buffer as well.  Two ranks cannot share one GPU under RCCL (it refuses duplicate
+devices), so the step meets its second and third rank over a test-only stand-in for librccl's five entry points
+(tests/native/fake_rccl.cpp: stream-ordered copies + a host callback that sums the ranks' data in POSIX shared memory),
+bound through RH_RCCL_LIB: offsets, the prepare launch's zeroing of the whole total, the plain-fill path of small and
+empty slices, the two-buffer rotation and the stream-ordered fence, across processes.  The real RCCL path at N > 1 is
+the driver's multi-GPU run (bench.py --collective lib): unmeasured here."""
 import ctypes as C
 
 import numpy as np
@@ -13,6 +17,45 @@ from ransac_jl_amd import _lib as L
 from ransac_jl_amd import dist as rdist, synth
 
 pytestmark = pytest.mark.gpu
+
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    subprocess.check_call([hipcc, "-O2", "-fPIC", "-shared", "-std=c++17", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"), "-o", so, "-lrt"])
+    return so
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_collective_across_processes_sharing_gpu0(world, fake_rccl, tmp_path):
+    """world ranks, one process each, all on GPU 0: every rank scores its slice of 18 batches (pairs and bursts of four in flight) through
+    rh_score_batch_allreduce_dev and must end up with EVERY candidate's count, equal to plain rh_score_batch_dev."""
+    env = dict(os.environ, RH_RCCL_LIB=fake_rccl, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idfile = str(tmp_path / "id.bin")
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "native", "comm_worker.py"), str(r), str(world), idfile,
+                                       str(tmp_path / ("out%d.txt" % r))], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:           # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
+        line = open(tmp_path / ("out%d.txt" % r)).read().split()
+        assert line[0] == "ok" and int(line[1]) == 10 and int(line[2]) > 10000
 
 
 def test_one_rank_library_collective_equals_plain_scoring():
