@@ -193,7 +193,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
     } else {
         rh_cls C;
 #pragma unroll
-        for (int f = 0; f < 14; f++) C.f[f] = rec->f[f];
+        for (int f = 0; f < 13; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
         // two words per pair, bits shifted in from the right (no 32-bit literal per point) and un-reversed afterwards:
         // s = surely an inlier, m = undecided (|t| <= 1/2, NaN included)

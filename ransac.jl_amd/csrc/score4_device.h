@@ -66,7 +66,7 @@ constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
 // plane:    0-2 n / wN | 3 -cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
 // sphere:   0-2 o | 3 R | 4 1 / wD | 5 eD_lo / wD | 6 sgn / wN | 7 -cN_hi / wN
 // cylinder: 0-2 a | 3-5 c0 | 6 R | 7 1 / wD | 8 eD_lo / wD | 9 sgn / wN | 10 -cN_hi / wN
-// cone:     0-2 apex | 3-5 a^ | 6 c' / wD | 7 s' / wD | 8 eD_lo / wD | 9 sgn c' / wL | 10 sgn s' / wL | 11 -cos(alpha) / wL | 12 alpha | 13 beta
+// cone:     0-2 apex | 3-5 a^ | 6 c' / wD | 7 s' / wD | 8 eD_lo / wD | 9 sgn c' / wL | 10 sgn s' / wL | 11 -cos(alpha) / wL | 12 beta
 
 // culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
 // the box tests of stage 1 read, coalesced, with lane = candidate
@@ -264,8 +264,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             if (dbg4 != nullptr) { dbg4[0] = 0.0; dbg4[1] = wL; dbg4[2] = eDlo; dbg4[3] = wD; }
             for (int i = 6; i < 12; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
-        o.f[12] = RH_CONE_ALPHA;    // next to the axis: rho^2 <= alpha |w|^2 + beta -> undecided
-        o.f[13] = cls_up(beta);
+        o.f[12] = cls_up(beta);     // next to the axis: rho^2 <= alpha |w|^2 + beta -> undecided (alpha = RH_CONE_ALPHA)
         const double e = band_ok ? (eps / cn) * (1.0 + 1e-9) + ek : 0.0;
         const bool box_ok = band_ok && cls_fin(e) && cls_fin(kk) && fabs(kk) <= 1e6 && cls_fin(beta);
         if (box_ok) {
@@ -416,7 +415,7 @@ static __device__ __forceinline__ void cls_cone_ab(const rh_cls &C, float x, flo
     const float an = __builtin_fmaf(C.f[5], nz, __builtin_fmaf(C.f[4], ny, C.f[3] * nx));
     b = __builtin_fmaf(qn, C.f[9], rho * __builtin_fmaf(an, C.f[10], C.f[11]));
     const float tt = __builtin_fmaf(h, h, n2);
-    near_axis = !(n2 > __builtin_fmaf(C.f[12], tt, C.f[13]));   // (NaN -> near)
+    near_axis = !(n2 > __builtin_fmaf(RH_CONE_ALPHA, tt, C.f[12]));   // (NaN -> near; alpha is the same for every cone)
 }
 static __device__ __forceinline__ float cls_cone_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {

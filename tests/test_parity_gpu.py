@@ -667,8 +667,8 @@ def test_full_size_properties(cfg):
     if cfg == "cfg5":
         cone_sel = [i for i in sel if cands[i].kind == L.CONE]
         assert len(cone_sel) >= 8 and counts[cone_sel].max() > 1000       # cones of the batch really collect inliers
-        # masks of a few candidates of every kind, bit for bit
-        msel = [i for i in sel if i < nmask][:12]
+        # masks of 48 candidates, every primitive of the scene once, bit for bit
+        msel = [i for i in range(nmask)][:48]       # one round of the 48 primitives: 16 planes, 12 spheres, 12 cylinders, 8 cones
         oc_c, oc_m = oc.score_masks_mt(to_orc_shapes(shape_array([cands[i] for i in msel]), len(msel)), to_orc_params(cp), 16)
         assert np.array_equal(oc_m, masks[msel]) and np.array_equal(oc_c, counts[msel])
     # refit: ascending, all enabled before, none after invalidation, disjoint extractions
@@ -704,6 +704,45 @@ def test_full_size_properties(cfg):
     if cfg == "cfg5":   # and the batch again on the thinned cloud (enabled bits in play at full size)
         again = R.score_batch(pc, sub_arr, cp)
         assert np.array_equal(again, oc.score_batch_mt(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp), 16))
+
+
+def test_subset_order_made_on_the_device_or_on_the_host_gives_the_same_results(monkeypatch):
+    """The internal order of subset 1 (k-d leaves of 64 points) is made on the device (kdorder.hip) unless RH_KD_HOST=1
+    keeps the host's nth_element recursion, the bounding cube on the device unless RH_AABB_HOST=1: counts, masks (in
+    SUBSET order) and an octree-sampling run (its Morton codes hang on the cube) must not depend on either -- and both must
+    equal the oracle's."""
+    prim = ["plane", "plane", "sphere", "cylinder", "cone", "cylinder"]
+    xyz, nrm, truth = synth.make_cloud(200_000, prim, 0.25, seed=77)
+    xyz[5] = [np.nan, 3.0, 4.0]                      # a NaN among the points: neither order may trip on it
+    subs = synth.make_subsets(200_000, 3, seed=77)
+    oc = orc.Cloud(xyz, nrm, subs[0])
+    cp = R.params_to_c(R.ransacparameters())
+    cands = make_candidates(truth, 300, seed=5)
+    arr = shape_array(cands)
+    ocounts, omasks = oc.score_batch(to_orc_shapes(arr, len(cands)), to_orc_params(cp), want_masks=True)
+    rp = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder], iteration={"minsubsetN": 300, "itermax": 40, "τ": 300, "prob_det": 0.9})
+    rcp = R.params_to_c(rp, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1, octree_sampling=True)
+    exp = oc.ransac(to_orc_params(rcp), seed=5)
+    assert ocounts.sum() > 10000 and len(exp["shapes"]) >= 3
+    radii = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("RH_KD_HOST", "1")
+            monkeypatch.setenv("RH_AABB_HOST", "1")
+        pc = R.RANSACCloud(xyz, nrm, subs)
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks), host
+        got, _, st = R.ransac(pc, rcp, seed=5, return_stats=True)
+        assert st["draws"] == exp["draws"] and len(got) == len(exp["shapes"])
+        for g, e in zip(got, exp["shapes"]):
+            assert bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
+        out = np.zeros(40, dtype=np.uint64)
+        L.check(R.lib().rh_dbg_cls_soundness(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        out = out.reshape(4, 10).astype(np.int64)
+        assert out[:, [2, 6, 7, 9]].sum() == 0
+        radii[host] = out[:, 1].sum() / out[:, 0].sum()      # share of (candidate, group) pairs the box tests skip
+    # the two orders cull alike (same tree, ties and binary32 keys aside)
+    assert abs(radii[True] - radii[False]) < 0.02, radii
 
 
 def test_full_size_ransac_cfg3_replays_through_the_abi():

@@ -13,6 +13,15 @@ run() {   # label, env assignments...
         grep ms_per gpurun_out/pmc_score/out.txt
     done
 }
+if [ "${WL:-cfg3}" = "cfg5" ]; then   # WL=cfg5 bash tools/region_counters.sh: the 50M-point workload, per kind incl. cones
+    run "cfg5 whole batch" WL=cfg5
+    run "cfg5 skeleton only (RH_G2_DBG=1)" WL=cfg5 RH_G2_DBG=1
+    run "cfg5 planes only" WL=cfg5 KINDS=plane
+    run "cfg5 spheres only" WL=cfg5 KINDS=sphere
+    run "cfg5 cylinders only" WL=cfg5 KINDS=cylinder
+    run "cfg5 cones only" WL=cfg5 KINDS=cone
+    exit 0
+fi
 run "whole batch" X=1
 run "skeleton only (RH_G2_DBG=1)" RH_G2_DBG=1
 run "planes only (1648 candidates)" KINDS=plane
