@@ -121,12 +121,12 @@ int rh_ensure_masks(rh_cloud *c, int64_t words)
     return RH_OK;
 }
 
-// v4 score kernel with masks: internal-order rows of mstride4 words (only the non-zero ones get written) and one
-// occupancy byte per word, zero between batches
+// v4 score kernel with masks: per candidate row a list of (internal word number, inlier word) entries, 16 bytes each,
+// at most one per group (mstride4 of them), and one int32 cursor per row, zero between batches
 static int ensure_masks4(rh_cloud *c, int64_t b)
 {
     c->mstride4 = (c->ngroups + 7) / 8 * 8;
-    const int64_t words = b * c->mstride4;
+    const int64_t words = 2 * b * c->mstride4;      // (two 64-bit words per entry)
     if (words > c->masks_int_cap) {
         RH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_masks_int);
@@ -135,14 +135,15 @@ static int ensure_masks4(rh_cloud *c, int64_t b)
         RH_TRY(dev_alloc(&c->d_masks_int, words));
         c->masks_int_cap = words;
     }
-    if (words > c->occ_cap) {
+    const int64_t cur_bytes = 4 * b;
+    if (cur_bytes > c->occ_cap) {
         RH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_occ);
         c->d_occ = nullptr;
         c->occ_cap = 0;
-        RH_TRY(dev_alloc(&c->d_occ, words));
-        RH_HIP(hipMemsetAsync(c->d_occ, 0, (size_t)words, c->stream));
-        c->occ_cap = words;
+        RH_TRY(dev_alloc(&c->d_occ, cur_bytes));
+        RH_HIP(hipMemsetAsync(c->d_occ, 0, (size_t)cur_bytes, c->stream));
+        c->occ_cap = cur_bytes;
     }
     return RH_OK;
 }
@@ -182,7 +183,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
-    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ);
+    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab); (void)hipFree(c->oct_code_o);
     (void)hipFree(c->oct_state); (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);

@@ -168,7 +168,9 @@ struct rh_cloud {
     int64_t masks_cap = 0;
     uint64_t *d_masks_int = nullptr;   // masks in internal order (before un-permuting)
     int64_t masks_int_cap = 0;
-    uint8_t *d_occ = nullptr;          // v4 score kernel: one byte per word of d_masks_int that exists (zero between batches)
+    uint8_t *d_occ = nullptr;          // v4 score kernel with masks: one int32 cursor per candidate row of the entry lists in d_masks_int (zero between batches)
+    uint64_t *unp_segmask = nullptr;   // mask un-permutation: per output segment and internal word, the bits that land in the segment
+    int64_t unp_seg_words = 0;         //   ... made for this segment width
     int64_t occ_cap = 0;
     bool masks4 = false;               // the batch being scored leaves its masks in the v4 form (rows mstride4 apart)
     int64_t mstride4 = 0;

@@ -40,6 +40,7 @@ using namespace rhdev32;
 
 typedef float rh_f32x4 __attribute__((ext_vector_type(4)));
 typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long rh_u64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int S4_TG = 4;                 // groups per tile (8, measured in round 4 -- the per-chunk work of stage 1 paid once per 8 box tests,
                                          // fuller batches: cfg3 0.0906 -> 0.0959 ms, cfg2 0.078 -> 0.104, cfg5 0.384 -> 0.375; R = 4 with it: worse still)
@@ -49,7 +50,7 @@ constexpr int S4_ROW = 65;               // padded row length of the tile arrays
 constexpr int S4_W = 4;                  // waves per block
 // R: 64-candidate chunks per block -- 8 on large subsets (cfg3: 0.108 ms; 4: 0.120, 12: 0.107, 16: 0.116), 4 where the
 // grid would otherwise be a few hundred blocks
-template <int R>
+template <int R, bool MASK = false>
 struct S4Shared {
     static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && R % S4_W == 0, "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
@@ -92,8 +93,9 @@ struct S4AllArgs {
     S4KindArgs k[4];
     int64_t ntiles, bstride, ngroups;
     const float *gb32;      // binary32 boxes of the groups, 8 floats each
-    // masks wanted: word [candidate as the caller numbers it][group] of the inlier masks in INTERNAL (k-d leaf) order --
-    // only non-zero words are written, occ holds one byte per word that says so (zero on entry)
+    // masks wanted: per candidate (as the caller numbers it) a LIST of its non-zero inlier words in internal (k-d leaf)
+    // order -- entries of 16 bytes (word number, word), mstride of them per row at most; occ = one int32 cursor per row
+    // (zero on entry)
     uint64_t *masks;
     uint8_t *occ;
     int64_t mstride;
@@ -120,7 +122,7 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
 // one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
 template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
-score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
+score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
              uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0,
@@ -265,10 +267,34 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
         if (MASK) word = sh.maskb[wv][lane] | sure;
     }
     if (MASK) {
-        if (act && word != 0) {
-            const int64_t row = orig[ci];
-            masks[row * mstride + g0 + g] = word;
-            occ[row * mstride + g0 + g] = 1;
+        // the pairs' inlier words join their candidates' LISTS (any order): entry = (internal word number, word), 16 bytes.  The
+        // pairs of a candidate sit in adjacent lanes: the first lane of such a run reserves the run's places with ONE add on
+        // the row's cursor.  (Measured, cfg3 launch, against round 3's two plain stores into sparse rows, 94 us: an add per
+        // entry at the end of the batch 116; places for every pair reserved at the start of the batch, the round trip behind
+        // the point loop, 287 -- the cursors' adds serialise; words parked in LDS and flushed once per segment 128.)
+        const bool nz = act && word != 0;
+        const uint64_t nzm = WB(nz);
+        if (nzm != 0) {
+            const int keyp = __shfl_up(act ? ci : -1 - lane, 1);
+            const uint64_t starts = WB(lane == 0 || keyp != (act ? ci : -1 - lane));
+            const uint64_t below = lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL);          // lanes 0 .. lane
+            const int rs = 63 - __builtin_clzll(starts & below);                            // first lane of my run
+            const uint64_t after = lane == 63 ? 0ULL : (starts >> (lane + 1));
+            const int re = after != 0 ? lane + __builtin_ctzll(after) : 63;               // last lane of my run
+            const uint64_t runm = (re == 63 ? ~0ULL : ((2ULL << re) - 1ULL)) & ~((1ULL << rs) - 1ULL);
+            const int tot = __popcll(nzm & runm);
+            int base = 0;
+            int64_t mrow = 0;
+            if (nz || (lane == rs && tot > 0)) mrow = orig[ci];
+            if (lane == rs && tot > 0) base = atomicAdd((int32_t *)occ + mrow, tot);
+            base = __shfl(base, rs);
+            if (nz) {
+                const int rank = __popcll(nzm & runm & ((1ULL << lane) - 1ULL));
+                rh_u64x2 ent;
+                ent.x = (uint64_t)(g0 + g);
+                ent.y = word;
+                ((rh_u64x2 *)masks)[mrow * mstride + base + rank] = ent;
+            }
         }
     }
     // one global atomic per (candidate, tile) with inliers: the pairs of a candidate sit in adjacent lanes
@@ -281,7 +307,7 @@ score4_batch(S4Shared<R> &sh, const int wv, const int lane, const int head, cons
 // pairs from the list until it is empty.
 template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
-score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, const int lo, const int hi,
+score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
                int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride)
 {
@@ -356,8 +382,8 @@ score4_segment(S4Shared<R> &sh, const S4KindArgs &K, const int64_t bstride, cons
 }
 
 // the tile as binary32 with the enabled words of one kind applied (one point per thread)
-template <int R>
-static __device__ __forceinline__ void s4_stage(S4Shared<R> &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
+template <class SH>
+static __device__ __forceinline__ void s4_stage(SH &sh, const double *__restrict__ pts, int64_t stride, int64_t s,
                                                 const uint64_t *__restrict__ enabled_words, const int64_t p0, const float *__restrict__ gb32,
                                                 const int64_t ngroups)
 {
@@ -410,7 +436,7 @@ template <int R, bool MASK, bool F32, bool TAIL = false>
 __global__ void __launch_bounds__(64 * S4_W, 8)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
-    __shared__ S4Shared<R> sh;
+    __shared__ S4Shared<R, MASK> sh;
     // Blocks go to the 8 XCDs round-robin by their linear id, each XCD with an L2 of its own.  With rows > 0 the id is
     // read as ((tile / 8) x rows + row) x 8 + tile % 8: the rows of one tile follow each other on ONE XCD, so the tile is
     // fetched from HBM once and staged from L2 by the other rows (cfg5, 9 rows over a 75-MB subset: the (tile, row) grid
@@ -648,70 +674,121 @@ cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
     }
 }
 
-// ---- masks in internal (k-d leaf) order -> subset order, from the sparse words the score kernel left.  One block per
-// (candidate row, output segment): the segment of the output row is assembled in LDS -- the block walks the row's
-// occupancy bytes, and every set bit of a word that exists is one LDS atomicOr at its subset position (perm) -- and
-// written out once, coalesced: the output needs neither a memset nor global atomics, and the 160 MB of (mostly empty)
-// internal-order rows are never read or zeroed.  (A first form walked each word's bits in one thread: 64 dependent
-// position loads for a dense word, 0.30 ms per cfg3 batch.)  The occupancy bytes are cleared by a kernel of their own.
-constexpr int S4_UNP_WORDS = 8192;   // words per segment: 64 KB of LDS (cfg5, 24 415 words per row: 4096 1.99 ms, 6144 1.87, 8192 1.62, 12288 1.78)
+// ---- masks -> subset order, from the entry lists the score kernel left (round 4; round 3 wrote the words into sparse
+// internal-order rows with an occupancy byte each, and the un-permutation searched them: 1.0 ms at cfg5, a chain of
+// dependent loads per block -- occupancy -> list -> words -> positions -- at two blocks per CU).  One block per (candidate
+// row, output segment): the segment of the output row is assembled in LDS and written out once, coalesced.  The block
+// streams the row's entries (coalesced 16-byte loads, several per thread in flight), keeps of each word the bits that
+// land in ITS segment (segmask[segment][word], made once per cloud; without it -- more than 8 segments -- a range test
+// after the look-up), and its waves look the surviving bits' positions up 64 at a time through a per-wave ring.
+// a row of up to 8192 words (524 288 subset points) is ONE segment (64 KB of LDS); longer rows are cut into segments of 3072
+// words (cfg5, 24 415 words per row, masks step: 8192 -> 0.883 ms, 6144 0.851, 4096 0.848, 3072 0.828, 2560 0.839, 2048 0.847,
+// 1536 0.891: smaller segments mean more blocks per CU for a chain of dependent loads, and more passes over the entries)
+constexpr int S4_UNP_WORDS = 8192, S4_UNP_WORDS_MULTI = 3072;
+constexpr int S6_UNROLL = 4;
 
+// WAVEWORD (rows of one segment): a wave per entry, a lane per bit -- the word's 64 positions are one coalesced load and
+// every set bit lands in the block's segment; four entries in flight per wave (round 3's inner loop, fed from the list)
+template <bool WAVEWORD>
 __global__ void __launch_bounds__(512)
-unpermute4_kernel(const uint64_t *__restrict__ in, const uint8_t *__restrict__ occ, int64_t mstride, int64_t ngroups,
-                  const int32_t *__restrict__ perm, int64_t swords, int64_t seg_words, uint64_t *__restrict__ out)
+unpermute6_kernel(const rh_u64x2 *__restrict__ ent, const int32_t *__restrict__ cursor, int64_t mstride, const int32_t *__restrict__ perm,
+                  int64_t swords, int64_t seg_words, const uint64_t *__restrict__ segmask, int64_t smstride, uint64_t *__restrict__ out)
 {
     extern __shared__ unsigned long long seg[];
-    __shared__ int nlist;
-    __shared__ int32_t list[2048];       // the row's words that exist (groups), in pieces of 2048
+    __shared__ uint32_t ring[8][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t row = blockIdx.x;
     const int64_t w0 = (int64_t)blockIdx.y * seg_words;
     const int nw = (int)(swords - w0 < seg_words ? swords - w0 : seg_words);
     for (int t = threadIdx.x; t < nw; t += 512) seg[t] = 0ULL;
-    if (threadIdx.x == 0) nlist = 0;
+    const int n = min(cursor[row], (int32_t)mstride);
     __syncthreads();
-    const int64_t lo = w0 << 6, hi = lo + ((int64_t)nw << 6);
-    const uint8_t *__restrict__ orow = occ + row * mstride;
-    const uint64_t *__restrict__ src = in + row * mstride;
-    const int64_t n8 = (ngroups + 7) >> 3;           // 8 occupancy bytes per load (rows are padded to a multiple of 8 bytes)
-    for (int64_t q0 = 0; q0 < n8; q0 += 2048 / 8) {   // at most 2048 words per piece
-        const int64_t q = q0 + threadIdx.x;
-        if (threadIdx.x < 2048 / 8 && q < n8) {
-            uint64_t o8 = ((const uint64_t *)orow)[q];
-            while (o8 != 0) {
-                const int byte = __builtin_ctzll(o8) >> 3;
-                o8 &= ~(0xFFULL << (byte * 8));
-                list[atomicAdd(&nlist, 1)] = (int32_t)(q * 8 + byte);
-            }
-        }
-        __syncthreads();
-        // a wave per word, a lane per bit: the 64 positions of a group come in one coalesced load; four words in flight
-        const int n = nlist;
+    const int32_t lo = (int32_t)(w0 << 6), span = nw << 6;
+    const rh_u64x2 *__restrict__ src = ent + row * mstride;
+    const uint64_t *__restrict__ sm = segmask != nullptr ? segmask + (int64_t)blockIdx.y * smstride : nullptr;
+    if (WAVEWORD) {
         for (int i0 = wv * 4; i0 < n; i0 += 8 * 4) {
-            int32_t g[4], j[4];
-            uint64_t m[4];
+            rh_u64x2 e[4];
+            int32_t j[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                g[k] = list[min(i0 + k, n - 1)];
-                m[k] = i0 + k < n ? src[g[k]] : 0ULL;
-                j[k] = perm[((int64_t)g[k] << 6) + lane];
+                e[k] = src[min(i0 + k, n - 1)];
+                j[k] = perm[((int64_t)e[k].x << 6) + lane] - lo;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (((m[k] >> lane) & 1ULL) && j[k] >= lo && j[k] < hi) atomicOr(&seg[(j[k] - lo) >> 6], 1ULL << (j[k] & 63));
+                if (i0 + k < n && ((e[k].y >> lane) & 1ULL) && j[k] >= 0 && j[k] < span) atomicOr(&seg[j[k] >> 6], 1ULL << (j[k] & 63));
         }
         __syncthreads();
-        if (threadIdx.x == 0) nlist = 0;
-        __syncthreads();
+        uint64_t *__restrict__ dstw = out + row * swords + w0;
+        for (int t = threadIdx.x; t < nw; t += 512) dstw[t] = seg[t];
+        return;
     }
+    int head = 0, fill = 0;   // the wave's ring (wave-uniform)
+    auto drain = [&](int k) {
+        wave_lds_sync();
+        if (lane < k) {
+            const uint32_t e = ring[wv][(head + lane) & 127];
+            const int32_t j = perm[e] - lo;
+            if (j >= 0 && j < span) atomicOr(&seg[j >> 6], 1ULL << (j & 63));
+        }
+        head = (head + k) & 127;
+        fill -= k;
+    };
+    for (int i0 = threadIdx.x; i0 - lane < n; i0 += 512 * S6_UNROLL) {   // (whole waves stay in the loop: ballots)
+        rh_u64x2 e[S6_UNROLL];
+#pragma unroll
+        for (int k = 0; k < S6_UNROLL; k++) {
+            const int i = i0 + k * 512;
+            e[k].x = 0; e[k].y = 0;
+            if (i < n) e[k] = src[i];
+        }
+        uint64_t m[S6_UNROLL];
+#pragma unroll
+        for (int k = 0; k < S6_UNROLL; k++) m[k] = (sm != nullptr && e[k].y != 0) ? (e[k].y & sm[e[k].x]) : e[k].y;
+#pragma unroll
+        for (int k = 0; k < S6_UNROLL; k++) {
+            const uint32_t gbase = (uint32_t)e[k].x << 6;
+            uint64_t mm = m[k];
+            for (;;) {
+                const bool has = mm != 0;
+                const uint64_t hm = WB(has);
+                if (hm == 0) break;
+                const int bit = has ? __builtin_ctzll(mm) : 0;
+                mm &= mm - 1;
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
+                if (has) ring[wv][(head + fill + rank) & 127] = gbase + (uint32_t)bit;
+                fill += __popcll(hm);
+                if (fill >= 64) drain(64);
+            }
+        }
+    }
+    if (fill > 0) drain(fill);
+    __syncthreads();
     uint64_t *__restrict__ dst = out + row * swords + w0;
     for (int t = threadIdx.x; t < nw; t += 512) dst[t] = seg[t];
 }
 
-__global__ void clear_occ_kernel(uint64_t *__restrict__ occ8, int64_t n8)
+__global__ void clear_cursors_kernel(int32_t *__restrict__ cursor, int32_t b)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n8 && occ8[i] != 0) occ8[i] = 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b) cursor[i] = 0;
+}
+
+// segmask[seg * smstride + g]: bit b set <=> point b of internal word g has its subset position in output segment seg
+__global__ void segmask_kernel(const int32_t *__restrict__ perm, int64_t s, int64_t ngroups, int64_t seg_bits, int nseg, int64_t smstride,
+                               uint64_t *__restrict__ segmask)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    for (int sgi = 0; sgi < nseg; sgi++) {
+        uint64_t m = 0;
+        for (int b = 0; b < 64; b++) {
+            const int64_t i = (g << 6) + b;
+            if (i < s && (int64_t)perm[i] / seg_bits == sgi) m |= 1ULL << b;
+        }
+        segmask[(int64_t)sgi * smstride + g] = m;
+    }
 }
 
 // binary32 boxes of the groups from the binary64 ones (7 planes of gstride doubles): 8 floats per group
@@ -965,24 +1042,45 @@ extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t
     return RH_OK;
 }
 
-// masks the v4 score kernel left in internal order (sparse words + occupancy bytes, rows mstride apart) -> dense rows in
-// subset order; the occupancy bytes are zero again afterwards
+// the entry lists the v4 score kernel left (rows of mstride 16-byte entries, one cursor per row in d_occ) -> dense rows in
+// subset order; the cursors are zero again afterwards
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out)
 {
     if (b == 0 || c->swords == 0) return RH_OK;
-    static int env_words = -1;
+    static int env_words = -1, env_nosm = -1;
     if (env_words < 0) { const char *e = getenv("RH_UNP_WORDS"); env_words = e ? atoi(e) : 0; }
-    const int64_t seg_words = std::min<int64_t>(c->swords, env_words > 0 ? std::min(env_words, 16384) : S4_UNP_WORDS);
+    if (env_nosm < 0) env_nosm = getenv("RH_UNP_NO_SEGMASK") ? 1 : 0;
+    const int64_t seg_words = std::min<int64_t>(c->swords, env_words > 0 ? std::min(env_words, 16384) : (c->swords <= S4_UNP_WORDS ? S4_UNP_WORDS : S4_UNP_WORDS_MULTI));
     const int nseg = cdiv4(c->swords, seg_words);
     static bool attr_set = false;
     if (!attr_set) {
-        RH_HIP(hipFuncSetAttribute((const void *)unpermute4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(unpermute4_kernel, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream, d_in,
-                       d_occ, mstride, c->ngroups, c->sub_perm, c->swords, seg_words, d_out);
-    const int64_t n8 = (int64_t)b * mstride / 8;
-    hipLaunchKernelGGL(clear_occ_kernel, dim3((unsigned)cdiv4(n8, 256)), dim3(256), 0, c->stream, (uint64_t *)d_occ, n8);
+    const uint64_t *sm = nullptr;
+    if (nseg > 1 && nseg <= 16 && !env_nosm) {   // which bits of a word belong to which segment: made once per cloud and segment width
+        if (c->unp_segmask == nullptr || c->unp_seg_words != seg_words) {
+            (void)hipFree(c->unp_segmask);
+            c->unp_segmask = nullptr;
+            RH_HIP(hipMalloc((void **)&c->unp_segmask, sizeof(uint64_t) * (size_t)nseg * (size_t)c->ng_pad));
+            hipLaunchKernelGGL(segmask_kernel, dim3((unsigned)cdiv4(c->ngroups, 256)), dim3(256), 0, c->stream, c->sub_perm, c->s, c->ngroups,
+                               seg_words * 64, nseg, c->ng_pad, c->unp_segmask);
+            RH_HIP(hipGetLastError());
+            c->unp_seg_words = seg_words;
+        }
+        sm = c->unp_segmask;
+    }
+    static int env_ww = -1;
+    if (env_ww < 0) { const char *e = getenv("RH_UNP_WAVEWORD"); env_ww = e ? atoi(e) : -1; }
+    const bool waveword = env_ww >= 0 ? env_ww != 0 : nseg == 1;
+    if (waveword)
+        hipLaunchKernelGGL(unpermute6_kernel<true>, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream,
+                           (const rh_u64x2 *)d_in, (const int32_t *)d_occ, mstride, c->sub_perm, c->swords, seg_words, sm, c->ng_pad, d_out);
+    else
+        hipLaunchKernelGGL(unpermute6_kernel<false>, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream,
+                           (const rh_u64x2 *)d_in, (const int32_t *)d_occ, mstride, c->sub_perm, c->swords, seg_words, sm, c->ng_pad, d_out);
+    hipLaunchKernelGGL(clear_cursors_kernel, dim3((unsigned)cdiv4(b, 256)), dim3(256), 0, c->stream, (int32_t *)d_occ, b);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
