@@ -114,19 +114,24 @@ def pmc_replay(kernel_key, enabled, suffix=""):
     out = {"traffic": None, "sq": {}, "replayed_from": None, "stale": None}
     if not enabled:
         return out
+    import re
+    pat = re.compile(kernel_key)          # a regular expression over the kernel's demangled name
+
+    def hit(name):
+        return pat.search(name) is not None
     # (suffix: "" = the default workload's passes, "_cfg5" = the passes taken with --workload cfg5)
     ft, fs, fm = _newest_profile("pmc_hbm_traffic%s.json" % suffix), _newest_profile("pmc_sq_counters%s.json" % suffix), _newest_profile("pmc_meta.json")
     files = []
     if ft:
         rows = json.load(open(ft))
-        rd = [r["mean_KB"] for r in rows if r["counter"] == "FETCH_SIZE" and kernel_key in r["kernel"]]
-        wr = [r["mean_KB"] for r in rows if r["counter"] == "WRITE_SIZE" and kernel_key in r["kernel"]]
+        rd = [r["mean_KB"] for r in rows if r["counter"] == "FETCH_SIZE" and hit(r["kernel"])]
+        wr = [r["mean_KB"] for r in rows if r["counter"] == "WRITE_SIZE" and hit(r["kernel"])]
         if rd and wr:
             out["traffic"] = (2.0 * rd[0] + wr[0]) * 1024.0
             files.append(os.path.relpath(ft, ROOT))
     if fs:
         for r in json.load(open(fs)):
-            if kernel_key in r["kernel"]:
+            if hit(r["kernel"]):
                 out["sq"][r["counter"]] = r["mean"]
         if out["sq"]:
             files.append(os.path.relpath(fs, ROOT))
@@ -587,13 +592,14 @@ def main():
             kname = ("score4_kernel" if v4 else "score_groups_all_kernel") + " (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
-            pmc_key = "score4_kernel<8, false, false, false>" if v4 else "score_groups_all_kernel<false, false, true"   # counts only, Float64: the timed step's launch
+            # counts only, Float64: the timed step's launch (rows of 4, 8, 12 or 16 chunks, picked by the grid's size)
+            pmc_key = r"score4_kernel<\d+, false, false, false>" if v4 else r"score_groups_all_kernel<false, false, true"
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
             sec = per_kind[dom]["ms_separate_launch"] * 1e-3
             kinds_in = [dom]
-            pmc_key = "score_groups_kernel<%d," % KINDS.index(dom)
+            pmc_key = r"score_groups_kernel<%d," % KINDS.index(dom)
         ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
         tests = ncand * S
         # the committed PMC passes were taken on the default workloads and batch split
@@ -729,7 +735,7 @@ def main():
         scan_ms, comp_ms, t_refit, list_scan = time_refit(pc._h, plane, "scan")
         t_scan = 1e-3 * scan_ms
         rbytes = n * REFIT_BYTES_PER_POINT
-        rpmc = pmc_replay("refit_mask_kernel<0>", pmc_ok)
+        rpmc = pmc_replay(r"refit_mask_kernel<0>", pmc_ok)
         out["roofline_refit"] = {"kernel": "refit_mask_kernel<plane>", "bound": "hbm", "achieved": rbytes / t_scan / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rbytes / t_scan / 1e9 / HBM_PEAK_GBS,
                                  "traffic": rpmc["traffic"], "traffic_replayed_from": rpmc["replayed_from"],

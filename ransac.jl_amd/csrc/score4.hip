@@ -845,9 +845,19 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.masks = d_masks_int;
     A.occ = d_occ;
     A.mstride = mstride;
-    static int env_r = -1;
-    if (env_r < 0) { const char *e = getenv("RH_S4_R"); env_r = e ? atoi(e) : 0; }
-    const int R = env_r == 4 || env_r == 8 ? env_r : (ntiles * ((nchunks + 7) / 8) < 3000 ? 4 : 8);
+    int env_r = 0;   // (read on every launch: the fuzzers vary it from case to case)
+    { const char *e = getenv("RH_S4_R"); env_r = e ? atoi(e) : 0; }
+    // R = chunks of 64 candidates per block row.  A block's fixed work -- prologue, staging its tile, the four kinds' dispatch --
+    // is a third of the launch's issue cycles at cfg3 and nearly half at cfg5 (profiles/r4/region_counters*.txt): longer rows pay
+    // it less often, as long as the grid still has a few blocks per slot.  Measured (round 4, counts only): cfg3 (1221 tiles)
+    // R = 8 0.0902 ms, 12 0.0880, 16 0.0930, 24 / 32 0.119; cfg5 (6104 tiles) 8 0.367, 12 0.330, 16 0.319, 24 0.343, 32 0.328;
+    // grids of a few hundred blocks (cfg2) stay at 4.  Open-ended windows keep 4 / 8 (their tail launch walks the same rows).
+    int R;
+    if (env_r == 4 || env_r == 8 || ((env_r == 12 || env_r == 16) && !open_count)) R = env_r;
+    else if (open_count) R = ntiles * ((nchunks + 7) / 8) < 3000 ? 4 : 8;
+    else if (ntiles * ((nchunks + 15) / 16) >= 16384) R = 16;
+    else if (ntiles * ((nchunks + 11) / 12) >= 3000) R = 12;
+    else R = 4;
     int64_t rows = (nchunks + R - 1) / R;
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
@@ -887,11 +897,18 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         return RH_OK;
     }
 #define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg)
+#define RH_S4_LAUNCH_R(MM, FF)                                                                                         \
+    do {                                                                                                               \
+        if (R == 4) RH_S4_LAUNCH(4, MM, FF);                                                                           \
+        else if (R == 12) RH_S4_LAUNCH(12, MM, FF);                                                                    \
+        else if (R == 16) RH_S4_LAUNCH(16, MM, FF);                                                                    \
+        else RH_S4_LAUNCH(8, MM, FF);                                                                                  \
+    } while (0)
     if (f32cloud) {   // Float32 cloud: c->sub (and the disabled list) hold the exactly converted values
-        if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, true); else RH_S4_LAUNCH(8, true, true); }
-        else { if (R == 4) RH_S4_LAUNCH(4, false, true); else RH_S4_LAUNCH(8, false, true); }
-    } else if (d_masks_int != nullptr) { if (R == 4) RH_S4_LAUNCH(4, true, false); else RH_S4_LAUNCH(8, true, false); }
-    else { if (R == 4) RH_S4_LAUNCH(4, false, false); else RH_S4_LAUNCH(8, false, false); }
+        if (d_masks_int != nullptr) RH_S4_LAUNCH_R(true, true); else RH_S4_LAUNCH_R(false, true);
+    } else if (d_masks_int != nullptr) RH_S4_LAUNCH_R(true, false);
+    else RH_S4_LAUNCH_R(false, false);
+#undef RH_S4_LAUNCH_R
 #undef RH_S4_LAUNCH
     if (open_count) {
         // nk_total_bound was a guess (a window of the candidate loop is queued before its list length is known): whatever
