@@ -274,7 +274,14 @@ function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_strea
     rng = Ref(RhRng((0, 0, 0, 0), C_NULL, 0, 0, 0))
     ccall((:rh_rng_seed, LIB), Cvoid, (Ptr{RhRng}, UInt64), rng, UInt64(seed))
     res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, C_NULL))
-    if mp == C_NULL
+    if eltype(eltype(pc.vertices)) === Float32
+        # a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): fits, scoring, liveness and refit in
+        # binary32, shapes come back holding Float32 values; FittedCone in shape_types is refused (RH_E_INVALID)
+        mp == C_NULL || error("ransac_device: mp is not available on a Float32 cloud")
+        GC.@preserve pc check(ccall((:rh_ransac_f32, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
+            h.handle, pointer(reinterpret(Cfloat, pc.vertices)), pointer(reinterpret(Cfloat, pc.normals)), cp, rng, res))
+    elseif mp == C_NULL
         GC.@preserve pc check(ccall((:rh_ransac, LIB), Cint,
             (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),
             h.handle, pointer(reinterpret(Cdouble, pc.vertices)), pointer(reinterpret(Cdouble, pc.normals)), cp, rng, res))

@@ -13,7 +13,8 @@
 // kernels.hip with the exact test in binary32 (its box tests and band prefilter stay binary64 on the converted values,
 // with margins widened for binary32 rounding: box_slack32, score_device.h) from 8192 subset points on, and on the
 // brute-force float kernel below for smaller subsets (RH_SCORE_PATH=brute forces it); refit, masks and the enabled
-// bits work as on a Float64 cloud.  rh_ransac and rh_refit_lsq stay Float64-only.
+// bits work as on a Float64 cloud.  rh_ransac runs on such a cloud too (binary32 fits: fit_shared.h; no cones); rh_refit_lsq
+// stays Float64-only.
 //
 // The four tests below are the float twins of score_device.h, statement by statement; the oracle's twin is
 // oracle/orc_f32.c.

@@ -16,7 +16,8 @@
 //    t = min(a, b) per point with sure <=> t > 0 and maybe <=> t > -1 (plane, sphere, cylinder).  A pair whose "sure"
 //    and "maybe" counts differ -- some point lies within the rounding margin of a threshold -- is redone as a whole by
 //    the reference's binary64 test (score_device.h, unchanged; lane = point, the points from global memory).  Cones
-//    have a binary32 band prefilter only: its survivors go through a per-wave ring to the exact test one by one.
+//    are classified the same way (the closed form of project2cone's frame, score4_device.h); their undecided POINTS go
+//    through a per-wave ring to the exact test one by one (a redo of the whole group costs 247 binary64 instructions).
 //  * A block's waves never wait for each other between staging and the end of a kind: each walks its own chunks
 //    (culling records prefetched one chunk ahead); only the partial last batches of the waves are merged.
 //
