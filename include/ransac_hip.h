@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 107
+#define RH_VERSION 108
 
 enum {
     RH_OK = 0,
@@ -324,6 +324,25 @@ int rh_comm_sync(rh_comm *m);
  * bounding box, Morton order of the cloud on the device), [3] after it (enabled bits).  RH_CREATE_PROF=1 prints the
  * stages on stderr. */
 int rh_cloud_create_ms(const rh_cloud *c, double *out4);
+
+/* ---- the reference's octree: pc.octree (src/octree.jl:237-244 buildoctree, :158-177 OctreeRefinery / needs_refinement /
+ * refine_data, :187-196 iswithinrectangle, :212-230 octreedepth, :11-22 getnthcell; utilities.jl:125-136 findAABB;
+ * RegionTrees' findleaf as src/fitting.jl:397 uses it; the enabled-cell gather of fitting.jl:405-407) ----
+ * Cells are numbered from 0 (the root) in creation order; depth of the root is 1 (octree.jl:240).  The tree has the
+ * reference's geometry with its quirks (root = Cell(minV, maxV) with maxV read as widths; vmin < p <= vmax membership;
+ * refinement while a cell holds more than 8 points, stopped at depth 48: *overflow).  It never changes what ransac()
+ * returns (every sample comes from the root cell) and rh_ransac does not build it. */
+typedef struct rh_octree rh_octree;
+int rh_octree_build(const double *xyz_aos, int64_t n, rh_octree **out);                 /* buildoctree(vertices); host-side set-up */
+int rh_octree_destroy(rh_octree *t);
+int rh_octree_info(const rh_octree *t, int32_t *n_cells, int32_t *octreedepth, int32_t *overflow);
+int rh_octree_findleaf(const rh_octree *t, const double *p3, int32_t *cell_out);        /* findleaf(pc.octree, p) */
+int rh_octree_getnthcell(const rh_octree *t, int32_t cell, int32_t n, int32_t *cell_out /* -1 = nothing */);
+int rh_octree_node_info(const rh_octree *t, int32_t cell, double *origin3, double *widths3, int32_t *depth, int32_t *parent,
+                        int32_t *children8 /* -1: a leaf */, int64_t *npoints);
+int rh_octree_node_points(const rh_octree *t, int32_t cell, int64_t *idx_out_1based, int64_t cap);   /* cell.data.incellpoints */
+/* cell.data.incellpoints[pc.isenabled[cell.data.incellpoints]] (fitting.jl:405-407) on the device, against cloud c's bits */
+int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t cell, int64_t *idx_out_1based, int64_t cap, int64_t *n_out);
 
 /* ---- diagnostics (tests) ---- */
 /* The batched score decides most (candidate, point) pairs with a binary32 evaluation of the reference's

@@ -108,6 +108,14 @@ SIGNATURES = {
     "rh_dev_free": (C.c_int, [_vp, _vp]),
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "rh_octree_build": (C.c_int, [_dp, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rh_octree_destroy": (C.c_int, [_vp]),
+    "rh_octree_info": (C.c_int, [_vp, _i32p, _i32p, _i32p]),
+    "rh_octree_findleaf": (C.c_int, [_vp, _dp, _i32p]),
+    "rh_octree_getnthcell": (C.c_int, [_vp, C.c_int32, C.c_int32, _i32p]),
+    "rh_octree_node_info": (C.c_int, [_vp, C.c_int32, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64)]),
+    "rh_octree_node_points": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.c_int64]),
+    "rh_octree_cell_enabled": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]),
     "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
     "rh_dbg_cls_soundness": (C.c_int, [_vp, _sp, C.c_int32, _pp, C.POINTER(C.c_uint64)]),
     "rh_dbg_oct_search_selftest": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),

@@ -256,6 +256,126 @@ def _cparams(params):
     return params if isinstance(params, L.Params) else params_to_c(params)
 
 
+# ------------------------------------------------------------------ octree ----
+class OctreeCell:
+    """A cell of the reference's octree (RegionTrees.Cell with OctreeNode data: octree.jl:147-150): `.data.incellpoints`
+    (1-based indices, a numpy array), `.data.depth` (root = 1), `.boundary` = (origin, widths), `.children`, `.parent`."""
+
+    class _Data:
+        def __init__(self, cell):
+            self._c = cell
+
+        @property
+        def depth(self):
+            return self._c._info()[2]
+
+        @property
+        def incellpoints(self):
+            n = self._c._info()[5]
+            out = np.zeros(max(1, n), dtype=np.int64)
+            check(lib().rh_octree_node_points(self._c._t._h, self._c.index, _p(out, C.c_int64), n))
+            return out[:n]
+
+    def __init__(self, tree, index):
+        self._t, self.index = tree, int(index)
+        self.data = OctreeCell._Data(self)
+
+    def _info(self):
+        o, w = np.zeros(3), np.zeros(3)
+        d, par, npts = C.c_int32(), C.c_int32(), C.c_int64()
+        ch = (C.c_int32 * 8)()
+        check(lib().rh_octree_node_info(self._t._h, self.index, _p(o, C.c_double), _p(w, C.c_double), C.byref(d), C.byref(par), ch, C.byref(npts)))
+        return o, w, d.value, par.value, list(ch), npts.value
+
+    @property
+    def boundary(self):
+        o, w = self._info()[:2]
+        return o, w
+
+    @property
+    def parent(self):
+        par = self._info()[3]
+        return None if par < 0 else OctreeCell(self._t, par)
+
+    @property
+    def children(self):
+        ch = self._info()[4]
+        return None if ch[0] < 0 else [OctreeCell(self._t, k) for k in ch]
+
+    def isleaf(self):
+        return self._info()[4][0] < 0
+
+    def __eq__(self, other):
+        return isinstance(other, OctreeCell) and other._t is self._t and other.index == self.index
+
+    def __hash__(self):
+        return hash((id(self._t), self.index))
+
+    def __repr__(self):
+        i = self._info()
+        return "OctreeNode: %d ps, %d d" % (i[5], i[2])
+
+
+class _Octree:
+    def __init__(self, vertices):
+        self.vertices = _f64(vertices).reshape(-1, 3)
+        self._h = C.c_void_p()
+        check(lib().rh_octree_build(_p(self.vertices, C.c_double), self.vertices.shape[0], C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().rh_octree_destroy(h)
+            except (AttributeError, TypeError):
+                pass
+            self._h = None
+
+
+def buildoctree(vertices):
+    """buildoctree(vertices) -> the root Cell (octree.jl:237-244)."""
+    return OctreeCell(_Octree(vertices), 0)
+
+
+def octreedepth(pc_or_cell):
+    """octreedepth(pc) / octreedepth(cell) (octree.jl:212-230): the depth of the deepest leaf."""
+    cell = pc_or_cell.octree if hasattr(pc_or_cell, "octree") else pc_or_cell
+    d = C.c_int32()
+    check(lib().rh_octree_info(cell._t._h, None, C.byref(d), None))
+    return d.value
+
+
+def findleaf(cell, p):
+    """findleaf(pc.octree, p) (RegionTrees; fitting.jl:397)."""
+    q = _f64(p).reshape(3)
+    out = C.c_int32()
+    check(lib().rh_octree_findleaf(cell._t._h, _p(q, C.c_double), C.byref(out)))
+    return OctreeCell(cell._t, out.value)
+
+
+def getnthcell(c, n):
+    """getnthcell(c, n) (octree.jl:11-22): the ancestor of c (or c) at depth n, None if there is none."""
+    out = C.c_int32()
+    check(lib().rh_octree_getnthcell(c._t._h, c.index, int(n), C.byref(out)))
+    return None if out.value < 0 else OctreeCell(c._t, out.value)
+
+
+def iswithinrectangle(rect, p):
+    """iswithinrectangle(rect, p) (octree.jl:187-196); rect = (origin, widths): vmin < p <= vmax on every axis."""
+    o, w = (np.asarray(rect[0], dtype=np.float64), np.asarray(rect[1], dtype=np.float64))
+    q = np.asarray(p, dtype=np.float64)
+    return bool(np.all(o < q) and np.all(o + w >= q))
+
+
+def cell_enabled_points(pc, cell):
+    """cell.data.incellpoints[pc.isenabled[cell.data.incellpoints]] (fitting.jl:405-407), gathered on the device."""
+    cap = cell._info()[5]
+    out = np.zeros(max(1, cap), dtype=np.int64)
+    n = C.c_int64()
+    check(lib().rh_octree_cell_enabled(pc._h, cell._t._h, cell.index, _p(out, C.c_int64), cap, C.byref(n)))
+    return out[: n.value]
+
+
 # ------------------------------------------------------------------- cloud ----
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
@@ -316,6 +436,13 @@ class RANSACCloud:
     @property
     def nchunks(self):
         return (self.size + 63) // 64
+
+    @property
+    def octree(self):
+        """pc.octree (octree.jl:47, built by the constructor there; here on first use: rh_ransac never reads it)"""
+        if getattr(self, "_octree", None) is None:
+            self._octree = buildoctree(self.vertices)
+        return self._octree
 
     @property
     def isenabled(self):
