@@ -25,6 +25,12 @@ for rnd in range(6):
         R.score_batch(pc, shapes, params, want_masks=(i % 2 == 0))
         for mode in (0, 1):
             got, _ = R.ransac(pc, params, seed=i, sampling_streams=mode, octree_sampling=bool(mode and i % 3 == 0))
+        if i % 10 == 0:   # a Float32 cloud's loop, the reference octree and its device gather as well
+            pc32 = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
+            p32 = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder], iteration={"minsubsetN": 64, "itermax": 32, "τ": 300, "prob_det": 0.7})
+            R.ransac(pc32, p32, seed=i, sampling_streams=1)
+            R.cell_enabled_points(pc, pc.octree.children[0])
+            del pc32
         del pc, got
     dev, host = snapshot()
     print("after %3d clouds / %3d ransac calls: device %.0f MiB in use, host max RSS %.0f MiB" % ((rnd + 1) * 50, (rnd + 1) * 100, dev, host), flush=True)
