@@ -755,7 +755,9 @@ static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_p
         if (c->f32_groups) {   // the culled kernel with the exact test in binary32
             int nmax = 0;
             for (int k = 0; k < 4; k++) nmax = std::max(nmax, (int)nk_bound[k]);
-            RH_TRY(rhk_prep_f32(c, c->f32_shapes, c->f32_via_orig, d_orig, off, d_nk, nmax));
+            // (the v4 kernel derives its float records from the binary64 ones: only the round-2 kernel reads these)
+            const bool v4 = d_cls != nullptr && d_box != nullptr && (d_masks_int == nullptr || c->masks4) && rh_score_v4_enabled(c) && c->gb32 != nullptr;
+            if (!v4) RH_TRY(rhk_prep_f32(c, c->f32_shapes, c->f32_via_orig, d_orig, off, d_nk, nmax));
             const rh_prep *pr[4];
             const int32_t *og[4], *nk[4];
             const void *p32[4];

@@ -174,24 +174,34 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         word = (act && !amb) ? (((uint64_t)whi << 32) | wlo) : 0ULL;
         // pairs the classifier could not decide: the exact test on the whole group, lane = point
         uint64_t redo = WB(amb);
-        while (redo != 0) {
-            const int k = __builtin_ctzll(redo);
-            redo &= redo - 1;
-            const uint32_t ek = __builtin_amdgcn_readlane(e, k);
-            const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
-            const int64_t gi = p0 + g2 * 64 + lane;
-            uint64_t mres;
-            if (F32) {   // Float32 cloud: the reference's test is the binary32 one (the points are floats, stored exactly)
+        if (F32) {
+            // Float32 cloud: the reference's test is the binary32 one, and the staged floats ARE the cloud's points (a
+            // disabled point is staged as zeros: masked out by the group's word) -- no trip to global memory for them
+            while (redo != 0) {
+                const int k = __builtin_ctzll(redo);
+                redo &= redo - 1;
+                const uint32_t ek = __builtin_amdgcn_readlane(e, k);
+                const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
                 const rh_prepf Pf = prepf_of<KIND>(rh_ld_prep_const(&prep[ci2]));   // (the float record follows from the binary64 one: score_device32.h)
-                mres = test_point32<KIND>(Pf, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
-                                          (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
-            } else {
-                const rh_prep P = rh_ld_prep_const(&prep[ci2]);
-                mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
-                                        pts[5 * stride + gi], eps, cosa);
+                const rh_f32x4 a = sh.pa[g2][lane];
+                const rh_f32x2 b = sh.pb[g2][lane];
+                uint64_t mres = test_point32<KIND>(Pf, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
+                mres &= sh.len[g2];
+                if (lane == k) { total = __popcll(mres); word = mres; }
             }
-            mres &= sh.len[g2];
-            if (lane == k) { total = __popcll(mres); word = mres; }
+        } else {
+            while (redo != 0) {
+                const int k = __builtin_ctzll(redo);
+                redo &= redo - 1;
+                const uint32_t ek = __builtin_amdgcn_readlane(e, k);
+                const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
+                const int64_t gi = p0 + g2 * 64 + lane;
+                const rh_prep P = rh_ld_prep_const(&prep[ci2]);
+                uint64_t mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
+                                                 pts[5 * stride + gi], eps, cosa);
+                mres &= sh.len[g2];
+                if (lane == k) { total = __popcll(mres); word = mres; }
+            }
         }
     } else {
         rh_cls C;
@@ -235,10 +245,11 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
             const uint32_t pe = sh.plist[head + slot];
             const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
             uint64_t r;
-            if (F32) {
+            if (F32) {   // (the staged floats are the points)
                 const rh_prepf Pv = prepf_of<KIND>(prep[cbase + (int)(pe >> S4_GB)]);
-                r = test_point32<KIND>(Pv, (float)pts[gi], (float)pts[stride + gi], (float)pts[2 * stride + gi], (float)pts[3 * stride + gi],
-                                       (float)pts[4 * stride + gi], (float)pts[5 * stride + gi], eps, cosa);
+                const rh_f32x4 a = sh.pa[pe & S4_GM][e2 & 63u];
+                const rh_f32x2 b = sh.pb[pe & S4_GM][e2 & 63u];
+                r = test_point32<KIND>(Pv, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
             } else {
                 const rh_prep Pv = prep[cbase + (int)(pe >> S4_GB)];
                 r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
@@ -434,7 +445,10 @@ static __device__ __forceinline__ void s4_stage(SH &sh, const double *__restrict
 // its blocks walk the rows from A.row0 on grid-stride.  A separate instantiation -- the loop around the four per-kind
 // bodies costs the register allocation dearly (96 scalar + 40 vector registers spilled), the one-row form none.
 template <int R, bool MASK, bool F32, bool TAIL = false>
-__global__ void __launch_bounds__(64 * S4_W, 8)
+#ifndef RH_S4_MINBLK
+#define RH_S4_MINBLK 8
+#endif
+__global__ void __launch_bounds__(64 * S4_W, RH_S4_MINBLK)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
     __shared__ S4Shared<R, MASK> sh;
