@@ -585,21 +585,21 @@ def main():
             nk = sum(1 for c in cands[lo:hi] if c[0] == k)
             if nk:
                 per_kind[k] = {"candidates": nk, "ms_separate_launch": acc[ki] / reps,
-                               "note": "diagnostic: the OLDER per-kind culled kernel (binary64, lane = point) launched alone"}
-        v4 = os.environ.get("RH_SCORE_V4", "1") != "0" and os.environ.get("RH_SCORE_PATH", "groups") == "groups" and S >= 8192
-        merged = os.environ.get("RH_SCORE_MERGED", "1") != "0" and os.environ.get("RH_SCORE_PATH", "groups") == "groups"
-        if merged:
-            kname = ("score4_kernel" if v4 else "score_groups_all_kernel") + " (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
+                               "note": "diagnostic: the same kernel launched over this kind's candidates alone"}
+        # the culled kernel (score4.hip: all kinds in one launch) from 8192 subset points on, else the brute-force kernel per kind
+        culled = os.environ.get("RH_SCORE_PATH", "groups") == "groups" and S >= 8192
+        if culled:
+            kname = "score4_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
             # counts only, Float64: the timed step's launch (rows of 4, 8, 12 or 16 chunks, picked by the grid's size)
-            pmc_key = r"score4_kernel<\d+, false, false, false>" if v4 else r"score_groups_all_kernel<false, false, true"
+            pmc_key = r"score4_kernel<\d+, false, false, false>"
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
             sec = per_kind[dom]["ms_separate_launch"] * 1e-3
             kinds_in = [dom]
-            pmc_key = r"score_groups_kernel<%d," % KINDS.index(dom)
+            pmc_key = r"score_kernel<%d," % KINDS.index(dom)
         ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
         tests = ncand * S
         # the committed PMC passes were taken on the default workloads and batch split

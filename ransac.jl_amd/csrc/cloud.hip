@@ -93,7 +93,6 @@ int rh_ensure_batch(rh_cloud *c, int64_t b)
     RH_TRY(dev_alloc(&c->d_prep, 4 * cap));
     (void)hipFree(c->d_qpre);
     c->d_qpre = nullptr;
-    c->qpre_valid = false;
     RH_HIP(hipMalloc(&c->d_qpre, (size_t)(4 * cap) * 64));   // rhdev::rh_pre (40 B) or rh4::rh_cls (64 B) per slot
     (void)hipFree(c->d_box);
     c->d_box = nullptr;
@@ -182,7 +181,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
-    (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre);
+    (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre); (void)hipFree(c->d_zero);
     (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab); (void)hipFree(c->oct_code_o);
@@ -728,82 +727,59 @@ static inline const uint64_t *enabled_for_kind(const rh_cloud *c, int kind, cons
     return c->sub_enabled;
 }
 
-// score candidates of one kind against subset 1; masks (optional) come out in INTERNAL order
-static int score_kind_subset(rh_cloud *c, int k, const rh_params *p, const rh_prep *d_prep, const int32_t *d_orig,
-                             const int32_t *d_nk, int32_t nk_bound, int32_t *d_counts, uint64_t *d_masks_int)
-{
-    if (c->use_groups)
-        return rhk_score_kind_groups(c, k, enabled_for_kind(c, k, p), d_prep, d_orig, d_nk, nk_bound, p->eps[k],
-                                     p->cos_alpha[k], d_counts, d_masks_int);
-    return rhk_score_kind(c, k, c->sub, c->s_pad, c->s, enabled_for_kind(c, k, p), d_prep, d_orig, d_nk, nk_bound,
-                          p->eps[k], p->cos_alpha[k], d_counts, d_masks_int, c->swords);
-}
-
-// all four kind bins (bin k at prep/orig + off[k], its size in d_nk[k]) against subset 1
-// d_cls: the bins' classifier records (64 B per slot, same offsets) for the v4 kernel, or null
+// all four kind bins (bin k at prep/orig + off[k], its size in d_nk[k]) against subset 1.
+// Culled path (subsets of RH_G2_MIN_POINTS points and more): ONE launch of score4.hip's kernel over all kinds, reading the
+// bins' classifier / culling records d_cls / d_box (64 B per slot at the same offsets / fields bstride apart); masks leave
+// it as entry lists (c->masks4).  ms_kind (the bench's per-kind leg): one launch per kind instead, the other kinds' bin
+// sizes read as zero, an event before each.  Small subsets: the brute-force kernel, one launch per kind, masks in internal
+// order.  Float32 clouds: the same two paths with the exact tests in binary32.
 static int score_bins_subset(rh_cloud *c, const rh_params *p, const rh_prep *d_prep, const int32_t *d_orig,
                              const int64_t off[4], const int32_t *d_nk, const int32_t nk_bound[4], int32_t total_bound,
                              int32_t *d_counts, uint64_t *d_masks_int, float *ms_kind, const void *d_cls = nullptr,
                              const float *d_box = nullptr, int64_t bstride = 0)
 {
-    if (c->f32) {   // Float32 cloud: float records from the batch's shapes, float kernels (f32.hip)
-        if (c->f32_shapes == nullptr) { rh_set_error("internal: Float32 scoring without the batch's shapes"); return RH_E_INTERNAL; }
-        const uint64_t *en[4];
-        for (int k = 0; k < 4; k++) en[k] = enabled_for_kind(c, k, p);
-        for (int k = 0; k < 4; k++)
-            if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
-        if (c->f32_groups) {   // the culled kernel with the exact test in binary32
-            int nmax = 0;
-            for (int k = 0; k < 4; k++) nmax = std::max(nmax, (int)nk_bound[k]);
-            // (the v4 kernel derives its float records from the binary64 ones: only the round-2 kernel reads these)
-            const bool v4 = d_cls != nullptr && d_box != nullptr && (d_masks_int == nullptr || c->masks4) && rh_score_v4_enabled(c) && c->gb32 != nullptr;
-            if (!v4) RH_TRY(rhk_prep_f32(c, c->f32_shapes, c->f32_via_orig, d_orig, off, d_nk, nmax));
-            const rh_prep *pr[4];
-            const int32_t *og[4], *nk[4];
-            const void *p32[4];
-            for (int k = 0; k < 4; k++) {
-                pr[k] = d_prep + off[k];
-                og[k] = d_orig + off[k];
-                nk[k] = d_nk + k;
-                p32[k] = (const char *)c->d_prep32 + (size_t)off[k] * 12 * sizeof(float);
-            }
-            const void *cl[4];
-            const float *bx[4];
-            for (int k = 0; k < 4; k++) {
-                cl[k] = d_cls ? (const char *)d_cls + (size_t)off[k] * 64 : nullptr;
-                bx[k] = d_box ? d_box + off[k] : nullptr;
-            }
-            return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, p32,
-                                        d_cls ? cl : nullptr, d_box ? bx : nullptr, bstride);
-        }
-        return rhk_score_all_f32(c, c->f32_shapes, c->f32_via_orig, en, d_orig, off, d_nk, nk_bound, p->eps, p->cos_alpha,
-                                 d_counts, d_masks_int);
-    }
-    static int merged = -1;
-    if (merged < 0) { const char *e = getenv("RH_SCORE_MERGED"); merged = e ? atoi(e) : 1; }
-    if (c->use_groups && merged && !ms_kind) {
-        const uint64_t *en[4];
+    const uint64_t *en[4];
+    for (int k = 0; k < 4; k++) en[k] = enabled_for_kind(c, k, p);
+    if (rh_score_v4_enabled(c)) {
+        if (d_cls == nullptr || d_box == nullptr) { rh_set_error("internal: culled scoring without the bins' classifier records"); return RH_E_INTERNAL; }
         const rh_prep *pr[4];
         const int32_t *og[4], *nk[4];
-        for (int k = 0; k < 4; k++) {
-            en[k] = enabled_for_kind(c, k, p);
-            pr[k] = d_prep + off[k];
-            og[k] = d_orig + off[k];
-            nk[k] = d_nk + k;
-        }
         const void *cl[4];
         const float *bx[4];
         for (int k = 0; k < 4; k++) {
-            cl[k] = d_cls ? (const char *)d_cls + (size_t)off[k] * 64 : nullptr;
-            bx[k] = d_box ? d_box + off[k] : nullptr;
+            pr[k] = d_prep + off[k];
+            og[k] = d_orig + off[k];
+            nk[k] = d_nk + k;
+            cl[k] = (const char *)d_cls + (size_t)off[k] * 64;
+            bx[k] = d_box + off[k];
         }
-        return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, nullptr,
-                                    d_cls ? cl : nullptr, d_box ? bx : nullptr, bstride);
+        if (!ms_kind)
+            return rhk_score_all_groups(c, en, pr, og, nk, total_bound, p->eps, p->cos_alpha, d_counts, d_masks_int, cl, bx, bstride);
+        if (c->d_zero == nullptr) {
+            RH_HIP(hipMalloc((void **)&c->d_zero, 64));
+            RH_HIP(hipMemsetAsync(c->d_zero, 0, 64, c->stream));
+        }
+        for (int k = 0; k < 4; k++) {
+            RH_HIP(hipEventRecord(c->evk[k], c->stream));
+            if (nk_bound[k] == 0) continue;
+            const int32_t *nk1[4];
+            for (int q = 0; q < 4; q++) nk1[q] = q == k ? nk[q] : c->d_zero;
+            RH_TRY(rhk_score_all_groups(c, en, pr, og, nk1, nk_bound[k], p->eps, p->cos_alpha, d_counts, d_masks_int, cl, bx, bstride));
+        }
+        return RH_OK;
+    }
+    if (c->f32) {   // Float32 cloud, small subset: float records from the batch's shapes, brute-force float kernel (f32.hip)
+        if (c->f32_shapes == nullptr) { rh_set_error("internal: Float32 scoring without the batch's shapes"); return RH_E_INTERNAL; }
+        for (int k = 0; k < 4; k++)
+            if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
+        return rhk_score_all_f32(c, c->f32_shapes, c->f32_via_orig, en, d_orig, off, d_nk, nk_bound, p->eps, p->cos_alpha,
+                                 d_counts, d_masks_int);
     }
     for (int k = 0; k < 4; k++) {
         if (ms_kind) RH_HIP(hipEventRecord(c->evk[k], c->stream));
         if (nk_bound[k] == 0) continue;
-        RH_TRY(score_kind_subset(c, k, p, d_prep + off[k], d_orig + off[k], d_nk + k, nk_bound[k], d_counts, d_masks_int));
+        RH_TRY(rhk_score_kind(c, k, c->sub, c->s_pad, c->s, en[k], d_prep + off[k], d_orig + off[k], d_nk + k, nk_bound[k],
+                              p->eps[k], p->cos_alpha[k], d_counts, d_masks_int, c->swords));
     }
     return RH_OK;
 }
@@ -834,7 +810,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     const bool staged = b <= 32 && !c->f32;   // (the staged form carries prepared Float64 records only)
     const size_t rec_bytes = sizeof(rh_prep) >= sizeof(rh_shape) ? sizeof(rh_prep) : sizeof(rh_shape);
     const size_t o_orig = (size_t)b * rec_bytes, o_nk = (o_orig + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
-    // (staged, counts only, v4 kernel: the classifier records -- host twin of the prep kernels' cls_make -- ride along)
+    // (staged, culled path: the classifier records -- host twin of the prep kernels' cls_make -- ride along)
     const bool staged_cls = staged && rh_score_v4_enabled(c);
     const size_t o_counts = o_nk + 64, o_cls = (o_counts + (size_t)b * sizeof(int32_t) + 63) / 64 * 64;
     const size_t o_box = o_cls + (size_t)b * 64;   // culling records: RH_BOX_FIELDS arrays of b floats
@@ -884,7 +860,6 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
         RH_HIP(hipMemcpyAsync(c->d_shapes, h_sorted, sizeof(rh_shape) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_orig, h_orig, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, c->stream));
         RH_HIP(hipMemcpyAsync(c->d_nk, h_nk, 4 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        c->qpre_valid = false;
         RH_TRY(rhk_prep_sorted(c, c->d_shapes, b, c->d_prep, c->d_counts, p->eps, p->cos_alpha));   // zeroes d_counts as well
         if (c->qpre_v4) { d_cls_use = c->d_qpre; d_box_use = c->d_box; bstride_use = 4 * c->batch_cap; }
     }
@@ -893,10 +868,10 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     if (masks_out && c->swords > 0) {
         RH_TRY(rh_ensure_masks(c, (int64_t)b * c->swords));
         d_masks = c->d_masks;
-        if (d_cls_use != nullptr) {   // the v4 kernel leaves sparse words + occupancy bytes: nothing to zero
+        if (d_cls_use != nullptr) {   // the culled kernel leaves entry lists: nothing to zero
             RH_TRY(ensure_masks4(c, b));
             c->masks4 = true;
-        } else {
+        } else {                      // the brute-force kernel ORs into dense rows in internal order
             RH_TRY(ensure_masks_int(c, (int64_t)b * c->swords));
             RH_HIP(hipMemsetAsync(c->d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
         }
@@ -935,12 +910,11 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     int32_t *nk_cur = c->d_nk2 + 4 * c->nk2_flip, *nk_next = c->d_nk2 + 4 * (1 - c->nk2_flip);
     c->nk2_flip = 1 - c->nk2_flip;
-    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps,
-                           (d_masks && ms_kind) ? nullptr : p->cos_alpha));   // (the per-kind timing leg keeps the older kernels)
+    RH_TRY(rhk_prep_binned(c, d_shapes, b, c->d_prep, c->d_orig, nk_cur, c->batch_cap, d_counts, nk_next, 1, p->eps, p->cos_alpha));
     uint64_t *d_masks_int = nullptr;
     c->masks4 = false;
     if (d_masks && c->swords > 0) {
-        if (c->qpre_v4 && !ms_kind) {   // the v4 kernel leaves sparse words + occupancy bytes: nothing to zero
+        if (c->qpre_v4) {   // the culled kernel leaves entry lists: nothing to zero
             RH_TRY(ensure_masks4(c, b));
             c->masks4 = true;
         } else {
@@ -951,7 +925,7 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     }
     const int64_t off[4] = { 0, c->batch_cap, 2 * (int64_t)c->batch_cap, 3 * (int64_t)c->batch_cap };
     const int32_t bound[4] = { b, b, b, b };
-    const void *d_cls = c->qpre_v4 && (!d_masks_int || c->masks4) ? c->d_qpre : nullptr;   // (made by rhk_prep_binned above)
+    const void *d_cls = c->qpre_v4 ? c->d_qpre : nullptr;   // (made by rhk_prep_binned above)
     c->f32_shapes = d_shapes;      // the caller's order: the float records go through d_orig
     c->f32_via_orig = 1;
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
@@ -962,7 +936,8 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
         RH_HIP(hipEventSynchronize(c->evk[1]));
         RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
         RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
-        if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+        if (d_masks_int && c->masks4) RH_HIP(hipMemsetAsync(c->d_occ, 0, sizeof(int32_t) * (size_t)b, c->stream));   // (the lists' cursors)
+        else if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
     }
     RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind, d_cls, c->d_box, 4 * c->batch_cap));
     if (d_masks_int && c->masks4) RH_TRY(rhk_unpermute_masks4(c, d_masks_int, c->d_occ, c->mstride4, b, d_masks));

@@ -1020,7 +1020,7 @@ struct Driver {
                 RUNH(hipMemsetAsync(st.counts, 0, sizeof(int32_t) * (size_t)pbase[4], c->stream));
                 // h_nk[0..3]: the kinds' lengths; [4..7]: zeros (a kind left out of a pass)
                 for (int q = 0; q < 4; q++) { h_nk[q] = st.n[q]; h_nk[4 + q] = 0; }
-                const bool v4 = rh_score_v4_enabled(c) && !getenv("RH_NO_V4_LIVENESS");
+                const bool v4 = rh_score_v4_enabled(c);   // (else: a small subset, brute force)
                 if (v4) {
                     // the culled binary32-classified kernel of the batch path, over the new entries of the disabled list:
                     // its records are made from the stored prepared candidates on the fly
@@ -1274,8 +1274,7 @@ struct Driver {
         // With the culled score kernel (it takes its candidate counts from device memory) the window's
         // candidates are scored on the device right after they are fitted, in the same stream: the
         // host gets list + counts in one wait instead of a second round trip per window.
-        // (Float32 cloud: the fused launch has no float records to hand to the older culled kernel -- the v4 kernel derives them)
-        const bool fused_score = c->use_groups && !getenv("RH_NO_FUSED_SCORE") && (!c->f32 || rh_score_v4_enabled(c));
+        const bool fused_score = rh_score_v4_enabled(c) && !getenv("RH_NO_FUSED_SCORE");
         int32_t cnt_est = 64;
         // Without the octree a window's draws depend only on (seed, k, j) and the enabled bits, so the
         // NEXT window is put on the stream before the host waits for this one: it is valid unless this
@@ -1295,7 +1294,7 @@ struct Driver {
         // device's level distribution against its own bit for bit.  The device ends the window (stop flag: the remaining
         // launches return at once) at the first iteration whose extraction test passes in its arithmetic; the decision
         // is the host's.
-        const bool chain = octree && fused_score && mp == nullptr && rh_score_v4_enabled(c) && !getenv("RH_NO_OCT_CHAIN");
+        const bool chain = octree && fused_score && mp == nullptr && !getenv("RH_NO_OCT_CHAIN");
         if (chain) {
             int64_t Kchain = 8;
             if (const char *e = getenv("RH_OCT_CHAIN_W")) Kchain = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
@@ -1389,7 +1388,7 @@ struct Driver {
                     if (rc == RH_OK) rc = rhk_prep_entries(c, w.d_entries, (const int32_t *)w.d_status, w.entries_cap, per_it, w.d_counts, 1, p->eps,
                                                            p->cos_alpha, c->oct_state);
                     if (rc == RH_OK) rc = rhk_score_all_groups(c, enw, pr, og, nkp, std::min<int32_t>(per_it, std::max<int32_t>((int32_t)((int64_t)cnt_est * bound_pct / 100) + 64, 1024)), p->eps,
-                                                               p->cos_alpha, w.d_counts, nullptr, nullptr, clsw, boxw, 4 * c->batch_cap);
+                                                               p->cos_alpha, w.d_counts, nullptr, clsw, boxw, 4 * c->batch_cap);
                     if (rc == RH_OK) rc = rhk_oct_advance(c, p, c->oct_state, w.d_entries, w.d_status, w.entries_cap, w.d_counts, it, k0 + it, w.h_list,
                                                           w.h_list_counts, w.h_list_rank, w.h_list_slot, w.h_hdr);
                     if (rc == RH_OK && hipEventRecord(w.ev_it[it], c->stream) != hipSuccess) { rh_set_error("hipEventRecord failed"); rc = RH_E_NODEVICE; }
@@ -1555,8 +1554,8 @@ struct Driver {
                     boxw[q] = c->d_box + (int64_t)q * c->batch_cap;
                 }
                 c->s4_open_count = true;   // (bound is a guess: the kernel's tail launch covers a longer list)
-                const int rcs = rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr, nullptr,
-                                                     c->qpre_v4 ? clsw : nullptr, c->qpre_v4 ? boxw : nullptr, 4 * c->batch_cap);
+                const int rcs = rhk_score_all_groups(c, enw, pr, og, nkp, bound, p->eps, p->cos_alpha, w.d_counts, nullptr,
+                                                     clsw, boxw, 4 * c->batch_cap);
                 c->s4_open_count = false;
                 if (rcs != RH_OK) return rcs;
                 w.scored = true;

@@ -10,8 +10,8 @@
 // k-d leaf order, the enabled-bit machinery, masks and index lists), plus float copies of the two point sets --
 // `full32` (original order, 24 bytes per point: what the refit scan streams, half the bytes of the Float64 scan) and
 // `sub32` (subset 1 in k-d leaf order) -- and float candidate records.  Batched scoring runs on the culled kernel of
-// kernels.hip with the exact test in binary32 (its box tests and band prefilter stay binary64 on the converted values,
-// with margins widened for binary32 rounding: box_slack32, score_device.h) from 8192 subset points on, and on the
+// score4.hip with the exact test in binary32 (its classifier margins bracket the reference's binary32 chain, score4_device.h)
+// from 8192 subset points on, and on the
 // brute-force float kernel below for smaller subsets (RH_SCORE_PATH=brute forces it); refit, masks and the enabled
 // bits work as on a Float64 cloud.  rh_ransac runs on such a cloud too (binary32 fits: fit_shared.h; no cones); rh_refit_lsq
 // stays Float64-only.

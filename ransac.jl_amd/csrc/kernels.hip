@@ -71,7 +71,8 @@ __device__ __forceinline__ void prep_one(const rh_shape &s, rh_prep &o)
     prep_derived(o, s.kind);
 }
 
-struct PreArgs { double eps[4]; double cosa[4]; double coord_mag, nrm_mag; int f32; int v4; float *box; int64_t bstride; };
+// thresholds and magnitudes behind the classifier / culling records (rh4::cls_make) the prep kernels leave beside the bins
+struct PreArgs { double eps[4]; double cosa[4]; double coord_mag, nrm_mag; int f32; float *box; int64_t bstride; };
 
 __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ counts_zero, rh4::rh_cls *__restrict__ cls, const PreArgs QA)
@@ -95,15 +96,13 @@ __global__ void prep_sorted_kernel(const rh_shape *__restrict__ shapes, int32_t 
 // in the batch -- often hypotheses of the same primitive -- end up in different 64-candidate chunks.  A chunk of
 // near-identical candidates makes the tiles it touches 64 x heavier than the rest (measured on the cfg3 batch
 // sorted by primitive: 0.231 ms instead of 0.180).
-// qpre (optional): the band constants of the prefilter (pre_make) per binned candidate, so that the score kernel reads
-// them with the record instead of computing them per (chunk, tile) and broadcasting them with v_readlane
-// (PreArgs::v4: the record written beside a candidate is the binary32 classifier record, rh4::rh_cls of score4_device.h,
-// instead of rh_pre)
+// cls (optional): the binary32 classifier record (rh4::rh_cls, score4_device.h) of every binned candidate, slot for slot,
+// and its culling record in QA.box -- what the culled score kernel (score4.hip) reads
 
 __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t b, rh_prep *__restrict__ prep,
                                    int32_t *__restrict__ orig, int32_t *__restrict__ nk, int64_t cap,
                                    int32_t *__restrict__ counts_zero, int32_t *__restrict__ nk_other, int32_t spread,
-                                   rh_pre *__restrict__ qpre, const PreArgs QA, int32_t *__restrict__ zero_extra, int32_t zero_extra_n)
+                                   rh4::rh_cls *__restrict__ cls, const PreArgs QA, int32_t *__restrict__ zero_extra, int32_t zero_extra_n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     // (a wider range of counts to zero: the other ranks' slices of a sharded batch, rh_score_batch_allreduce_dev)
@@ -139,18 +138,16 @@ __global__ void prep_binned_kernel(const rh_shape *__restrict__ shapes, int32_t 
     prep_one(s, P);
     prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
-    if (qpre != nullptr) {
-        if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
-                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
-        else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
-    }
+    if (cls != nullptr)
+        rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, cls[(int64_t)kind * cap + slot],
+                      QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
 }
 
 // the sampler's candidate list (count on the device): bin by kind like prep_binned_kernel, zero the counts
 __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, const int32_t *__restrict__ count_ptr,
                                     int32_t cap_entries, rh_prep *__restrict__ prep, int32_t *__restrict__ orig,
                                     int32_t *__restrict__ nk, int64_t cap, int32_t *__restrict__ counts,
-                                    rh_pre *__restrict__ qpre, const PreArgs QA, const rh_oct_state *__restrict__ ost)
+                                    rh4::rh_cls *__restrict__ cls, const PreArgs QA, const rh_oct_state *__restrict__ ost)
 {
     // (an iteration of a chained octree window takes the entries from its start in the list on; nothing after a stop)
     if (ost != nullptr && ost->stop != 0) return;
@@ -185,11 +182,9 @@ __global__ void prep_entries_kernel(const rh_cand_entry *__restrict__ entries, c
     prep_one(s, P);
     prep[(int64_t)kind * cap + slot] = P;
     orig[(int64_t)kind * cap + slot] = i;
-    if (qpre != nullptr) {
-        if (QA.v4) rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, ((rh4::rh_cls *)qpre)[(int64_t)kind * cap + slot],
-                                 QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
-        else if (kind != RH_PLANE) qpre[(int64_t)kind * cap + slot] = pre_make_any(P, kind, QA.eps[kind], QA.coord_mag, QA.f32 != 0);
-    }
+    if (cls != nullptr)
+        rh4::cls_make(P, kind, QA.eps[kind], QA.cosa[kind], QA.coord_mag, QA.nrm_mag, cls[(int64_t)kind * cap + slot],
+                      QA.box + ((int64_t)kind * cap + slot), QA.bstride, nullptr, QA.f32 != 0);
 }
 
 // ------------------------------------------------------------- score ------
@@ -272,297 +267,6 @@ score_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
         const int v = lcnt[tid];
         if (v != 0) atomicAdd(&counts[orig[c0 + tid]], v);
     }
-}
-
-// LDS of one block of the culled score kernel (declared once per kernel, shared by the per-kind bodies)
-struct G2Shared {
-    // points of the tile as three 16-byte planes (x,y) (z,nx) (ny,nz): one ds_read_b128 each per test.
-    // Disabled / out-of-range points are staged with x = NaN: every distance test is then false, so
-    // the inner loop needs no enabled word.
-    rh_f64x2 lp[3][RH_G2_TILE];
-    double lb[7][RH_G2_TG];
-    uint64_t len[RH_G2_TG];
-    uint16_t pq[4][128];     // per-wave ring of (candidate-in-chunk << 8 | point-in-tile)
-    int32_t pcnt[4][64];     // per-wave inlier counts of the current chunk
-    int next_chunk;
-};
-
-// F32: a Float32 cloud -- staging, box tests and band prefilter as for Float64 (binary64 on the exactly converted values,
-// with the wider margins of box_slack32), the EXACT test in binary32 on the float record of the candidate (prep32)
-template <int KIND, bool MASK, int NT, bool F32 = false, bool QARR = false>
-__device__ __forceinline__ void
-score_groups_body(G2Shared &sh, const int chunk_lo, const int chunk_hi, const double *__restrict__ pts, int64_t stride, int64_t s,
-                  const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
-                  int64_t ngroups, const rh_prep *__restrict__ prep, const rh_prepf *__restrict__ prep32,
-                  const int32_t *__restrict__ orig,
-                  const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
-                  int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg,
-                  const int64_t tile, const rh_pre *__restrict__ qarr = nullptr)
-{
-    static_assert(NT == 256, "four waves per block: one tile of RH_G2_TG groups, G2Shared::pq / pcnt rows");
-    auto &lp = sh.lp;
-    auto &lb = sh.lb;
-    auto &len = sh.len;
-    auto &pq = sh.pq;
-    auto &pcnt = sh.pcnt;
-    int &next_chunk = sh.next_chunk;
-    constexpr bool QUEUED = !MASK && KIND != RH_PLANE;     // plane: the exact test is as cheap as a prefilter
-
-    const int nk = *nk_ptr;     // chunk_lo < chunk_hi <= ceil(nk / 64): 64-candidate chunks of this block
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t g0 = tile * RH_G2_TG;
-    const int64_t p0 = g0 * 64;
-    const double qnan = __builtin_nan("");
-#pragma unroll
-    for (int i = 0; i < RH_G2_TILE / NT; i++) {
-        const int li = tid + i * NT;
-        const int64_t gi = p0 + li;
-        uint64_t v = valid_mask((gi >> 6) << 6, s);
-        if (enabled_words != nullptr && v != 0) v &= enabled_words[gi >> 6];
-        const bool on = (v >> (gi & 63)) & 1ULL;
-        rh_f64x2 a, b, c;
-        a.x = on ? pts[gi] : qnan;
-        a.y = pts[stride + gi];
-        b.x = pts[2 * stride + gi];
-        b.y = pts[3 * stride + gi];
-        c.x = pts[4 * stride + gi];
-        c.y = pts[5 * stride + gi];
-        lp[0][li] = a; lp[1][li] = b; lp[2][li] = c;
-    }
-    if (tid < 7 * RH_G2_TG) {   // one thread per (bound component, group): the loads go out together
-        const int k = tid / RH_G2_TG, gl = tid % RH_G2_TG;
-        const int64_t g = g0 + gl;
-        lb[k][gl] = g < ngroups ? gb[k * gstride + g] : 0.0;
-    } else if (tid >= 128 && tid < 128 + RH_G2_TG) {
-        const int64_t g = g0 + (tid - 128);
-        uint64_t v = valid_mask(g << 6, s);
-        if (enabled_words != nullptr && v != 0) v &= enabled_words[g];
-        len[tid - 128] = v;
-    }
-    if (tid == 0) next_chunk = chunk_lo;
-    __syncthreads();
-    // which groups of the tile have an enabled point at all: once per block into a scalar (stage 1 asked the LDS word
-    // per group and chunk -- four blocking round trips per chunk)
-    unsigned live = 0;
-#pragma unroll
-    for (int g = 0; g < RH_G2_TG; g++) live |= len[g] != 0 ? (1u << g) : 0u;
-    live = __builtin_amdgcn_readfirstlane(live);
-
-    for (;;) {
-        int chunk = 0;
-        if (lane == 0) chunk = atomicAdd(&next_chunk, 1);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        if (chunk >= chunk_hi) break;
-        const int cbase = chunk << 6;
-        const int ci = cbase + lane;
-        // The boxes of the tile's groups are read from LDS again for every chunk: left alone, the compiler hoists the 24-28
-        // (wave-uniform!) doubles out of the chunk loop and carries them in 48-56 vector registers through stage 2,
-        // which is what set the kernel's register count (plane body: 76).
-        asm volatile("" ::: "memory");
-
-        // ---- stage 1: lane = candidate, one box test per group of the tile
-        unsigned surv = 0;
-        rh_pre Ql = { 0.0, 0.0, 0.0, 0.0, 0.0 };
-        if (ci < nk) {
-            const rh_prep Pl = prep[ci];
-            const double slack = F32 ? box_slack32<KIND>(Pl, coord_mag) : box_slack(Pl, coord_mag);
-#pragma unroll 4
-            for (int g = 0; g < RH_G2_TG; g++) {
-                if (!((live >> g) & 1u)) continue;
-                const bool skip = box_skip<KIND, F32>(Pl, lb[0][g], lb[1][g], lb[2][g], lb[3][g], lb[4][g], lb[5][g],
-                                                 lb[6][g], eps, slack);
-                surv |= skip ? 0u : (1u << g);
-            }
-            if (dbg == 2) surv = (1u << RH_G2_TG) - 1u;
-            if (QUEUED && !QARR) Ql = pre_make<KIND>(Pl, eps, slack, coord_mag);   // (QARR: the prep kernel has left them in qarr)
-        }
-        if (dbg == 1) surv = 0;
-
-        uint64_t todo = WB(surv != 0);
-        int acc = 0;
-        if constexpr (QUEUED) {
-            // ---- stage 2a: lane = point, band prefilter; passing pairs go on the wave's ring
-            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-            int qh = 0, qn = 0;                       // ring head / fill (wave-uniform)
-            pcnt[wv][lane] = 0;
-            // ---- stage 2b: lane = queued pair, exact test, one LDS add per inlier
-            auto drain = [&](int k) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const bool act = lane < k;
-                const unsigned e = act ? pq[wv][(qh + lane) & 127] : 0u;
-                const int l2 = (int)(e >> 8), i2 = (int)(e & 255u);
-                const rh_f64x2 a = lp[0][i2], b = lp[1][i2], c = lp[2][i2];
-                uint64_t r;
-                if (F32) {
-                    const rh_prepf Pv = prep32[cbase + l2];
-                    r = test_point32<KIND>(Pv, (float)a.x, (float)a.y, (float)b.x, (float)b.y, (float)c.x, (float)c.y, eps, cosa);
-                } else {
-                    const rh_prep Pv = prep[cbase + l2];
-                    r = test_point<KIND>(Pv, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
-                }
-                if (act && ((r >> lane) & 1ULL)) atomicAdd(&pcnt[wv][l2], 1);
-            };
-            if (todo != 0) {
-                int l = __builtin_ctzll(todo);
-                rh_prep P = rh_ld_prep_const(&prep[cbase + l]);
-                rh_pre Qs;
-                if constexpr (QARR) Qs = rh_ld_pre_const(&qarr[cbase + l]);
-                for (;;) {
-                    todo &= todo - 1;
-                    const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
-                    // the NEXT candidate's record: requested here, used after this candidate's groups (scalar loads in
-                    // flight while the group loop runs; the compiler owns the registers and the wait)
-                    const rh_prep Pn = rh_ld_prep_const(&prep[cbase + ln]);
-                    rh_pre Qn;
-                    if constexpr (QARR) Qn = rh_ld_pre_const(&qarr[cbase + ln]);
-                    unsigned rem = __builtin_amdgcn_readlane(surv, l);
-                    rh_pre Q;
-                    if constexpr (QARR) {
-                        Q = Qs;
-                    } else {
-                        Q.a = rl_f64(Ql.a, l); Q.b = rl_f64(Ql.b, l);
-                        if (KIND == RH_CYLINDER) Q.c = rl_f64(Ql.c, l);
-                        if (KIND == RH_CONE) { Q.c = rl_f64(Ql.c, l); Q.d = rl_f64(Ql.d, l); Q.e = rl_f64(Ql.e, l); }
-                    }
-                    while (rem != 0) {
-                        const int g = __builtin_ctz(rem);
-                        rem &= rem - 1;
-                        const int i = (g << 6) + lane;
-                        const rh_f64x2 a = lp[0][i];
-                        const double z = lp[1][i].x;
-                        const bool pass = pre_test<KIND, F32>(P, Q, a.x, a.y, z);
-                        const uint64_t m = WB(pass);
-                        if (m != 0) {
-                            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                            if (pass) pq[wv][(qh + qn + rank) & 127] = (uint16_t)(((l << 8) | (g << 6)) | lane);
-                            qn += __popcll(m);
-                            if (qn >= 64) { drain(64); qh = (qh + 64) & 127; qn -= 64; }
-                        }
-                    }
-                    P = Pn;
-                    if constexpr (QARR) Qs = Qn;
-                    if (todo == 0) break;
-                    l = ln;
-                }
-                if (qn > 0) drain(qn);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                acc = pcnt[wv][lane];
-            }
-        } else if (todo != 0) {
-            // ---- stage 2: lane = point, exact test for the surviving (candidate, group) pairs
-            int l = __builtin_ctzll(todo);
-            // (Float32 cloud: this path only needs the float record; the double one serves the other instantiation)
-            rh_prep P;
-            rh_prepf P32;
-            if (F32) P32 = ld_prepf(&prep32[cbase + l]); else P = rh_ld_prep_const(&prep[cbase + l]);
-            for (;;) {
-                todo &= todo - 1;
-                const int ln = todo != 0 ? __builtin_ctzll(todo) : l;
-                rh_prep Pn;
-                rh_prepf Pn32;
-                if (F32) Pn32 = ld_prepf(&prep32[cbase + ln]); else Pn = rh_ld_prep_const(&prep[cbase + ln]);   // lands while this candidate's groups run
-                unsigned rem = __builtin_amdgcn_readlane(surv, l);
-                int n = 0;
-                while (rem != 0) {
-                    const int g = __builtin_ctz(rem);
-                    rem &= rem - 1;
-                    const int i = (g << 6) + lane;
-                    const rh_f64x2 a = lp[0][i], b = lp[1][i], c = lp[2][i];
-                    const uint64_t m = F32 ? test_point32<KIND>(P32, (float)a.x, (float)a.y, (float)b.x, (float)b.y, (float)c.x, (float)c.y, eps, cosa)
-                                           : test_point<KIND>(P, a.x, a.y, b.x, b.y, c.x, c.y, eps, cosa);
-                    n += __popcll(m);
-                    if (MASK) {
-                        if (lane == 0 && m != 0) masks[(int64_t)orig[cbase + l] * mask_stride + g0 + g] = m;
-                    }
-                }
-                acc = (lane == l) ? n : acc;
-                if (F32) P32 = Pn32; else P = Pn;
-                if (todo == 0) break;
-                l = ln;
-            }
-        }
-        if (acc != 0) atomicAdd(&counts[orig[ci]], acc);
-    }
-}
-
-template <int KIND, bool MASK, int NT>
-__global__ void __launch_bounds__(NT)
-score_groups_kernel(const double *__restrict__ pts, int64_t stride, int64_t s,
-                    const uint64_t *__restrict__ enabled_words, const double *__restrict__ gb, int64_t gstride,
-                    int64_t ngroups, const rh_prep *__restrict__ prep, const int32_t *__restrict__ orig,
-                    const int32_t *__restrict__ nk_ptr, double eps, double cosa, double coord_mag,
-                    int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
-{
-    __shared__ G2Shared sh;
-    const int nchunks = (*nk_ptr + 63) >> 6;
-    const int cpb = (nchunks + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int chunk_lo = (int)blockIdx.y * cpb, chunk_hi = min(nchunks, chunk_lo + cpb);
-    if (chunk_lo >= chunk_hi) return;
-    score_groups_body<KIND, MASK, NT>(sh, chunk_lo, chunk_hi, pts, stride, s, enabled_words, gb, gstride, ngroups, prep,
-                                      nullptr, orig, nk_ptr, eps, cosa, coord_mag, counts, masks, mask_stride, dbg, blockIdx.x);
-}
-
-// All four kinds in ONE launch.  The 64-candidate chunks of the four kind bins are laid end to end,
-// the expensive kinds first (cone, cylinder, sphere, plane), and cut into gridDim.y equal rows; a
-// block runs the per-kind body on each segment of its row (almost always one).  The per-launch
-// floor (tile staging, box tests, tail) is paid once and the cheap kinds fill the tail.
-struct G2KindArgs {
-    const rh_pre *pre;        // band constants of the bin (prep kernels), or null
-    const rh_prep *prep;
-    const rh_prepf *prep32;   // Float32 clouds: the float records of the same bins (else null)
-    const int32_t *orig, *nk;
-    const uint64_t *en;
-    double eps, cosa;
-};
-struct G2AllArgs {
-    G2KindArgs k[4];
-    int64_t ntiles;    // grid.x is padded beyond this (see rhk_score_all_groups)
-};
-
-// WAVES: 0 = the register count the compiler arrives at (6 waves per SIMD: the cone body needs 75-79); 8 = capped at
-// 64 registers -- the plane / sphere / cylinder bodies fit (34 / 50 / 58 once the group boxes are not hoisted), the cone
-// body spills 7 registers and is still faster at 8 waves.  The host picks the variant by the size of the grid.
-template <bool MASK, bool F32 = false, bool QARR = false, int WAVES = 0>
-__global__ void __launch_bounds__(256, WAVES == 8 ? 8 : 1)
-score_groups_all_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const double *__restrict__ gb,
-                        int64_t gstride, int64_t ngroups, const G2AllArgs A, double coord_mag,
-                        int32_t *__restrict__ counts, uint64_t *__restrict__ masks, int64_t mask_stride, int dbg)
-{
-    __shared__ G2Shared sh;
-    // (tile, candidate row) of this block; grid.x is padded to a multiple of 8 (the padding exits here)
-    const int64_t tile = blockIdx.x;
-    const int row = blockIdx.y, rows = gridDim.y;
-    if (tile >= A.ntiles) return;
-    int nch[4], total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
-    const int cpb = (total + rows - 1) / rows;
-    const int lo = row * cpb, hi = min(total, lo + cpb);
-    if (lo >= hi) return;
-    int base = 0;
-    bool ran = false;
-#define RH_G2_BODY(K)                                                                                                  \
-    {                                                                                                                  \
-        const int slo = max(lo, base) - base, shi = min(hi, base + nch[K]) - base;                                     \
-        if (slo < shi) {                                                                                               \
-            if (ran) __syncthreads();   /* the previous segment's waves are done with the tile in LDS */              \
-            score_groups_body<K, MASK, 256, F32, QARR>(sh, slo, shi, pts, stride, s, A.k[K].en, gb, gstride, ngroups,  \
-                                                 A.k[K].prep, A.k[K].prep32, A.k[K].orig, A.k[K].nk, A.k[K].eps,      \
-                                                 A.k[K].cosa, coord_mag, counts, masks, mask_stride, dbg, tile,       \
-                                                 A.k[K].pre);                                                         \
-            ran = true;                                                                                                \
-        }                                                                                                              \
-        base += nch[K];                                                                                                \
-    }
-    RH_G2_BODY(RH_CONE)
-    RH_G2_BODY(RH_CYLINDER)
-    RH_G2_BODY(RH_SPHERE)
-    RH_G2_BODY(RH_PLANE)
-#undef RH_G2_BODY
 }
 
 // one wave per 64-point group: axis-aligned box of its valid points
@@ -1204,30 +908,15 @@ int rhk_pack_records(rh_cloud *c, const double *d_xyz, const double *d_nrm, int6
     return RH_OK;
 }
 
-static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa);
-
-// eps + cosa (bins in c->d_prep only): also leave the v4 kernel's classifier records in c->d_qpre, slot for slot
-int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep, int32_t *d_counts_to_zero,
-                    const double *eps, const double *cosa)
-{
-    const bool own = d_prep == c->d_prep && eps != nullptr && cosa != nullptr;
-    const PreArgs QA = pre_args(c, own ? eps : nullptr, own ? cosa : nullptr);
-    c->qpre_valid = false;   // (no band constants of the older kernel are written here)
-    if (b == 0) return RH_OK;
-    hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep,
-                       d_counts_to_zero, QA.v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA);
-    RH_HIP(hipGetLastError());
-    return RH_OK;
-}
-
-// prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
+// The culled score path (score4.hip) is there for this cloud: a subset of RH_G2_MIN_POINTS points or more, in k-d leaf order
+// with group boxes.  Smaller subsets are scored by the brute-force kernel (score_kernel).
 bool rh_score_v4_enabled(const rh_cloud *c)
 {
-    static int env = -1;
-    if (env < 0) { const char *e = getenv("RH_SCORE_V4"); env = e ? atoi(e) : 1; }
-    return env != 0 && (c->f32 ? c->f32_groups : c->use_groups);
+    return c->f32 ? c->f32_groups : c->use_groups;
 }
 
+// eps + cosa given (and the bins are the cloud's own): the prep kernel also leaves the classifier and culling records of
+// the bins in c->d_qpre / c->d_box; c->qpre_v4 says so to the score dispatch
 static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa)
 {
     PreArgs QA;
@@ -1235,16 +924,25 @@ static PreArgs pre_args(rh_cloud *c, const double *eps, const double *cosa)
     QA.coord_mag = c->coord_mag;
     QA.nrm_mag = c->nrm_mag;
     QA.f32 = c->f32 ? 1 : 0;
-    QA.v4 = cosa != nullptr && rh_score_v4_enabled(c) && c->d_box != nullptr ? 1 : 0;
     QA.box = c->d_box;
     QA.bstride = 4 * c->batch_cap;
-    // (what rhk_score_all_groups checks before it trusts c->d_qpre: made for these thresholds, for the bins in c->d_prep)
-    c->qpre_valid = eps != nullptr && c->d_qpre != nullptr;
-    c->qpre_v4 = QA.v4 != 0;
-    for (int k = 0; k < 4; k++) { c->qpre_eps[k] = QA.eps[k]; c->qpre_cosa[k] = QA.cosa[k]; }
+    c->qpre_v4 = eps != nullptr && cosa != nullptr && rh_score_v4_enabled(c) && c->d_box != nullptr && c->d_qpre != nullptr;
     return QA;
 }
 
+int rhk_prep_sorted(rh_cloud *c, const rh_shape *d_shapes_sorted, int32_t b, rh_prep *d_prep, int32_t *d_counts_to_zero,
+                    const double *eps, const double *cosa)
+{
+    const bool own = d_prep == c->d_prep && eps != nullptr && cosa != nullptr;
+    const PreArgs QA = pre_args(c, own ? eps : nullptr, own ? cosa : nullptr);
+    if (b == 0) return RH_OK;
+    hipLaunchKernelGGL(prep_sorted_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes_sorted, b, d_prep,
+                       d_counts_to_zero, c->qpre_v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// prep + bin the first min(*d_count, cap_entries) entries into c->d_prep / c->d_orig / c->d_nk (batch_cap >= cap_entries)
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
                      int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps, const double *cosa,
                      const rh_oct_state *ost)
@@ -1254,7 +952,7 @@ int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t 
     if (launch_bound <= 0) return RH_OK;
     hipLaunchKernelGGL(prep_entries_kernel, dim3(cdiv(launch_bound, 256)), dim3(256), 0, c->stream, d_entries, d_count,
                        cap_entries, c->d_prep, c->d_orig, c->d_nk, c->batch_cap, d_counts,
-                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA, ost);
+                       c->qpre_v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA, ost);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1285,7 +983,7 @@ int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d
     c->zero_extra = nullptr; c->zero_extra_n = 0;
     hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
                        d_nk, cap, d_counts_to_zero, d_nk_other, no_spread ? 1 : rh_spread_multiplier(b),
-                       c->qpre_valid ? (rh_pre *)c->d_qpre : (rh_pre *)nullptr, QA, zx, zxn);
+                       c->qpre_v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA, zx, zxn);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }
@@ -1658,153 +1356,29 @@ int rhk_compact_generic(hipStream_t stream, const uint64_t *mask, int64_t nwords
     return RH_OK;
 }
 
-struct GroupSet {   // a point set in 64-point groups with boxes: subset 1, or a segment of `dis`
-    const double *pts;
-    int64_t stride, s;
-    const double *gb;
-    int64_t gstride, ngroups, mask_stride;
-    double coord_mag;
-};
-
-template <int KIND>
-static int launch_score_groups(rh_cloud *c, const GroupSet &G, const uint64_t *en, const rh_prep *prep,
-                               const int32_t *orig, const int32_t *nk, int32_t nk_bound, double eps, double cosa,
-                               int32_t *counts, uint64_t *masks)
-{
-    const int64_t ntiles = (G.ngroups + RH_G2_TG - 1) / RH_G2_TG;
-    const int nchunks = cdiv(nk_bound, 64);
-    if (ntiles == 0 || nchunks == 0) return RH_OK;
-    static int env_blocks = -1;
-    if (env_blocks < 0) { const char *e = getenv("RH_G2_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
-    // candidate rows: enough blocks to fill the chip several times over, at least ~8 chunks per block
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
-    static int env_cpb = -1;
-    if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
-    // 64-candidate chunks per block: 8 for large subsets (measured best at >= 1000 tiles), down to 2 for small ones,
-    // where the grid would otherwise be a few hundred blocks
-    const int min_cpb = env_cpb > 0 ? env_cpb : (int)std::min<int64_t>(8, std::max<int64_t>(2, ntiles / 150));
-    int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
-    if (rows < 1) rows = 1;
-    if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
-    if (rows < 1) rows = 1;
-    dim3 grid((unsigned)ntiles, (unsigned)rows);
-#define RH_G2_LAUNCH(M, NT)                                                                                          \
-    hipLaunchKernelGGL((score_groups_kernel<KIND, M, NT>), grid, dim3(NT), 0, c->stream, G.pts, G.stride, G.s, en,  \
-                       G.gb, G.gstride, G.ngroups, prep, orig, nk, eps, cosa, G.coord_mag, counts, masks,          \
-                       G.mask_stride, dbg)
-    if (masks) RH_G2_LAUNCH(true, 256);
-    else RH_G2_LAUNCH(false, 256);
-#undef RH_G2_LAUNCH
-    RH_HIP(hipGetLastError());
-    return RH_OK;
-}
-
-static int score_groups_dispatch(rh_cloud *c, const GroupSet &G, int kind, const uint64_t *en, const rh_prep *d_prep,
-                                 const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
-                                 int32_t *d_counts, uint64_t *d_masks_int)
-{
-    switch (kind) {
-    case RH_PLANE: return launch_score_groups<RH_PLANE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_SPHERE: return launch_score_groups<RH_SPHERE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_CYLINDER: return launch_score_groups<RH_CYLINDER>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    case RH_CONE: return launch_score_groups<RH_CONE>(c, G, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-    }
-    rh_set_error("unknown shape kind %d", kind);
-    return RH_E_INVALID;
-}
-
-int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *en, const rh_prep *d_prep, const int32_t *d_orig,
-                          const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
-                          uint64_t *d_masks_int)
-{
-    GroupSet G = { c->sub, c->s_pad, c->s, c->gb, c->ng_pad, c->ngroups, c->swords, c->coord_mag };
-    return score_groups_dispatch(c, G, kind, en, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, d_masks_int);
-}
-
-// all kinds against subset 1 in one launch; nk_total_bound >= the number of candidates over all kinds
+// all kinds against subset 1 in one launch of the culled kernel (score4.hip); cls / box: the bins' classifier and culling
+// records (prep kernels); nk_total_bound >= the number of candidates over all kinds
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
                          const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                         const void *const prep32[4], const void *const cls[4], const float *const box[4], int64_t bstride)
+                         const void *const cls[4], const float *const box[4], int64_t bstride)
 {
-    const int64_t ntiles = (c->ngroups + RH_G2_TG - 1) / RH_G2_TG;
-    const int nchunks = cdiv(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
-    if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
-    static int env_blocks = -1, dbg = -1, env_cpb = -1;
-    if (env_blocks < 0) { const char *e = getenv("RH_G2_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
-    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
-    if (env_cpb < 0) { const char *e = getenv("RH_G2_CPB"); env_cpb = e ? atoi(e) : 0; }
-    const int min_cpb = env_cpb > 0 ? env_cpb : (int)std::min<int64_t>(8, std::max<int64_t>(2, ntiles / 150));   // see launch_score_groups
-    int64_t rows = (env_blocks > 0 ? env_blocks : 16384) / ntiles;
-    if (rows > (nchunks + min_cpb - 1) / min_cpb) rows = (nchunks + min_cpb - 1) / min_cpb;
-    if (rows < 1) rows = 1;
-    if (rows > 65535) rows = 65535;
-    // the band constants the prep kernel left for exactly these bins and thresholds (else the kernel makes them itself)
-    bool qarr = c->qpre_valid && c->d_qpre != nullptr && d_masks_int == nullptr && !getenv("RH_G2_NO_QARR");
-    for (int k = 0; k < 4 && qarr; k++)
-        qarr = prep[k] == c->d_prep + (int64_t)k * c->batch_cap && c->qpre_eps[k] == eps[k];
-    // classifier records of exactly these bins and thresholds from the caller: the v4 kernel (score4.hip)
-    if (cls != nullptr && box != nullptr && (d_masks_int == nullptr || c->masks4) && rh_score_v4_enabled(c) && c->gb32 != nullptr)
-        return rhk_score4_all(c, en, prep, (const void *const *)cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts,
-                              d_masks_int, d_masks_int ? c->d_occ : nullptr, c->mstride4, prep32);
-    if (c->qpre_v4) qarr = false;   // (what lies beside the bins in d_qpre are not band constants)
-    G2AllArgs A;
-    for (int k = 0; k < 4; k++)
-        A.k[k] = { qarr ? (const rh_pre *)c->d_qpre + (int64_t)k * c->batch_cap : nullptr, prep[k],
-                   prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
-    // XCD-aware launch: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with its own L2.  With
-    // grid.x padded to a multiple of 8 a tile meets the SAME XCD in every candidate row, so all rows but the first stage
-    // it from that L2 instead of HBM (0.1685 -> 0.165 ms on cfg3).  Measured and rejected: the rows of a tile back to
-    // back on its XCD (0.183 ms: the order "expensive kinds first" is what keeps the tail short) and one contiguous
-    // range of tiles per XCD (0.194 ms: tiles are spatial neighbours, so the XCDs get unequal work).  RH_G2_XCD=0: A/B.
-    static int env_swz = -1;
-    if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
-    A.ntiles = ntiles;
-    // (only with >= 128 tiles per XCD: then the XCDs' shares even out -- with cfg2's 123 tiles, 15 per XCD and a few dense
-    // primitives, pinning tiles to XCDs unbalances them: 0.125 -> 0.165 ms)
-    const bool pad8 = env_swz && ntiles >= 1024;
-    dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
-#define RH_G2_ALL(M, F, Q, W)                                                                                               \
-    hipLaunchKernelGGL((score_groups_all_kernel<M, F, Q, W>), grid, dim3(256), 0, c->stream, c->sub, c->s_pad, c->s, c->gb,     \
-                       c->ng_pad, c->ngroups, A, c->coord_mag, d_counts, d_masks_int, c->swords, dbg)
-    static int env_w8 = -1;
-    if (env_w8 < 0) { const char *e = getenv("RH_G2_W8"); env_w8 = e ? atoi(e) : 1; }
-    // 8 waves per SIMD need 2048 resident blocks to fill the chip: worth it from ~4 rounds of them on (cfg3: 11 016
-    // blocks 0.1551 -> 0.1445 ms, cfg5 with its cones 0.676 -> 0.648; cfg2's 4 182 blocks 0.115 -> 0.120: not there)
-    const bool w8 = (env_w8 && (int64_t)grid.x * grid.y >= 8192) || env_w8 == 2;   // (2: forced, 0: never -- A/B)
-    if (prep32 != nullptr) {   // Float32 cloud: the exact tests in binary32
-        if (d_masks_int) RH_G2_ALL(true, true, false, 0);
-        else if (qarr && w8) RH_G2_ALL(false, true, true, 8);
-        else if (qarr) RH_G2_ALL(false, true, true, 0);
-        else if (w8) RH_G2_ALL(false, true, false, 8);
-        else RH_G2_ALL(false, true, false, 0);
-    } else if (d_masks_int && w8) RH_G2_ALL(true, false, false, 8);
-    else if (d_masks_int) RH_G2_ALL(true, false, false, 0);
-    else if (qarr && w8) RH_G2_ALL(false, false, true, 8);
-    else if (qarr) RH_G2_ALL(false, false, true, 0);
-    else if (w8) RH_G2_ALL(false, false, false, 8);
-    else RH_G2_ALL(false, false, false, 0);
-#undef RH_G2_ALL
-    RH_HIP(hipGetLastError());
-    return RH_OK;
+    if (c->ngroups == 0 || nk_total_bound <= 0) return RH_OK;
+    if (cls == nullptr || box == nullptr || !rh_score_v4_enabled(c) || c->gb32 == nullptr || (d_masks_int != nullptr && !c->masks4)) {
+        rh_set_error("internal: the culled score kernel without its records (classifier, culling, group boxes, mask lists)");
+        return RH_E_INTERNAL;
+    }
+    return rhk_score4_all(c, en, prep, cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts, d_masks_int,
+                          d_masks_int ? c->d_occ : nullptr, c->mstride4);
 }
 
-// liveness pass: candidates against dis[first, first + cnt) (counts only); boxes are rebuilt for the segment
+// liveness pass of a cloud without the culled path: candidates against dis[first, first + cnt) (counts only), brute force
 int rhk_score_kind_dis(rh_cloud *c, int kind, int64_t first, int64_t cnt, const rh_prep *d_prep, const int32_t *d_orig,
                        const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts)
 {
     if (cnt <= 0 || nk_bound <= 0) return RH_OK;
-    // (Float32 cloud: the older culled kernel wants float records beside the binary64 ones; the brute-force kernel derives them)
-    if (cnt < 512 || nk_bound < 256 || c->f32)   // tiny: the brute-force kernel has less overhead
-        return rhk_score_kind(c, kind, c->dis + first, c->dis_stride, cnt, nullptr, d_prep, d_orig, d_nk, nk_bound, eps,
-                              cosa, d_counts, nullptr, 0);
-    const int64_t ng = (cnt + 63) / 64;
-    hipLaunchKernelGGL(group_bounds_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, c->stream, c->dis + first, c->dis_stride, cnt,
-                       ng, c->dis_gb, c->ng_pad);
-    RH_HIP(hipGetLastError());
-    GroupSet G = { c->dis + first, c->dis_stride, cnt, c->dis_gb, c->ng_pad, ng, 0, c->coord_mag };
-    return score_groups_dispatch(c, G, kind, nullptr, d_prep, d_orig, d_nk, nk_bound, eps, cosa, d_counts, nullptr);
+    return rhk_score_kind(c, kind, c->dis + first, c->dis_stride, cnt, nullptr, d_prep, d_orig, d_nk, nk_bound, eps,
+                          cosa, d_counts, nullptr, 0);
 }
 
 int rhk_group_bounds_of(rh_cloud *c, const double *pts, int64_t stride, int64_t count, int64_t ngroups, double *gb, int64_t gstride)

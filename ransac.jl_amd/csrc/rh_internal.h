@@ -183,12 +183,10 @@ struct rh_cloud {
     float *full32 = nullptr;           // 6 planes x n_pad, original order (the refit scan streams these: 24 B per point)
     float *sub32 = nullptr;            // 6 planes x s_pad, subset 1 in k-d leaf order
     void *d_prep32 = nullptr;          // [4 * batch_cap] float records (rh_prepf), grown with the batch workspaces
-    void *d_qpre = nullptr;            // [4 * batch_cap] band constants of the prefilter (rhdev::rh_pre) of the bins in d_prep
+    void *d_qpre = nullptr;            // [4 * batch_cap] classifier records (rh4::rh_cls, 64 B) of the bins in d_prep; culling records: d_box
     float *d_box = nullptr;            // [RH_BOX_FIELDS][4 * batch_cap] culling records of the same bins (v4 score kernel), structure of arrays
-    bool qpre_valid = false;           // ... made by the last prep kernel, for the thresholds qpre_eps
-    double qpre_eps[4] = { 0, 0, 0, 0 };
-    bool qpre_v4 = false;              // ... and they are classifier records of the v4 score kernel (rh4::rh_cls), made for qpre_cosa too
-    double qpre_cosa[4] = { 0, 0, 0, 0 };
+    bool qpre_v4 = false;              // ... made by the last prep kernel (for the thresholds it was given)
+    int32_t *d_zero = nullptr;         // 64 zero bytes: the bin size a kind left out of a launch reads (per-kind timing leg)
     const rh_shape *f32_shapes = nullptr;   // the batch being scored: its shapes on the device ...
     int f32_via_orig = 0;                   // ... indexed through d_orig (caller's order) or directly (sorted like the bins)
 
@@ -228,16 +226,15 @@ struct rh_cand_entry;
 struct rh_oct_state;
 int rhk_prep_entries(rh_cloud *c, const rh_cand_entry *d_entries, const int32_t *d_count, int32_t cap_entries,
                      int32_t launch_bound, int32_t *d_counts, int nk_is_zero, const double *eps = nullptr,
-                     const double *cosa = nullptr, const rh_oct_state *ost = nullptr);   // eps: also fill d_qpre; cosa too: with the v4 kernel's classifier records
+                     const double *cosa = nullptr, const rh_oct_state *ost = nullptr);   // eps + cosa: also leave the classifier / culling records in d_qpre / d_box
 int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d_prep, int32_t *d_orig,
                     int32_t *d_nk, int64_t cap, int32_t *d_counts_to_zero, int32_t *d_nk_other, int nk_is_zero,
-                    const double *eps = nullptr, const double *cosa = nullptr);   // eps (+ cosa): also fill d_qpre (bins in c->d_prep only)
+                    const double *eps = nullptr, const double *cosa = nullptr);   // eps + cosa: also leave the classifier / culling records (bins in c->d_prep only)
 bool rh_score_v4_enabled(const rh_cloud *c);
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
                    int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts,
-                   uint64_t *d_masks_int = nullptr, uint8_t *d_occ = nullptr, int64_t mstride = 0,   // masks: sparse words + occupancy bytes
-                   const void *const prep32[4] = nullptr);   // Float32 cloud: binary32 records of the bins (exact tests in binary32)
+                   uint64_t *d_masks_int = nullptr, uint8_t *d_occ = nullptr, int64_t mstride = 0);   // masks: entry lists + row cursors
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out);   // score4.hip
 // score nk candidates of one kind; nk_host < 0: count is only known on the device (d_nk),
 // launch for an upper bound of nk_bound candidates
@@ -245,16 +242,13 @@ int rhk_score_kind(rh_cloud *c, int kind, const double *pts, int64_t stride, int
                    const uint64_t *enabled_words_or_null, const rh_prep *d_prep, const int32_t *d_orig,
                    const int32_t *d_nk, int32_t nk_bound, double eps, double cosa, int32_t *d_counts,
                    uint64_t *d_masks_or_null, int64_t mask_stride);
-// culled path over c->sub (k-d leaf order + per-group boxes); masks (optional) are in INTERNAL order
-int rhk_score_kind_groups(rh_cloud *c, int kind, const uint64_t *enabled_words_or_null, const rh_prep *d_prep,
-                          const int32_t *d_orig, const int32_t *d_nk, int32_t nk_bound, double eps, double cosa,
-                          int32_t *d_counts, uint64_t *d_masks_int_or_null);
+// culled path over c->sub (k-d leaf order + per-group boxes): all kinds in one launch of score4.hip's kernel; masks
+// (optional) leave it as entry lists (rhk_unpermute_masks4)
 int rhk_score_all_groups(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4],
                          const int32_t *const orig[4], const int32_t *const nk[4], int32_t nk_total_bound,
                          const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                         const void *const prep32[4] = nullptr,    // prep32: Float32 cloud, float records of the same bins
-                         const void *const cls[4] = nullptr,       // cls / box: classifier and culling records (score4_device.h) of the
-                         const float *const box[4] = nullptr, int64_t bstride = 0);   // same bins and thresholds -> v4 kernel
+                         const void *const cls[4],                 // cls / box: classifier and culling records (score4_device.h) of the
+                         const float *const box[4], int64_t bstride);   // same bins and thresholds
 int rhk_gb32_build(rh_cloud *c);
 int rhk_store_cls(rh_cloud *c, const rh_prep *const prep[4], const int32_t n[4], const int32_t pbase[5], const double eps[4],
                   const double cosa[4], void *d_cls, float *d_box, int64_t bstride);

@@ -82,7 +82,6 @@ struct S4KindArgs {
     const rh_cls *cls;      // classifier records of the bin
     const float *box;       // culling records of the bin: field f of slot i at box[f * bstride + i]
     const rh_prep *prep;    // binary64 records of the bin
-    const rh_prepf *prep32; // Float32 cloud: the binary32 records of the bin (score_device32.h) for its exact test, else null
     const int32_t *orig, *nk;
     const uint64_t *en;
     double eps, cosa;
@@ -126,8 +125,7 @@ static __device__ __forceinline__ void
 score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
-             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0,
-             const rh_prepf *__restrict__ prep32)
+             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0)
 {
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
@@ -389,7 +387,7 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
         score4_batch<KIND, R, MASK, F32>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
-                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, K.prep32);
+                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0);
     }
 }
 
@@ -835,11 +833,10 @@ int rhk_gb32_build(rh_cloud *c)
 int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *const prep[4], const void *const cls[4],
                    const float *const box[4], int64_t bstride, const int32_t *const orig[4], const int32_t *const nk[4],
                    int32_t nk_total_bound, const double eps[4], const double cosa[4], int32_t *d_counts, uint64_t *d_masks_int,
-                   uint8_t *d_occ, int64_t mstride, const void *const prep32[4])
+                   uint8_t *d_occ, int64_t mstride)
 {
     const bool open_count = c->s4_open_count;
-    const bool f32cloud = c->f32;   // the exact tests in binary32, on float records derived from `prep` (prep32 is no longer read)
-    (void)prep32;
+    const bool f32cloud = c->f32;   // the exact tests in binary32, on float records derived from `prep`
     // the points: subset 1 in internal order, or the set rhk_score4_dis put in place (a segment of the disabled list)
     rh_s4_points PS = { c->sub, c->s_pad, c->s, c->ngroups, c->gb32 };
     if (c->s4_points != nullptr) PS = *c->s4_points;
@@ -851,7 +848,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
-        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], prep32 ? (const rh_prepf *)prep32[k] : nullptr, orig[k], nk[k], en[k], eps[k], cosa[k] };
+        A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
     A.stop = c->s4_stop;
     A.ntiles = ntiles;
     A.bstride = bstride;
@@ -990,7 +987,7 @@ int rhk_score4_dis(rh_cloud *c, int64_t first, int64_t cnt, const rh_prep *const
     const rh_s4_points PS = { c->dis + first, c->dis_stride, cnt, ng, c->dis_gb32 };
     const uint64_t *en[4] = { nullptr, nullptr, nullptr, nullptr };
     c->s4_points = &PS;
-    const int rc = rhk_score4_all(c, en, prep, cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts, nullptr, nullptr, 0, nullptr);
+    const int rc = rhk_score4_all(c, en, prep, cls, box, bstride, orig, nk, nk_total_bound, eps, cosa, d_counts, nullptr, nullptr, 0);
     c->s4_points = nullptr;
     return rc;
 }

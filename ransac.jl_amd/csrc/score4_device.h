@@ -211,7 +211,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         // cone: the two-sided classifier works on the closed form of the reference's frame (cls_cone_t below); the culling
         // record keeps the band form: with t = p - apex, h = t . a^, rho^2 = |t|^2 - h^2 the reference's distance is
         // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = cos / sin of -opang/2): |dist| < eps <=> rho in (k h - e, k h + e),
-        // k = -s / c, e = eps sqrt(c^2 + s^2) / c   (c > 0) -- score_device.h pre_make<RH_CONE>
+        // k = -s / c, e = eps sqrt(c^2 + s^2) / c   (c > 0)
         for (int i = 0; i < 8; i++) ok = ok && cls_fin(P.f[i]) && fabs(P.f[i]) <= RH_CLS_BIG;
         const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7], sgn = P.f[8];
         const double an = sqrt((ax * ax + ay * ay) + az * az), cs = sqrt(c * c + sn * sn);

@@ -256,115 +256,4 @@ static __device__ __forceinline__ bool box_skip(const rh_prep &P, double cx, dou
     }
 }
 
-// ---- stage 2a / 2b: band prefilter + pair queue (sphere, cylinder, cone) ----------------------
-// Of the points of a surviving (candidate, group) pair only ~10-30 % lie inside the candidate's
-// distance band, so running the exact test on the whole group wastes most lanes.  Stage 2a
-// evaluates a cheap CONSERVATIVE form of the distance half of the test on every lane
-// (squared distances against a band widened by `slack`, no sqrt / divide / normalisation) and
-// pushes the passing (candidate, point) pairs on a per-wave LDS ring; stage 2b pops 64 pairs at a
-// time and runs the exact test with one pair per lane (candidate record per lane), so its lanes are
-// dense.  A pair the exact test would accept always passes 2a: 2a uses the same leading operations
-// (sphere, cylinder) or a closed form of the same distance (cone) and its band is wider by >= 10^5 x
-// the rounding error; NaN (disabled points are staged as NaN) fails both.
-struct rh_pre { double a, b, c, d, e; };
-
-template <int KIND>
-static __device__ __forceinline__ rh_pre pre_make(const rh_prep &P, double eps, double slack, double coord_mag)
-{
-    rh_pre o = { -1.0, __builtin_inf(), 0.0, 0.0, 0.0 };
-    if (KIND == RH_SPHERE || KIND == RH_CYLINDER) {
-        const double R = KIND == RH_SPHERE ? P.f[3] : P.f[6];
-        const double hi = (R + eps) + slack, lo = (R - eps) - slack;
-        double hi2 = hi > 0.0 ? hi * hi * (1.0 + 1e-9) : 0.0;
-        if (!(hi == hi)) hi2 = __builtin_inf();
-        o.a = lo > 0.0 ? lo * lo * (1.0 - 1e-9) : -1.0;   // NaN -> -1: everything passes the lower bound
-        o.b = hi2;
-        if (KIND == RH_CYLINDER) {
-            // The prefilter takes rho^2 in closed form: with t = p - c0, sd = a . t and q = t - a sd (the exact test's
-            // vector) |q|^2 = |t|^2 - (2 - |a|^2) sd^2 for ANY stored axis a.  Its rounding differs from the exact
-            // test's component form by a few ulp of |t|^2 (1 + |k| |a|^2), so the band is widened by 10^7 x that, as an
-            // absolute amount per candidate: M bounds every coordinate of p and c0, i.e. |t|^2 <= 12 M^2.
-            const double k = P.f[9];                    // 2 - |a|^2, f[10] = 1 + |k| |a|^2, f[8] = 1 + |c0|_1 (prep_derived)
-            const double M = coord_mag + P.f[8];
-            const double s2 = 1.2e-8 * (M * M) * P.f[10];
-            o.c = k;
-            o.a = (s2 == s2) ? o.a - s2 : -1.0;
-            o.b = (s2 == s2) ? o.b + s2 : __builtin_inf();
-        }
-        return o;
-    }
-    // cone: with t = p - apex, h = t . a^ (a^ = unit axis), rho^2 = |t|^2 - h^2 the reference's distance is
-    // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = the record's cos / sin of -opang/2): |dist| < eps  <=>
-    // rho in (k h - e, k h + e), k = -s / c, e = eps sqrt(c^2 + s^2) / c     (c > 0)
-    const double ax = P.f[3], ay = P.f[4], az = P.f[5], c = P.f[6], sn = P.f[7];
-    const double an = sqrt((ax * ax + ay * ay) + az * az), cs = sqrt(c * c + sn * sn);
-    const bool ok = (c > 1e-6 * cs) & (an > 0.0) & (an < __builtin_inf());
-    const double ia = 1.0 / an;
-    o.a = ok ? ax * ia : 0.0; o.b = ok ? ay * ia : 0.0; o.c = ok ? az * ia : 0.0;
-    o.d = ok ? -sn / c : 0.0;
-    const double e = (eps * cs / c) * (1.0 + 1e-9) + slack * (1.0 + fabs(sn / c));
-    o.e = (ok & (e == e)) ? e : __builtin_inf();              // inf: every (non-NaN) point goes to the exact test
-    return o;
-}
-
-static __device__ __forceinline__ rh_pre rh_ld_pre_const(const rh_pre *p)
-{
-    const RH_CONST_AS rh_pre *q = (const RH_CONST_AS rh_pre *)(uintptr_t)p;   // wave-uniform: scalar loads of the fields used
-    rh_pre o;
-    o.a = q->a; o.b = q->b; o.c = q->c; o.d = q->d; o.e = q->e;
-    return o;
-}
-
-// pre_make for a kind known at run time (the prep kernels fill the batch's band constants with it)
-static __device__ __forceinline__ rh_pre pre_make_any(const rh_prep &P, int kind, double eps, double coord_mag, bool f32)
-{
-    rh_pre o = { -1.0, __builtin_inf(), 0.0, 0.0, 0.0 };
-    if (kind == RH_SPHERE) return pre_make<RH_SPHERE>(P, eps, f32 ? box_slack32<RH_SPHERE>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
-    if (kind == RH_CYLINDER) return pre_make<RH_CYLINDER>(P, eps, f32 ? box_slack32<RH_CYLINDER>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
-    if (kind == RH_CONE) return pre_make<RH_CONE>(P, eps, f32 ? box_slack32<RH_CONE>(P, coord_mag) : box_slack(P, coord_mag), coord_mag);
-    return o;
-}
-
-static __device__ __forceinline__ double rl_f64(double v, int l)
-{
-    union { double d; uint32_t u[2]; } cv;
-    cv.d = v;
-    cv.u[0] = __builtin_amdgcn_readlane(cv.u[0], l);
-    cv.u[1] = __builtin_amdgcn_readlane(cv.u[1], l);
-    return cv.d;
-}
-
-// per lane: may this point pass the distance half of the exact test?  (a bool, not a wave mask: the caller predicates
-// its queue push on it directly -- extracting the lane's bit from a ballot again costs three vector instructions)
-template <int KIND, bool F32 = false>
-static __device__ __forceinline__ bool pre_test(const rh_prep &P, const rh_pre &Q, double px, double py, double pz)
-{
-    if (KIND == RH_SPHERE) {
-        const double dx = px - P.f[0], dy = py - P.f[1], dz = pz - P.f[2];
-        const double n2 = dot3f(dx, dy, dz, dx, dy, dz);
-        return (n2 >= Q.a) & (n2 <= Q.b);
-    }
-    if (KIND == RH_CYLINDER) {
-        const double ax = P.f[0], ay = P.f[1], az = P.f[2];
-        const double cx = P.f[3], cy = P.f[4], cz = P.f[5];
-        const double tx = px - cx, ty = py - cy, tz = pz - cz;
-        const double sd = dot3f(ax, ay, az, tx, ty, tz);
-        const double tt = dot3f(tx, ty, tz, tx, ty, tz);
-        const double n2 = __builtin_fma(-(Q.c * sd), sd, tt);   // = |t - a sd|^2 (pre_make): 13 instructions instead of 24
-        return (n2 >= Q.a) & (n2 <= Q.b);
-    }
-    const double tx = px - P.f[0], ty = py - P.f[1], tz = pz - P.f[2];
-    const double tt = dot3f(tx, ty, tz, tx, ty, tz);
-    const double h = dot3f(tx, ty, tz, Q.a, Q.b, Q.c);
-    const double rho2 = __builtin_fma(-h, h, tt);
-    const double u = Q.d * h;
-    const double lo = u - Q.e, hi = u + Q.e;
-    const double s2 = (F32 ? 1e-5 : 1e-9) * tt + 1e-300;
-    const double hi2 = hi * hi * (1.0 + 1e-9) + s2, lo2 = lo * lo * (1.0 - 1e-9) - s2;
-    // next to the axis the reference's frame is ill-conditioned: hand those points to the exact test
-    // (binary32 exact test: within ~0.03 rad of the axis, where its frame loses more than the slack covers)
-    const bool near_axis = rho2 <= (F32 ? 1e-3 : 1e-10) * tt;
-    return near_axis | ((hi > 0.0) & (rho2 <= hi2) & ((lo <= 0.0) | (rho2 >= lo2)));
-}
-
 }  // namespace rhdev

@@ -274,7 +274,7 @@ def test_f32_ransac_cfg1_end_to_end(streams, octree):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("env", [None, "RH_HOST_SAMPLER", "RH_NO_FUSED_SCORE", "RH_NO_FAST_EXTRACT", "RH_NO_PIPELINE", "RH_NO_V4_LIVENESS"])
+@pytest.mark.parametrize("env", [None, "RH_HOST_SAMPLER", "RH_NO_FUSED_SCORE", "RH_NO_FAST_EXTRACT", "RH_NO_PIPELINE"])
 def test_f32_ransac_multi_primitive(seed, env, monkeypatch):
     prim = ["plane", "plane", "sphere", "cylinder", "cylinder", "sphere"]
     xyz, nrm, truth = synth.make_cloud(60_000, prim, 0.2, seed=40 + seed)

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 _ENV = ("RH_SCORE_PATH", "RH_S4_R", "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
-        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS",
+        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE",
         "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS")
 
 

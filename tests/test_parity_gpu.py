@@ -631,7 +631,7 @@ def test_full_size_octree_leg_is_the_same_run_under_every_switch(monkeypatch):
     ref = run()
     assert len(ref[3]) >= 10 and ref[1] > 100_000
     assert run() == ref
-    for sw in ("RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS", "RH_NO_OCT_TAB", "RH_OCT_ONE_WINDOW", "RH_NO_FUSED_SCORE"):
+    for sw in ("RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_OCT_TAB", "RH_OCT_ONE_WINDOW", "RH_NO_FUSED_SCORE"):
         monkeypatch.setenv(sw, "1")
         assert run() == ref, sw
         monkeypatch.delenv(sw)

@@ -35,14 +35,14 @@ def one(case, rng, f32=False):
         env = rng.choice([None, None, None, "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_NO_FAST_EXTRACT"])
     if octree:
         # the chained windows (level update, store and its compaction on the device), and each of their pieces switched off
-        env = rng.choice([None, None, None, None, "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS", "RH_NO_OCT_TAB", "RH_HOST_SAMPLER",
+        env = rng.choice([None, None, None, None, "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_OCT_TAB", "RH_HOST_SAMPLER",
                           "RH_NO_FUSED_SCORE", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS"])
         if rng.integers(0, 3) == 0:      # thousands of minimal sets per iteration: windows beyond their launch bounds, a large store
             it["minsubsetN"] = int(rng.choice([1500, 4000]))
             it["itermax"] = int(rng.choice([12, 30]))
             params = R.ransacparameters(types, iteration=it)
     for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_LONG_WINDOW_SETS",
-              "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_V4_LIVENESS", "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS"):
+              "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS"):
         os.environ.pop(k, None)
     if env in ("RH_OCT_CHAIN_W", "RH_OCT_WINDOW_ITERS"):
         os.environ[env] = str(rng.choice([1, 2, 3, 64]))
