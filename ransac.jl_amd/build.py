@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libransac_hip.so")
-SOURCES = ["kernels.hip", "score4.hip", "f32.hip", "cloud.hip", "kdorder.hip", "korder.hip", "driver.hip", "sampler.hip", "lsq.hip", "cc.hip", "octree.hip", "comm.hip", "fit.cpp"]
+SOURCES = ["kernels.hip", "score4.hip", "f32.hip", "cloud.hip", "kdorder.hip", "korder.hip", "driver.hip", "driver_extract.hip", "driver_windows.hip", "driver_store.hip", "mp.hip", "sampler.hip", "lsq.hip", "cc.hip", "octree.hip", "comm.hip", "fit.cpp"]
 # -ffp-contract=off: never fuse a*b+c -- inlier sets must match the CPU path bit for bit.
 # -fno-slp-vectorize: the vectoriser pairs binary32 operations into v_pk_fma_f32 / v_pk_mul_f32 -- no faster than two
 # plain ones on gfx950 (4.2 against 2 x 2.3 issue cycles, profiles/r3/ubench_valu_rates.txt) and every pair pays v_mov
