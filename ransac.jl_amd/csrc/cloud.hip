@@ -562,7 +562,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
                 // side by side -- 112 ms single-threaded at s = 312 500, a fifth of that on 16 cores.
                 constexpr int KD_PAR_LEVELS = 4;
                 const unsigned hw = std::thread::hardware_concurrency();
-                const int par_levels = getenv("RH_KD_THREADS_OFF") ? 0 : (hw >= 16 ? KD_PAR_LEVELS : (hw >= 8 ? 3 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0))));
+                const int par_levels = (hw >= 16 ? KD_PAR_LEVELS : (hw >= 8 ? 3 : (hw >= 4 ? 2 : (hw >= 2 ? 1 : 0))));
                 std::function<void(int64_t, int64_t, int)> build = [&](int64_t lo_i, int64_t hi_i, int depth) {
                     if (depth >= par_levels || hi_i - lo_i < 4096) { subtree(lo_i, hi_i); return; }
                     const int64_t mid = split(lo_i, hi_i);

@@ -42,8 +42,7 @@ int Driver::run_chained_windows(const size_t status_bytes)
     const int32_t per_it = (int32_t)std::min<int64_t>((int64_t)p->minsubsetN * T, (int64_t)INT32_MAX / 2);
     // the score launch of an iteration is sized for this share of the previous iteration's candidates (the tail
     // launch covers the rest)
-    int64_t bound_pct = 200;
-    if (const char *e = getenv("RH_OCT_BOUND_PCT")) bound_pct = std::max<int64_t>(100, std::min<int64_t>(atoll(e), 1000));
+    const int64_t bound_pct = 200;
     // Two windows in flight.  A window that is not the first after an extraction CONTINUES from the state the device
     // holds (level scores and distribution, best score, counters, store fill): nothing is uploaded, the next
     // window is queued before the host has replayed the current one, and the device never waits for the host

@@ -792,9 +792,7 @@ int launch_score(rh_cloud *c, const double *pts, int64_t stride, int64_t s, cons
     // Blocks that
     // share a candidate tile differ in blockIdx.x, so consecutive ids (dealt round-robin over the
     // XCDs) stream different point tiles against the same SGPR-resident candidates.
-    static int env_blocks = -1;
-    if (env_blocks < 0) { const char *e = getenv("RH_SCORE_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
-    int64_t splits = (env_blocks > 0 ? env_blocks : 65536) / ctiles;   // one tile per block unless the grid gets huge: best balance (measured)
+    int64_t splits = 65536 / ctiles;   // one tile per block unless the grid gets huge: best balance (measured)
     if (splits < 1) splits = 1;
     if (splits > ntiles) splits = ntiles;
     dim3 grid((unsigned)splits, (unsigned)ctiles);

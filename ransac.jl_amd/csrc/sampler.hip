@@ -803,9 +803,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; oc.code_o = c->oct_code_o; }
     // (octree sampling is a chain of dependent random reads per set: one wave per block spreads a window of a few thousand
     // sets over four times as many compute units -- each with its own address translation -- as 256-thread blocks would)
-    static int env_sb = -1;
-    if (env_sb < 0) { const char *e = getenv("RH_SAMPLE_BLOCK"); env_sb = e ? atoi(e) : 0; }
-    const int sblock = (env_sb == 64 || env_sb == 128 || env_sb == 256) ? env_sb : (d_P != nullptr ? 64 : 256);
+    const int sblock = d_P != nullptr ? 64 : 256;
     const dim3 gs((unsigned)((total + sblock - 1) / sblock)), gf((unsigned)((total + 127) / 128));
     if (d_P == nullptr && n_enabled > 0 && !cone && !no_fused) {   // rank-space sampling + fits in one kernel, no hand-over
         const dim3 gk((unsigned)((total + 127) / 128));

@@ -843,9 +843,8 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     const int64_t ntiles = (PS.ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
     if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
-    static int dbg = -1, env_swz = -1;
-    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }
-    if (env_swz < 0) { const char *e = getenv("RH_G2_XCD"); env_swz = e ? atoi(e) : 1; }
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }   // (1: no pair survives stage 1 -- the skeleton alone, tools/region_counters.sh)
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
         A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
@@ -872,30 +871,25 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     else R = 4;
     int64_t rows = (nchunks + R - 1) / R;
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
-    const bool pad8 = env_swz && ntiles >= 1024;   // XCD-aware grid (kernels.hip)
+    // XCD-aware grid: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with an L2 of its own; with grid.x
+    // padded to a multiple of 8 a tile meets the same XCD in every row (only with >= 128 tiles per XCD: cfg2's 15 per XCD unbalance)
+    const bool pad8 = ntiles >= 1024;
     dim3 grid((unsigned)(pad8 ? ((ntiles + 7) / 8) * 8 : ntiles), (unsigned)rows);
     const unsigned tiles_x = grid.x;   // the tail / loop launches keep the (tile, row) grid
     A.row0 = 0;
     A.rows = 0;
-    static int env_xrow = -1;
-    if (env_xrow < 0) { const char *e = getenv("RH_S4_XROW"); env_xrow = e ? atoi(e) : 1; }
     // (measured, round 4: cfg2 -- 123 tiles x 17 rows -- 0.0753 -> 0.0663 ms; cfg3 -- 1221 x 9 -- 0.0927 -> 0.1041: with every row
     // in flight at once the record gathers of stage 2 spread over all 4096 candidates instead of a row's 512; cfg5 0.388
-    // either way.  So: small launches only; RH_S4_XROW=0 / 2 = never / always.)
-    if (env_xrow && rows > 1 && (env_xrow == 2 || ((ntiles + 7) / 8) * 8 * rows <= 4096)) {
+    // either way.  So: small launches only.)
+    if (rows > 1 && ((ntiles + 7) / 8) * 8 * rows <= 4096) {
         A.rows = (int)rows;
         grid = dim3((unsigned)(((ntiles + 7) / 8) * 8 * rows), 1);
     }
-    static int env_loop = -2;
-    if (env_loop < -1) { const char *e = getenv("RH_S4_LOOP"); env_loop = e ? atoi(e) : -1; }
     // the candidate loop's windows with few candidates (octree sampling: ~1000 local shapes per iteration, few pairs
     // survive the boxes): one block per tile walks ALL the rows -- the tile is staged once instead of once per row
     // (measured on the cfg3 octree leg, 18 chunks: 27 us against 39 + 7 for rows + tail; from ~40 chunks on the rows win:
-    // sweep of the threshold 32 / 40 / 48 / 64 -> 0.0491 / 0.0498 / 0.0498 / 0.0499 s for the leg).  RH_S4_LOOP=n: for every
-    // unmasked launch of up to n chunks, 0: never; RH_S4_LOOP_OPEN=n: the threshold for open-ended windows (32).
-    static int env_loop_open = -2;
-    if (env_loop_open < -1) { const char *e = getenv("RH_S4_LOOP_OPEN"); env_loop_open = e ? atoi(e) : -1; }
-    const int loop_max = env_loop >= 0 ? env_loop : (open_count ? (env_loop_open >= 0 ? env_loop_open : 32) : 0);
+    // sweep of the threshold 32 / 40 / 48 / 64 -> 0.0491 / 0.0498 / 0.0498 / 0.0499 s for the leg)
+    const int loop_max = open_count ? 32 : 0;
     if (loop_max > 0 && d_masks_int == nullptr && nchunks <= loop_max) {
         dim3 gt(tiles_x, 1);
         if (f32cloud) {
@@ -1076,9 +1070,8 @@ extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out)
 {
     if (b == 0 || c->swords == 0) return RH_OK;
-    static int env_words = -1, env_nosm = -1;
-    if (env_words < 0) { const char *e = getenv("RH_UNP_WORDS"); env_words = e ? atoi(e) : 0; }
-    if (env_nosm < 0) env_nosm = getenv("RH_UNP_NO_SEGMASK") ? 1 : 0;
+    int env_words = 0;   // RH_UNP_WORDS=n (tests; read per call): segments of n words, so that a small cloud's rows span several / many
+    { const char *e = getenv("RH_UNP_WORDS"); env_words = e ? atoi(e) : 0; }
     const int64_t seg_words = std::min<int64_t>(c->swords, env_words > 0 ? std::min(env_words, 16384) : (c->swords <= S4_UNP_WORDS ? S4_UNP_WORDS : S4_UNP_WORDS_MULTI));
     const int nseg = cdiv4(c->swords, seg_words);
     static bool attr_set = false;
@@ -1088,7 +1081,7 @@ int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int6
         attr_set = true;
     }
     const uint64_t *sm = nullptr;
-    if (nseg > 1 && nseg <= 16 && !env_nosm) {   // which bits of a word belong to which segment: made once per cloud and segment width
+    if (nseg > 1 && nseg <= 16) {   // which bits of a word belong to which segment: made once per cloud and segment width
         if (c->unp_segmask == nullptr || c->unp_seg_words != seg_words) {
             (void)hipFree(c->unp_segmask);
             c->unp_segmask = nullptr;
@@ -1100,9 +1093,7 @@ int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int6
         }
         sm = c->unp_segmask;
     }
-    static int env_ww = -1;
-    if (env_ww < 0) { const char *e = getenv("RH_UNP_WAVEWORD"); env_ww = e ? atoi(e) : -1; }
-    const bool waveword = env_ww >= 0 ? env_ww != 0 : nseg == 1;
+    const bool waveword = nseg == 1;
     if (waveword)
         hipLaunchKernelGGL(unpermute6_kernel<true>, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream,
                            (const rh_u64x2 *)d_in, (const int32_t *)d_occ, mstride, c->sub_perm, c->swords, seg_words, sm, c->ng_pad, d_out);

@@ -88,6 +88,31 @@ def test_score_counts_and_masks_all_kinds(small_scene):
     assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
 
 
+@pytest.mark.parametrize("seg_words", [0, 128, 8])
+def test_masks_through_every_form_of_the_list_to_row_pass(small_scene, monkeypatch, seg_words):
+    """The culled kernel leaves the masks as per-candidate entry lists; a second pass turns them into dense rows in
+    subset order, one block per (row, segment of the row).  RH_UNP_WORDS (read per call) sets the segment width, so that the
+    20000-point subset of this scene (313 words per row) is one segment (wave-per-entry form), 3 segments (the per-segment
+    bit masks that full-size clouds with up to 16 segments use) or 40 (the form without them) -- bit-equal rows every time,
+    with and without disabled points."""
+    pc, oc, truth = small_scene
+    if seg_words:
+        monkeypatch.setenv("RH_UNP_WORDS", str(seg_words))
+    cp = R.params_to_c(R.ransacparameters())
+    arr = shape_array(make_candidates(truth, 130, seed=5))
+    for frac in (1.0, 0.6):
+        en = np.random.default_rng(3).random(60_000) < frac
+        pc.set_enabled(en)
+        bits = np.zeros(((60_000 + 63) // 64) * 64, dtype=np.uint8); bits[:60_000] = en
+        oc.set_enabled(np.packbits(bits, bitorder="little").view(np.uint64))
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        ocounts, omasks = oc.score_batch(to_orc_shapes(arr, 130), to_orc_params(cp), want_masks=True)
+        assert counts.sum() > 5000
+        assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+    pc.enable_all()
+    oc.enable_all()
+
+
 def test_binary32_classifier_stays_inside_its_margins(small_scene):
     """The batched score decides most pairs in binary32 and sends only those within a rounding margin of a
     threshold to the binary64 test (csrc/score4_device.h).  The audit evaluates every (candidate, point) pair of
