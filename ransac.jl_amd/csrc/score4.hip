@@ -141,33 +141,29 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
 #pragma unroll
         for (int f = 0; f < NF; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
-        int cs = 0;
-        float tmin = 2.0f;           // min |t| over the group's points: <= 1/2 <=> some point is undecided
-        uint32_t wlo = 0, whi = 0;   // MASK: the pair's inlier word as far as it is sure
-        auto point_t = [&](int j) {
+        // The books of the pair over its 64 points (score4_device.h, cls_plane_u): the sign bit of a point's u -- surely an
+        // inlier -- is shifted into the pair's word from the right (un-reversed afterwards), and the unsigned minimum of the
+        // u's bit patterns ends <= bits(1.0f) iff some point was undecided.  No compare, no carry chain: v_alignbit_b32 +
+        // half a v_min3_u32 per point.
+        uint32_t wlo = 0, whi = 0, umin = 0xffffffffu;
+        auto point_u = [&](int j) {
             const rh_f32x4 a = rowa[j];
             const rh_f32x2 b = rowb[j];
-            const float t = KIND == RH_PLANE ? cls_plane_t(C, a.x, a.y, a.z, a.w, b.x, b.y)
-                                             : cls_round_t<KIND == RH_PLANE ? RH_SPHERE : KIND>(C, a.x, a.y, a.z, a.w, b.x, b.y);
-            tmin = fminf(tmin, __builtin_fabsf(t));
-            return t > 0.5f ? 1u : 0u;
+            const float u = KIND == RH_PLANE ? cls_plane_u(C, a.x, a.y, a.z, a.w, b.x, b.y)
+                                             : cls_round_u<KIND == RH_PLANE ? RH_SPHERE : KIND>(C, a.x, a.y, a.z, a.w, b.x, b.y);
+            const uint32_t ub = __builtin_bit_cast(uint32_t, u);
+            umin = umin < ub ? umin : ub;
+            return ub;
         };
-        if (MASK) {
-            // (two loops of 32: one loop with `j < 32 ? lo : hi` inside is not unrolled and pays a scalar compare and
-            // branch per point; the bits are shifted in from the right and un-reversed afterwards -- `|= 1u << j` needs
-            // a 32-bit literal per point, a scalar move each on this ISA)
 #pragma unroll 8
-            for (int j = 0; j < 32; j++) wlo = wlo + wlo + point_t(j);
+        for (int j = 0; j < 32; j++) wlo = __builtin_amdgcn_alignbit(wlo, point_u(j), 31);
 #pragma unroll 8
-            for (int j = 32; j < 64; j++) whi = whi + whi + point_t(j);
-        } else {
-#pragma unroll 8
-            for (int j = 0; j < 64; j++) cs += (int)point_t(j);
-        }
-        if (MASK) { wlo = __brev(wlo); whi = __brev(whi); cs = __popc(wlo) + __popc(whi); }
-        // (t = -1/2 exactly -- surely outside by the margins -- counts as undecided too: the redo is exact either way;
-        // a NaN t can only come from a non-finite record or point, and those never get here: exact_only, weird)
-        const bool amb = act && (!(tmin > 0.5f) || exact_only);
+        for (int j = 32; j < 64; j++) whi = __builtin_amdgcn_alignbit(whi, point_u(j), 31);
+        if (MASK) { wlo = __brev(wlo); whi = __brev(whi); }
+        const int cs = __popc(wlo) + __popc(whi);
+        // (u = 1 exactly -- surely outside by the margins -- counts as undecided too: the redo is exact either way; a NaN u
+        // can only come from a non-finite record or point, and those never get here: exact_only, weird)
+        const bool amb = act && (umin <= 0x3f800000u || exact_only);
         total = (act && !amb) ? cs : 0;
         word = (act && !amb) ? (((uint64_t)whi << 32) | wlo) : 0ULL;
         // pairs the classifier could not decide: the exact test on the whole group, lane = point
@@ -206,25 +202,26 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
 #pragma unroll
         for (int f = 0; f < 13; f++) C.f[f] = rec->f[f];
         const bool exact_only = weird || is_nan_bits(rec->f[RH_CLS_FLAG]);
-        // two words per pair, bits shifted in from the right (no 32-bit literal per point) and un-reversed afterwards:
-        // s = surely an inlier, m = undecided (|t| <= 1/2, NaN included)
+        // two words per pair, sign bits shifted in from the right and un-reversed afterwards: s = surely an inlier (u < 0),
+        // m = not surely out (u < 1, the sign of u - 1); undecided = m & ~s
         uint32_t slo = 0, shi = 0, mlo = 0, mhi = 0;
 #pragma unroll 4
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[j];
             const rh_f32x2 b = rowb[j];
-            const float t = cls_cone_t(C, a.x, a.y, a.z, a.w, b.x, b.y);
-            slo = slo + slo + (t > 0.5f ? 1u : 0u);
-            mlo = mlo + mlo + (!(__builtin_fabsf(t) > 0.5f) ? 1u : 0u);
+            const float u = cls_cone_u(C, a.x, a.y, a.z, a.w, b.x, b.y);
+            slo = __builtin_amdgcn_alignbit(slo, __builtin_bit_cast(uint32_t, u), 31);
+            mlo = __builtin_amdgcn_alignbit(mlo, __builtin_bit_cast(uint32_t, u - 1.0f), 31);
         }
 #pragma unroll 4
         for (int j = 0; j < 32; j++) {
             const rh_f32x4 a = rowa[32 + j];
             const rh_f32x2 b = rowb[32 + j];
-            const float t = cls_cone_t(C, a.x, a.y, a.z, a.w, b.x, b.y);
-            shi = shi + shi + (t > 0.5f ? 1u : 0u);
-            mhi = mhi + mhi + (!(__builtin_fabsf(t) > 0.5f) ? 1u : 0u);
+            const float u = cls_cone_u(C, a.x, a.y, a.z, a.w, b.x, b.y);
+            shi = __builtin_amdgcn_alignbit(shi, __builtin_bit_cast(uint32_t, u), 31);
+            mhi = __builtin_amdgcn_alignbit(mhi, __builtin_bit_cast(uint32_t, u - 1.0f), 31);
         }
+        mlo &= ~slo; mhi &= ~shi;
         slo = __brev(slo); shi = __brev(shi); mlo = __brev(mlo); mhi = __brev(mhi);
         const uint64_t lg = sh.len[g];
         // (a disabled point is staged as zeros: whatever the classifier makes of it, its bit is masked out here)
@@ -512,10 +509,10 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
 }
 
 // ---- audit of the classifier's margins (tests): every (candidate, point) of a batch against subset 1.
-// a32 / b32 are what the score kernel computes (the very same functions); a64 / b64 the same scaled quantities from
-// the reference's binary64 arithmetic.  |x32 - x64| has to stay below 1/2 for the classification to be sound; by
+// a32 / b32 are what the score kernel computes (the very same functions: ua, ub of score4_device.h); a64 / b64 the same scaled
+// quantities from the reference's binary64 arithmetic.  |x32 - x64| has to stay below 1/2 for the classification to be sound; by
 // construction (RH_CLS_SAFETY) it should stay below ~1/8.  out[kind * 2 + {0, 1}] = max over the batch of |a32 - a64|,
-// |b32 - b64| (sphere / cylinder: only where the distance half is not far outside, a64 > -2 -- the norm's error is relative
+// |b32 - b64| (sphere / cylinder: only where the distance half is not far outside, ua64 < 2 -- the norm's error is relative
 // to the norm); out[8 + kind] = pairs looked at.
 struct S4AuditCand { rh_prep P; rh_cls C; double cNhi, wN, eDlo, wD, cosa; int kind, usable; };
 
@@ -539,8 +536,8 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             cls_plane_ab(Q.C, (float)x, (float)y, (float)z, (float)nx, (float)ny, (float)nz, a32, b32);
             const double dn = (P.f[3] * nx + P.f[4] * ny) + P.f[5] * nz;
             const double d = (P.f[6] * (x - P.f[0]) + P.f[7] * (y - P.f[1])) + P.f[8] * (z - P.f[2]);
-            a64 = (dn - Q.cNhi) / Q.wN + RH_CLS_SHIFT;
-            b64 = (Q.eDlo - fabs(d)) / Q.wD + RH_CLS_SHIFT;
+            a64 = (Q.cNhi - dn) / Q.wN;
+            b64 = (fabs(d) - Q.eDlo) / Q.wD;
             ea = fabs((double)a32 - a64);
             eb = fabs((double)b32 - b64);
             counted = true;
@@ -559,11 +556,11 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
             const double nr = sqrt((qx * qx + qy * qy) + qz * qz);
             const double inv = 1.0 / nr;
             const double dt = ((inv * qx) * nx + (inv * qy) * ny) + (inv * qz) * nz;
-            a64 = (Q.eDlo - fabs(nr - R)) / Q.wD + RH_CLS_SHIFT;
-            b64 = (sgn * dt - Q.cNhi) / Q.wN + RH_CLS_SHIFT;
+            a64 = (fabs(nr - R) - Q.eDlo) / Q.wD;
+            b64 = (Q.cNhi - sgn * dt) / Q.wN;
             // the norm's error is relative (4.5 u nr): far outside the band it exceeds any fixed margin and cannot matter
-            // (a is a few thousand widths below -1 there); what has to hold is the bound NEAR the band
-            if (a64 > -2.0 + RH_CLS_SHIFT) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
+            // (ua is a few thousand widths above 1 there); what has to hold is the bound NEAR the band
+            if (a64 < 2.0) { ea = fabs((double)a32 - a64); eb = fabs((double)b32 - b64); }
             counted = true;
         } else if (Q.kind == RH_CONE) {
             // a64 / b64 from the reference's own frame (cone_frame: its dist and its normal cosine), the closed form only
@@ -579,8 +576,8 @@ cls_audit_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
                 const double h = ((P.f[3] * wx + P.f[4] * wy) + P.f[5] * wz) / an;
                 const double qx = wx - h * (P.f[3] / an), qy = wy - h * (P.f[4] / an), qz = wz - h * (P.f[5] / an);
                 const double rho = sqrt((qx * qx + qy * qy) + qz * qz);
-                a64 = (Q.eDlo - fabs(dist)) / Q.wD + RH_CLS_SHIFT;
-                b64 = rho * (P.f[8] * dt - Q.cosa) / Q.wN;
+                a64 = (fabs(dist) - Q.eDlo) / Q.wD;
+                b64 = 0.5 - rho * (P.f[8] * dt - Q.cosa) / Q.wN;
                 ea = fabs((double)a32 - a64);
                 eb = fabs((double)b32 - b64);
                 counted = true;
@@ -635,16 +632,17 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
     const bool skip = box_skip32<KIND>(Q.box, G);
     const bool exact_only = is_nan_bits(Q.C.f[RH_CLS_FLAG]);
     const float fx = (float)x, fy = (float)y, fz = (float)z, fnx = (float)nx, fny = (float)ny, fnz = (float)nz;
-    float t, t0;
-    if (KIND == RH_PLANE) { t = cls_plane_t(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = cls_plane_t(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
-    else if (KIND == RH_CONE) { t = cls_cone_t(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = 0.0f; }
-    else { t = cls_round_t<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, fx, fy, fz, fnx, fny, fnz);
-           t0 = cls_round_t<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
+    float t, t0;   // (the u of score4_device.h: sign bit = surely in, 0 <= u <= 1 undecided)
+    if (KIND == RH_PLANE) { t = cls_plane_u(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = cls_plane_u(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
+    else if (KIND == RH_CONE) { t = cls_cone_u(Q.C, fx, fy, fz, fnx, fny, fnz); t0 = 0.5f; }
+    else { t = cls_round_u<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, fx, fy, fz, fnx, fny, fnz);
+           t0 = cls_round_u<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f); }
     const float sum = (fabsf(fx) + fabsf(fy)) + (fabsf(fz) + fabsf(fnx)) + (fabsf(fny) + fabsf(fnz));
     const bool weird = WB(!(sum < __builtin_inff()) && ((valid >> lane) & 1ULL)) != 0;   // the kernel: every candidate exact-only on this tile
     const bool decided = !exact_only && !weird;
-    const uint64_t sin_ = WB(decided && t > 0.5f) & valid;
-    const uint64_t amb = (WB(!decided || !(__builtin_fabsf(t) > 0.5f))) & valid;
+    // (the cone's per-point undecided bit is the sign of u - 1, not-surely-in: u = 1 exactly counts as surely out there)
+    const uint64_t sin_ = WB(decided && cls_sure(t)) & valid;
+    const uint64_t amb = (WB(!decided || (KIND == RH_CONE ? (!cls_sure(t) && cls_sure(t - 1.0f)) : cls_undecided(t)))) & valid;
     const uint64_t sout = valid & ~sin_ & ~amb;
     if (lane == 0) {
         unsigned long long *o = out + KIND * 10;
@@ -657,7 +655,7 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
         if (sin_ & ~ex) atomicAdd(&o[6], (unsigned long long)__popcll(sin_ & ~ex));
         if (sout & ex) atomicAdd(&o[7], (unsigned long long)__popcll(sout & ex));
         if (ex) atomicAdd(&o[8], (unsigned long long)__popcll(ex));
-        if (blockIdx.x == 0 && !exact_only && t0 > 0.5f) atomicAdd(&o[9], 1ULL);
+        if (blockIdx.x == 0 && !exact_only && cls_sure(t0)) atomicAdd(&o[9], 1ULL);
     }
 }
 

@@ -23,7 +23,7 @@
 //                                         |L32 - L| <= Nm (3 e + 8.7 u nr) + |c| (sqrt(3) e + 6 u nr)
 //   cylinder  q = t - a (a . t), t = p - c0: per component e_q = u T (3.01 + 8.04 |a|_inf |a|_1);  then as the sphere
 //             with e_q for e
-//   cone      the reference's frame in closed form (cone.jl:68-85 reduces to it, derivation at cls_cone_t): with w = p - apex,
+//   cone      the reference's frame in closed form (cone.jl:68-85 reduces to it, derivation at cls_cone_u): with w = p - apex,
 //             h = w . a^, q = w - h a^, rho = |q| (e_q as the cylinder's with the unit axis a^), c', s' = cos / sin of
 //             -opang/2 normalised:  D = c' rho + s' h  (the test is |D| < eps)
 //                                         |D32 - D|   <= |c'| (sqrt(3) e_q + 5.5 u rho) + |s'| (6 u |a^|_1 T + 2 u |h|) + 4 u eps
@@ -38,13 +38,12 @@
 // tools/cls_audit.py hold it below 0.3.  (Round 3 started with a safety factor of 4 and widths rounded up to powers of
 // two: 8.6 % of the cylinder pairs of the cfg3 batch were redone in binary64 then.)
 //
-// The records are SCALED: with wN, wD = 2 x margin, the kernel computes a = (dn - cN_hi) / wN and b = (eD_lo - |d|) / wD
-// directly (the scaling is folded into the coefficients before they are rounded to binary32), so that with t = min(a, b)
-//     sure <=> t > 0,   maybe <=> t > -1                       (two compares for both sides of both tests).
+// The records are SCALED: with wN, wD = 2 x margin, the kernel computes ua = (cN_hi - dn) / wN and ub = (|d| - eD_lo) / wD
+// directly (the scaling is folded into the coefficients before they are rounded to binary32), so that with u = max(ua, ub)
+//     sure <=> u < 0,   maybe <=> u <= 1                        (read off the bit pattern of u: cls_plane_u below).
 //
 // Guards.  Non-finite or huge inputs would make binary32 overflow where binary64 does not, so a candidate is marked
 // EXACT-ONLY (field RH_CLS_FLAG = NaN) unless all its parameters are finite and below 2^20 (cylinder axis components
-constexpr double RH_CLS_SHIFT = 0.5;   // added to both scaled quantities of a record: see cls_plane_ab
 // below 16) and M, Nm <= 2^20; a tile with an infinite or NaN value in an enabled point treats every candidate as
 // exact-only.  Exact-only means: every enabled point is ambiguous.  Disabled points are staged as zeros and masked out
 // (plane: their zero normal fails the angle test by itself, which needs cos(alpha) - margin > 0, else exact-only).
@@ -63,10 +62,10 @@ struct rh_cls {
     float f[16];
 };
 constexpr int RH_CLS_FLAG = 15;   // NaN = exact-only
-// plane:    0-2 n / wN | 3 -cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
-// sphere:   0-2 o | 3 R | 4 1 / wD | 5 eD_lo / wD | 6 sgn / wN | 7 -cN_hi / wN
-// cylinder: 0-2 a | 3-5 c0 | 6 R | 7 1 / wD | 8 eD_lo / wD | 9 sgn / wN | 10 -cN_hi / wN
-// cone:     0-2 apex | 3-5 a^ | 6 c' / wD | 7 s' / wD | 8 eD_lo / wD | 9 sgn c' / wL | 10 sgn s' / wL | 11 -cos(alpha) / wL | 12 beta
+// plane:    0-2 -n / wN | 3 cN_hi / wN | 4-6 oz / wD | 7 -(oz . P0) / wD | 8 eD_lo / wD
+// sphere:   0-2 o | 3 R | 4 1 / wD | 5 -eD_lo / wD | 6 -sgn / wN | 7 cN_hi / wN
+// cylinder: 0-2 a | 3-5 c0 | 6 R | 7 1 / wD | 8 -eD_lo / wD | 9 -sgn / wN | 10 cN_hi / wN
+// cone:     0-2 apex | 3-5 a^ | 6 c' / wD | 7 s' / wD | 8 eD_lo / wD | 9 -sgn c' / wL | 10 -sgn s' / wL | 11 cos(alpha) / wL | 12 beta
 
 // culling record of a candidate, structure-of-arrays over the batch (field f of slot i at box[f * stride + i]): what
 // the box tests of stage 1 read, coalesced, with lane = candidate
@@ -126,11 +125,11 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             const double iN = 1.0 / wN, iD = 1.0 / wD;
             const double cNhi = cosa + 0.5 * wN, eDlo = eps - 0.5 * wD;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
-            o.f[0] = (float)(P.f[3] * iN); o.f[1] = (float)(P.f[4] * iN); o.f[2] = (float)(P.f[5] * iN);
-            o.f[3] = (float)(-cNhi * iN + RH_CLS_SHIFT);
+            o.f[0] = (float)(-P.f[3] * iN); o.f[1] = (float)(-P.f[4] * iN); o.f[2] = (float)(-P.f[5] * iN);
+            o.f[3] = (float)(cNhi * iN);
             o.f[4] = (float)(P.f[6] * iD); o.f[5] = (float)(P.f[7] * iD); o.f[6] = (float)(P.f[8] * iD);
             o.f[7] = (float)(-zp * iD);
-            o.f[8] = (float)(eDlo * iD + RH_CLS_SHIFT);
+            o.f[8] = (float)(eDlo * iD);
             if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             for (int i = 0; i < 9; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
@@ -171,8 +170,8 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
         double mN = nrmin > 0.0 ? S * ((3.0 * Nm + s3 * (fabs(cosa) + 0.25)) * e / nrmin + (8.7 * Nm + 6.0 * (fabs(cosa) + 0.25)) * u) + 1e-30
                                 : __builtin_nan("");
         if (!(mN <= 0.25)) mN = __builtin_nan("");
-        // scaled like the plane record: a = (eD_lo - |nr - R|) / wD, b = (sgn (q . np) / nr - cN_hi) / wN, t = min(a, b);
-        // a point whose distance half fails surely has a <= -1 whatever b is
+        // scaled like the plane record: ua = (|nr - R| - eD_lo) / wD, ub = (cN_hi - sgn (q . np) / nr) / wN, u = max(ua, ub);
+        // a point whose distance half fails surely has ua > 1 whatever ub is
         ok = ok && cls_fin(mD) && cls_fin(mN) && (sgn == 1.0 || sgn == -1.0) && mD < 1e30;
         // (constant indices only: a run-time index would move the record to scratch memory)
         if (sph) { o.f[0] = (float)P.f[0]; o.f[1] = (float)P.f[1]; o.f[2] = (float)P.f[2]; o.f[3] = (float)R; }
@@ -183,7 +182,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             const double eDlo = eps - 0.5 * wD, cNhi = cosa + 0.5 * wN;
             ok = cosa - 0.5 * wN > 0.0;   // a zero normal (a disabled point) must fail the angle test surely
             const double iN = 1.0 / wN, iD = 1.0 / wD;
-            const float s0 = (float)iD, s1 = (float)(eDlo * iD + RH_CLS_SHIFT), s2 = (float)(sgn * iN), s3f = (float)(-cNhi * iN + RH_CLS_SHIFT);
+            const float s0 = (float)iD, s1 = (float)(-eDlo * iD), s2 = (float)(-sgn * iN), s3f = (float)(cNhi * iN);
             if (dbg4 != nullptr) { dbg4[0] = cNhi; dbg4[1] = wN; dbg4[2] = eDlo; dbg4[3] = wD; }
             if (sph) { o.f[4] = s0; o.f[5] = s1; o.f[6] = s2; o.f[7] = s3f; }
             else { o.f[7] = s0; o.f[8] = s1; o.f[9] = s2; o.f[10] = s3f; }
@@ -208,7 +207,7 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             }
         }
     } else {
-        // cone: the two-sided classifier works on the closed form of the reference's frame (cls_cone_t below); the culling
+        // cone: the two-sided classifier works on the closed form of the reference's frame (cls_cone_u below); the culling
         // record keeps the band form: with t = p - apex, h = t . a^, rho^2 = |t|^2 - h^2 the reference's distance is
         // -(c rho + s h) / sqrt(c^2 + s^2) (c, s = cos / sin of -opang/2): |dist| < eps <=> rho in (k h - e, k h + e),
         // k = -s / c, e = eps sqrt(c^2 + s^2) / c   (c > 0)
@@ -259,8 +258,8 @@ __host__ __device__ inline void cls_make(const rh_prep &P, int kind, double eps,
             const double wD = 2.0 * mD, iD = 1.0 / wD, eDlo = eps - 0.5 * wD;
             const double wL = 2.0 * mL, iL = f32cloud ? 0.0 : 1.0 / wL;
             o.f[6] = (float)(cp * iD); o.f[7] = (float)(sp * iD);
-            o.f[8] = (float)(eDlo * iD + RH_CLS_SHIFT);
-            o.f[9] = (float)(sgn * cp * iL); o.f[10] = (float)(sgn * sp * iL); o.f[11] = (float)(-cosa * iL);
+            o.f[8] = (float)(eDlo * iD);
+            o.f[9] = (float)(-sgn * cp * iL); o.f[10] = (float)(-sgn * sp * iL); o.f[11] = (float)(cosa * iL);
             if (dbg4 != nullptr) { dbg4[0] = 0.0; dbg4[1] = wL; dbg4[2] = eDlo; dbg4[3] = wD; }
             for (int i = 6; i < 12; i++) ok = ok && fabs((double)o.f[i]) < 1e30;
         }
@@ -349,25 +348,36 @@ static __device__ __forceinline__ bool box_skip32(const float (&B)[RH_BOX_FIELDS
     return (rho2 > s2) & ((hi <= 0.0f) | (rho2 > hi2) | ((lo > 0.0f) & (rho2 < lo2)));
 }
 
-// ---- plane: t = min(a, b) of the scaled record, SHIFTED by RH_CLS_SHIFT = 1/2 (the record's two additive constants carry
-// it): sure <=> t > 1/2, maybe <=> |t| <= 1/2, surely not <=> t < -1/2.  The shift makes "a maybe among the 64 points" a
-// running minimum of |t| -- one instruction per point where a second counter took a compare and an add
-static __device__ __forceinline__ void cls_plane_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &b)
+// ---- The classifier's value of a (candidate, point) pair: u = max(ua, ub), the scaled "outsideness" of the two tests --
+// ua = (threshold_lo - quantity) / width for the test that wants its quantity large (the normal's cosine), (quantity -
+// threshold_lo) / width for the one that wants it small (the distance), widths = 2 x margin:
+//     u < 0  (sign bit set)   both tests pass by more than their margins: SURELY an inlier
+//     0 <= u <= 1             some test is within its margin and none fails surely: UNDECIDED -> the exact test
+//     u > 1                   some test fails by more than its margin: surely not
+// so that the 64-point loop of the score kernel (score4.hip) keeps the books with two instructions per point and no
+// compare: the sign bit of u is shifted into the pair's inlier word (v_alignbit_b32), and a running UNSIGNED minimum over
+// the bit patterns of the u (v_min3_u32, two points per instruction) ends <= bits(1.0f) iff some point was undecided --
+// non-negative floats order like their bit patterns and every negative one lies above them.  (Measured on this GPU,
+// tools/ubench/count_seq.hip: v_cmp / v_cndmask / v_addc / v_min_f32 hold the issue port 4.2 cycles each, fma / add / mul
+// 2.3-2.9; round 3's t = min(a, b) with `count += t > 1/2` and a running minimum of |t| cost 14.6 cycles per point beside the
+// arithmetic, this form 10.5.)  u = -0 counts as surely-in: it stands for a test passed by exactly its margin, and the
+// margins carry a factor RH_CLS_SAFETY over the first-order bound.
+static __device__ __forceinline__ void cls_plane_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &ua, float &ub)
 {
-    a = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
+    ua = __builtin_fmaf(C.f[2], nz, __builtin_fmaf(C.f[1], ny, __builtin_fmaf(C.f[0], nx, C.f[3])));
     const float d = __builtin_fmaf(C.f[6], z, __builtin_fmaf(C.f[5], y, __builtin_fmaf(C.f[4], x, C.f[7])));
-    b = C.f[8] - __builtin_fabsf(d);
+    ub = __builtin_fabsf(d) - C.f[8];
 }
-static __device__ __forceinline__ float cls_plane_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+static __device__ __forceinline__ float cls_plane_u(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
     float a, b;
     cls_plane_ab(C, x, y, z, nx, ny, nz, a, b);
-    return fminf(a, b);
+    return fmaxf(a, b);
 }
 
-// ---- sphere / cylinder: the same shifted t = min(a, b) from the scaled record
+// ---- sphere / cylinder: the same u = max(ua, ub) from the scaled record
 template <int KIND>
-static __device__ __forceinline__ void cls_round_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &bb)
+static __device__ __forceinline__ void cls_round_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &ua, float &ub)
 {
     float qx, qy, qz;
     constexpr int b = KIND == RH_SPHERE ? 3 : 6;
@@ -378,30 +388,32 @@ static __device__ __forceinline__ void cls_round_ab(const rh_cls &C, float x, fl
         const float sd = __builtin_fmaf(C.f[2], tz, __builtin_fmaf(C.f[1], ty, C.f[0] * tx));
         qx = __builtin_fmaf(-C.f[0], sd, tx); qy = __builtin_fmaf(-C.f[1], sd, ty); qz = __builtin_fmaf(-C.f[2], sd, tz);
     }
-    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    // (+ 1e-37: a point ON the centre / axis gives nr = 0 and a zero cosine -- surely out, as the exact test's NaN says --
+    // instead of 0 x inf = NaN, whose sign bit the books below would read; any other n2 absorbs it unchanged)
+    const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, __builtin_fmaf(qx, qx, 1e-37f)));
     const float inr = __builtin_amdgcn_rsqf(n2);
     const float nr = n2 * inr;
     const float dt = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx)) * inr;
-    a = __builtin_fmaf(-__builtin_fabsf(nr - C.f[b]), C.f[b + 1], C.f[b + 2]);
-    bb = __builtin_fmaf(dt, C.f[b + 3], C.f[b + 4]);
+    ua = __builtin_fmaf(__builtin_fabsf(nr - C.f[b]), C.f[b + 1], C.f[b + 2]);
+    ub = __builtin_fmaf(dt, C.f[b + 3], C.f[b + 4]);
 }
 template <int KIND>
-static __device__ __forceinline__ float cls_round_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+static __device__ __forceinline__ float cls_round_u(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
     float a, b;
     cls_round_ab<KIND>(C, x, y, z, nx, ny, nz, a, b);
-    return fminf(a, b);
+    return fmaxf(a, b);
 }
 
-// ---- cone: the same shifted t = min(a, b).  The reference builds a frame per point (project2cone, cone.jl:68-85): with
+// ---- cone: the same u = max(ua, ub).  The reference builds a frame per point (project2cone, cone.jl:68-85): with
 // w = p - apex = h a^ + rho e_rho (a^ the unit axis, e_rho the unit radial direction, phi^ = a^ x e_rho)
 //     rot_ax = normalize(axis x normalize(-w)) = -phi^,   comp_n = normalize(axis x rot_ax) = e_rho,
 //     current_normal = normalize(R(rot_ax, -opang/2) comp_n) = (c e_rho + s (rot_ax x comp_n)) / |(c, s)| = c' e_rho + s' a^
 // so dist = dot(-current_normal, apex - p) = -(c' rho + s' h) and the normal's cosine is c' (q . n) / rho + s' (a^ . n).
-// a = (eD_lo - |D|) / wD + 1/2 with D = c' rho + s' h;  b = L / wL with L = sgn (c' q . n + s' rho a^ . n) - cos(alpha) rho
+// ua = (|D| - eD_lo) / wD with D = c' rho + s' h;  ub = 1/2 - L / wL with L = sgn (c' q . n + s' rho a^ . n) - cos(alpha) rho
 // (the angle test multiplied through by rho > 0: its margin is absolute, nothing is divided by a small rho).  Next to the
-// axis the reference's frame is ill-conditioned (and NaN on it): t = 0, undecided, the exact test answers.
-static __device__ __forceinline__ void cls_cone_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &a, float &b,
+// axis the reference's frame is ill-conditioned (and NaN on it): u = 1/2, undecided, the exact test answers.
+static __device__ __forceinline__ void cls_cone_ab(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz, float &ua, float &ub,
                                                    bool &near_axis)
 {
     const float wx = x - C.f[0], wy = y - C.f[1], wz = z - C.f[2];
@@ -410,20 +422,23 @@ static __device__ __forceinline__ void cls_cone_ab(const rh_cls &C, float x, flo
     const float n2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
     const float rho = n2 * __builtin_amdgcn_rsqf(n2);
     const float D = __builtin_fmaf(C.f[6], rho, C.f[7] * h);
-    a = C.f[8] - __builtin_fabsf(D);
+    ua = __builtin_fabsf(D) - C.f[8];
     const float qn = __builtin_fmaf(qz, nz, __builtin_fmaf(qy, ny, qx * nx));
     const float an = __builtin_fmaf(C.f[5], nz, __builtin_fmaf(C.f[4], ny, C.f[3] * nx));
-    b = __builtin_fmaf(qn, C.f[9], rho * __builtin_fmaf(an, C.f[10], C.f[11]));
+    ub = __builtin_fmaf(qn, C.f[9], __builtin_fmaf(rho, __builtin_fmaf(an, C.f[10], C.f[11]), 0.5f));
     const float tt = __builtin_fmaf(h, h, n2);
     near_axis = !(n2 > __builtin_fmaf(RH_CONE_ALPHA, tt, C.f[12]));   // (NaN -> near; alpha is the same for every cone)
 }
-static __device__ __forceinline__ float cls_cone_t(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
+static __device__ __forceinline__ float cls_cone_u(const rh_cls &C, float x, float y, float z, float nx, float ny, float nz)
 {
     float a, b;
     bool near_axis;
     cls_cone_ab(C, x, y, z, nx, ny, nz, a, b, near_axis);
-    return near_axis ? 0.0f : fminf(a, b);
+    return near_axis ? 0.5f : fmaxf(a, b);
 }
+// what the books say of a u (score kernel, audits)
+static __device__ __forceinline__ bool cls_sure(float u) { return (__builtin_bit_cast(uint32_t, u) >> 31) != 0; }
+static __device__ __forceinline__ bool cls_undecided(float u) { return __builtin_bit_cast(uint32_t, u) <= 0x3f800000u; }   // 0 <= u <= 1
 #endif   // __HIPCC__
 
 }  // namespace rh4
