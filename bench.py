@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--e2e-runs", type=int, default=5, help="timed rh_ransac runs of the end-to-end leg (median reported)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end ransac leg")
     ap.add_argument("--no-f32", action="store_true", help="skip the Float32-cloud leg")
+    ap.add_argument("--no-per-kind", action="store_true", help="skip the diagnostic launches of the score kernel over one kind at a time (profiling passes: "
+                    "they carry the product launch's kernel name)")
     ap.add_argument("--e2e-iters", type=int, default=16384, help="itermax of the end-to-end ransac leg")
     ap.add_argument("--e2e-cpu-iters", type=int, default=768, help="iterations of the oracle's end-to-end prefix")
     ap.add_argument("--e2e-octree-iters", type=int, default=256, help="itermax of the octree-sampling end-to-end leg")
@@ -179,7 +181,7 @@ def compact_line(out, detail_file=None):
     line["config"] = {k: cfg.get(k) for k in ("workload", "points", "subset_points", "candidates_per_step", "score_mode", "parallelism")}
     line["roofline"] = {"kernel": rf.get("kernel"), "bound": rf.get("bound"), "achieved": _num(rf.get("achieved")),
                         "peak": _num(rf.get("peak")), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
-                        "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
+                        "frac_upper": _num(rf.get("frac_upper"), 4), "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
                         "counters": rf.get("counters")}
     line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": cb.get("sample")} if cb else None)
@@ -204,7 +206,7 @@ def compact_line(out, detail_file=None):
         "cfg2_value": _get(out, "cfg2", "value"), "cfg2_ms": _get(out, "cfg2", "ms_per_step"),
         "cfg2_oracle_checked": _get(out, "cfg2", "oracle_checked"),
         "cfg5_value": _get(out, "cfg5", "value"), "cfg5_ms": _get(out, "cfg5", "ms_per_step"),
-        "cfg5_frac": _get(out, "cfg5", "roofline", "frac"),
+        "cfg5_frac": _get(out, "cfg5", "roofline", "frac"), "cfg5_frac_upper": _get(out, "cfg5", "roofline", "frac_upper"),
         "cfg5_masks_ms": _get(out, "cfg5", "masks_out", "ms_per_step"),
         "cfg5_refit_scan_ms": _get(out, "cfg5", "roofline_refit", "ms_per_launch"),
         "cfg5_refit_scan_frac_hbm": _get(out, "cfg5", "roofline_refit", "frac"),
@@ -577,6 +579,8 @@ def main():
         acc = [0.0] * 5
         msk = (C.c_float * 5)()
         for _ in range(reps):   # [4]: the launch of the timed steps (all kinds, one kernel); [0..3]: one launch per kind
+            if args.no_per_kind:
+                msk[0] = -1.0   # (the library's sign for "the product launch only")
             L.check(lib.rh_score_batch_dev_timed(pc._h, batch.slice_ptr(lo), hi - lo, C.byref(cp),
                                                  C.c_void_p(counts.data_ptr() + 4 * lo), None, msk))
             for k in range(5):
@@ -606,16 +610,26 @@ def main():
         pmc_ok = args.workload in ("cfg3", "cfg5") and n == n_default and world == 1 and "RH_SCORE_PATH" not in os.environ
         pmc = pmc_replay(pmc_key, pmc_ok, "" if args.workload == "cfg3" else "_" + args.workload)
         sq = pmc["sq"]
-        # Issue model (tools/ubench/valu_rates.hip, this GPU, 8 waves per SIMD): SIMD cycles a wave64 instruction holds the
-        # vector issue port -- binary64 add 4.2 / mul 4.3 / fma 4.75 / sqrt-rcp-rsq 16.2, everything 32-bit 2.3 -- and
-        # 4.2 for a scalar instruction (one scalar ALU per CU).  1024 SIMDs x 2.4 GHz cycles per second are there.
+        # Issue model (tools/ubench/valu_rates.hip + count_seq.hip, this GPU, 8 waves per SIMD): SIMD cycles a wave64 instruction
+        # holds the vector issue port.  Classes with a counter of their own: binary64 add 4.2 / mul 4.3 / fma 4.75 / sqrt-rcp-rsq
+        # 16.2; binary32 fma 2.45, add / mul 2.3, sqrt-rcp-rsq 8.15; conversions 4.3.  The rest (integer, min / max, compares,
+        # selects, moves, lane operations) measures 2.3 (v_and, v_sub) .. 4.2 (v_min / v_max / v_cmp / v_cndmask / v_alignbit /
+        # v_min3): priced at 2.3 for `frac` -- a LOWER bound of the issue cycles -- and at 4.2 for `frac_upper`.  A scalar
+        # instruction: 4.2 (one scalar ALU per CU).  1024 SIMDs x 2.4 GHz cycles per second are there.
         CYC = {"SQ_INSTS_VALU_ADD_F64": 4.2, "SQ_INSTS_VALU_MUL_F64": 4.3, "SQ_INSTS_VALU_FMA_F64": 4.75, "SQ_INSTS_VALU_TRANS_F64": 16.2}
+        CYC32 = {"SQ_INSTS_VALU_FMA_F32": 2.45, "SQ_INSTS_VALU_ADD_F32": 2.3, "SQ_INSTS_VALU_MUL_F32": 2.3, "SQ_INSTS_VALU_TRANS_F32": 8.15,
+                 "SQ_INSTS_VALU_CVT": 4.3}
         simd_cycles_per_s = 1024 * 2.4e9
         insts = sq.get("SQ_INSTS_VALU")
-        arith = vcyc = None
+        arith = vcyc = vcyc_hi = rest = None
         if insts is not None and all(k in sq for k in CYC):
             arith = sum(sq[k] for k in CYC)
-            vcyc = sum(sq[k] * CYC[k] for k in CYC) + (insts - arith) * 2.3
+            if all(k in sq for k in CYC32):
+                rest = insts - arith - sum(sq[k] for k in CYC32)
+                classed = sum(sq[k] * CYC[k] for k in CYC) + sum(sq[k] * CYC32[k] for k in CYC32)
+                vcyc, vcyc_hi = classed + rest * 2.3, classed + rest * 4.2
+            else:   # (passes without the binary32 class counters: everything 32-bit at 2.3)
+                vcyc = sum(sq[k] * CYC[k] for k in CYC) + (insts - arith) * 2.3
         scyc = None if "SQ_INSTS_SALU" not in sq else sq["SQ_INSTS_SALU"] * 4.2
         alg_bytes = tests * SCORE_BYTES_PER_TEST + ncand * (64 + 4)
         flops = sum(FLOPS_PER_TEST[k] * per_kind[k]["candidates"] * S for k in kinds_in)
@@ -623,6 +637,8 @@ def main():
             "kernel": kname, "bound": "valu_issue",
             "achieved": None if vcyc is None else vcyc / sec, "peak": simd_cycles_per_s, "unit": "SIMD vector-issue cycles/s",
             "frac": None if vcyc is None else vcyc / sec / simd_cycles_per_s,
+            "frac_upper": None if vcyc_hi is None else vcyc_hi / sec / simd_cycles_per_s,
+            "valu_insts_unclassed_per_launch": rest,
             "frac_scalar_issue": None if scyc is None else scyc / sec / simd_cycles_per_s,
             "frac_fp64_arith": None if arith is None else sum(sq[k] * CYC[k] for k in CYC) / sec / simd_cycles_per_s,
             "frac_unweighted_x4": None if insts is None else insts * 4 / sec / simd_cycles_per_s,
@@ -641,8 +657,10 @@ def main():
                         "~90 % of the (candidate, group) pairs, bit-exactly -- so this exceeds the HBM peak by design"},
             "note": "The batched score is bound by instruction issue, not by HBM (SURVEY.md 8d: every point is reused across the "
                     "batch).  frac = the share of the chip's vector-issue cycles the launch fills, every instruction class "
-                    "weighted with its MEASURED issue cost (tools/ubench/valu_rates.hip: binary64 add 4.2 / mul 4.3 / fma 4.75 / "
-                    "transcendental 16.2 cycles, 32-bit 2.3); frac_scalar_issue = the same for the scalar port (4.2 cycles each); "
+                    "weighted with its MEASURED issue cost (tools/ubench/valu_rates.hip, count_seq.hip: binary64 add 4.2 / mul 4.3 / "
+                    "fma 4.75 / transcendental 16.2 cycles; binary32 fma 2.45, add / mul 2.3, transcendental 8.15; conversions 4.3; "
+                    "the instructions without a class counter -- integer, min / max, compares, selects, moves: 2.3 .. 4.2 measured -- at "
+                    "2.3 for frac (a lower bound) and at 4.2 for frac_upper); frac_scalar_issue = the same for the scalar port (4.2 cycles each); "
                     "frac_unweighted_x4 = round 2's figure (every vector instruction priced as binary64).  The v4 kernel computes "
                     "in binary32 with a rigorous two-sided classifier and runs the reference's binary64 test only on pairs it cannot "
                     "decide (frac_fp64_arith is that remainder).  The launch time is measured here; the counter values are REPLAYED "

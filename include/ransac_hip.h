@@ -276,7 +276,8 @@ int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int
 /* rh_score_batch_dev twice, bracketed by HIP events on the cloud's stream: first the way
  * rh_score_batch_dev runs it (one kernel for all kinds) -> ms_out[4]; then one launch per kind
  * with an event before each and after the last -> ms_out[0..3] (0 for kinds without candidates
- * ~ an empty launch).  Waits for the batch. */
+ * ~ an empty launch).  Waits for the batch.  ms_out[0] < 0 on entry: the first form only
+ * (profiling passes that must see the product's launches alone). */
 int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                              int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_out /* [5] */);
 /* device time of the most recent rh_refit on this cloud: the full-cloud scan kernel and the

@@ -899,6 +899,7 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     RH_TRY(enter(c));
     RH_TRY(rh_validate_params(p));
     if (b < 0 || (b > 0 && (!d_shapes || !d_counts))) { rh_set_error("rh_score_batch_dev: bad arguments"); return RH_E_INVALID; }
+    const bool product_only = ms_kind && ms_kind[0] < 0.f;   // (profiling passes: no per-kind launches beside the product's)
     if (ms_kind) for (int k = 0; k < 5; k++) ms_kind[k] = 0.f;
     if (b == 0) return RH_OK;
     RH_TRY(rh_ensure_batch(c, b));
@@ -935,15 +936,18 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
         RH_HIP(hipEventRecord(c->evk[1], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[1]));
         RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
-        RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
-        if (d_masks_int && c->masks4) RH_HIP(hipMemsetAsync(c->d_occ, 0, sizeof(int32_t) * (size_t)b, c->stream));   // (the lists' cursors)
-        else if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+        if (!product_only) {
+            RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
+            if (d_masks_int && c->masks4) RH_HIP(hipMemsetAsync(c->d_occ, 0, sizeof(int32_t) * (size_t)b, c->stream));   // (the lists' cursors)
+            else if (d_masks_int) RH_HIP(hipMemsetAsync(d_masks_int, 0, sizeof(uint64_t) * (size_t)b * (size_t)c->swords, c->stream));
+        }
     }
-    RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind, d_cls, c->d_box, 4 * c->batch_cap));
+    if (!product_only)
+        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, ms_kind, d_cls, c->d_box, 4 * c->batch_cap));
     if (d_masks_int && c->masks4) RH_TRY(rhk_unpermute_masks4(c, d_masks_int, c->d_occ, c->mstride4, b, d_masks));
     else if (d_masks_int) RH_TRY(rhk_unpermute_masks(c, d_masks_int, b, d_masks));
     c->masks4 = false;
-    if (ms_kind) {
+    if (ms_kind && !product_only) {
         RH_HIP(hipEventRecord(c->evk[4], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[4]));
         for (int k = 0; k < 4; k++) RH_HIP(hipEventElapsedTime(&ms_kind[k], c->evk[k], c->evk[k + 1]));
