@@ -265,6 +265,79 @@ fit_sets_kernel(const double *__restrict__ ws, const int32_t *__restrict__ set_l
     }
 }
 
+// Octree sampling without cones: sample_sets_kernel and fit_sets_kernel in ONE launch (an iteration of a chained window is a
+// chain of dependent launches -- sample, fit, prepare, score, advance -- and every launch less is ~5 us of its ~180).  A
+// thread samples its set exactly like sample_sets_kernel (same stream, same draws), gathers the points into registers and
+// fits every shape type like fit_sets_kernel; no hand-over workspace.  Blocks of one wave, like the octree sampler's.
+template <int DN>
+__global__ void __launch_bounds__(64)
+sample_fit_oct_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int32_t n_enabled, const rhfit::OctView oc,
+                      const double *__restrict__ Pwin, const rh_params prm, uint64_t seed, int64_t k0, int32_t n_iters,
+                      unsigned long long *__restrict__ draws_per_iter, int32_t *__restrict__ gave_up_flag, SetShard sh,
+                      const rh_oct_state *__restrict__ ost, rh_cand_entry *__restrict__ out, int32_t cap, int32_t *__restrict__ out_count,
+                      int32_t *__restrict__ nk_zero, int32_t it0, int f32)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4 && nk_zero != nullptr) nk_zero[t] = 0;   // the kind bins prep_entries_kernel fills next
+    if (ost != nullptr) {   // an iteration of a chained octree window (n_iters = 1; draws_per_iter already points at its counter)
+        if (ost->stop != 0) return;
+        Pwin = ost->P;
+    }
+    const int64_t total = (int64_t)n_iters * sh.m_local;
+    if (t >= total) return;
+    const int32_t it = (int32_t)(t / sh.m_local);
+    const int32_t j = sh.lo + (int32_t)(t - (int64_t)it * sh.m_local) * sh.step;
+    uint64_t x = rhfit::set_stream_init(seed, (uint64_t)(k0 + it), (uint64_t)j);
+    constexpr int CAP = DN > 0 ? DN : RH_MAX_DRAWN;
+    int64_t sd[CAP];
+    uint32_t nd = 0;
+    bool gave_up = false;
+    const int drawN = DN > 0 ? DN : prm.drawN;
+    int level = 1;
+    const bool ok = rhfit::sample_minimal_set_octree<DN>(en, oc, Pwin + (int64_t)it * oc.depth, n, (int64_t)n_enabled, drawN, &x, sd, &nd,
+                                                         &gave_up, &level);
+    {   // draws per iteration: one atomic per (wave, iteration)
+        uint64_t todo = __builtin_amdgcn_ballot_w64(true);
+        const int lane = threadIdx.x & 63;
+        while (todo != 0) {
+            const int leader = __builtin_ctzll(todo);
+            const int32_t itl = __shfl(it, leader);
+            const uint64_t grp = __builtin_amdgcn_ballot_w64(it == itl) & todo;
+            unsigned v = (it == itl) ? nd : 0u;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == leader) atomicAdd(&draws_per_iter[itl], (unsigned long long)v);
+            todo &= ~grp;
+        }
+    }
+    if (gave_up) atomicExch(gave_up_flag, 1);
+    if (!ok) return;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    double fp[3 * CAP], fn[3 * CAP];
+#pragma unroll
+    for (int q = 0; q < drawN; q++) {
+        const f64x2 *r = (const f64x2 *)(rec + 8 * (sd[q] - 1));   // one 64-byte record per point
+        const f64x2 a = r[0], b = r[1], c = r[2];
+        fp[3 * q] = a.x; fp[3 * q + 1] = a.y; fp[3 * q + 2] = b.x;
+        fn[3 * q] = b.y; fn[3 * q + 1] = c.x; fn[3 * q + 2] = c.y;
+    }
+    for (int ti = 0; ti < prm.n_shape_types; ti++) {
+        rh_shape s;
+        for (int q = 0; q < 10; q++) s.v[q] = 0.0;
+        s.kind = -1;
+        s.outwards = 0;
+        const bool fitted = fit_kind<false>(prm.shape_types[ti], fp, fn, drawN, prm, f32, &s);
+        if (!fitted) continue;
+        const int32_t pos = atomicAdd(out_count, 1);
+        if (pos < cap) {
+            const int64_t tg = (int64_t)(it0 + it) * prm.minsubsetN + j;   // the slot is GLOBAL (iteration, set, type)
+            out[pos].slot = tg * prm.n_shape_types + ti;
+            out[pos].level = level;
+            out[pos].pad = 0;
+            out[pos].shape = s;
+        }
+    }
+}
+
 // End of a window's chain: one block copies the status block, the head of the candidate list and the
 // head of its counts straight into pinned host memory (three copy-engine transfers cost ~15 us per
 // window), then zeroes the status block for the buffer's next window.
@@ -813,6 +886,17 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
         else
             hipLaunchKernelGGL(sample_fit_ranks_kernel<0>, gk, dim3(128), 0, c->stream, crec, c->rec, c->n, en, n_enabled, *prm,
                                seed, k0, n_iters, d_out, cap, d_count, d_draws, d_gave_up, d_nk_zero, sh, c->f32 ? 1 : 0);
+        RH_HIP(hipGetLastError());
+        return RH_OK;
+    }
+    if (d_P != nullptr && !cone && !no_fused) {   // octree sampling: sampler + fits in one launch (sample_fit_oct_kernel)
+        const dim3 go((unsigned)((total + 63) / 64));
+        if (prm->drawN == 3)
+            hipLaunchKernelGGL(sample_fit_oct_kernel<3>, go, dim3(64), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P, *prm, seed, k0,
+                               n_iters, d_draws, d_gave_up, sh, ost, d_out, cap, d_count, d_nk_zero, it0, c->f32 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(sample_fit_oct_kernel<0>, go, dim3(64), 0, c->stream, c->rec, c->n, en, n_enabled, oc, d_P, *prm, seed, k0,
+                               n_iters, d_draws, d_gave_up, sh, ost, d_out, cap, d_count, d_nk_zero, it0, c->f32 ? 1 : 0);
         RH_HIP(hipGetLastError());
         return RH_OK;
     }

@@ -105,17 +105,21 @@ template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLA
 
 #define RH4_CONST_AS __attribute__((address_space(4)))
 
-// segmented sum over runs of equal keys in adjacent lanes (runs of up to S4_TG = 8: the groups of one candidate): the
+// lane i <- lane i - 1 (lane 0 <- 0) / lane i <- lane i + 1 (lane 63 <- 0): DPP moves across the whole wave, no trip through LDS
+static __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+static __device__ __forceinline__ int wave_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+
+// segmented sum over runs of equal keys in adjacent lanes (runs of up to S4_TG = 4: the groups of one candidate): the
 // LAST lane of a run gets the run's total, the others 0
 static __device__ __forceinline__ int run_total(int v, int key, int lane)
 {
-    int u = __shfl_up(v, 1), k1 = __shfl_up(key, 1);
-    if (lane >= 1 && k1 == key) v += u;
-    u = __shfl_up(v, 2); k1 = __shfl_up(key, 2);
-    if (lane >= 2 && k1 == key) v += u;
-    u = __shfl_up(v, 4); k1 = __shfl_up(key, 4);
-    if (lane >= 4 && k1 == key) v += u;
-    const int kn = __shfl_down(key, 1);
+    static_assert(S4_TG <= 4, "two steps cover runs of four");
+    // (every move with all lanes active: a DPP move reads nothing from a lane that is switched off)
+    const int k1 = wave_shr1(key), u1 = wave_shr1(v);
+    v += (lane >= 1 && k1 == key) ? u1 : 0;
+    const int k2 = wave_shr1(k1), u2 = wave_shr1(wave_shr1(v));
+    v += (lane >= 2 && k2 == key) ? u2 : 0;
+    const int kn = wave_shl1(key);
     return (lane == 63 || kn != key) ? v : 0;
 }
 
@@ -282,7 +286,7 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         const bool nz = act && word != 0;
         const uint64_t nzm = WB(nz);
         if (nzm != 0) {
-            const int keyp = __shfl_up(act ? ci : -1 - lane, 1);
+            const int keyp = wave_shr1(act ? ci : -1 - lane);   // (wave-uniform branch: all lanes active)
             const uint64_t starts = WB(lane == 0 || keyp != (act ? ci : -1 - lane));
             const uint64_t below = lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL);          // lanes 0 .. lane
             const int rs = 63 - __builtin_clzll(starts & below);                            // first lane of my run
