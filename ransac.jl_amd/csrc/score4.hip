@@ -139,6 +139,35 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
     const rh_cls *__restrict__ rec = &cls[ci];
     int total = 0;
     uint64_t word = 0;   // MASK: the inlier word of the lane's pair
+    // Undecided POINTS go to the exact test through a per-wave ring of (pair of the batch << 6 | point of its group), 64 at a
+    // time, lane = ring entry: the reference's test of the cloud's element type on the entry's own record; what it accepts is
+    // added to the pair's count (and word) in LDS.  (Float32 cloud: the staged floats are the points; Float64: global memory.)
+    int qbh = 0, qbn = 0;   // ring head / fill (wave-uniform)
+    auto drain_b = [&](int k) {
+        wave_lds_sync();
+        const bool on = lane < k;
+        const unsigned e2 = on ? sh.qb[wv][(qbh + lane) & 127] : 0u;
+        const int slot = (int)(e2 >> 6);
+        const uint32_t pe = sh.plist[head + slot];
+        const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
+        uint64_t r;
+        if (F32) {
+            const rh_prepf Pv = prepf_of<KIND>(prep[cbase + (int)(pe >> S4_GB)]);
+            const rh_f32x4 a = sh.pa[pe & S4_GM][e2 & 63u];
+            const rh_f32x2 b = sh.pb[pe & S4_GM][e2 & 63u];
+            r = test_point32<KIND>(Pv, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
+        } else {
+            const rh_prep Pv = prep[cbase + (int)(pe >> S4_GB)];
+            r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
+                                 pts[5 * stride + gi], eps, cosa);
+        }
+        if (on && ((r >> lane) & 1ULL)) {
+            atomicAdd(&sh.cntb[wv][slot], 1);
+            if (MASK) atomicOr(&sh.maskb[wv][slot], 1ULL << (e2 & 63u));
+        }
+        qbh = (qbh + k) & 127;
+        qbn -= k;
+    };
     if (KIND != RH_CONE) {
         constexpr int NF = KIND == RH_PLANE ? 9 : (KIND == RH_SPHERE ? 8 : 11);
         rh_cls C;
@@ -170,36 +199,42 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         const bool amb = act && (umin <= 0x3f800000u || exact_only);
         total = (act && !amb) ? cs : 0;
         word = (act && !amb) ? (((uint64_t)whi << 32) | wlo) : 0ULL;
-        // pairs the classifier could not decide: the exact test on the whole group, lane = point
+        // Pairs with an undecided point (a percent of them): the classifier once more with lane = POINT (the candidate's record
+        // through scalar loads, the points from LDS), which says WHICH points are undecided -- only those take the exact test,
+        // 64 at a time through the ring, whatever pair they belong to.  (Round 3 ran the exact test on the whole group of every
+        // such pair: 40 binary64 instructions per wave and pair, a tenth of the launch's issue cycles.)
         uint64_t redo = WB(amb);
-        if (F32) {
-            // Float32 cloud: the reference's test is the binary32 one, and the staged floats ARE the cloud's points (a
-            // disabled point is staged as zeros: masked out by the group's word) -- no trip to global memory for them
+        if (redo != 0) {
+            sh.cntb[wv][lane] = 0;
+            if (MASK) sh.maskb[wv][lane] = 0ULL;
             while (redo != 0) {
                 const int k = __builtin_ctzll(redo);
                 redo &= redo - 1;
                 const uint32_t ek = __builtin_amdgcn_readlane(e, k);
                 const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
-                const rh_prepf Pf = prepf_of<KIND>(rh_ld_prep_const(&prep[ci2]));   // (the float record follows from the binary64 one: score_device32.h)
+                const RH4_CONST_AS rh_cls *rk = (const RH4_CONST_AS rh_cls *)(uintptr_t)&cls[ci2];   // (wave-uniform: scalar loads)
+                rh_cls Ck;
+#pragma unroll
+                for (int f = 0; f < NF; f++) Ck.f[f] = rk->f[f];
+                const bool xo = weird || is_nan_bits(rk->f[RH_CLS_FLAG]);
                 const rh_f32x4 a = sh.pa[g2][lane];
                 const rh_f32x2 b = sh.pb[g2][lane];
-                uint64_t mres = test_point32<KIND>(Pf, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
-                mres &= sh.len[g2];
-                if (lane == k) { total = __popcll(mres); word = mres; }
+                const float u = KIND == RH_PLANE ? cls_plane_u(Ck, a.x, a.y, a.z, a.w, b.x, b.y)
+                                                 : cls_round_u<KIND == RH_PLANE ? RH_SPHERE : KIND>(Ck, a.x, a.y, a.z, a.w, b.x, b.y);
+                const uint64_t lg = sh.len[g2];
+                const uint64_t sure = xo ? 0ULL : (WB(cls_sure(u)) & lg);
+                const uint64_t und = xo ? lg : (WB(cls_undecided(u)) & lg);   // (exact-only: every enabled point)
+                if (lane == k) { total = __popcll(sure); word = sure; }
+                const bool has = (und >> lane) & 1ULL;
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(und >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)und, 0));
+                if (has) sh.qb[wv][(qbh + qbn + rank) & 127] = (uint16_t)((k << 6) | lane);
+                qbn += __popcll(und);
+                if (qbn >= 64) drain_b(64);
             }
-        } else {
-            while (redo != 0) {
-                const int k = __builtin_ctzll(redo);
-                redo &= redo - 1;
-                const uint32_t ek = __builtin_amdgcn_readlane(e, k);
-                const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
-                const int64_t gi = p0 + g2 * 64 + lane;
-                const rh_prep P = rh_ld_prep_const(&prep[ci2]);
-                uint64_t mres = test_point<KIND>(P, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
-                                                 pts[5 * stride + gi], eps, cosa);
-                mres &= sh.len[g2];
-                if (lane == k) { total = __popcll(mres); word = mres; }
-            }
+            if (qbn > 0) drain_b(qbn);
+            wave_lds_sync();
+            total += sh.cntb[wv][lane];
+            if (MASK) word |= sh.maskb[wv][lane];
         }
     } else {
         rh_cls C;
@@ -234,33 +269,6 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         if (!act) { mask = 0; sure = 0; }
         sh.cntb[wv][lane] = 0;
         if (MASK) sh.maskb[wv][lane] = 0ULL;
-        int qbh = 0, qbn = 0;   // ring head / fill (wave-uniform)
-        // lane = (pair, point) of the ring: the reference's binary64 test; the point comes from global memory
-        auto drain_b = [&](int k) {
-            wave_lds_sync();
-            const bool on = lane < k;
-            const unsigned e2 = on ? sh.qb[wv][(qbh + lane) & 127] : 0u;
-            const int slot = (int)(e2 >> 6);
-            const uint32_t pe = sh.plist[head + slot];
-            const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
-            uint64_t r;
-            if (F32) {   // (the staged floats are the points)
-                const rh_prepf Pv = prepf_of<KIND>(prep[cbase + (int)(pe >> S4_GB)]);
-                const rh_f32x4 a = sh.pa[pe & S4_GM][e2 & 63u];
-                const rh_f32x2 b = sh.pb[pe & S4_GM][e2 & 63u];
-                r = test_point32<KIND>(Pv, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
-            } else {
-                const rh_prep Pv = prep[cbase + (int)(pe >> S4_GB)];
-                r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
-                                     pts[5 * stride + gi], eps, cosa);
-            }
-            if (on && ((r >> lane) & 1ULL)) {
-                atomicAdd(&sh.cntb[wv][slot], 1);
-                if (MASK) atomicOr(&sh.maskb[wv][slot], 1ULL << (e2 & 63u));
-            }
-            qbh = (qbh + k) & 127;
-            qbn -= k;
-        };
         // the set bits of the 64 masks, one per lane and round, compacted onto the ring
         while (WB(mask != 0) != 0) {
             const bool has = mask != 0;
@@ -444,8 +452,10 @@ static __device__ __forceinline__ void s4_stage(SH &sh, const double *__restrict
 // its blocks walk the rows from A.row0 on grid-stride.  A separate instantiation -- the loop around the four per-kind
 // bodies costs the register allocation dearly (96 scalar + 40 vector registers spilled), the one-row form none.
 template <int R, bool MASK, bool F32, bool TAIL = false>
+// 7 blocks of four waves per CU = 7 waves per SIMD = 72 vector registers (measured against 8 / 64 registers: cfg3 0.0816 ->
+// 0.0807 ms, cfg5 0.3006 -> 0.2973; 6 / 80 registers is slower: profiles/r4/experiments.txt)
 #ifndef RH_S4_MINBLK
-#define RH_S4_MINBLK 8
+#define RH_S4_MINBLK 7
 #endif
 __global__ void __launch_bounds__(64 * S4_W, RH_S4_MINBLK)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)

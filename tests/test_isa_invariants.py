@@ -1,8 +1,8 @@
 """Build-time invariants of the hand-written score kernel, checked on the gfx950 ISA hipcc emits (no GPU needed).
 
 Performance tripwires only -- no correctness property of the kernel depends on what is checked here: the counts-only
-instantiations of score4_kernel (the timed step's launches) keep their hot loops free of scratch traffic at the 64
-registers that 8 waves per SIMD allow, and the candidate records of the exact tests arrive through compiler-tracked
+instantiations of score4_kernel (the timed step's launches) keep their hot loops free of scratch traffic at the 72
+registers that 7 waves per SIMD allow, and the candidate records of the exact tests arrive through compiler-tracked
 scalar loads (no inline-asm memory access)."""
 import os
 import re
@@ -57,7 +57,7 @@ def test_no_inline_asm_memory_access_in_the_score_kernel(isa):
 
 
 def test_score_kernel_register_budget(isa):
-    """Every instantiation the dispatch can launch is there, all within 64 vector registers (8 waves per SIMD).  The
+    """Every instantiation the dispatch can launch is there, all within 72 vector registers (7 waves per SIMD).  The
     counts-only sized launches -- the timed step -- spill at most one of them; the mask-writing and the row-walking
     (open-ended windows) forms are allowed the handful the round measured (profiles/r4/experiments.txt)."""
     ks = _kernels(isa)
@@ -70,7 +70,7 @@ def test_score_kernel_register_budget(isa):
             assert (R, False, f32, True) in ks
     for key, v in ks.items():
         R, mask, f32, tail = key
-        assert v["vgpr"] <= 64, (key, v)
+        assert v["vgpr"] <= 72, (key, v)
         if not mask and not tail:
             assert v["vgpr_spill"] <= 2, (key, v)
         else:
