@@ -457,7 +457,7 @@ template <int R, bool MASK, bool F32, bool TAIL = false>
 #ifndef RH_S4_MINBLK
 #define RH_S4_MINBLK 7
 #endif
-__global__ void __launch_bounds__(64 * S4_W, RH_S4_MINBLK)
+__global__ void __launch_bounds__(64 * S4_W, F32 ? 8 : RH_S4_MINBLK)   // (the Float32 instantiations: 8 / 64 registers, 0.0916 -> see experiments.txt)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
 {
     __shared__ S4Shared<R, MASK> sh;
