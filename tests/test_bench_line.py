@@ -34,7 +34,7 @@ def canned(big=True):
                    "prewarm_ms": 40.0, "parallelism": "candidate-sharded x1, int32 sum all-reduce"},
         "tests_per_sec": 1.36e13, "rccl_ranks_seen": 1, "collective_backend": None, "collective_issued_by": None,
         "roofline": {"kernel": "score4_kernel (plane+sphere+cylinder in one launch)", "bound": "valu_issue", "achieved": 1.3e12,
-                     "peak": 2.4576e12, "unit": "SIMD vector-issue cycles/s", "frac": 0.53123456, "traffic": 27.7e6, "ms_per_launch": 0.0904,
+                     "peak": 2.4576e12, "unit": "SIMD vector-issue cycles/s", "frac": 0.53123456, "frac_upper": 0.712345, "traffic": 27.7e6, "ms_per_launch": 0.0904,
                      "counters": "replayed:profiles/r3", "replayed_from": [PROSE, PROSE], "note": PROSE,
                      "effective_algorithmic": {"GBs": 658000.0, "note": PROSE}},
         "cpu_baseline": {"value": 61.2, "unit": "candidates/s", "cores": 1, "kind": "port", "sample": PROSE, "host_cpus": 128},
@@ -80,7 +80,7 @@ def test_compact_line_is_small_and_complete(tmp_path):
         assert k in line, k
     for k in ("workload", "points", "subset_points", "candidates_per_step", "score_mode"):
         assert line["config"][k] is not None, k
-    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch"):
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_upper", "traffic", "ms_per_launch"):
         assert line["roofline"][k] is not None, k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert line["cpu_baseline"][k] is not None, k

@@ -360,6 +360,48 @@ def test_points_on_cone_axis_are_incompatible():
     assert int(masks[0, 0]) == 0b1100
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_candidates_through_cloud_points_match_oracle(f32):
+    """Spheres centred ON a point of the cloud, cylinders and cones whose axis runs THROUGH points, cones with the apex on a
+    point: the reference's normalisations give NaN there (incompatible), and the classifier of the culled kernel must not
+    read anything else off its own 0 x inf (score4_device.h: the 1e-37 under the square root, the cone's axis guard).  A
+    20 000-point subset so that the culled kernel runs; candidates with tiny and with scene-sized radii."""
+    rng = np.random.default_rng(17)
+    xyz, nrm, truth = synth.make_cloud(20_000, ["plane", "sphere", "cylinder", "cone"], 0.2, seed=31)
+    if f32:
+        xyz, nrm = xyz.astype(np.float32).astype(np.float64), nrm.astype(np.float32).astype(np.float64)
+    subs = synth.make_subsets(20_000, 1, seed=31)
+    cands = []
+    for i in rng.integers(0, 20_000, size=40):
+        p, q = xyz[i], xyz[rng.integers(0, 20_000)]
+        ax = q - p
+        if not np.linalg.norm(ax) > 1e-6:
+            continue
+        for r in (0.0, 1e-3, 0.3, 5.0, 40.0):
+            cands.append(R.FittedSphere(p, r, bool(rng.integers(0, 2))))
+            cands.append(R.FittedCylinder(ax / np.linalg.norm(ax), p, r, bool(rng.integers(0, 2))))     # axis through p and q
+        for om in (0.05, 0.8, 2.5):
+            cands.append(R.FittedCone(p, ax, om, bool(rng.integers(0, 2))))                            # apex on p, axis through q
+    arr = shape_array(cands)
+    if f32:
+        for i in range(len(cands)):
+            R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
+        pc = R.RANSACCloud(xyz.astype(np.float32), nrm.astype(np.float32), subs, force_eltype=np.float32)
+        oc = orc.Cloud32(xyz.astype(np.float32), nrm.astype(np.float32), subs[0])
+    else:
+        pc, oc = R.RANSACCloud(xyz, nrm, subs), orc.Cloud(xyz, nrm, subs[0])
+    for eps in (0.3, 5.0):
+        prm = R.ransacparameters()
+        for k in ("plane", "sphere", "cylinder", "cone"):
+            prm[k]["ϵ"] = eps
+        cp = R.params_to_c(prm)
+        counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
+        ocounts, omasks = oc.score_batch(to_orc_shapes(arr, len(cands)), to_orc_params(cp), want_masks=True)
+        assert np.array_equal(counts, ocounts) and np.array_equal(masks, omasks)
+        assert np.array_equal(R.score_batch(pc, arr, cp), ocounts)
+    assert counts.sum() > 1000
+
+
 def run_both(xyz, nrm, subs, params, seed, **kw):
     pc = R.RANSACCloud(xyz, nrm, subs)
     oc = orc.Cloud(xyz, nrm, subs[0])
