@@ -60,6 +60,9 @@ def parse():
                     help="N > 1 partitioning: candidates (each rank scores its 4096 of the N x 4096 batch on a replica "
                          "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
                          "on its 1/N slice of subset 1; the all-reduce is a true sum)")
+    ap.add_argument("--spread-regions", type=int, default=5,
+                    help="after the timed region, repeat the same K-step region this many times and report min / median / max of the "
+                         "metric as `value_spread` (the headline `value` stays the first region)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 50M-point / cones leg (a child process at N = 1)")
     ap.add_argument("--no-cfg2", action="store_true", help="skip the 1M-point / 6-primitive leg (a child process at N = 1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -186,6 +189,9 @@ def compact_line(out, detail_file=None):
     line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": cb.get("sample")} if cb else None)
     line["oracle_checked"] = out.get("oracle_checked")
+    vs = out.get("value_spread") or {}
+    if vs:
+        line["value_spread"] = [_num(vs.get("min"), 5), _num(vs.get("median"), 5), _num(vs.get("max"), 5)]
     flat = {
         "rccl_ranks_seen": out.get("rccl_ranks_seen"),
         "cpu_mt_value": _get(out, "cpu_baseline_mt", "value"), "cpu_mt_cores": _get(out, "cpu_baseline_mt", "cores"),
@@ -396,7 +402,7 @@ def main():
                     "scene_generation_s": t_scene, "hip_context_ms_before": 1e3 * t_hip_context,
                     "note": "rh_cloud_create alone, first cloud of the process, HIP context already there (setup_seconds also "
                             "holds numpy's scene generation): total wall time, of which the k-d leaf order of subset 1 (on the "
-                            "device: one radix sort per level, kdorder.hip; RH_KD_HOST=1: the host's nth_element recursion), the "
+                            "device: one radix sort per level, kdorder.hip), the "
                             "part before it (allocations, uploads, AoS -> SoA, bounding box, Morton order of the cloud) and after it"}
     params = R.ransacparameters(types)
     cp = R.params_to_c(params, score_mode=L.SCORE_F64)   # Int64 score wraps at this size
@@ -493,6 +499,21 @@ def main():
         dt = float(tmax.item())
     ms_per_step = 1e3 * dt / args.steps
     value = b_global * args.steps / dt
+    # the same K-step region a few more times (each with its own fence on both sides): the spread of `value` on this box.
+    # `value` itself is the FIRST region above, exactly as the contract times it.
+    spread_vals = []
+    for _ in range(max(0, args.spread_regions)):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt1 = time.perf_counter() - t1
+        if multi:
+            tm1 = torch.tensor([dt1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm1, op=dist.ReduceOp.MAX)
+            dt1 = float(tm1.item())
+        spread_vals.append(b_global * args.steps / dt1)
     counts_h = (lib_bufs[(lib_k[0] - 1) & 1] if libcomm is not None else
                 scorer.result(scorer.k - 1) if scorer is not None else counts).cpu().numpy()
 
@@ -509,6 +530,9 @@ def main():
                                    "int32 sum all-reduce" % (world, world)) if points_mode
                    else "candidate-sharded x%d, int32 sum all-reduce" % world},
         "tests_per_sec": value * S,
+        "value_spread": ({"regions": len(spread_vals), "min": min(spread_vals), "median": sorted(spread_vals)[len(spread_vals) // 2],
+                          "max": max(spread_vals), "note": "%d further timed regions of %d steps each, same fences; `value` is the first region"
+                                                           % (len(spread_vals), args.steps)} if spread_vals else None),
         "rccl_ranks_seen": ranks_seen,
         "collective_backend": (os.environ.get("RH_BENCH_BACKEND", "nccl") if multi else None),
         "collective_issued_by": (("libransac_hip (rh_score_batch_allreduce_dev: librccl directly)" if libcomm is not None else
@@ -591,7 +615,8 @@ def main():
                 per_kind[k] = {"candidates": nk, "ms_separate_launch": acc[ki] / reps,
                                "note": "diagnostic: the same kernel launched over this kind's candidates alone"}
         # the culled kernel (score4.hip: all kinds in one launch) from 8192 subset points on, else the brute-force kernel per kind
-        culled = os.environ.get("RH_SCORE_PATH", "groups") == "groups" and S >= 8192
+        forced_path = R.get_option("score_path")            # rh_set_option; None / 0: the library's own choice
+        culled = forced_path in (None, 0, 2) and S >= 8192
         if culled:
             kname = "score4_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
             sec = acc[4] / reps * 1e-3
@@ -607,7 +632,7 @@ def main():
         ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
         tests = ncand * S
         # the committed PMC passes were taken on the default workloads and batch split
-        pmc_ok = args.workload in ("cfg3", "cfg5") and n == n_default and world == 1 and "RH_SCORE_PATH" not in os.environ
+        pmc_ok = args.workload in ("cfg3", "cfg5") and n == n_default and world == 1 and forced_path in (None, 0)
         pmc = pmc_replay(pmc_key, pmc_ok, "" if args.workload == "cfg3" else "_" + args.workload)
         sq = pmc["sq"]
         # Issue model (tools/ubench/valu_rates.hip + count_seq.hip, this GPU, 8 waves per SIMD): SIMD cycles a wave64 instruction
@@ -720,7 +745,8 @@ def main():
         except Exception as e:   # never fatal for the headline
             out["masks_out"] = {"error": repr(e)[:300]}
         out["per_kind"] = per_kind
-        out["score_path"] = os.environ.get("RH_SCORE_PATH", "groups (culled)")
+        out["score_path"] = {None: "groups (culled)", 0: "groups (culled)", 1: "brute", 2: "groups (culled)"}[forced_path]
+        out["library_variant"] = L.variant()
         out["event_ms_per_step"] = ev_ms.value / args.steps
 
         # refit: the streaming scan (HBM-bound: the roofline object) and the culled scan the library takes at this size
@@ -728,9 +754,10 @@ def main():
         plane = R.FittedPlane(t["point"], t["normal"]).to_c()
 
         def time_refit(handle, cshape, path, reps=5):
-            """rh_refit `reps` times with RH_REFIT_PATH=path: (scan ms from HIP events, compaction ms, host wall s, index list)"""
-            old_path = os.environ.get("RH_REFIT_PATH")
-            os.environ["RH_REFIT_PATH"] = path
+            """rh_refit `reps` times with the option refit_path = path on that cloud: (scan ms from HIP events, compaction ms,
+            host wall s, index list)"""
+            check_set = lib.rh_set_option(handle, b"refit_path", L.REFIT_PATH[path])
+            L.check(check_set)
             try:
                 idx = np.zeros(n, dtype=np.int64)
                 nout = C.c_int64()
@@ -745,10 +772,7 @@ def main():
                 wall = (time.perf_counter() - t0) / reps
                 return sum(scan_ms) / len(scan_ms), sum(comp_ms) / len(comp_ms), wall, idx[:nout.value].copy()
             finally:
-                if old_path is None:
-                    os.environ.pop("RH_REFIT_PATH", None)
-                else:
-                    os.environ["RH_REFIT_PATH"] = old_path
+                L.check(lib.rh_set_option(handle, b"refit_path", L.OPTION_UNSET))
 
         scan_ms, comp_ms, t_refit, list_scan = time_refit(pc._h, plane, "scan")
         t_scan = 1e-3 * scan_ms
@@ -761,7 +785,7 @@ def main():
                                  "algorithmic_bytes_per_launch": rbytes,
                                  "compaction_ms": comp_ms, "rh_refit_host_wall_ms": 1e3 * t_refit,
                                  "inliers": int(len(list_scan)),
-                                 "note": "the HBM-bound kernel of the path (RH_REFIT_PATH=scan): one pass over the whole cloud "
+                                 "note": "the HBM-bound kernel of the path (option refit_path = scan): one pass over the whole cloud "
                                          "in original order (48.125 B/point); HIP events on the library's stream; host wall "
                                          "adds the compaction, two syncs and the D2H of the index list.  Clouds of 2^21 "
                                          "points and more take the culled scan instead: `refit_culled`"}
@@ -1056,15 +1080,15 @@ def main():
             except Exception as e:   # the headline line must not depend on these legs
                 return {"error": repr(e)[:300]}
         if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg2:
-            out["cfg2"] = child_leg("cfg2", ["--oracle-check", "256"],
-                                    "python bench.py --workload cfg2 --no-cpu --no-e2e --oracle-check 256 (child process): BASELINE "
+            out["cfg2"] = child_leg("cfg2", ["--oracle-check", "4096"],
+                                    "python bench.py --workload cfg2 --no-cpu --no-e2e --oracle-check 4096 (child process; the whole timed batch against the oracle): BASELINE "
                                     "configs[1], 1M points = 2 planes + 2 spheres + 2 cylinders without outliers, S = 31 250, B = 4096")
         if world == 1 and args.workload == "cfg3" and n == n_default and not args.no_cfg5:
-            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "96", "--e2e-iters", "4096", "--e2e-runs", "5",
+            out["cfg5"] = child_leg("cfg5", ["--steps", "60", "--warmup", "10", "--oracle-check", "1024", "--e2e-iters", "4096", "--e2e-runs", "5",
                                              "--e2e-cpu-iters", "48", "--no-e2e-octree", "--no-cpu-baseline"],
-                                    "python bench.py --workload cfg5 --steps 60 --warmup 10 --oracle-check 96 --e2e-iters 4096 --e2e-runs 5 "
+                                    "python bench.py --workload cfg5 --steps 60 --warmup 10 --oracle-check 1024 --e2e-iters 4096 --e2e-runs 5 "
                                     "--e2e-cpu-iters 48 --no-e2e-octree --no-cpu-baseline (child process): one replica of the 50M-point cloud on "
-                                    "this GPU, S = 1 562 500, cones in the batch; 96 candidates of all four kinds checked against the "
+                                    "this GPU, S = 1 562 500, cones in the batch; 1024 candidates of all four kinds (spread evenly over the timed batch) checked against the "
                                     "oracle; the refit scan streams 2.4 GB; a bounded end-to-end leg (4096 iterations, the oracle's loop "
                                     "compared on a 48-iteration prefix)")
         write_detail(out, args.detail_out)

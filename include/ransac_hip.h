@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RH_VERSION 108
+#define RH_VERSION 109
 
 enum {
     RH_OK = 0,
@@ -251,7 +251,8 @@ void rh_result_free(rh_result *r);
  * creates the segment.  slot_bytes bounds one rank's candidate list of one window (<= 0: 1 MiB).  rh_ransac_mp:
  * every rank holds a replica of the cloud in the same state and passes the same parameters and seed; the minimal sets
  * of every iteration are dealt round-robin to the ranks, the ranks exchange their windows' candidate lists through
- * the segment, and every rank returns exactly what rh_ransac returns for the same inputs. */
+ * the segment, and every rank returns exactly what rh_ransac returns for the same inputs.  Float64 clouds only
+ * (RH_E_INVALID on a Float32 cloud: that combination has never been held against the single-GPU run). */
 typedef struct rh_mp rh_mp;
 int rh_mp_open(const char *shm_name, int32_t rank, int32_t world, int64_t slot_bytes, rh_mp **out);
 int rh_mp_close(rh_mp *m);
@@ -345,27 +346,28 @@ int rh_octree_node_points(const rh_octree *t, int32_t cell, int64_t *idx_out_1ba
 /* cell.data.incellpoints[pc.isenabled[cell.data.incellpoints]] (fitting.jl:405-407) on the device, against cloud c's bits */
 int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t cell, int64_t *idx_out_1based, int64_t cap, int64_t *n_out);
 
-/* ---- diagnostics (tests) ---- */
-/* The batched score decides most (candidate, point) pairs with a binary32 evaluation of the reference's
- * compatibles* quantities (plane.jl:114-130, sphere.jl:144-172, cylinder.jl:194-221) and keeps the binary64
- * test for the pairs within a rounding margin of a threshold (csrc/score4_device.h).  This runs every
- * candidate of `shapes` against every point of subset 1 and returns the worst binary32 error in units of
- * the margin width: out[2k], out[2k+1] = max |a32 - a64|, |b32 - b64| for kind k (plane, sphere, cylinder, cone;
- * sound below 1/2), out[8+k] = pairs looked at.  Host shapes, synchronous. */
-int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, double *out /* [12] */);
-/* diagnostics: the DECISIONS of the score kernel's culling box test and binary32 classifier against the exact test, over
- * every (candidate, point) of shapes x subset 1: per kind k (plane, sphere, cylinder, cone) out[10 k + ...] = 0 pairs
- * (candidate, 64-point group), 1 pairs the box test skips, 2 skipped pairs that hold an exact inlier (must be 0), 3 points,
- * 4 classified surely-in, 5 surely-out, 6 surely-in that the exact test rejects (must be 0), 7 surely-out that it accepts
- * (must be 0), 8 exact inliers, 9 candidates whose classifier takes the all-zero point (a disabled point as staged) for an
- * inlier (must be 0).  The soundness the bit-exact counts rest on, as a count (score4_device.h). */
-int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out /* [40] */);
-/* The device's octree sampler finds a point's cell and the r-th enabled point of a cell with a cell directory and
- * bracketed 8-ary searches (csrc/fit_shared.h: cell_bounds_code, lower_bound_in, select_in, select_in_many, select_bit)
- * where the host form uses plain binary searches.  Host-only self-check of those routines against the plain ones on a
- * synthetic Morton order of n points (duplicate codes, random enabled bits, every level): *mismatches = the number of
- * disagreements over `queries` random queries.  Needs no GPU. */
-int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t queries, int64_t *mismatches);
+/* ---- tuning options ----
+ * The library reads NO environment variable: what a caller may tune goes through this call, for one cloud or, with
+ * cloud = NULL, process-wide (the value a cloud without its own setting sees).  value = RH_OPTION_UNSET clears a setting.
+ *   "score_path"  RH_SCORE_PATH_AUTO (default: the culled kernel from 8192 subset points on) / _BRUTE / _GROUPS -- which
+ *                 batched score kernel clouds created from now on use (scorecandidates!, src/fitting.jl:181-190); fixed when
+ *                 a cloud is created because its internal point order depends on it: process-wide only
+ *   "refit_path"  RH_REFIT_PATH_AUTO (default: the culled scan from 2^21 points on) / _SCAN / _CULLED -- which full-cloud
+ *                 scan rh_refit and rh_ransac take (refit, src/shapes/plane.jl:137-143); read on every refit
+ *   "s4_rows"     0 (default: by the launch's size) / 4 / 8 / 12 / 16 -- 64-candidate chunks per block row of the culled
+ *                 score kernel; read on every launch
+ *   "unp_words"   0 (default) or the segment width, in 64-bit words, of the pass that turns the score kernel's inlier
+ *                 lists into dense subset-order mask rows (inpoints, src/shapes/plane.jl:68); read on every call
+ * Results never depend on any of them (tests/test_parity_gpu.py runs every parity test under both score paths).
+ * Unknown keys and out-of-range values: RH_E_INVALID.  The diag build (libransac_hip_diag.so, include/ransac_hip_diag.h)
+ * knows more keys -- the A/B switches of the experiments -- and falls back to RH_* environment variables; the product
+ * build does neither. */
+#define RH_OPTION_UNSET INT64_MIN
+enum { RH_SCORE_PATH_AUTO = 0, RH_SCORE_PATH_BRUTE = 1, RH_SCORE_PATH_GROUPS = 2 };
+enum { RH_REFIT_PATH_AUTO = 0, RH_REFIT_PATH_SCAN = 1, RH_REFIT_PATH_CULLED = 2 };
+int rh_set_option(rh_cloud *c_or_null, const char *key, int64_t value);
+int rh_get_option(const rh_cloud *c_or_null, const char *key, int64_t *value_out, int32_t *is_set_out_or_null);
+int rh_build_variant(void);   /* 0 = product, 1 = diag (-DRH_DIAG) */
 
 #ifdef __cplusplus
 }

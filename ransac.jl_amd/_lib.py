@@ -5,6 +5,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libransac_hip.so")
+# the -DRH_DIAG build of the same sources (build.py): the A/B switches of the experiments, RH_* environment variables and
+# the rh_dbg_* audits live there and only there.  RH_LIB_VARIANT=diag makes it this process's library (tests marked `diag`,
+# tools/fuzz_*.py, the profiling tools); the default is the product library, which reads no environment variable.
+SO_PATH_DIAG = os.path.join(_HERE, "libransac_hip_diag.so")
+OPTION_UNSET = -(1 << 63)
+SCORE_PATH = {"auto": 0, "brute": 1, "groups": 2}
+REFIT_PATH = {"auto": 0, "scan": 1, "culled": 2}
 
 PLANE, SPHERE, CYLINDER, CONE = 0, 1, 2, 3
 KIND_NAMES = {PLANE: "plane", SPHERE: "sphere", CYLINDER: "cylinder", CONE: "cone"}
@@ -116,9 +123,9 @@ SIGNATURES = {
     "rh_octree_node_info": (C.c_int, [_vp, C.c_int32, _dp, _dp, _i32p, _i32p, _i32p, C.POINTER(C.c_int64)]),
     "rh_octree_node_points": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.c_int64]),
     "rh_octree_cell_enabled": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64)]),
-    "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
-    "rh_dbg_cls_soundness": (C.c_int, [_vp, _sp, C.c_int32, _pp, C.POINTER(C.c_uint64)]),
-    "rh_dbg_oct_search_selftest": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
+    "rh_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "rh_get_option": (C.c_int, [_vp, C.c_char_p, _i64p, _i32p]),
+    "rh_build_variant": (C.c_int, []),
     "rh_cloud_create_ms": (C.c_int, [_vp, _dp]),
     "rh_comm_unique_id": (C.c_int, [_vp]),
     "rh_comm_create": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
@@ -128,7 +135,22 @@ SIGNATURES = {
     "rh_comm_sync": (C.c_int, [_vp]),
 }
 
-_lib = None
+# include/ransac_hip_diag.h: exported by the diag build only
+DIAG_SIGNATURES = {
+    "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
+    "rh_dbg_cls_soundness": (C.c_int, [_vp, _sp, C.c_int32, _pp, C.POINTER(C.c_uint64)]),
+    "rh_dbg_oct_search_selftest": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
+}
+
+_libs = {}
+
+
+def variant():
+    """which build this process uses by default: "product" (libransac_hip.so) unless RH_LIB_VARIANT=diag"""
+    v = os.environ.get("RH_LIB_VARIANT", "product")
+    if v not in ("product", "diag"):
+        raise RuntimeError("RH_LIB_VARIANT=%r: expected 'product' or 'diag'" % v)
+    return v
 
 
 def _share_torch_hip_runtime():
@@ -152,23 +174,30 @@ def _share_torch_hip_runtime():
         pass
 
 
-def lib():
-    """The loaded library.  Raises if libransac_hip.so is missing (run `python -c 'import
-    __graft_entry__ as g; g.build()'` or `python ransac.jl_amd/build.py`)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO_PATH):
+def lib(which=None):
+    """The loaded library (which = None: this process's default variant, see variant()).  Raises if the shared object is
+    missing (run `python -c 'import __graft_entry__ as g; g.build()'` or `python ransac.jl_amd/build.py`)."""
+    which = which or variant()
+    L = _libs.get(which)
+    if L is None:
+        path = SO_PATH if which == "product" else SO_PATH_DIAG
+        if not os.path.exists(path):
             raise RuntimeError(
                 "%s is missing: the HIP extension has not been built and this package has no CPU "
-                "fallback (build it with ransac.jl_amd/build.py)" % SO_PATH)
+                "fallback (build it with ransac.jl_amd/build.py)" % path)
         _share_torch_hip_runtime()
-        L = C.CDLL(SO_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        L = C.CDLL(path)
+        sigs = dict(SIGNATURES)
+        if which == "diag":
+            sigs.update(DIAG_SIGNATURES)
+        for name, (res, args) in sigs.items():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        _lib = L
-    return _lib
+        if L.rh_build_variant() != (1 if which == "diag" else 0):
+            raise RuntimeError("%s is not the %s build" % (path, which))
+        _libs[which] = L
+    return L
 
 
 def check(rc):

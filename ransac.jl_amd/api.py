@@ -11,6 +11,49 @@ from . import _lib as L
 from ._lib import CONE, CYLINDER, PLANE, SPHERE, check, lib
 
 
+# ----------------------------------------------------------------- options ----
+def _opt_value(key, value):
+    if value is None:
+        return L.OPTION_UNSET
+    if isinstance(value, str):
+        table = {"score_path": L.SCORE_PATH, "refit_path": L.REFIT_PATH}.get(key)
+        if table is None or value not in table:
+            raise ValueError("option %r has no value %r" % (key, value))
+        return table[value]
+    return int(value)
+
+
+def set_option(key, value, cloud=None):
+    """rh_set_option (include/ransac_hip.h): a tuning option for one cloud or, with cloud=None, process-wide.  value: an
+    int, one of the names of score_path ("auto" / "brute" / "groups") and refit_path ("auto" / "scan" / "culled"), or None
+    to clear the setting.  The library itself reads no environment variable."""
+    check(lib().rh_set_option(None if cloud is None else cloud._h, key.encode(), _opt_value(key, value)))
+
+
+def get_option(key, cloud=None):
+    """the option's value as the library sees it for this cloud, or None when nobody has set it"""
+    v, st = C.c_int64(), C.c_int32()
+    check(lib().rh_get_option(None if cloud is None else cloud._h, key.encode(), C.byref(v), C.byref(st)))
+    return v.value if st.value else None
+
+
+class option:
+    """with option("refit_path", "scan"): ...   -- set, then put back what was there"""
+
+    def __init__(self, key, value, cloud=None):
+        self.key, self.value, self.cloud = key, value, cloud
+
+    def __enter__(self):
+        # what the cloud / the process itself holds (not what a cloud inherits): cleared again on exit when it held nothing
+        self.old = get_option(self.key, self.cloud) if self.cloud is None else None
+        set_option(self.key, self.value, self.cloud)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old, self.cloud)
+        return False
+
+
 # ------------------------------------------------------------------ shapes ----
 class FittedShape:
     """abstract supertype of all fitted shapes (fitting.jl:6)"""

@@ -343,11 +343,12 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double ms_kd = 0, ms_before_kd = 0;
     // RH_CREATE_PROF=1: wall time of every stage on stderr (each stamp waits for the stream: the stages stop overlapping)
-    const bool prof = getenv("RH_CREATE_PROF") != nullptr;
+    const bool prof = rh_opt_on(nullptr, RH_OPT_CREATE_PROF);
     double t_prev = 0;
 
     rh_cloud *c = new (std::nothrow) rh_cloud();
     if (!c) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
+    rh_opt_init_cloud(c);
     c->device = device;
     c->n = n;
     c->s = s;
@@ -392,7 +393,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CK(dev_alloc(&c->sub, 6 * c->s_pad));
     CK(dev_alloc(&c->dis, 6 * c->dis_stride));
     CK(dev_alloc(&c->sub_idx0, s));
-    CK(dev_alloc(&c->sub_perm, s));
+    CK(dev_alloc(&c->sub_perm, c->s_pad));   // (whole 64-lane reads of the last group stay inside the allocation: the mask pass, score4.hip)
+    CKH(hipMemsetAsync(c->sub_perm, 0, sizeof(int32_t) * (size_t)std::max<int64_t>(c->s_pad, 1), c->stream));
     c->ngroups = (s + 63) / 64;
     c->ng_pad = ((c->ngroups + RH_G2_TG - 1) / RH_G2_TG) * RH_G2_TG + RH_G2_TG;
     CK(dev_alloc(&c->gb, 7 * c->ng_pad));
@@ -402,10 +404,10 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     CKH(hipMemsetAsync(c->dis_gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     CKH(hipMemsetAsync(c->gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
     {
-        const char *e = getenv("RH_SCORE_PATH");   // "brute" / "groups" force a path (tests, A/B runs)
+        const int64_t e = rh_opt_int(nullptr, RH_OPT_SCORE_PATH, RH_SCORE_PATH_AUTO);   // rh_set_option(NULL, "score_path", ...): force a path (tests, A/B runs)
         c->use_groups = s >= RH_G2_MIN_POINTS;
-        if (e && e[0] == 'b') c->use_groups = false;
-        if (e && e[0] == 'g') c->use_groups = s > 0;
+        if (e == RH_SCORE_PATH_BRUTE) c->use_groups = false;
+        if (e == RH_SCORE_PATH_GROUPS) c->use_groups = s > 0;
     }
     CK(dev_alloc(&c->enabled, c->nwords));
     CK(dev_alloc(&c->sub_enabled, c->swords));
@@ -433,7 +435,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
         CK(rhk_transpose_aos(c, t_xyz, t_nrm, n, nullptr, n, c->full, c->n_pad));
         CK(rhk_pack_records(c, t_xyz, t_nrm, n, c->rec));
         stamp("AoS -> SoA, records");
-        if (getenv("RH_AABB_HOST")) cloud_aabb(xyz, n, c->k_lo, &c->k_size, &c->k_mag);   // (A/B: 25 ms at 10M points, 120 ms at 50M)
+        if (rh_opt_on(nullptr, RH_OPT_AABB_HOST)) cloud_aabb(xyz, n, c->k_lo, &c->k_size, &c->k_mag);   // (A/B: 25 ms at 10M points, 120 ms at 50M)
         else CK(cloud_aabb_device(c, t_xyz, xyz, n));
         stamp("bounding box");
         CK(rhk_korder_build(c, t_xyz, t_nrm, c->k_lo, c->k_size, c->k_mag));
@@ -448,8 +450,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
             // Where the order is made: on the device (kdorder.hip: a radix sort per level of the same balanced k-d tree; the
             // subset's coordinate / normal magnitudes come out of the same pass) unless RH_KD_HOST=1 or RH_SUB_ORDER=morton
             // ask for the host forms below (A/B; the counts do not depend on the order).
-            const char *ord_env0 = getenv("RH_SUB_ORDER");
-            const bool kd_device = !getenv("RH_KD_HOST") && !(ord_env0 && ord_env0[0] == 'm');
+            const bool ord_morton = rh_opt_on(nullptr, RH_OPT_SUB_ORDER);
+            const bool kd_device = !rh_opt_on(nullptr, RH_OPT_KD_HOST) && !ord_morton;
             if (kd_device) {
                 for (int64_t j = 0; j < s; j++) h_idx[j] = (int32_t)(subset1[j] - 1);
                 int32_t *d_idx_in = nullptr;
@@ -493,8 +495,7 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
             // keeps the Morton order (A/B).
             std::vector<int32_t> order((size_t)s);
             for (int64_t j = 0; j < s; j++) order[(size_t)j] = (int32_t)j;
-            const char *ord_env = getenv("RH_SUB_ORDER");
-            if (ord_env && ord_env[0] == 'm') {
+            if (ord_morton) {
                 std::vector<std::pair<uint64_t, int32_t>> keys((size_t)s);
                 for (int64_t j = 0; j < s; j++) {
                     const double *pp = xyz + 3 * (subset1[j] - 1);
@@ -829,7 +830,7 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     for (int k = 0; k < 4; k++) { fill[k] = off[k]; h_nk[k] = nk[k]; }
     // counting sort by kind, walking the batch in the spread order (kernels.hip: neighbours in the batch, often
     // hypotheses of the same primitive, go to different 64-candidate chunks)
-    const int64_t spread = getenv("RH_NO_SPREAD") ? 1 : rh_spread_multiplier(b);
+    const int64_t spread = rh_opt_on(c, RH_OPT_NO_SPREAD) ? 1 : rh_spread_multiplier(b);
     for (int32_t t = 0; t < b; t++) {
         const int32_t i = (int32_t)(((int64_t)t * spread) % b);
         const int k = shapes[i].kind;

@@ -31,11 +31,13 @@ Rccl *rccl()
     tried = true;
     // RH_RCCL_LIB: a library to bind instead (tests/native/fake_rccl.cpp: the same five entry points over host shared
     // memory, so that the step can meet a second rank on a one-GPU box -- RCCL refuses two ranks on one device)
-    const char *forced = getenv("RH_RCCL_LIB");
+#ifdef RH_DIAG
+    const char *forced = rh_opt_env_string("RH_RCCL_LIB");   // (diag build only: the product library binds librccl and nothing else)
     if (forced && forced[0]) {
         r.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
         if (!r.h) return nullptr;
     }
+#endif
     const char *names[] = { "librccl.so.1", "librccl.so" };
     for (const char *n : names)   // one already in the process (PyTorch's) first
         if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

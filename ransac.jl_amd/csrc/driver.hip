@@ -45,7 +45,7 @@ Driver::~Driver()
     if (c) (void)hipStreamSynchronize(c->stream);   // no copy may still be landing in the pinned blocks
     if (c) (void)hipStreamSynchronize(c->copy_stream);
     arena_release(arena);   // null once the result owns it
-    if (c && clean && c->drv_cache == nullptr && !getenv("RH_NO_DRIVER_CACHE")) {
+    if (c && clean && c->drv_cache == nullptr && !rh_opt_on(c, RH_OPT_NO_DRIVER_CACHE)) {
         DriverCache *dc = new DriverCache;
         dc->win[0] = win[0]; dc->win[1] = win[1];
         dc->st = st;
@@ -141,6 +141,13 @@ void Driver::rebuild_mprefix()
 int Driver::fit_set(std::vector<rh_shape> &cands)
 {
     for (int q = 0; q < drawN; q++) {
+        if (xyz32 != nullptr) {   // rh_ransac_f32: the sampled rows of the caller's Float32 arrays, converted exactly
+            for (int a = 0; a < 3; a++) {
+                fp[3 * (size_t)q + a] = (double)xyz32[3 * (sd[(size_t)q] - 1) + a];
+                fn[3 * (size_t)q + a] = (double)nrm32[3 * (sd[(size_t)q] - 1) + a];
+            }
+            continue;
+        }
         memcpy(&fp[3 * (size_t)q], xyz + 3 * (sd[(size_t)q] - 1), 24);
         memcpy(&fn[3 * (size_t)q], nrm + 3 * (sd[(size_t)q] - 1), 24);
     }
@@ -351,7 +358,7 @@ int Driver::run_sequential()
 using namespace rhdrv;
 
 static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng, rh_mp *mp,
-                       rh_result *out);
+                       rh_result *out, const float *xyz32 = nullptr, const float *nrm32 = nullptr);
 
 extern "C" int rh_ransac(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng,
                          rh_result *out)
@@ -366,9 +373,8 @@ extern "C" int rh_ransac_f32(rh_cloud *c, const float *xyz, const float *nrm, co
     if (!c) { rh_set_error("rh_ransac_f32: NULL argument"); return RH_E_INVALID; }
     if (!c->f32) { rh_set_error("rh_ransac_f32: the cloud is not a Float32 cloud (rh_cloud_create_f32)"); return RH_E_INVALID; }
     if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac_f32: xyz/nrm are NULL"); return RH_E_INVALID; }
-    std::vector<double> x((size_t)(3 * c->n)), n((size_t)(3 * c->n));
-    for (int64_t i = 0; i < 3 * c->n; i++) { x[(size_t)i] = (double)xyz[i]; n[(size_t)i] = (double)nrm[i]; }
-    return ransac_impl(c, x.data(), n.data(), p, rng, nullptr, out);
+    // (no copy of the cloud: only the host-side fits of sampling_streams = 0 read points, and they convert the rows they sample)
+    return ransac_impl(c, nullptr, nullptr, p, rng, nullptr, out, xyz, nrm);
 }
 
 // ransac() on ONE scene by the `world` processes of `mp` (one per GPU, each with a replica of the cloud in the same
@@ -396,7 +402,7 @@ extern "C" int rh_ransac_mp(rh_cloud *c, const double *xyz, const double *nrm, c
 }
 
 static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const rh_params *p, rh_rng *rng, rh_mp *mp,
-                       rh_result *out)
+                       rh_result *out, const float *xyz32, const float *nrm32)
 {
     if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
     memset(out, 0, sizeof *out);
@@ -410,7 +416,11 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
                 return RH_E_INVALID;
             }
     }
-    if (c->n > 0 && (!xyz || !nrm)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
+    if (c->n > 0 && (!xyz || !nrm) && (!xyz32 || !nrm32)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
+    if (c->f32 && mp != nullptr) {   // (the ranks' exchange has only ever been held against the single-GPU run on Float64 clouds)
+        rh_set_error("rh_ransac_mp is not available on a Float32 cloud");
+        return RH_E_INVALID;
+    }
     if (p->drawN < 2 || p->drawN > 16) {   // @assert drawN > 1: src/fitting.jl:386
         rh_set_error("rh_ransac: drawN=%d outside 2..16", p->drawN);
         return RH_E_INVALID;
@@ -431,13 +441,14 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
     const double t_start = now_s();
 
     bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;
-    if (getenv("RH_HOST_SAMPLER")) device_sampler = false;   // A/B and tests: the same streams drawn on the host
+    if (rh_opt_on(c, RH_OPT_HOST_SAMPLER)) device_sampler = false;   // A/B and tests: the same streams drawn on the host
     if (mp != nullptr && !device_sampler) {
-        rh_set_error("rh_ransac_mp: the minimal sets are dealt to the ranks by the device sampler (drawN <= 8, minsubsetN > 0, no RH_HOST_SAMPLER)");
+        rh_set_error("rh_ransac_mp: the minimal sets are dealt to the ranks by the device sampler (drawN <= 8, minsubsetN > 0, device sampler not switched off)");
         return RH_E_INVALID;
     }
     Driver d;
     d.c = c; d.p = p; d.xyz = xyz; d.nrm = nrm; d.rng = rng;
+    d.xyz32 = xyz == nullptr ? xyz32 : nullptr; d.nrm32 = xyz == nullptr ? nrm32 : nullptr;
     d.mp = mp;
     d.host_sampling = !device_sampler;
     RH_TRY(d.init());
@@ -468,7 +479,7 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
     if (d.oa_n > 0) fprintf(stderr, "[rh_ransac] oct_advance phases (us, mean of %lld): copy %.2f scatter %.2f hist %.2f scan %.2f emit %.2f sums+ranks %.2f sync %.2f final %.2f\n", d.oa_n,
                             d.oa_t[0] / d.oa_n, d.oa_t[1] / d.oa_n, d.oa_t[2] / d.oa_n, d.oa_t[3] / d.oa_n, d.oa_t[4] / d.oa_n, d.oa_t[5] / d.oa_n, d.oa_t[6] / d.oa_n, 0.0);
 #endif
-    if (getenv("RH_DRIVER_PROF")) {
+    if (rh_opt_on(c, RH_OPT_DRIVER_PROF)) {
         fprintf(stderr, "[rh_ransac] init %.4f loop %.4f tail %.4f s\n", t_init, t_loop, out->seconds - t_init - t_loop);
         fprintf(stderr, "[rh_ransac] %lld windows: enqueue %.4f wait %.4f lists %.4f record %.4f s; total %.4f\n", (long long)d.nwin,
                 d.tw[0], d.tw[1], d.tw[2], d.tw[3], out->seconds);

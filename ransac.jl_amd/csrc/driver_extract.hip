@@ -173,7 +173,7 @@ int Driver::maybe_extract(int64_t k, bool *did)
         const bool all_disabled = (q == RH_SPHERE && !p->sphere_uses_enabled);
         live_work += (int64_t)st.n[q] * ((all_disabled ? c->n_dis : 0) + store[(size_t)best].sigma);
     }
-    const bool fast = !managed && sum_n <= LIVE_MAX && live_work <= ((int64_t)1 << 24) && !getenv("RH_NO_FAST_EXTRACT");
+    const bool fast = !managed && sum_n <= LIVE_MAX && live_work <= ((int64_t)1 << 24) && !rh_opt_on(c, RH_OPT_NO_FAST_EXTRACT);
     // (device-managed store: the kinds laid end to end, each padded to a multiple of RH_STORE_PAD)
     int32_t pbase[5] = { 0, 0, 0, 0, 0 };
     for (int q = 0; q < 4; q++) pbase[q + 1] = pbase[q] + (st.n[q] + RH_STORE_PAD - 1) / RH_STORE_PAD * RH_STORE_PAD;

@@ -206,6 +206,7 @@ struct Driver {
     rh_cloud *c;
     const rh_params *p;
     const double *xyz, *nrm;
+    const float *xyz32 = nullptr, *nrm32 = nullptr;   // rh_ransac_f32: the caller's Float32 arrays (xyz / nrm are null then); only the host-side fits read points
     rh_rng *rng;
     int drawN;
 

@@ -19,9 +19,9 @@ int Driver::run_chained_windows(const size_t status_bytes)
     std::vector<int32_t> counts, levels, wcounts, order, wslots;
     const int T = p->n_shape_types;
     int64_t Kchain = 8;
-    if (const char *e = getenv("RH_OCT_CHAIN_W")) Kchain = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
+    if (const int64_t e = rh_opt_int(c, RH_OPT_OCT_CHAIN_W, 0)) Kchain = std::max<int64_t>(1, std::min<int64_t>(e, RH_CHAIN_MAX));
     if (c->oct_state == nullptr) RUNH(hipMalloc((void **)&c->oct_state, sizeof(rh_oct_state)));
-    managed = !getenv("RH_NO_MANAGED_STORE");   // (the store is empty here: run_streams_device is where a run starts)
+    managed = !rh_opt_on(c, RH_OPT_NO_MANAGED_STORE);   // (the store is empty here: run_streams_device is where a run starts)
     auto ensure_pinned = [&](Window &w) -> int {
         if (w.h_ost == nullptr) {
             RUNH(hipHostMalloc((void **)&w.h_ost, sizeof(rh_oct_state)));
@@ -123,11 +123,11 @@ int Driver::run_chained_windows(const size_t status_bytes)
     struct Flight { int wi; int64_t k0; int32_t W; };
     Flight fl[2];
     int nfl = 0, next_w = 0;
-    const int max_flight = getenv("RH_OCT_ONE_WINDOW") ? 1 : 2;
+    const int max_flight = rh_opt_on(c, RH_OPT_OCT_ONE_WINDOW) ? 1 : 2;
     // (iterations per window: the launches of Kchain iterations are in the queue at most, whatever the number of
     // windows they are cut into -- a deeper queue makes the launches themselves slow)
     int64_t Wfl = std::max<int64_t>(1, max_flight == 2 ? (Kchain * 3) / 8 : Kchain);   // (8 -> two windows of 3: swept 2 / 3 / 4 / 6 -> 0.0482 / 0.0474 / 0.0484 / 0.0492 s)
-    if (const char *e = getenv("RH_OCT_WINDOW_ITERS")) Wfl = std::max<int64_t>(1, std::min<int64_t>(atoll(e), RH_CHAIN_MAX));
+    if (const int64_t e = rh_opt_int(c, RH_OPT_OCT_WINDOW_ITERS, 0)) Wfl = std::max<int64_t>(1, std::min<int64_t>(e, RH_CHAIN_MAX));
     bool need_upload = true;
     int64_t k = 1, k_enq = 1;
     for (;;) {
@@ -259,20 +259,20 @@ int Driver::run_streams_device()
     // With the culled score kernel (it takes its candidate counts from device memory) the window's
     // candidates are scored on the device right after they are fitted, in the same stream: the
     // host gets list + counts in one wait instead of a second round trip per window.
-    const bool fused_score = rh_score_v4_enabled(c) && !getenv("RH_NO_FUSED_SCORE");
+    const bool fused_score = rh_score_v4_enabled(c) && !rh_opt_on(c, RH_OPT_NO_FUSED_SCORE);
     int32_t cnt_est = 64;
     // Without the octree a window's draws depend only on (seed, k, j) and the enabled bits, so the
     // NEXT window is put on the stream before the host waits for this one: it is valid unless this
     // one ends in an extraction (then it is dropped and drawn again).  The GPU samples window
     // w + 1 while the host replays window w.
-    const bool pipeline = !octree && !getenv("RH_NO_PIPELINE");
+    const bool pipeline = !octree && !rh_opt_on(c, RH_OPT_NO_PIPELINE);
     std::vector<rh_cand_entry> entries;
     std::vector<rh_shape> cands;
     std::vector<int32_t> counts, levels, wcounts, order, wslots;
     std::vector<int64_t> slots;
     const int T = p->n_shape_types;
     // (octree windows of one process are CHAINED: run_chained_windows)
-    const bool chain = octree && fused_score && mp == nullptr && !getenv("RH_NO_OCT_CHAIN");
+    const bool chain = octree && fused_score && mp == nullptr && !rh_opt_on(c, RH_OPT_NO_OCT_CHAIN);
     if (chain) return run_chained_windows(status_bytes);
     auto issue = [&](Window &w, int64_t k0, int32_t W) -> int {
         const double *d_P = nullptr;

@@ -173,6 +173,7 @@ extern "C" int64_t rh_rng_range(rh_rng *r, int64_t n)
     return 1 + (int64_t)(((unsigned __int128)rng_next(r) * (unsigned __int128)(uint64_t)n) >> 64);
 }
 
+#ifdef RH_DIAG
 // ---- self-check of the device sampler's search routines (ransac_hip.h), on the host --------------------------------
 extern "C" int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t queries, int64_t *mismatches)
 {
@@ -249,3 +250,4 @@ extern "C" int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t quer
     *mismatches = bad;
     return RH_OK;
 }
+#endif   // RH_DIAG

@@ -973,8 +973,7 @@ int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d
     const bool own = d_prep == c->d_prep && cap == c->batch_cap;
     PreArgs QA = pre_args(c, own ? eps : nullptr, own ? cosa : nullptr);
     if (b == 0) return RH_OK;
-    static int no_spread = -1;
-    if (no_spread < 0) no_spread = getenv("RH_NO_SPREAD") ? 1 : 0;
+    const int no_spread = rh_opt_on(c, RH_OPT_NO_SPREAD) ? 1 : 0;
     // (consumed by this launch: set by rh_score_batch_allreduce_dev around its score call)
     int32_t *zx = c->zero_extra;
     const int32_t zxn = c->zero_extra_n;
@@ -1011,8 +1010,7 @@ int rhk_refit_mask(rh_cloud *c, const rh_prep &P, int kind, double eps, double c
         c->k_sums_ready = apply;
         return RH_OK;
     }
-    static int env_blocks = -1;
-    if (env_blocks < 0) { const char *e = getenv("RH_REFIT_BLOCKS"); env_blocks = e ? atoi(e) : 0; }
+    const int env_blocks = (int)rh_opt_int(c, RH_OPT_REFIT_BLOCKS, 0);
     int64_t blocks = cdiv(c->nwords, 4 * RH_RF_WPW);
     // one group of words per wave up to 32768 blocks, a grid-stride loop beyond (measured with 4-word groups, plane
     // scan: 10M points 0.0771 ms at 2048 blocks, 0.0743 at 4096-9766; 50M points 0.364 ms at 2048, 0.350 at 32768+)

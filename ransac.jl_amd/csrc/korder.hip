@@ -274,9 +274,9 @@ int rhk_korder_sync_enabled(rh_cloud *c)
 bool rhk_refit_is_culled(const rh_cloud *c)
 {
     if (!c->k_built) return false;
-    const char *e = getenv("RH_REFIT_PATH");
-    if (e && e[0] == 's') return false;
-    if (e && e[0] == 'c') return true;
+    const int64_t e = rh_opt_int(c, RH_OPT_REFIT_PATH, RH_REFIT_PATH_AUTO);   // rh_set_option(.., "refit_path", ..)
+    if (e == RH_REFIT_PATH_SCAN) return false;
+    if (e == RH_REFIT_PATH_CULLED) return true;
     return c->n >= RH_KREFIT_MIN;
 }
 
@@ -291,8 +291,7 @@ static int launch_refitk(rh_cloud *c, const T *pts, const PREP &PX, const rh_pre
     if (b2 > 2048) b2 = 2048;
     const dim3 g2((unsigned)b2);
     const int ap = apply ? 1 : 0;
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("RH_KREFIT_DBG") ? 1 : 0;
+    const int dbg = rh_opt_on(c, RH_OPT_KREFIT_DBG) ? 1 : 0;
 #define RH_K(K)                                                                                                              \
     do {                                                                                                                     \
         hipLaunchKernelGGL((refitk_boxes_kernel<K, F32>), g1, blk, 0, c->stream, c->kgb, c->kg_pad, ng, c->n, c->oct_men, P, eps, \

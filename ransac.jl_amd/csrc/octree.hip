@@ -35,7 +35,8 @@ struct rh_octree {
     int64_t n = 0;
     int overflow = 0;
     // device copy of the index lists (made on the first gather, for that cloud's device)
-    int64_t *d_idx = nullptr;
+    int64_t *d_idx = nullptr;          // rh_octree_cell_enabled's device scratch (the requested cell's list, its enabled points, their number)
+    int64_t d_cap = 0;
     int d_device = -1;
 };
 
@@ -239,26 +240,27 @@ extern "C" int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t node, i
     const rh_octree_node &nd = t->nodes[(size_t)node];
     if (nd.count == 0) return RH_OK;
     RH_HIP(hipSetDevice(c->device));
-    if (t->d_idx == nullptr || t->d_device != c->device) {
-        if (t->d_idx) (void)hipFree(t->d_idx);
+    // the cell's own slice of the index lists goes up (not the tree's whole multi-level list: n x depth x 8 bytes), into
+    // scratch the tree keeps for the next call: [cell list | enabled list | count]
+    const int64_t ocap = cap < nd.count ? cap : nd.count;
+    const int64_t need = nd.count + (ocap > 0 ? ocap : 1) + 1;
+    if (t->d_idx == nullptr || t->d_device != c->device || t->d_cap < need) {
+        if (t->d_idx) { if (t->d_device >= 0) (void)hipSetDevice(t->d_device); (void)hipFree(t->d_idx); (void)hipSetDevice(c->device); }
         t->d_idx = nullptr;
-        RH_HIP(hipMalloc((void **)&t->d_idx, sizeof(int64_t) * t->idx.size()));
-        RH_HIP(hipMemcpy(t->d_idx, t->idx.data(), sizeof(int64_t) * t->idx.size(), hipMemcpyHostToDevice));
+        t->d_cap = 0;
+        RH_HIP(hipMalloc((void **)&t->d_idx, sizeof(int64_t) * (size_t)need));
+        t->d_cap = need;
         t->d_device = c->device;
     }
-    int64_t *d_out = nullptr, *d_n = nullptr;
-    const int64_t ocap = cap < nd.count ? cap : nd.count;
-    RH_HIP(hipMalloc((void **)&d_out, sizeof(int64_t) * (size_t)(ocap > 0 ? ocap : 1)));
-    if (hipMalloc((void **)&d_n, sizeof(int64_t)) != hipSuccess) { (void)hipFree(d_out); rh_set_error("rh_octree_cell_enabled: hipMalloc failed"); return RH_E_NOMEM; }
-    hipLaunchKernelGGL(cell_enabled_kernel, dim3(1), dim3(1024), 0, c->stream, t->d_idx + nd.first, nd.count, c->enabled, c->n, d_out, ocap, d_n);
+    int64_t *d_out = t->d_idx + nd.count, *d_n = d_out + (ocap > 0 ? ocap : 1);
+    RH_HIP(hipMemcpyAsync(t->d_idx, t->idx.data() + nd.first, sizeof(int64_t) * (size_t)nd.count, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(cell_enabled_kernel, dim3(1), dim3(1024), 0, c->stream, t->d_idx, nd.count, c->enabled, c->n, d_out, ocap, d_n);
     int64_t total = 0;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&total, d_n, sizeof total, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && total > 0 && total <= cap)
         e = hipMemcpy(idx_out, d_out, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
-    (void)hipFree(d_n);
     if (e != hipSuccess) { rh_set_error("rh_octree_cell_enabled: %s", hipGetErrorString(e)); return RH_E_NODEVICE; }
     *n_out = total;
     if (total > cap) { rh_set_error("rh_octree_cell_enabled: %lld enabled points in the cell, capacity %lld", (long long)total, (long long)cap); return RH_E_CAPACITY; }

@@ -27,6 +27,34 @@ void rh_set_error(const char *fmt, ...);
         if (rc_ != RH_OK) return rc_; \
     } while (0)
 
+// ---- options (options.cpp): what rh_set_option stores; the diag build also reads the RH_* environment ---------
+enum rh_opt_id {
+    RH_OPT_SCORE_PATH = 0,      // product keys (rh_set_option, include/ransac_hip.h)
+    RH_OPT_S4_ROWS,
+    RH_OPT_UNP_WORDS,
+    RH_OPT_REFIT_PATH,
+    RH_OPT_N_PRODUCT,
+    // A/B switches and diagnostics: alive in the diag build only (in the product build they read as unset)
+    RH_OPT_CREATE_PROF = RH_OPT_N_PRODUCT, RH_OPT_AABB_HOST, RH_OPT_SUB_ORDER, RH_OPT_KD_HOST, RH_OPT_NO_SPREAD, RH_OPT_OCT_CHAIN_W,
+    RH_OPT_NO_MANAGED_STORE, RH_OPT_OCT_ONE_WINDOW, RH_OPT_OCT_WINDOW_ITERS, RH_OPT_NO_FUSED_SCORE, RH_OPT_NO_PIPELINE,
+    RH_OPT_NO_OCT_CHAIN, RH_OPT_REFIT_BLOCKS, RH_OPT_NO_FUSED_SAMPLER, RH_OPT_NO_CREC, RH_OPT_LONG_WINDOW_SETS, RH_OPT_NO_OCT_TAB,
+    RH_OPT_NO_DRIVER_CACHE, RH_OPT_HOST_SAMPLER, RH_OPT_DRIVER_PROF, RH_OPT_G2_DBG, RH_OPT_KREFIT_DBG, RH_OPT_NO_FAST_EXTRACT,
+    RH_OPT_NO_OCT_FUSE,
+    RH_OPT_COUNT
+};
+struct rh_cloud;
+int64_t rh_opt(const rh_cloud *c, int id);               // cloud -> process -> (diag) environment; RH_OPTION_UNSET = nobody said
+void rh_opt_init_cloud(rh_cloud *c);
+#ifdef RH_DIAG
+const char *rh_opt_env_string(const char *name);         // string-valued diagnostics (RH_RCCL_LIB): diag build only
+static inline bool rh_opt_on(const rh_cloud *c, int id) { const int64_t v = rh_opt(c, id); return v != RH_OPTION_UNSET && v != 0; }
+static inline int64_t rh_opt_int(const rh_cloud *c, int id, int64_t dflt) { const int64_t v = rh_opt(c, id); return v == RH_OPTION_UNSET ? dflt : v; }
+#else
+// product build: the diag ids are compile-time "unset" -- the A/B branches fold away
+static inline bool rh_opt_on(const rh_cloud *c, int id) { if (id >= RH_OPT_N_PRODUCT) return false; const int64_t v = rh_opt(c, id); return v != RH_OPTION_UNSET && v != 0; }
+static inline int64_t rh_opt_int(const rh_cloud *c, int id, int64_t dflt) { if (id >= RH_OPT_N_PRODUCT) return dflt; const int64_t v = rh_opt(c, id); return v == RH_OPTION_UNSET ? dflt : v; }
+#endif
+
 // ---- device-side candidate record ------------------------------------------
 // Per-candidate constants hoisted out of the per-point loop.  Every hoisted value is
 // a pure function of the candidate computed with the same IEEE operations the
@@ -60,6 +88,7 @@ struct rh_s4_points {   // what the v4 score kernel runs over (score4.hip): poin
     const float *gb32;
 };
 struct rh_cloud {
+    int64_t opt[RH_OPT_COUNT];         // rh_set_option on this cloud (RH_OPTION_UNSET: the process-wide value holds); rh_opt_init_cloud
     int device = -1;
     hipStream_t stream = nullptr;      // the stream every launch / copy of this cloud goes to
     hipStream_t own_stream = nullptr;  // created with the cloud; `stream` is this or the caller's (rh_cloud_set_stream)

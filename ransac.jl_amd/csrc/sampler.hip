@@ -834,13 +834,12 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     }
     bool cone = false;
     for (int i = 0; i < prm->n_shape_types; i++) cone |= prm->shape_types[i] == RH_CONE;
-    const bool no_fused = getenv("RH_NO_FUSED_SAMPLER") != nullptr;   // read per call: the tests flip it
+    const bool no_fused = rh_opt_on(c, RH_OPT_NO_FUSED_SAMPLER);   // read per call: the tests flip it
     // Windows with many root-cell sets pay for two structures that are rebuilt after every extraction: the
     // flat select list (4 B per enabled point) and, from it, the rank-ordered compact records (64 B per
     // enabled point).  Short windows -- the ones between extractions -- search the directory instead.
-    const bool no_crec = getenv("RH_NO_CREC") != nullptr;
-    const char *ms = getenv("RH_LONG_WINDOW_SETS");
-    const int64_t long_sets = ms ? atoll(ms) : (int64_t)1 << 16;
+    const bool no_crec = rh_opt_on(c, RH_OPT_NO_CREC);
+    const int64_t long_sets = rh_opt_int(c, RH_OPT_LONG_WINDOW_SETS, (int64_t)1 << 16);
     const bool long_window = d_P == nullptr && n_enabled > 0 && total >= long_sets;
     const double *crec = nullptr;
     if (long_window) {
@@ -873,7 +872,7 @@ int rhk_sample_fit(rh_cloud *c, const rh_params *prm, uint64_t seed, int64_t k0,
     rhfit::OctView oc;
     oc.code = c->oct_code; oc.perm = c->oct_perm; oc.pos = c->oct_pos; oc.men = c->oct_men; oc.prefix = c->oct_prefix;
     oc.n = c->n; oc.nwords = c->nwords; oc.depth = c->oct_depth;
-    if (!getenv("RH_NO_OCT_TAB")) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; oc.code_o = c->oct_code_o; }
+    if (!rh_opt_on(c, RH_OPT_NO_OCT_TAB)) { oc.tab = c->oct_tab; oc.tab_level = c->oct_tab_level; oc.code_o = c->oct_code_o; }
     // (octree sampling is a chain of dependent random reads per set: one wave per block spreads a window of a few thousand
     // sets over four times as many compute units -- each with its own address translation -- as 256-thread blocks would)
     const int sblock = d_P != nullptr ? 64 : 256;

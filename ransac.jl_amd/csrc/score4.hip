@@ -29,6 +29,9 @@
 #include <vector>
 
 #include "rh_internal.h"
+#ifdef RH_DIAG
+#include "ransac_hip_diag.h"
+#endif
 #include "score_device.h"
 #include "score4_device.h"
 #include "score_device32.h"
@@ -458,8 +461,14 @@ template <int R, bool MASK, bool F32, bool TAIL = false>
 #define RH_S4_MINBLK 7
 #endif
 __global__ void __launch_bounds__(64 * S4_W, F32 ? 8 : RH_S4_MINBLK)   // (the Float32 instantiations: 8 / 64 registers, 0.0916 -> see experiments.txt)
-score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg)
+score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg_arg)
 {
+#ifdef RH_DIAG
+    const int dbg = dbg_arg;   // diag build: 1 = no pair survives stage 1 (the skeleton alone), 2 = every pair does
+#else
+    constexpr int dbg = 0;     // the product kernel has no such switch
+    (void)dbg_arg;
+#endif
     __shared__ S4Shared<R, MASK> sh;
     // Blocks go to the 8 XCDs round-robin by their linear id, each XCD with an L2 of its own.  With rows > 0 the id is
     // read as ((tile / 8) x rows + row) x 8 + tile % 8: the rows of one tile follow each other on ONE XCD, so the tile is
@@ -522,6 +531,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
 #undef RH_S4_BODY
 }
 
+#ifdef RH_DIAG
 // ---- audit of the classifier's margins (tests): every (candidate, point) of a batch against subset 1.
 // a32 / b32 are what the score kernel computes (the very same functions: ua, ub of score4_device.h); a64 / b64 the same scaled
 // quantities from the reference's binary64 arithmetic.  |x32 - x64| has to stay below 1/2 for the classification to be sound; by
@@ -699,6 +709,8 @@ cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
     }
 }
 
+#endif   // RH_DIAG
+
 // ---- masks -> subset order, from the entry lists the score kernel left (round 4; round 3 wrote the words into sparse
 // internal-order rows with an occupancy byte each, and the un-permutation searched them: 1.0 ms at cfg5, a chain of
 // dependent loads per block -- occupancy -> list -> words -> positions -- at two blocks per CU).  One block per (candidate
@@ -855,8 +867,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     const int64_t ntiles = (PS.ngroups + S4_TG - 1) / S4_TG;
     const int nchunks = cdiv4(nk_total_bound, 64) + 3;   // every bin may end in a partial chunk
     if (ntiles == 0 || nk_total_bound <= 0) return RH_OK;
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("RH_G2_DBG"); dbg = e ? atoi(e) : 0; }   // (1: no pair survives stage 1 -- the skeleton alone, tools/region_counters.sh)
+    const int dbg = (int)rh_opt_int(c, RH_OPT_G2_DBG, 0);   // (diag build only -- 1: no pair survives stage 1, the skeleton alone: tools/region_counters.sh)
     S4AllArgs A;
     for (int k = 0; k < 4; k++)
         A.k[k] = { (const rh_cls *)cls[k], box[k], prep[k], orig[k], nk[k], en[k], eps[k], cosa[k] };
@@ -868,8 +879,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.masks = d_masks_int;
     A.occ = d_occ;
     A.mstride = mstride;
-    int env_r = 0;   // (read on every launch: the fuzzers vary it from case to case)
-    { const char *e = getenv("RH_S4_R"); env_r = e ? atoi(e) : 0; }
+    const int env_r = (int)rh_opt_int(c, RH_OPT_S4_ROWS, 0);   // rh_set_option(.., "s4_rows", ..), read on every launch: the fuzzers vary it from case to case
     // R = chunks of 64 candidates per block row.  A block's fixed work -- prologue, staging its tile, the four kinds' dispatch --
     // is a third of the launch's issue cycles at cfg3 and nearly half at cfg5 (profiles/r4/region_counters*.txt): longer rows pay
     // it less often, as long as the grid still has a few blocks per slot.  Measured (round 4, counts only): cfg3 (1221 tiles)
@@ -998,6 +1008,7 @@ int rhk_score4_dis(rh_cloud *c, int64_t first, int64_t cnt, const rh_prep *const
     return rc;
 }
 
+#ifdef RH_DIAG
 // diagnostics (tests): the classifier's worst binary32 error on a batch, in units of its margin widths (see
 // cls_audit_kernel); out[12]: per kind (plane, sphere, cylinder, -) the two maxima, then the numbers of pairs
 extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, double *out)
@@ -1077,13 +1088,14 @@ extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t
     return RH_OK;
 }
 
+#endif   // RH_DIAG
+
 // the entry lists the v4 score kernel left (rows of mstride 16-byte entries, one cursor per row in d_occ) -> dense rows in
 // subset order; the cursors are zero again afterwards
 int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int64_t mstride, int32_t b, uint64_t *d_out)
 {
     if (b == 0 || c->swords == 0) return RH_OK;
-    int env_words = 0;   // RH_UNP_WORDS=n (tests; read per call): segments of n words, so that a small cloud's rows span several / many
-    { const char *e = getenv("RH_UNP_WORDS"); env_words = e ? atoi(e) : 0; }
+    const int env_words = (int)rh_opt_int(c, RH_OPT_UNP_WORDS, 0);   // rh_set_option(.., "unp_words", n) (tests; read per call): segments of n words, so that a small cloud's rows span several / many
     const int64_t seg_words = std::min<int64_t>(c->swords, env_words > 0 ? std::min(env_words, 16384) : (c->swords <= S4_UNP_WORDS ? S4_UNP_WORDS : S4_UNP_WORDS_MULTI));
     const int nseg = cdiv4(c->swords, seg_words);
     static bool attr_set = false;

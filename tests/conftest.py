@@ -10,6 +10,28 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "diag: needs libransac_hip_diag.so (-DRH_DIAG: the experiments' A/B switches through RH_* "
+                                       "environment variables, the rh_dbg_* audits).  GPU tests with this mark run in ONE child "
+                                       "process with RH_LIB_VARIANT=diag (tests/test_diag_suite_gpu.py); everything else -- and "
+                                       "bench.py, smoke() -- loads the product library, which reads no environment variable")
+
+
+def pytest_collection_modifyitems(config, items):
+    """One library per process: a `gpu` test marked `diag` is deselected unless this process was started for the diag
+    build (RH_LIB_VARIANT=diag), and in that process nothing else is collected."""
+    diag_proc = os.environ.get("RH_LIB_VARIANT") == "diag"
+    keep, drop = [], []
+    for it in items:
+        is_gpu, is_diag = it.get_closest_marker("gpu") is not None, it.get_closest_marker("diag") is not None
+        if is_gpu and is_diag != diag_proc:
+            drop.append(it)
+        elif diag_proc and not is_gpu:
+            drop.append(it)
+        else:
+            keep.append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def pytest_sessionstart(session):
@@ -21,7 +43,7 @@ def pytest_sessionstart(session):
     spec = importlib.util.spec_from_file_location("rh_build", os.path.join(ROOT, "ransac.jl_amd", "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.build()
+    mod.build_all()
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -314,3 +314,55 @@ def test_octview_searches_match_std(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert out.stdout.strip().endswith("0 bad")
+
+
+def test_product_library_reads_no_environment_and_ships_no_diagnostics():
+    """libransac_hip.so sits under someone else's process: it must not change what it computes because of a variable in
+    that process's environment.  The A/B switches of the experiments (RH_NO_PIPELINE, ...), the skeleton-only launch
+    (RH_G2_DBG), the fake-RCCL hook (RH_RCCL_LIB) and the rh_dbg_* audits exist in the diag build only
+    (libransac_hip_diag.so, -DRH_DIAG); what a caller may tune goes through rh_set_option."""
+    import subprocess
+    out = subprocess.run(["strings", L.SO_PATH], capture_output=True, text=True, check=True).stdout
+    rh = [ln for ln in out.splitlines() if "RH_" in ln]
+    assert len(rh) <= 5, rh        # (what is left: HIP call texts of error messages that name RH_* constants of the sources)
+    assert not any(re.search(r"\bRH_[A-Z0-9_]+=|getenv\(\"RH_", ln) for ln in rh), rh
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.SO_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rh_dbg_" not in nm and "rh_set_option" in nm
+    # no source of ours calls getenv outside the diag build (rocPRIM's headers read a variable of their own)
+    csrc = os.path.join(ROOT, "ransac.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        if f == "options.cpp":
+            text = re.sub(r"#ifdef RH_DIAG.*?#endif", "", text, flags=re.S)
+        assert "getenv" not in text, f
+    lib = R.lib()
+    assert lib.rh_build_variant() == 0
+    # product keys work, diag keys are unknown here
+    R.set_option("s4_rows", 8)
+    assert R.get_option("s4_rows") == 8
+    R.set_option("s4_rows", None)
+    assert R.get_option("s4_rows") is None
+    for bad_key, bad_val in (("no_pipeline", 1), ("g2_dbg", 1), ("s4_rows", 5), ("refit_path", 7)):
+        with pytest.raises(R.RansacHipError):
+            R.set_option(bad_key, bad_val)
+
+
+def test_diag_library_exports_the_diag_header_and_knows_the_switches():
+    src = open(os.path.join(ROOT, "include", "ransac_hip_diag.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(rh_[a-z0-9_]+)\s*\(", src)))
+    assert syms == sorted(L.DIAG_SIGNATURES)
+    d = L.lib("diag")
+    assert d.rh_build_variant() == 1
+    for s in syms + header_symbols():
+        assert hasattr(d, s), s
+    assert d.rh_set_option(None, b"no_pipeline", 1) == 0 and d.rh_set_option(None, b"no_pipeline", L.OPTION_UNSET) == 0
+    # the diag build falls back to the environment; the product build does not
+    v, st = C.c_int64(), C.c_int32()
+    os.environ["RH_S4_R"] = "12"
+    try:
+        assert d.rh_get_option(None, b"s4_rows", C.byref(v), C.byref(st)) == 0 and st.value == 1 and v.value == 12
+        assert R.lib("product").rh_get_option(None, b"s4_rows", C.byref(v), C.byref(st)) == 0 and st.value == 0
+    finally:
+        del os.environ["RH_S4_R"]

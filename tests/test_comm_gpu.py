@@ -34,6 +34,7 @@ def fake_rccl(tmp_path_factory):
     return so
 
 
+@pytest.mark.diag      # (RH_RCCL_LIB, the hook that binds the stand-in, exists in the diag build only)
 @pytest.mark.parametrize("world", [2, 3])
 def test_library_collective_across_processes_sharing_gpu0(world, fake_rccl, tmp_path):
     """world ranks, one process each, all on GPU 0: every rank scores its slice of 18 batches (pairs and bursts of four in flight) through

@@ -21,6 +21,14 @@ KIND = {"plane": 0, "sphere": 1, "cylinder": 2, "cone": 3}
 dp = C.POINTER(C.c_double)
 
 
+@pytest.fixture
+def score_path_option(path):
+    """rh_set_option(NULL, "score_path", path) for the clouds the test creates (the library reads no environment)"""
+    with R.option("score_path", path):
+        yield path
+
+
+
 def orc_shape(c, lib=None):
     s = orc.Shape()
     s.kind = KIND[c["kind"]]
@@ -134,8 +142,7 @@ def _vector_cloud():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["groups", "brute"])
-def test_hip_kernels_give_the_hand_derived_answers(path, monkeypatch):
-    monkeypatch.setenv("RH_SCORE_PATH", path)
+def test_hip_kernels_give_the_hand_derived_answers(path, score_path_option):
     pts, nrm, where = _vector_cloud()
     n = len(pts)
     sub = np.random.default_rng(3).permutation(n).astype(np.int64) + 1      # subset 1 = the whole cloud, shuffled
@@ -167,10 +174,9 @@ def test_hip_kernels_give_the_hand_derived_answers(path, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["groups", "brute"])
-def test_hip_float32_kernels_give_the_hand_derived_answers(path, monkeypatch):
+def test_hip_float32_kernels_give_the_hand_derived_answers(path, score_path_option):
     """The vectors whose numbers are binary32 numbers on a Float32 cloud (rh_cloud_create_f32): both scorers and the
     refit scan give the derived answer and equal the oracle's binary32 twin on the whole cloud."""
-    monkeypatch.setenv("RH_SCORE_PATH", path)
     pts, nrm, where = _vector_cloud()
     p32, n32 = pts.astype(np.float32), nrm.astype(np.float32)      # exact for the representable vectors (filler rounds)
     n = len(pts)

@@ -36,16 +36,8 @@ def to_orc(arr, b):
 @pytest.fixture(scope="module", params=["groups", "brute"])
 def scene32(request):
     """both scorers: the culled kernel with the exact test in binary32, and the brute-force float kernel"""
-    import os
-    old = os.environ.get("RH_SCORE_PATH")
-    os.environ["RH_SCORE_PATH"] = request.param
-    try:
+    with R.option("score_path", request.param):
         yield _scene32()
-    finally:
-        if old is None:
-            os.environ.pop("RH_SCORE_PATH", None)
-        else:
-            os.environ["RH_SCORE_PATH"] = old
 
 
 def _scene32():
@@ -274,7 +266,7 @@ def test_f32_ransac_cfg1_end_to_end(streams, octree):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("env", [None, "RH_HOST_SAMPLER", "RH_NO_FUSED_SCORE", "RH_NO_FAST_EXTRACT", "RH_NO_PIPELINE"])
+@pytest.mark.parametrize("env", [None] + [pytest.param(e, marks=pytest.mark.diag) for e in ("RH_HOST_SAMPLER", "RH_NO_FUSED_SCORE", "RH_NO_FAST_EXTRACT", "RH_NO_PIPELINE")])
 def test_f32_ransac_multi_primitive(seed, env, monkeypatch):
     prim = ["plane", "plane", "sphere", "cylinder", "cylinder", "sphere"]
     xyz, nrm, truth = synth.make_cloud(60_000, prim, 0.2, seed=40 + seed)

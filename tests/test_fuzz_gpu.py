@@ -15,15 +15,20 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 pytestmark = pytest.mark.gpu
 
-_ENV = ("RH_SCORE_PATH", "RH_S4_R", "RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
-        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE",
+# the driver's A/B switches (diag build only: the e2e fuzzer draws them; the score / refit fuzzers set product options)
+_ENV = ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
+        "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE",
         "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS")
+_OPTS = ("score_path", "s4_rows", "refit_path")
 
 
 @pytest.fixture(autouse=True)
 def _restore_env():
+    import ransac_jl_amd as R
     old = {k: os.environ.get(k) for k in _ENV}
     yield
+    for k in _OPTS:
+        R.set_option(k, None)
     for k, v in old.items():
         if v is None:
             os.environ.pop(k, None)
@@ -57,6 +62,7 @@ def test_score_fuzz_slice_float32(seed, ncases):
     assert not bad, bad[:5]
 
 
+@pytest.mark.diag
 @pytest.mark.parametrize("seed,ncases,f32", [(61001, 60, False), (61002, 60, False), (61003, 60, True)])
 def test_classifier_and_box_soundness_slice(seed, ncases, f32):
     """The bit-exact counts rest on two claims about the v4 score kernel's shortcuts (csrc/score4_device.h): the binary32
@@ -96,6 +102,7 @@ def test_refit_fuzz_slice(seed, ncases, f32):
     assert not bad, bad[:5]
 
 
+@pytest.mark.diag
 @pytest.mark.parametrize("seed,ncases,f32", [(31, 15, False), (32, 15, False), (33, 15, True), (34, 15, True)])
 def test_e2e_fuzz_slice(seed, ncases, f32):
     """f32: ransac() on Float32 clouds (octree.jl:102-109) -- fits, scoring, liveness and refit in binary32 -- against the

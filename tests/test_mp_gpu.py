@@ -45,11 +45,12 @@ def _digest(got, stats, pc):
     return key, h.hexdigest()
 
 
-def _rank(rank, world, name, which, octree, q):
+def _rank(rank, world, name, which, octree, q, refit_path=None):
     try:
         sys.path.insert(0, ROOT)
         import ransac_jl_amd as R
         from ransac_jl_amd import _lib as L
+        R.set_option("refit_path", refit_path)
         xyz, nrm, subs, it, cones = _scene(which)
         pc = R.RANSACCloud(xyz, nrm, subs, device=0)
         cp = _params(R, L, it, cones, octree)
@@ -64,15 +65,14 @@ def _rank(rank, world, name, which, octree, q):
 @pytest.mark.parametrize("which,world,octree,refit_path", [("small", 2, False, None), ("small", 3, False, None),
                                                             ("cones", 2, False, "culled"), ("small", 2, True, None),
                                                             ("small", 2, True, "culled"), ("cfg2", 2, False, "culled")])
-def test_ransac_mp_equals_single_process(which, world, octree, refit_path, monkeypatch):
+def test_ransac_mp_equals_single_process(which, world, octree, refit_path):
     # refit_path: the culled refit scan (korder.hip; by default from 2^21 points on) forced on these clouds, in this process
     # and in the ranks; with the octree it also maintains the Morton-order enabled bits the sampler reads
-    if refit_path:
-        monkeypatch.setenv("RH_REFIT_PATH", refit_path)
     import ransac_jl_amd as R
     from ransac_jl_amd import _lib as L
     xyz, nrm, subs, it, cones = _scene(which)
     pc = R.RANSACCloud(xyz, nrm, subs)
+    R.set_option("refit_path", refit_path, cloud=pc)      # (rh_set_option: the library reads no environment variable)
     cp = _params(R, L, it, cones, octree)
     got, _, st = R.ransac(pc, cp, seed=77, return_stats=True)
     want = _digest(got, st, pc)
@@ -87,7 +87,7 @@ def test_ransac_mp_equals_single_process(which, world, octree, refit_path, monke
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "/rh_mp_test_%d_%s_%d" % (os.getpid(), which, world)
-    procs = [ctx.Process(target=_rank, args=(r, world, name, which, octree, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, name, which, octree, q, refit_path)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=300) for _ in procs]

@@ -14,11 +14,11 @@ from ransac_jl_amd import _lib as L
 @pytest.mark.parametrize("n,seed", [(1, 1), (63, 2), (64, 3), (65, 4), (1000, 5), (4096, 6), (50_000, 7), (200_003, 8)])
 def test_directory_and_bracketed_searches_equal_the_plain_ones(n, seed):
     bad = C.c_int64(-1)
-    L.check(R.lib().rh_dbg_oct_search_selftest(n, seed, 4000, C.byref(bad)))
+    L.check(L.lib("diag").rh_dbg_oct_search_selftest(n, seed, 4000, C.byref(bad)))
     assert bad.value == 0
 
 
 def test_selftest_rejects_bad_arguments():
     bad = C.c_int64(0)
     with pytest.raises(R.RansacHipError):
-        L.check(R.lib().rh_dbg_oct_search_selftest(0, 1, 10, C.byref(bad)))
+        L.check(L.lib("diag").rh_dbg_oct_search_selftest(0, 1, 10, C.byref(bad)))

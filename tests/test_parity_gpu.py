@@ -18,14 +18,8 @@ pytestmark = pytest.mark.gpu
 def score_path(request):
     """Every test runs against both scoring kernels: the culled one (k-d leaf groups + box tests)
     and the brute-force one.  The path is chosen when a cloud is created."""
-    import os
-    old = os.environ.get("RH_SCORE_PATH")
-    os.environ["RH_SCORE_PATH"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("RH_SCORE_PATH", None)
-    else:
-        os.environ["RH_SCORE_PATH"] = old
+    with R.option("score_path", request.param):   # rh_set_option(NULL, "score_path", ..): read when a cloud is created
+        yield request.param
 
 
 def to_orc_params(cp):
@@ -89,15 +83,14 @@ def test_score_counts_and_masks_all_kinds(small_scene):
 
 
 @pytest.mark.parametrize("seg_words", [0, 128, 8])
-def test_masks_through_every_form_of_the_list_to_row_pass(small_scene, monkeypatch, seg_words):
+def test_masks_through_every_form_of_the_list_to_row_pass(small_scene, seg_words):
     """The culled kernel leaves the masks as per-candidate entry lists; a second pass turns them into dense rows in
-    subset order, one block per (row, segment of the row).  RH_UNP_WORDS (read per call) sets the segment width, so that the
+    subset order, one block per (row, segment of the row).  the option "unp_words" (read per call) sets the segment width, so that the
     20000-point subset of this scene (313 words per row) is one segment (wave-per-entry form), 3 segments (the per-segment
     bit masks that full-size clouds with up to 16 segments use) or 40 (the form without them) -- bit-equal rows every time,
     with and without disabled points."""
     pc, oc, truth = small_scene
-    if seg_words:
-        monkeypatch.setenv("RH_UNP_WORDS", str(seg_words))
+    R.set_option("unp_words", seg_words if seg_words else None, cloud=pc)
     cp = R.params_to_c(R.ransacparameters())
     arr = shape_array(make_candidates(truth, 130, seed=5))
     for frac in (1.0, 0.6):
@@ -113,6 +106,7 @@ def test_masks_through_every_form_of_the_list_to_row_pass(small_scene, monkeypat
     oc.enable_all()
 
 
+@pytest.mark.diag
 def test_binary32_classifier_stays_inside_its_margins(small_scene):
     """The batched score decides most pairs in binary32 and sends only those within a rounding margin of a
     threshold to the binary64 test (csrc/score4_device.h).  The audit evaluates every (candidate, point) pair of
@@ -198,8 +192,9 @@ def test_scorecandidate_mirror_returns_reference_tuple(small_scene):
         R.scorecandidate(pc, cand, 2, params)
 
 
-def test_score_is_invariant_to_the_order_of_the_batch(small_scene, monkeypatch):
-    """The library spreads neighbouring candidates over different 64-candidate chunks (RH_NO_SPREAD=1: batch
+@pytest.mark.parametrize("no_spread", [False, pytest.param(True, marks=pytest.mark.diag)])
+def test_score_is_invariant_to_the_order_of_the_batch(small_scene, monkeypatch, no_spread):
+    """The library spreads neighbouring candidates over different 64-candidate chunks (diag build, RH_NO_SPREAD=1: batch
     order); counts and masks follow the caller's order whatever the internal one, host and device batches."""
     pc, oc, truth = small_scene
     cp = R.params_to_c(R.ransacparameters())
@@ -211,9 +206,10 @@ def test_score_is_invariant_to_the_order_of_the_batch(small_scene, monkeypatch):
         arr = shape_array([cands[i] for i in perm])
         counts, masks = R.score_batch(pc, arr, cp, want_masks=True)
         assert np.array_equal(counts, ref_counts[perm]) and np.array_equal(masks, ref_masks[perm])
-    monkeypatch.setenv("RH_NO_SPREAD", "1")
-    counts, _ = R.score_batch(pc, shape_array(cands), cp, want_masks=True)
-    assert np.array_equal(counts, ref_counts)
+    if no_spread:
+        monkeypatch.setenv("RH_NO_SPREAD", "1")
+        counts, _ = R.score_batch(pc, shape_array(cands), cp, want_masks=True)
+        assert np.array_equal(counts, ref_counts)
 
 
 def test_score_respects_enabled_bits_and_sphere_quirk(small_scene):
@@ -455,17 +451,17 @@ def test_ransac_multi_primitive_all_kinds(seed, fixed):
 @pytest.mark.parametrize("prims,kinds,seed,host", [
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, False),   # device sampler + speculation
     (["plane", "sphere", "cylinder", "cone"], "all", 12, False),                             # cones on the device as well
-    (["plane", "sphere", "cylinder", "cone"], "all", 12, True),                              # host twin of the sampler
+    pytest.param(["plane", "sphere", "cylinder", "cone"], "all", 12, True, marks=pytest.mark.diag),                              # host twin of the sampler
     (["plane", "plane"], "p", 13, False),
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_PIPELINE"),      # one window at a time
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SCORE"),   # scores through the host
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FAST_EXTRACT"),  # liveness after the host saw the lengths
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_PIPELINE", marks=pytest.mark.diag),      # one window at a time
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FUSED_SCORE", marks=pytest.mark.diag),   # scores through the host
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_NO_FAST_EXTRACT", marks=pytest.mark.diag),  # liveness after the host saw the lengths
     # windows this short search the select directory; RH_LONG_WINDOW_SETS=0 sends them down the long-window
     # path (flat select list, rank-ordered compact records, sampling + fits in one kernel) and its variants
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS"),
-    (["plane", "sphere", "cylinder", "cone"], "all", 12, "RH_LONG_WINDOW_SETS"),
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_FUSED_SAMPLER"),  # sample + fit as two kernels
-    (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_CREC"),           # index-space sampling
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS", marks=pytest.mark.diag),
+    pytest.param(["plane", "sphere", "cylinder", "cone"], "all", 12, "RH_LONG_WINDOW_SETS", marks=pytest.mark.diag),
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_FUSED_SAMPLER", marks=pytest.mark.diag),  # sample + fit as two kernels
+    pytest.param(["plane", "sphere", "cylinder", "plane", "sphere", "cylinder"], "psc", 11, "RH_LONG_WINDOW_SETS,RH_NO_CREC", marks=pytest.mark.diag),           # index-space sampling
 ])
 def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
     """sampling_streams = 1: sampling + fitting + scoring on the device, iterations speculated in
@@ -494,7 +490,7 @@ def test_ransac_per_set_streams(prims, kinds, seed, host, monkeypatch):
 @pytest.mark.parametrize("prims,kinds,seed,host", [
     (["plane", "sphere", "cylinder", "plane", "sphere", "cylinder", "plane", "sphere"], "psc", 21, False),
     (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22, False),     # cones fitted on the device too
-    (["plane", "sphere", "cylinder", "cone", "cone"], "all", 22, True),      # same streams drawn on the host
+    pytest.param(["plane", "sphere", "cylinder", "cone", "cone"], "all", 22, True, marks=pytest.mark.diag),      # same streams drawn on the host
 ])
 def test_ransac_octree_sampling(prims, kinds, seed, host, monkeypatch):
     """octree_sampling = 1 (fixed behaviour, docs/src/ransac.md:73-96): level-weighted cells of a
@@ -558,7 +554,7 @@ def test_ransac_octree_iterations_beyond_the_advance_kernels_lds_buffer():
     assert_same_run(pc, oc, got, exp, stats)
 
 
-@pytest.mark.parametrize("cache", [True, False])
+@pytest.mark.parametrize("cache", [True, pytest.param(False, marks=pytest.mark.diag)])
 def test_ransac_calls_in_a_row_on_one_cloud(cache, monkeypatch):
     """rh_ransac parks its windows, device store and pinned scratch on the cloud for the next call
     (RH_NO_DRIVER_CACHE=1: every call allocates its own).  Four runs in a row on one cloud, with different shape
@@ -676,6 +672,7 @@ def test_largestconncomp_random_bitmaps(shape, density, seed):
         assert np.array_equal(got, orc.largestconncomp(bm, conn8=conn8))
 
 
+@pytest.mark.diag
 def test_full_size_octree_leg_is_the_same_run_under_every_switch(monkeypatch):
     """The bench's octree-sampling leg at full size (cfg3: 10M points, minsubsetN = 4096, ~1000 candidates per iteration,
     a store of ~100 000 candidates at the first extraction) -- too large for the oracle, so the size-independent property:
@@ -725,7 +722,9 @@ def test_full_size_properties(cfg):
     assert np.array_equal(R.score_batch(pc, arr, cp), counts)
     assert counts.max() <= subs[0].size and counts.sum() > 4096 * 100
     oc = orc.Cloud(c["xyz"], c["nrm"], subs[0])
-    sel = list(range(0, 4096, 97)) if cfg != "cfg5" else list(range(0, 4096, 43))    # cfg5: 96 candidates, 16 of them cones
+    # oracle on: the whole batch (cfg2), every second candidate (cfg3; bench.py checks all 4096 on every run), every fourth
+    # (cfg5: 1024 candidates, 170 of them cones; ~5 s on 16 threads at S = 1 562 500)
+    sel = list(range(0, 4096, {"cfg2": 1, "cfg3": 2, "cfg5": 4}[cfg]))
     kinds_in = {cands[i].kind for i in sel}
     assert kinds_in == ({L.PLANE, L.SPHERE, L.CYLINDER, L.CONE} if cfg == "cfg5" else {L.PLANE, L.SPHERE, L.CYLINDER})
     sub_arr = shape_array([cands[i] for i in sel])
@@ -734,10 +733,12 @@ def test_full_size_properties(cfg):
     if cfg == "cfg5":
         cone_sel = [i for i in sel if cands[i].kind == L.CONE]
         assert len(cone_sel) >= 8 and counts[cone_sel].max() > 1000       # cones of the batch really collect inliers
-        # masks of 48 candidates, every primitive of the scene once, bit for bit
-        msel = [i for i in range(nmask)][:48]       # one round of the 48 primitives: 16 planes, 12 spheres, 12 cylinders, 8 cones
+    # masks against the oracle's, bit for bit: every row the GPU wrote (4096 at cfg2 / cfg3; cfg5: 480 rows = ten rounds of the
+    # 48 primitives), in slices that bound the oracle's memory
+    for m0 in range(0, nmask, 512):
+        msel = list(range(m0, min(nmask, m0 + 512)))
         oc_c, oc_m = oc.score_masks_mt(to_orc_shapes(shape_array([cands[i] for i in msel]), len(msel)), to_orc_params(cp), 16)
-        assert np.array_equal(oc_m, masks[msel]) and np.array_equal(oc_c, counts[msel])
+        assert np.array_equal(oc_m, masks[msel]) and np.array_equal(oc_c, counts[msel]), (cfg, m0)
     # refit: ascending, all enabled before, none after invalidation, disjoint extractions
     seen = np.zeros(n, dtype=bool)
     todo = cands[:6] if cfg == "cfg2" else [cands[0], cands[16], cands[28], cands[40], cands[47]]   # cfg5: every kind, two cones
@@ -749,19 +750,14 @@ def test_full_size_properties(cfg):
         if cfg == "cfg5" and j in (0, 3):      # a plane and a cone scan against the oracle's list, on the enabled set as it stands
             assert np.array_equal(ex.inpoints, oc.refit(to_orc_shapes(shape_array([cand]), 1)[0], to_orc_params(cp)))
         if cfg == "cfg3" and j in (0, 2):      # a plane and a cylinder: the 10M-point scan against the oracle's list, both scans
-            import os
             want = oc.refit(to_orc_shapes(shape_array([cand]), 1)[0], to_orc_params(cp))
             assert want.size > 1000 and np.array_equal(ex.inpoints, want)
-            old = os.environ.get("RH_REFIT_PATH")
             try:
-                for path in ("scan", "culled"):        # (the switch is read on every refit)
-                    os.environ["RH_REFIT_PATH"] = path
+                for path in ("scan", "culled"):        # (the option is read on every refit)
+                    R.set_option("refit_path", path, cloud=pc)
                     assert np.array_equal(R.refit(cand, pc, cp).inpoints, want), path
             finally:
-                if old is None:
-                    os.environ.pop("RH_REFIT_PATH", None)
-                else:
-                    os.environ["RH_REFIT_PATH"] = old
+                R.set_option("refit_path", None, cloud=pc)
         seen[ex.inpoints - 1] = True
         R.invalidate_indexes(pc, ex.inpoints)
         oc.invalidate(ex.inpoints)
@@ -773,6 +769,7 @@ def test_full_size_properties(cfg):
         assert np.array_equal(again, oc.score_batch_mt(to_orc_shapes(sub_arr, len(sel)), to_orc_params(cp), 16))
 
 
+@pytest.mark.diag
 def test_subset_order_made_on_the_device_or_on_the_host_gives_the_same_results(monkeypatch):
     """The internal order of subset 1 (k-d leaves of 64 points) is made on the device (kdorder.hip) unless RH_KD_HOST=1
     keeps the host's nth_element recursion, the bounding cube on the device unless RH_AABB_HOST=1: counts, masks (in

@@ -2,6 +2,9 @@
 """rh_cloud_create alone: two clouds of the same scene in one process (the first pays the library's one-time costs), with the
 stage times of RH_CREATE_PROF=1 on stderr.   python tools/cloud_create_time.py [cfg3|cfg5]"""
 import os, sys, time
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

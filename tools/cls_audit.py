@@ -3,6 +3,8 @@
 scenes at several coordinate scales with jittered-truth and arbitrary candidates.  Sound below 0.5; expected below 0.25
 (the margins carry a safety factor of 2).  python tools/cls_audit.py [cases] [seed]"""
 import ctypes as C, os, sys
+if __name__ == "__main__":
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")   # the A/B switches / rh_dbg_* audits live in the diag build (libransac_hip_diag.so)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ransac_jl_amd as R

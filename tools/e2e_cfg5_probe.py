@@ -2,6 +2,9 @@
 """The bounded cfg5 end-to-end leg of bench.py alone (50M points, cones, itermax 4096), several rh_ransac calls in a row
 with the driver's own breakdown (RH_DRIVER_PROF=1): what the first calls on a cloud pay that later ones do not."""
 import os, sys, time
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ransac_jl_amd as R

@@ -3,6 +3,8 @@
 (cloud, parameter, mode) combinations.  Not part of the test suite (minutes of oracle time);
 run on a GPU box:  python tools/fuzz_e2e.py [n_cases] [seed]"""
 import os, sys, time
+if __name__ == "__main__":
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")   # the A/B switches / rh_dbg_* audits live in the diag build (libransac_hip_diag.so)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ransac_jl_amd as R
@@ -42,7 +44,7 @@ def one(case, rng, f32=False):
             it["itermax"] = int(rng.choice([12, 30]))
             params = R.ransacparameters(types, iteration=it)
     for k in ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER", "RH_LONG_WINDOW_SETS",
-              "RH_NO_FAST_EXTRACT", "RH_REFIT_PATH", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS"):
+              "RH_NO_FAST_EXTRACT", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE", "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS"):
         os.environ.pop(k, None)
     if env in ("RH_OCT_CHAIN_W", "RH_OCT_WINDOW_ITERS"):
         os.environ[env] = str(rng.choice([1, 2, 3, 64]))
@@ -53,7 +55,7 @@ def one(case, rng, f32=False):
     if rng.integers(0, 4) == 0:          # a quarter: liveness pass after the host has seen the list lengths
         os.environ["RH_NO_FAST_EXTRACT"] = "1"
     # the culled refit scan (korder.hip) on these small clouds in two cases of three, the plain scan in the third
-    os.environ["RH_REFIT_PATH"] = str(rng.choice(["culled", "culled", "scan"]))
+    R.set_option("refit_path", str(rng.choice(["culled", "culled", "scan"])))
     if f32:
         pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
         oc = orc.Cloud(xyz, nrm, subs[0], f32=True)

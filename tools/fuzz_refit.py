@@ -33,7 +33,7 @@ def one(case, rng, f32=False):
         xyz[int(rng.integers(0, n)), int(rng.integers(0, 3))] = float(rng.choice([np.nan, np.inf, -np.inf]))
     subs = synth.make_subsets(n, int(rng.choice([1, 2, 16])), seed=case) if n >= 16 else [np.arange(1, n + 1)]
     path = str(rng.choice(["culled", "culled", "culled", "scan"]))
-    os.environ["RH_REFIT_PATH"] = path
+    R.set_option("refit_path", path)          # rh_set_option: product and diag build alike
     if f32:
         xyz, nrm = xyz.astype(np.float32), nrm.astype(np.float32)
         pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)

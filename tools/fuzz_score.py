@@ -63,12 +63,10 @@ def one(case, rng, f32=False):
         if "radius" in t: t["radius"] = t["radius"] * (scale / 100.0)
     r = int(rng.choice([1, 2, 3, 16]))
     subs = synth.make_subsets(n, r, seed=case)
-    os.environ["RH_SCORE_PATH"] = str(rng.choice(["groups", "groups", "brute"]))
+    spath = str(rng.choice(["groups", "groups", "brute"]))
+    R.set_option("score_path", spath)               # rh_set_option: product and diag build alike
     rr = int(rng.choice([0, 0, 4, 8, 12, 16]))      # rows of the v4 kernel: the library's own choice, or every instantiation
-    if rr:
-        os.environ["RH_S4_R"] = str(rr)
-    else:
-        os.environ.pop("RH_S4_R", None)
+    R.set_option("s4_rows", rr if rr else None)
     if f32:   # a Float32 cloud: binary32 arithmetic on both sides (oracle/orc_f32.c)
         xyz, nrm = xyz.astype(np.float32), nrm.astype(np.float32)
         pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
@@ -101,7 +99,7 @@ def one(case, rng, f32=False):
     else:
         ok = np.array_equal(got, exp)
         tot = int(np.sum(exp))
-    return ok, "n=%d r=%d scale=%g path=%s R=%d b=%d masks=%d inliers=%d" % (n, r, scale, os.environ["RH_SCORE_PATH"], rr, b, want_masks, tot)
+    return ok, "n=%d r=%d scale=%g path=%s R=%d b=%d masks=%d inliers=%d" % (n, r, scale, spath, rr, b, want_masks, tot)
 
 
 def main():

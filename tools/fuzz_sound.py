@@ -8,6 +8,8 @@ arbitrary / degenerate / far-away-point shapes (tools/fuzz_score.py's generator)
   (iv)  candidates whose classifier would count the all-zero point a disabled point is staged as
 must all be 0.  python tools/fuzz_sound.py [ncases] [seed]   (F32=1: Float32 clouds)"""
 import os, sys, time
+if __name__ == "__main__":
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")   # the A/B switches / rh_dbg_* audits live in the diag build (libransac_hip_diag.so)
 import ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,9 @@
 `rocprofv3 --kernel-trace --stats -- python tools/prof_e2e.py [itermax] [runs] [root|octree] [cfg3|cfg5]` and
 RH_DRIVER_PROF=1."""
 import os
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import sys
 import time
 

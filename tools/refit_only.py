@@ -3,6 +3,9 @@
 from HIP events (rh_last_refit_ms) per kind, with the culled scan (default from 2^21 points on) or RH_REFIT_PATH=scan.
 RH_KREFIT_DBG=1 prints how many groups survive the box test."""
 import ctypes as C, os, sys
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ransac_jl_amd as R

@@ -2,6 +2,9 @@
 """The bench's timed step alone (cfg3 cloud, 4096 jittered candidates, rh_score_batch_dev) for kernel A/B runs under
 rocprofv3: prints ms per step from HIP events.  RH_* switches are read by the library."""
 import ctypes as C, os, sys, time
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
+    os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
