@@ -184,7 +184,9 @@ def compact_line(out, detail_file=None):
     line["config"] = {k: cfg.get(k) for k in ("workload", "points", "subset_points", "candidates_per_step", "score_mode", "parallelism")}
     line["roofline"] = {"kernel": rf.get("kernel"), "bound": rf.get("bound"), "achieved": _num(rf.get("achieved")),
                         "peak": _num(rf.get("peak")), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
-                        "frac_upper": _num(rf.get("frac_upper"), 4), "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
+                        "frac_upper": _num(rf.get("frac_upper"), 4), "frac_guide": _num(rf.get("frac_guide"), 4),
+                        "frac_necessary": _num(rf.get("frac_necessary"), 4), "frac_necessary_guide": _num(rf.get("frac_necessary_guide"), 4),
+                        "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
                         "counters": rf.get("counters")}
     line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": cb.get("sample")} if cb else None)
@@ -211,6 +213,8 @@ def compact_line(out, detail_file=None):
         "cloud_create_ms": _get(out, "cloud_create", "ms_total"),
         "cfg2_value": _get(out, "cfg2", "value"), "cfg2_ms": _get(out, "cfg2", "ms_per_step"),
         "cfg2_oracle_checked": _get(out, "cfg2", "oracle_checked"),
+        "cfg2_frac": _get(out, "cfg2", "roofline", "frac"), "cfg2_frac_necessary": _get(out, "cfg2", "roofline", "frac_necessary"),
+        "cfg5_frac_necessary": _get(out, "cfg5", "roofline", "frac_necessary"),
         "cfg5_value": _get(out, "cfg5", "value"), "cfg5_ms": _get(out, "cfg5", "ms_per_step"),
         "cfg5_frac": _get(out, "cfg5", "roofline", "frac"), "cfg5_frac_upper": _get(out, "cfg5", "roofline", "frac_upper"),
         "cfg5_masks_ms": _get(out, "cfg5", "masks_out", "ms_per_step"),
@@ -632,47 +636,52 @@ def main():
         ncand = sum(per_kind[k]["candidates"] for k in kinds_in)
         tests = ncand * S
         # the committed PMC passes were taken on the default workloads and batch split
-        pmc_ok = args.workload in ("cfg3", "cfg5") and n == n_default and world == 1 and forced_path in (None, 0)
+        pmc_ok = n == n_default and world == 1 and forced_path in (None, 0)
         pmc = pmc_replay(pmc_key, pmc_ok, "" if args.workload == "cfg3" else "_" + args.workload)
         sq = pmc["sq"]
-        # Issue model (tools/ubench/valu_rates.hip + count_seq.hip, this GPU, 8 waves per SIMD): SIMD cycles a wave64 instruction
-        # holds the vector issue port.  Classes with a counter of their own: binary64 add 4.2 / mul 4.3 / fma 4.75 / sqrt-rcp-rsq
-        # 16.2; binary32 fma 2.45, add / mul 2.3, sqrt-rcp-rsq 8.15; conversions 4.3.  The rest (integer, min / max, compares,
-        # selects, moves, lane operations) measures 2.3 (v_and, v_sub) .. 4.2 (v_min / v_max / v_cmp / v_cndmask / v_alignbit /
-        # v_min3): priced at 2.3 for `frac` -- a LOWER bound of the issue cycles -- and at 4.2 for `frac_upper`.  A scalar
-        # instruction: 4.2 (one scalar ALU per CU).  1024 SIMDs x 2.4 GHz cycles per second are there.
-        CYC = {"SQ_INSTS_VALU_ADD_F64": 4.2, "SQ_INSTS_VALU_MUL_F64": 4.3, "SQ_INSTS_VALU_FMA_F64": 4.75, "SQ_INSTS_VALU_TRANS_F64": 16.2}
-        CYC32 = {"SQ_INSTS_VALU_FMA_F32": 2.45, "SQ_INSTS_VALU_ADD_F32": 2.3, "SQ_INSTS_VALU_MUL_F32": 2.3, "SQ_INSTS_VALU_TRANS_F32": 8.15,
-                 "SQ_INSTS_VALU_CVT": 4.3}
+        # ---- work-based roofline (round 5).  The batched score is bound by vector-instruction ISSUE, not by HBM (every
+        # point is reused across the batch).  What a launch issues is ACCOUNTED, not assumed: tools/isa_account.py multiplies the
+        # static opcode histogram of every region of the kernel's gfx950 ISA with how often the region runs (the diag build's event
+        # counters of this very workload, tools/s4_stats.py), prices every opcode -- MI355X_MICROARCH.md's rates (frac_guide) and
+        # the rates measured on this GPU (frac; frac_upper - frac = the classes priced by analogy) -- and is held against the
+        # hardware's per-class instruction counters of the same launch (isa_account_<wl>.json: `validation`).  frac_necessary =
+        # the floor any kernel with this culling granularity has to issue (one box test per (candidate, group) + the classifier's
+        # own per-point mix over the 64 points of every pair whose group really holds a band point) over the same denominator.
+        # The priced cycles per launch are REPLAYED from the committed accounting of the newest round, the launch time is live.
         simd_cycles_per_s = 1024 * 2.4e9
-        insts = sq.get("SQ_INSTS_VALU")
-        arith = vcyc = vcyc_hi = rest = None
-        if insts is not None and all(k in sq for k in CYC):
-            arith = sum(sq[k] for k in CYC)
-            if all(k in sq for k in CYC32):
-                rest = insts - arith - sum(sq[k] for k in CYC32)
-                classed = sum(sq[k] * CYC[k] for k in CYC) + sum(sq[k] * CYC32[k] for k in CYC32)
-                vcyc, vcyc_hi = classed + rest * 2.3, classed + rest * 4.2
-            else:   # (passes without the binary32 class counters: everything 32-bit at 2.3)
-                vcyc = sum(sq[k] * CYC[k] for k in CYC) + (insts - arith) * 2.3
-        scyc = None if "SQ_INSTS_SALU" not in sq else sq["SQ_INSTS_SALU"] * 4.2
+        acc_file = _newest_profile("isa_account_%s.json" % args.workload) if pmc_ok else None
+        acc = json.load(open(acc_file)) if acc_file else None
+        acc_stale = None
+        if acc_file:
+            fm = os.path.join(os.path.dirname(acc_file), "pmc_meta.json")
+            try:
+                acc_stale = json.load(open(fm)).get("lib_source_hash") != _lib_hash()
+            except Exception:
+                acc_stale = True
         alg_bytes = tests * SCORE_BYTES_PER_TEST + ncand * (64 + 4)
         flops = sum(FLOPS_PER_TEST[k] * per_kind[k]["candidates"] * S for k in kinds_in)
-        out["roofline"] = {
-            "kernel": kname, "bound": "valu_issue",
-            "achieved": None if vcyc is None else vcyc / sec, "peak": simd_cycles_per_s, "unit": "SIMD vector-issue cycles/s",
-            "frac": None if vcyc is None else vcyc / sec / simd_cycles_per_s,
-            "frac_upper": None if vcyc_hi is None else vcyc_hi / sec / simd_cycles_per_s,
-            "valu_insts_unclassed_per_launch": rest,
-            "frac_scalar_issue": None if scyc is None else scyc / sec / simd_cycles_per_s,
-            "frac_fp64_arith": None if arith is None else sum(sq[k] * CYC[k] for k in CYC) / sec / simd_cycles_per_s,
-            "frac_unweighted_x4": None if insts is None else insts * 4 / sec / simd_cycles_per_s,
-            "sq_active_inst_valu": sq.get("SQ_ACTIVE_INST_VALU"), "sq_busy_cycles": sq.get("SQ_BUSY_CYCLES"), "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"),
+        rf = {"kernel": kname, "bound": "valu_issue", "achieved": None, "peak": simd_cycles_per_s, "unit": "SIMD vector-issue cycles/s",
+              "frac": None, "frac_upper": None, "frac_guide": None, "frac_necessary": None, "frac_necessary_guide": None}
+        if acc:
+            scl = acc.get("scale_to_hardware_valu", 1.0)
+            m = acc["model"]
+            den = sec * simd_cycles_per_s
+            rf.update({
+                "achieved": scl * m["valu_issue_cycles_measured_lower"] / sec,
+                "frac": scl * m["valu_issue_cycles_measured_lower"] / den, "frac_upper": scl * m["valu_issue_cycles_measured"] / den,
+                "frac_guide": scl * m["valu_issue_cycles_guide"] / den,
+                "frac_necessary": acc["necessary_cycles_measured"] / den, "frac_necessary_guide": acc["necessary_cycles_guide"] / den,
+                "frac_scalar_issue": m["salu_issue_cycles"] / den,
+                "priced_directly_share": m["priced_directly_share"], "model_vs_hardware_valu": 1.0 / scl,
+                "valu_insts_per_launch": scl * m["valu_instructions"], "salu_insts_per_launch": m["salu_instructions"],
+                "accounting": os.path.relpath(acc_file, ROOT), "accounting_is_stale": acc_stale})
+        src = acc_file or (os.path.join(ROOT, pmc["replayed_from"][0]) if pmc["replayed_from"] else None)
+        rf.update({
+            "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"), "sq_wait_any": sq.get("SQ_WAIT_ANY"),
             "traffic": pmc["traffic"],
-            "counters": None if not pmc["replayed_from"] else ("replayed:" + os.path.dirname(pmc["replayed_from"][0]) + (" (stale)" if pmc["stale"] else "")),
+            "counters": None if src is None else ("replayed:" + os.path.dirname(os.path.relpath(src, ROOT)) + (" (stale)" if (acc_stale if acc_file else pmc["stale"]) else "")),
             "traffic_frac_of_hbm_peak": None if pmc["traffic"] is None else pmc["traffic"] / sec / 1e9 / HBM_PEAK_GBS,
             "ms_per_launch": sec * 1e3, "ms_source": "HIP events on the library's stream, this run",
-            "valu_insts_per_launch": insts, "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"), "fp64_arith_insts_per_launch": arith,
             "replayed_from": pmc["replayed_from"], "replay_is_stale": pmc["stale"],
             "effective_algorithmic": {
                 "GBs": alg_bytes / sec / 1e9, "bytes_per_launch": alg_bytes, "tests_per_launch": tests,
@@ -680,18 +689,14 @@ def main():
                 "note": "NOT a roofline: 48.25 B (SURVEY.md 8d) x every (candidate, point) pair of the batch / time.  The "
                         "kernel never streams those bytes -- tiles are staged once and box tests on the k-d leaves reject "
                         "~90 % of the (candidate, group) pairs, bit-exactly -- so this exceeds the HBM peak by design"},
-            "note": "The batched score is bound by instruction issue, not by HBM (SURVEY.md 8d: every point is reused across the "
-                    "batch).  frac = the share of the chip's vector-issue cycles the launch fills, every instruction class "
-                    "weighted with its MEASURED issue cost (tools/ubench/valu_rates.hip, count_seq.hip: binary64 add 4.2 / mul 4.3 / "
-                    "fma 4.75 / transcendental 16.2 cycles; binary32 fma 2.45, add / mul 2.3, transcendental 8.15; conversions 4.3; "
-                    "the instructions without a class counter -- integer, min / max, compares, selects, moves: 2.3 .. 4.2 measured -- at "
-                    "2.3 for frac (a lower bound) and at 4.2 for frac_upper); frac_scalar_issue = the same for the scalar port (4.2 cycles each); "
-                    "frac_unweighted_x4 = round 2's figure (every vector instruction priced as binary64).  The v4 kernel computes "
-                    "in binary32 with a rigorous two-sided classifier and runs the reference's binary64 test only on pairs it cannot "
-                    "decide (frac_fp64_arith is that remainder).  The launch time is measured here; the counter values are REPLAYED "
-                    "from the committed rocprofv3 --pmc passes named in replayed_from (replay_is_stale = the library has changed "
-                    "since).  traffic = HBM bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE, same passes",
-        }
+            "note": "frac = priced vector-issue cycles of the launch / (time x 1024 SIMDs x 2.4 GHz), every opcode priced with the issue "
+                    "cost measured on this GPU (tools/ubench: binary32 fma 2.45, add / mul 2.3; min / max / compare / select / most integer "
+                    "4.2; transcendental 8.15; binary64 4.2-4.75 / 16.2), the few classes priced by analogy at 2.3 (frac) .. 4.2 "
+                    "(frac_upper); frac_guide = the same with MI355X_MICROARCH.md's rates (32-bit 2, binary64 4, transcendental 8 / 16); "
+                    "frac_necessary = the necessary-work floor (box test per (candidate, group) + the classifier over the pairs that "
+                    "hold a band point) over the same denominator.  Instruction counts: tools/isa_account.py (static ISA histogram x "
+                    "event counters, validated against the SQ_INSTS_* class counters: model_vs_hardware_valu); launch time: this run"})
+        out["roofline"] = rf
         # the host-buffer form of the same step (rh_score_batch: H2D of the shapes, D2H of the counts, one sync)
         hcounts = np.zeros(hi - lo, dtype=np.int32)
         harr = (L.Shape * (hi - lo)).from_buffer_copy(bytes(arr)[C.sizeof(L.Shape) * lo:C.sizeof(L.Shape) * hi])

@@ -125,7 +125,7 @@ int rh_cloud_create(const double *xyz_aos, const double *nrm_aos, int64_t n,
  * rh_select_enabled and the enabled-bit calls work and every per-point operation is a binary32 operation (the shapes'
  * fields are rounded to binary32 on entry; rh_shape_finalize_f32 prepares a Float32 shape: fields rounded, the cone's
  * cos / sin as binary32); eps and cos_alpha stay doubles and are compared after exact promotion, like Julia compares a
- * Float32 with a Float64.  rh_ransac runs on such a cloud without cones (rh_ransac_f32); rh_refit_lsq is Float64-only. */
+ * Float32 with a Float64.  rh_ransac runs on such a cloud too (rh_ransac_f32), all four kinds; rh_refit_lsq is Float64-only. */
 int rh_cloud_create_f32(const float *xyz_aos, const float *nrm_aos, int64_t n,
                         const int64_t *subset1_idx_1based, int64_t s, int device, rh_cloud **out);
 void rh_shape_finalize_f32(rh_shape *s);
@@ -187,8 +187,10 @@ int rh_fit(int kind, const double *p, const double *n, int32_t lp, const rh_para
 /* The same on the points of a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109: p[i], n[i] are
  * SVector{3,Float32}, so plane.jl:33-57 / sphere.jl:29-114 / cylinder.jl:34-168 run in Float32 and return Float32 shapes;
  * the parameters stay what the caller made them, utilities.jl:488-503).  p, n carry the Float32 values as doubles.
- * RH_CONE is refused: cone.jl:40-50 takes rank() and \ of Float32 matrices (LAPACK single precision), which nothing
- * here can be pinned on. */
+ * RH_CONE (round 5): cone.jl:39-61 + 87-128 in binary32 -- rank() and \ of a Matrix{Float32} (LAPACK's single-precision
+ * SVD and LU upstream) are a one-sided Jacobi SVD and an LU with partial pivoting in float here, acos / cos / sin the
+ * deterministic double kernels rounded once: like the Float64 cone fit a restatement the reference cannot pin (it holds no
+ * cone fixture); held bit for bit against the oracle's own binary32 twin. */
 int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm,
                rh_shape *out, int32_t *fitted);
 
@@ -208,6 +210,18 @@ typedef struct {
 void rh_rng_seed(rh_rng *r, uint64_t seed);
 /* rand(1:n) = 1 + floor(next * n / 2^64) */
 int64_t rh_rng_range(rh_rng *r, int64_t n);
+
+/* samplepointcloud4!(pc, ..) (src/fitting.jl:383-430) k times in a row, as ONE launch: what the reference's loop does once
+ * per minimal set (iterations.jl:80-99) -- first point by rejection on rand(1:n) (:388-395), the other drawN - 1 as the
+ * rand(1:count)-th enabled point of the root cell with one redraw when it repeats the first (:414-423), reject when two
+ * coincide (:425-428).  The draws are the caller's generator's (an injected stream first), consumed exactly as k sequential
+ * calls would consume them -- same number, same order -- so a loop that samples a whole iteration's sets through this call
+ * takes the same decisions as one that calls rh_rng_range / rh_select_enabled per point (the device evaluates the call
+ * for every start position of a window of draws, the host follows the chain).  idx_out: k x drawN points (1-based);
+ * ok_out[j]: the reference's first return value; level_out (optional): its second (1: every set comes from the root cell,
+ * SURVEY.md 0.5; 0 with ok = 0).  RH_E_INVALID without an enabled point (the reference would draw for ever). */
+int rh_sample_sets(rh_cloud *c, int32_t drawN, rh_rng *rng, int32_t k, int64_t *idx_out_1based, int32_t *ok_out,
+                   int32_t *level_out_or_null);
 
 typedef struct {
     rh_shape shape;
@@ -238,8 +252,8 @@ int rh_ransac(rh_cloud *c, const double *xyz_aos, const double *nrm_aos, const r
               rh_rng *rng, rh_result *out);
 /* ransac(pc, params) on a Float32 cloud (rh_cloud_create_f32; octree.jl:102-109): the minimal-set fits (plane.jl:33-57,
  * sphere.jl:29-114, cylinder.jl:34-168), scoring, candidate liveness and refit all run in binary32, the thresholds stay
- * what the caller made them (utilities.jl:488-503); extracted shapes hold binary32 numbers.  FittedCone in shape_types
- * is refused with RH_E_INVALID (its fit is not restated in binary32).  rh_ransac itself accepts such a cloud when handed
+ * what the caller made them (utilities.jl:488-503); extracted shapes hold binary32 numbers (cones included: rh_fit_f32).
+ * rh_ransac itself accepts such a cloud when handed
  * the Float32 values as doubles; this entry takes Julia's Vector{SVector{3,Float32}} memory as is. */
 int rh_ransac_f32(rh_cloud *c, const float *xyz_aos, const float *nrm_aos, const rh_params *p,
                   rh_rng *rng, rh_result *out);

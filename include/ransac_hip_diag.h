@@ -25,14 +25,22 @@ int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_pa
  * (candidate, 64-point group), 1 pairs the box test skips, 2 skipped pairs that hold an exact inlier (must be 0), 3 points,
  * 4 classified surely-in, 5 surely-out, 6 surely-in that the exact test rejects (must be 0), 7 surely-out that it accepts
  * (must be 0), 8 exact inliers, 9 candidates whose classifier takes the all-zero point (a disabled point as staged) for an
- * inlier (must be 0).  The soundness the bit-exact counts rest on, as a count (score4_device.h). */
-int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out /* [40] */);
+ * inlier (must be 0).  The soundness the bit-exact counts rest on, as a count (score4_device.h).  out[40 + k]: pairs whose
+ * group holds a BAND point (one whose distance half alone is not surely failed: no test on the group's position box can
+ * decide such a pair -- the floor of the necessary pair work, bench.py's frac_necessary); out[44 + k]: pairs with an exact inlier. */
+int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out /* [48] */);
 /* The device's octree sampler finds a point's cell and the r-th enabled point of a cell with a cell directory and
  * bracketed 8-ary searches (csrc/fit_shared.h: cell_bounds_code, lower_bound_in, select_in, select_in_many, select_bit)
  * where the host form uses plain binary searches.  Host-only self-check of those routines against the plain ones on a
  * synthetic Morton order of n points (duplicate codes, random enabled bits, every level): *mismatches = the number of
  * disagreements over `queries` random queries.  Needs no GPU. */
 int rh_dbg_oct_search_selftest(int64_t n, uint64_t seed, int64_t queries, int64_t *mismatches);
+
+/* Event counters of the culled score kernel's launches on cloud c (csrc/score4.hip, S4_STAT: chunk visits, box-tested
+ * candidates, surviving pairs, batches, pairs of the second pass, undecided points, ring drains, ... per kind; blocks and
+ * stagings): what tools/isa_account.py multiplies with the static instruction histogram of the kernel's regions.
+ * mode 1: switch on + zero, 0: read into out[128], 2: switch off. */
+int rh_dbg_s4_stats(rh_cloud *c, int mode, uint64_t *out /* [128] or NULL */);
 
 #ifdef __cplusplus
 }

@@ -180,7 +180,7 @@ end
 `ransac(pc, params)` (src/iterations.jl:35-162) with the three hot calls swapped; sampling, `fit`,
 `findhighestscore`, `prob`, `removeinvalidshapes!` are the reference's own functions.
 """
-function ransac(h::HIPCloud, params; reset_rand = false)
+function ransac(h::HIPCloud, params; reset_rand = false, batched_sampling = false, seed::Integer = 1234)
     pc = h.pc
     reset_rand && RANSAC.Random.seed!(1234)
     it = params.iteration
@@ -189,9 +189,21 @@ function ransac(h::HIPCloud, params; reset_rand = false)
     start_time = time_ns()
     candidates = FittedShape[]; scoredshapes = IterationCandidates(); extracted = ExtractedShape[]
     levels = Int[]; sd = Vector{Int}(undef, it.drawN); countcandidates = [0, 0, 0]
+    rng = RhRng((UInt64(0), UInt64(0), UInt64(0), UInt64(0)), C_NULL, 0, 0, 0)
+    batched_sampling && ccall((:rh_rng_seed, LIB), Cvoid, (Ref{RhRng}, UInt64), rng, UInt64(seed))
     for k in 1:it.itermax
         count(pc.isenabled) < it.τ && break
-        for i in 1:it.minsubsetN
+        if batched_sampling
+            # the iteration's minsubsetN calls of samplepointcloud4! as ONE launch (rh_sample_sets) on the library's generator:
+            # the same sets and the same number of draws as minsubsetN sequential calls, without a round trip per point
+            sets, ok, lev = sample_sets!(h, rng, it.drawN, it.minsubsetN)
+            for i in 1:it.minsubsetN
+                ok[i] != 0 || continue
+                sdi = view(sets, :, i)
+                forcefitshapes!(view(pc.vertices, sdi), view(pc.normals, sdi), params, candidates, levels, Int(lev[i]), pc)
+            end
+        end
+        for i in 1:(batched_sampling ? 0 : it.minsubsetN)
             res = samplepointcloud4!(sd, pc, params)
             res[1] || continue
             forcefitshapes!(view(pc.vertices, sd), view(pc.normals, sd), params, candidates, levels, res[2], pc)
@@ -217,6 +229,26 @@ function ransac(h::HIPCloud, params; reset_rand = false)
     end
     return extracted, trunc((time_ns() - start_time) / 1_000_000_000, digits = 2)
 end
+
+"""
+`samplepointcloud4!` (src/fitting.jl:383-430) for the `k` minimal sets of an iteration as ONE launch: `rh_sample_sets`.
+Returns (`drawN x k` point indices, accept flags, octree levels); `rng` (an `RhRng`, `rh_rng_seed`) is advanced exactly as
+`k` sequential calls would advance it.
+"""
+function sample_sets!(h::HIPCloud, rng, drawN::Integer, k::Integer)
+    idx = Matrix{Int64}(undef, drawN, k); ok = Vector{Int32}(undef, k); lev = Vector{Int32}(undef, k)
+    check(ccall((:rh_sample_sets, LIB), Cint, (Ptr{Cvoid}, Int32, Ref{RhRng}, Int32, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}),
+                h.handle, drawN, rng, k, idx, ok, lev))
+    return idx, ok, lev
+end
+
+"""
+`rh_set_option`: a tuning option for one cloud (or process-wide with `h = nothing`); the library reads no environment
+variable.  Keys: "score_path" (0 auto / 1 brute / 2 groups; process-wide, before the cloud is created), "refit_path"
+(0 auto / 1 scan / 2 culled), "s4_rows", "unp_words"; `typemin(Int64)` clears a setting.
+"""
+set_option(h::Union{HIPCloud,Nothing}, key::AbstractString, value::Integer) =
+    check(ccall((:rh_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), h === nothing ? C_NULL : h.handle, key, value))
 
 # ---- the whole loop on the device: rh_ransac (driver.hip) -------------------------------------
 # Mirrors of rh_rng / rh_extracted / rh_result (include/ransac_hip.h).  The index lists live in one
@@ -276,7 +308,7 @@ function ransac_device(h::HIPCloud, params; seed::Integer = 1234, sampling_strea
     res = Ref(RhResult(C_NULL, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, C_NULL))
     if eltype(eltype(pc.vertices)) === Float32
         # a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): fits, scoring, liveness and refit in
-        # binary32, shapes come back holding Float32 values; FittedCone in shape_types is refused (RH_E_INVALID)
+        # binary32, shapes come back holding Float32 values (all four kinds)
         mp == C_NULL || error("ransac_device: mp is not available on a Float32 cloud")
         GC.@preserve pc check(ccall((:rh_ransac_f32, LIB), Cint,
             (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{RhParams}, Ptr{RhRng}, Ptr{RhResult}),

@@ -260,8 +260,10 @@ void orc32_invalidate(orc_cloud32 *c, const int64_t *idx, int64_t n)
  * source ((v[1]+v[2])/2, -1*crossv) take the vectors' type, and the Float64 parameters only ever appear on one side of
  * a comparison (collin_threshold, cosd(parallelthrdeg), sphere_par, cos(alpha), eps: the Float32 side is promoted
  * exactly).  The statements follow ransac_oracle.c's binary64 fits one for one; p / n arrive as doubles holding the
- * Float32 values.  The cone's fit is NOT restated: cone.jl:40-50 calls rank() and \ on Float32 matrices (LAPACK's
- * single-precision SVD and LU), which no fixture of the reference pins.
+ * Float32 values.  The cone's fit (round 5): cone.jl:39-61 + 87-128 in binary32 -- rank() and \ of a Matrix{Float32} are
+ * LAPACK's single-precision SVD and LU upstream, restated here as a one-sided Jacobi SVD and an LU with partial pivoting
+ * in float, acos as the oracle's double kernel rounded once (Julia's Float32 acos is accurate to < 1 ulp, not always
+ * correctly rounded): UNPINNED beyond the restatement, like the Float64 cone fit -- the reference holds no cone fixture.
  */
 static inline f3 fadd(f3 a, f3 b) { f3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return r; }
 static inline f3 fdivs(f3 a, float s) { f3 r = { a.x / s, a.y / s, a.z / s }; return r; }
@@ -406,13 +408,154 @@ static int fit_cylinder32(const double *p, const double *n, int lp, const orc_pa
     return 0;
 }
 
-/* fit(T, p, n, pc, params) on Float32 points; kind ORC_CONE: never fits (see above; orc_ransac refuses it beforehand) */
+/* ---- cone.jl:39-61 in binary32 ---- */
+static void svdvals_cols32(float *M, int r, int c, float *sv)   /* one-sided Jacobi on the columns, r >= c */
+{
+    for (int sweep = 0; sweep < 60; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < c - 1; p++)
+            for (int q = p + 1; q < c; q++) {
+                float a = 0, b = 0, g = 0;
+                for (int i = 0; i < r; i++) {
+                    a += M[i * c + p] * M[i * c + p];
+                    b += M[i * c + q] * M[i * c + q];
+                    g += M[i * c + p] * M[i * c + q];
+                }
+                if (g == 0.0f || fabsf(g) <= 1e-37f + 1.2e-7f * sqrtf(a * b)) continue;
+                rotated = 1;
+                float zeta = (b - a) / (2 * g);
+                float t = (zeta >= 0 ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1 + zeta * zeta));
+                float cs = 1 / sqrtf(1 + t * t), sn = cs * t;
+                for (int i = 0; i < r; i++) {
+                    float mp = M[i * c + p], mq = M[i * c + q];
+                    M[i * c + p] = cs * mp - sn * mq;
+                    M[i * c + q] = sn * mp + cs * mq;
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < c; j++) {
+        float a = 0;
+        for (int i = 0; i < r; i++) a += M[i * c + j] * M[i * c + j];
+        sv[j] = sqrtf(a);
+    }
+}
+
+static int rank32(const float *A, int m, int n)   /* count(svdvals .> min(m,n) * eps(Float32) * maximum(svdvals)) */
+{
+    float M[16], sv[4];
+    int r, c;
+    if (m >= n) { r = m; c = n; for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[i * c + j] = A[i * n + j]; }
+    else { r = n; c = m; for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[j * c + i] = A[i * n + j]; }
+    svdvals_cols32(M, r, c, sv);
+    float smax = 0;
+    for (int j = 0; j < c; j++) if (sv[j] > smax) smax = sv[j];
+    float tol = (float)(m < n ? m : n) * 1.1920928955078125e-07f * smax;
+    int cnt = 0;
+    for (int j = 0; j < c; j++) if (sv[j] > tol) cnt++;
+    return cnt;
+}
+
+static int solve3_32(const float A_in[9], const float b_in[3], float x[3])   /* r \ ds: LU with partial pivoting */
+{
+    float A[9], b[3];
+    memcpy(A, A_in, sizeof A);
+    memcpy(b, b_in, sizeof b);
+    for (int k = 0; k < 3; k++) {
+        int piv = k;
+        float amax = fabsf(A[k * 3 + k]);
+        for (int i = k + 1; i < 3; i++)
+            if (fabsf(A[i * 3 + k]) > amax) { amax = fabsf(A[i * 3 + k]); piv = i; }
+        if (amax == 0.0f) return -1;
+        if (piv != k) {
+            for (int j = 0; j < 3; j++) { float t = A[k * 3 + j]; A[k * 3 + j] = A[piv * 3 + j]; A[piv * 3 + j] = t; }
+            float t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < 3; i++) {
+            float l = A[i * 3 + k] / A[k * 3 + k];
+            A[i * 3 + k] = l;
+            for (int j = k + 1; j < 3; j++) A[i * 3 + j] -= l * A[k * 3 + j];
+            b[i] -= l * b[k];
+        }
+    }
+    for (int i = 2; i >= 0; i--) {
+        float sacc = b[i];
+        for (int j = i + 1; j < 3; j++) sacc -= A[i * 3 + j] * x[j];
+        x[i] = sacc / A[i * 3 + i];
+    }
+    return 0;
+}
+
+static float clamp1f(float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); }
+
+static int fit3pointcone32(const double *p, const double *n, orc_shape *out)
+{
+    float r[9], rv[12], ds[3], apx[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = (float)n[3 * i + j];
+    if (rank32(r, 3, 3) != 3) return 0;
+    for (int i = 0; i < 3; i++) ds[i] = fdot(Fd(p + 3 * i), Fd(n + 3 * i));
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) rv[i * 4 + j] = r[i * 3 + j];
+        rv[i * 4 + 3] = -1 * ds[i];
+    }
+    if (rank32(rv, 3, 4) != 3) return 0;
+    if (solve3_32(r, ds, apx)) return 0;
+    f3 ap = { apx[0], apx[1], apx[2] };
+    f3 a3p[3];
+    for (int i = 0; i < 3; i++) {
+        f3 d = fsub(Fd(p + 3 * i), ap);
+        a3p[i] = fadd(ap, fdivs(d, fnorm(d)));
+    }
+    f3 ax = fnormalize(fcross(fsub(a3p[1], a3p[0]), fsub(a3p[2], a3p[0])));
+    f3 midp = fdivs(fadd(fadd(a3p[0], a3p[1]), a3p[2]), 3.0f);
+    f3 dirv = fnormalize(fsub(midp, ap));
+    if (fdot(ax, dirv) < 0) ax = fscale(ax, -1.0f);
+    float angles[3];
+    for (int i = 0; i < 3; i++) angles[i] = (float)orc_acos((double)clamp1f(fdot(fnormalize(fsub(Fd(p + 3 * i), ap)), ax)));
+    float opangle = 2 * ((angles[0] + angles[1]) + angles[2]) / 3;
+    memset(out, 0, sizeof *out);
+    out->kind = ORC_CONE;
+    out->outwards = 1;
+    set_f(&out->v[0], ap);
+    set_f(&out->v[3], ax);
+    out->v[6] = (double)opangle;
+    orc32_shape_finalize(out);
+    return 1;
+}
+
+/* validatecone: cone.jl:87-115; fit(::Type{FittedCone}): cone.jl:123-128 */
+static int fit_cone32(const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
+{
+    if (lp < 3 || lp > 16) return 0;
+    orc_shape cone;
+    if (!fit3pointcone32(p, n, &cone)) return 0;
+    float dist[16];
+    f3 cn[16];
+    for (int i = 0; i < lp; i++) project2cone32(&cone, Fd(p + 3 * i), &dist[i], &cn[i]);
+    for (int i = 0; i < lp; i++)
+        if ((double)dist[i] > prm->eps[ORC_CONE]) return 0; /* no abs: Q11, cone.jl:93 */
+    if (cone.v[6] < prm->minconeopang) return 0;
+    double thr = prm->cos_alpha[ORC_CONE];
+    int ok = 1, inv = 1;
+    for (int i = 0; i < lp; i++) {
+        double dotp = (double)fdot(cn[i], Fd(n + 3 * i));
+        if (!(dotp > thr)) ok = 0;
+        if (!(dotp < -thr)) inv = 0;
+    }
+    *out = cone;
+    if (ok) { out->outwards = 1; return 1; }
+    if (inv) { out->outwards = 0; return 1; }
+    return 0;
+}
+
+/* fit(T, p, n, pc, params) on Float32 points */
 int orc32_fit(int kind, const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out)
 {
     switch (kind) {
     case ORC_PLANE: return fit_plane32(p, n, lp, prm, out);
     case ORC_SPHERE: return fit_sphere32(p, n, lp, prm, out);
     case ORC_CYLINDER: return fit_cylinder32(p, n, lp, prm, out);
+    case ORC_CONE: return fit_cone32(p, n, lp, prm, out);
     default: return 0;
     }
 }

@@ -1544,9 +1544,6 @@ int orc_ransac(orc_cloud *c, const double *xyz, const double *nrm, const orc_par
     memset(out, 0, sizeof *out);
     if (octree_depth < 1) octree_depth = 1;
     if (p->drawN < 2 || p->drawN > 16) return -1;
-    if (c->f32)
-        for (int t = 0; t < p->n_shape_types; t++)
-            if (p->shape_types[t] == ORC_CONE) return -3; /* the cone's fit is not restated in binary32 (orc_f32.c) */
     /* nomodRANSACCloud passes (levelscore, levelweight) into (levelweight, levelscore): octree.jl:82-84 */
     double *levelweight = (double *)calloc((size_t)octree_depth, 8);
     double *levelscore = (double *)malloc(8 * (size_t)octree_depth);

@@ -163,7 +163,7 @@ int64_t orc32_refit(const orc_cloud32 *c, const orc_shape *s, const orc_params *
 int orc32_fit(int kind, const double *p, const double *n, int lp, const orc_params *prm, orc_shape *out);
 /* A cloud of Float32 values (given as doubles) whose per-point tests and fits run in binary32: orc_scorecandidate,
  * orc_refit and orc_ransac then take the orc32 paths -- the whole loop on a Float32 cloud (RANSACCloud(...;
- * force_eltype = Float32), octree.jl:102-109).  orc_ransac returns -3 when shape_types holds ORC_CONE on such a cloud. */
+ * force_eltype = Float32), octree.jl:102-109).  All four kinds are fitted (the cone: orc_f32.c, round 5). */
 void orc_cloud_set_f32(orc_cloud *c, int f32);
 void orc32_invalidate(orc_cloud32 *c, const int64_t *idx_1based, int64_t n);
 

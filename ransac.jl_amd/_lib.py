@@ -90,6 +90,7 @@ SIGNATURES = {
     "rh_refit_lsq": (C.c_int, [_vp, _sp, _pp, C.c_int32, _sp, _i64p, _dp, _i32p]),
     "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
     "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),
+    "rh_sample_sets": (C.c_int, [_vp, C.c_int32, C.POINTER(Rng), C.c_int32, _i64p, _i32p, _i32p]),
     "rh_fit": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
     "rh_fit_f32": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
     "rh_estimatescore": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp, _dp, _dp]),
@@ -140,6 +141,7 @@ DIAG_SIGNATURES = {
     "rh_dbg_cls_audit": (C.c_int, [_vp, _sp, C.c_int32, _pp, _dp]),
     "rh_dbg_cls_soundness": (C.c_int, [_vp, _sp, C.c_int32, _pp, C.POINTER(C.c_uint64)]),
     "rh_dbg_oct_search_selftest": (C.c_int, [C.c_int64, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
+    "rh_dbg_s4_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64)]),
 }
 
 _libs = {}
@@ -181,6 +183,8 @@ def lib(which=None):
     L = _libs.get(which)
     if L is None:
         path = SO_PATH if which == "product" else SO_PATH_DIAG
+        if which == "product" and os.environ.get("RH_LIB_PATH"):   # kernel A/B runs (tools/): another build of the product library
+            path = os.environ["RH_LIB_PATH"]
         if not os.path.exists(path):
             raise RuntimeError(
                 "%s is missing: the HIP extension has not been built and this package has no CPU "

@@ -435,7 +435,7 @@ class RANSACCloud:
 
     def __init__(self, vertices, normals, subsets, device=0, seed=None, force_eltype=None):
         """force_eltype = numpy.float32: a Float32 cloud (octree.jl:102-109) -- scoring and refit then compute in
-        binary32 like the reference does on such a cloud, and so does ransac() (fits included; no cones); refit_lsq stays Float64-only."""
+        binary32 like the reference does on such a cloud, and so does ransac() (fits included, all four kinds); refit_lsq stays Float64-only."""
         self.is_f32 = force_eltype is not None and np.dtype(force_eltype) == np.float32
         if force_eltype is not None and not self.is_f32 and np.dtype(force_eltype) != np.float64:
             raise ValueError("force_eltype must be float32 or float64")
@@ -536,7 +536,7 @@ class RANSACCloud:
 # ---------------------------------------------------------------- hot path ----
 def fit(T, p, n, pc, params):
     """fit(::Type{T}, p, n, pc, params) -> T or None (shapes/*.jl `fit`).  Float32 points (a Float32 cloud's, or numpy
-    float32 arrays) are fitted in Float32 like Julia fits SVector{3,Float32}s (rh_fit_f32; no cones)."""
+    float32 arrays) are fitted in Float32 like Julia fits SVector{3,Float32}s (rh_fit_f32)."""
     f32 = bool(getattr(pc, "is_f32", False)) or (getattr(p, "dtype", None) == np.float32 and getattr(n, "dtype", None) == np.float32)
     if f32:
         p, n = np.asarray(p, dtype=np.float32), np.asarray(n, dtype=np.float32)
@@ -742,6 +742,18 @@ def select_enabled(pc, ranks):
     return out[: r.size]
 
 
+def sample_sets(pc, drawN, rng, k):
+    """samplepointcloud4!(pc, ...) (fitting.jl:383-430) k times in a row on `rng` (an _lib.Rng: rh_rng_seed / an injected
+    stream) -- one launch for the k minimal sets of an iteration, the generator advanced exactly as k sequential calls would
+    advance it.  Returns (idx, ok, level): k x drawN point indices (1-based), the reference's two return values per set."""
+    k = int(k)
+    idx = np.zeros((max(1, k), int(drawN)), dtype=np.int64)
+    ok = np.zeros(max(1, k), dtype=np.int32)
+    lev = np.zeros(max(1, k), dtype=np.int32)
+    check(lib().rh_sample_sets(pc._h, int(drawN), C.byref(rng), k, _p(idx, C.c_int64), _p(ok, C.c_int32), _p(lev, C.c_int32)))
+    return idx[:k], ok[:k].astype(bool), lev[:k]
+
+
 class _ResultOwner:
     """Keeps an rh_result (and with it the pinned block of index lists) alive; frees it on collection."""
 
@@ -806,7 +818,7 @@ def ransac(pc, params, setenabled=False, reset_rand=False, seed=1234, stream=Non
     if mp is not None:
         check(lib().rh_ransac_mp(pc._h, _p(pc.vertices, C.c_double), _p(pc.normals, C.c_double), C.byref(cp),
                                  C.byref(rng), mp._h, C.byref(res)))
-    elif getattr(pc, "is_f32", False):   # a Float32 cloud: the loop in binary32 (no cones), from the Float32 arrays as they are
+    elif getattr(pc, "is_f32", False):   # a Float32 cloud: the loop in binary32, from the Float32 arrays as they are
         check(lib().rh_ransac_f32(pc._h, _p(pc.vertices32, C.c_float), _p(pc.normals32, C.c_float), C.byref(cp),
                                   C.byref(rng), C.byref(res)))
     else:

@@ -182,7 +182,7 @@ static void cloud_free(rh_cloud *c)
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre); (void)hipFree(c->d_zero);
-    (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
+    (void)hipFree(c->s4_stats); (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab); (void)hipFree(c->oct_code_o);
     (void)hipFree(c->oct_state); (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);
@@ -1063,6 +1063,71 @@ extern "C" int rh_select_enabled(rh_cloud *c, const int64_t *ranks, int32_t k, i
     RH_TRY(rhk_select(c, c->d_ranks, k, c->d_ranks + c->ranks_cap));
     RH_HIP(hipMemcpyAsync(idx_out, c->d_ranks + c->ranks_cap, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
+    return RH_OK;
+}
+
+// samplepointcloud4! (fitting.jl:383-430) k times in a row on the caller's random stream: see sample_sets_seq_kernel.
+extern "C" int rh_sample_sets(rh_cloud *c, int32_t drawN, rh_rng *rng, int32_t k, int64_t *idx_out, int32_t *ok_out, int32_t *level_out)
+{
+    RH_TRY(enter(c));
+    if (!rng || k < 0 || drawN < 2 || drawN > 16 || (k > 0 && (!idx_out || !ok_out))) { rh_set_error("rh_sample_sets: bad arguments (drawN 2..16)"); return RH_E_INVALID; }
+    if (k == 0) return RH_OK;
+    if (c->n == 0) { rh_set_error("rh_sample_sets: the cloud is empty"); return RH_E_INVALID; }
+    if (!c->select_valid) RH_TRY(rhk_build_select(c));
+    int32_t count = 0;
+    RH_HIP(hipMemcpyAsync(&count, c->d_total, sizeof count, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    if (count <= 0) { rh_set_error("rh_sample_sets: no enabled point (the reference would draw for ever, fitting.jl:393)"); return RH_E_INVALID; }
+    const int W = drawN + 2;
+    constexpr int64_t L_MAX = 1 << 20;
+    // draws a call takes: 1 / (enabled share) for the first point + drawN - 1 (+ the rare redraw)
+    const double per_call = (double)c->n / (double)count + (double)drawN;
+    double grow = 1.5;
+    int32_t done = 0;
+    while (done < k) {
+        int64_t L64 = (int64_t)(grow * per_call * (k - done)) + 8 * drawN + 64;
+        if (L64 > L_MAX) L64 = L_MAX;
+        const int32_t L = (int32_t)L64;
+        // the draws of a COPY of the generator (an injected stream first, like rh_rng_range); the caller's own generator is
+        // then advanced by exactly what the calls that completed consumed
+        rh_rng tmp = *rng;
+        const size_t bytes_raw = sizeof(uint64_t) * (size_t)L, bytes_rec = sizeof(int64_t) * (size_t)L * (size_t)W;
+        RH_TRY(rh_ensure_pin(c, (int64_t)(bytes_raw + bytes_rec)));
+        uint64_t *h_raw = (uint64_t *)c->h_pin;
+        int64_t *h_rec = (int64_t *)(h_raw + L);
+        for (int32_t i = 0; i < L; i++) h_raw[i] = rh_rng_next_raw(&tmp);
+        const int64_t need = (int64_t)L * (1 + W);
+        if (need > 2 * c->ranks_cap) {   // (d_ranks holds 2 x ranks_cap words)
+            RH_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_ranks);
+            c->d_ranks = nullptr;
+            c->ranks_cap = 0;
+            RH_TRY(dev_alloc(&c->d_ranks, 2 * ((need + 1) / 2)));
+            c->ranks_cap = (need + 1) / 2;
+        }
+        uint64_t *d_raw = (uint64_t *)c->d_ranks;
+        int64_t *d_rec = c->d_ranks + L;
+        RH_HIP(hipMemcpyAsync(d_raw, h_raw, bytes_raw, hipMemcpyHostToDevice, c->stream));
+        RH_TRY(rhk_sample_sets_seq(c, d_raw, L, drawN, d_rec));
+        RH_HIP(hipMemcpyAsync(h_rec, d_rec, bytes_rec, hipMemcpyDeviceToHost, c->stream));
+        RH_HIP(hipStreamSynchronize(c->stream));
+        int64_t p = 0;
+        const int32_t done_before = done;
+        while (done < k && p < L) {
+            const int64_t *r = h_rec + p * W;
+            if (r[drawN] <= 0) break;   // the draws ran out inside this call: it is played again from here in the next round
+            for (int q = 0; q < drawN; q++) idx_out[(int64_t)done * drawN + q] = r[q];
+            ok_out[done] = (int32_t)r[drawN + 1];
+            if (level_out) level_out[done] = r[drawN + 1] ? 1 : 0;   // argmax(levelweight[1:depth]) = 1 always: SURVEY.md 0.5
+            p += r[drawN];
+            done++;
+        }
+        for (int64_t i = 0; i < p; i++) (void)rh_rng_next_raw(rng);
+        if (done == done_before) {   // not one call finished inside the window: a longer one, or give up
+            if (L64 >= L_MAX) { rh_set_error("rh_sample_sets: a call did not finish within %d draws (%d of %lld points enabled)", L, count, (long long)c->n); return RH_E_INTERNAL; }
+            grow *= 4.0;
+        }
+    }
     return RH_OK;
 }
 

@@ -407,15 +407,6 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
     if (!c || !p || !rng || !out) { rh_set_error("rh_ransac: NULL argument"); return RH_E_INVALID; }
     memset(out, 0, sizeof *out);
     RH_TRY(rh_validate_params(p));
-    if (c->f32) {
-        // Float32 cloud: fits, scoring, liveness and refit in binary32.  Its cone fit would need rank() and \ of Float32
-        // matrices the way LAPACK's single precision does them (cone.jl:40-50): no fixture exists to pin a restatement on
-        for (int t = 0; t < p->n_shape_types && t < 8; t++)
-            if (p->shape_types[t] == RH_CONE) {
-                rh_set_error("rh_ransac: FittedCone is not available in shape_types on a Float32 cloud (its fit is not restated in binary32)");
-                return RH_E_INVALID;
-            }
-    }
     if (c->n > 0 && (!xyz || !nrm) && (!xyz32 || !nrm32)) { rh_set_error("rh_ransac: xyz/nrm are NULL"); return RH_E_INVALID; }
     if (c->f32 && mp != nullptr) {   // (the ranks' exchange has only ever been held against the single-GPU run on Float64 clouds)
         rh_set_error("rh_ransac_mp is not available on a Float32 cloud");

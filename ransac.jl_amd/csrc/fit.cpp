@@ -92,7 +92,6 @@ extern "C" int rh_fit(int kind, const double *p, const double *n, int32_t lp, co
 
 // fit on a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): p / n hold the Float32 values (as
 // doubles, exactly); the fit runs in binary32 (fit_shared.h) and its shape holds binary32 numbers.  Cones: not available
-// (cone.jl:40-50 takes rank() and \ of Float32 matrices -- LAPACK's single-precision SVD / LU, no fixture to restate them on)
 extern "C" int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm, rh_shape *out,
                           int32_t *fitted)
 {
@@ -105,7 +104,7 @@ extern "C" int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp
     case RH_PLANE: ok = fit_plane32(p, n, lp, *prm, &s); break;
     case RH_SPHERE: ok = fit_sphere32(p, n, lp, *prm, &s); break;
     case RH_CYLINDER: ok = fit_cylinder32(p, n, lp, *prm, &s); break;
-    case RH_CONE: rh_set_error("rh_fit_f32: the cone fit is not available for Float32 clouds"); return RH_E_INVALID;
+    case RH_CONE: ok = fit_cone32(p, n, lp, *prm, &s); break;
     default: rh_set_error("rh_fit_f32: unknown kind %d", kind); return RH_E_INVALID;
     }
     *fitted = ok ? 1 : 0;
@@ -167,6 +166,8 @@ static uint64_t rng_next(rh_rng *r)
     s[3] = rotl64(s[3], 45);
     return result;
 }
+
+uint64_t rh_rng_next_raw(rh_rng *r) { return rng_next(r); }   // rh_sample_sets (cloud.hip): the raw draws rh_rng_range scales
 
 extern "C" int64_t rh_rng_range(rh_rng *r, int64_t n)
 {

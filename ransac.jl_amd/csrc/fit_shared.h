@@ -244,28 +244,46 @@ RH_HD void cone_finalize(rh_shape *s)
     s->v[7] = rh_cos(th);
     s->v[8] = rh_sin(th);
 }
+// ... of a Float32 cone (opang a binary32 number): Float32 cos / sin of the Float32 angle.  Julia's Float32 kernels evaluate a
+// double-precision polynomial of the widened argument and round once (base/special/trig.jl, after msun's k_cosf.c / k_sinf.c);
+// here: the deterministic double kernels on the widened angle, rounded once -- the same bits but for the one-in-2^29 double
+// rounding case
+RH_HD void cone_finalize32(rh_shape *s)
+{
+    const float th = -(float)s->v[6] / 2.0f;
+    s->v[7] = (double)(float)rh_cos((double)th);
+    s->v[8] = (double)(float)rh_sin((double)th);
+}
+RH_HD double rh_acos_t(double x) { return rh_acos(x); }
+RH_HD float rh_acos_t(float x) { return (float)rh_acos((double)x); }   // (rounded once from the deterministic double kernel)
+template <typename T> struct FitEps;
+template <> struct FitEps<double> { static RH_HD double eps() { return 2.220446049250313e-16; } static RH_HD double tiny() { return 1e-300; } static RH_HD double jac() { return 2.2e-16; } };
+template <> struct FitEps<float> { static RH_HD float eps() { return 1.1920928955078125e-07f; } static RH_HD float tiny() { return 1e-37f; } static RH_HD float jac() { return 1.2e-7f; } };
 
-// ---- LinearAlgebra stand-ins for cone.jl:44,48,50 ----
+// ---- LinearAlgebra stand-ins for cone.jl:44,48,50 (T = the cloud's element type: rank() and \ of a Matrix{Float32} on a
+// Float32 cloud -- LAPACK's single-precision SVD and LU upstream; like the Float64 instantiation a restatement that nothing
+// of the reference can pin beyond its accept / reject fixtures) ----
 // singular values via one-sided Jacobi on the columns (rows x cols, rows >= cols)
-RH_HD void jacobi_svals(double *M, int rows, int cols, double *sv)
+template <typename T>
+RH_HD void jacobi_svals(T *M, int rows, int cols, T *sv)
 {
     for (int sweep = 0; sweep < 60; sweep++) {
         bool rotated = false;
         for (int p = 0; p + 1 < cols; p++)
             for (int q = p + 1; q < cols; q++) {
-                double a = 0, b = 0, g = 0;
+                T a = 0, b = 0, g = 0;
                 for (int i = 0; i < rows; i++) {
                     a += M[i * cols + p] * M[i * cols + p];
                     b += M[i * cols + q] * M[i * cols + q];
                     g += M[i * cols + p] * M[i * cols + q];
                 }
-                if (g == 0.0 || fabs(g) <= 1e-300 + 2.2e-16 * sqrt(a * b)) continue;
+                if (g == T(0) || rh_fabs_t(g) <= FitEps<T>::tiny() + FitEps<T>::jac() * rh_sqrt_t(a * b)) continue;
                 rotated = true;
-                const double zeta = (b - a) / (2 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                const double cs = 1 / sqrt(1 + t * t), sn = cs * t;
+                const T zeta = (b - a) / (2 * g);
+                const T t = (zeta >= 0 ? T(1) : T(-1)) / (rh_fabs_t(zeta) + rh_sqrt_t(1 + zeta * zeta));
+                const T cs = 1 / rh_sqrt_t(1 + t * t), sn = cs * t;
                 for (int i = 0; i < rows; i++) {
-                    const double mp = M[i * cols + p], mq = M[i * cols + q];
+                    const T mp = M[i * cols + p], mq = M[i * cols + q];
                     M[i * cols + p] = cs * mp - sn * mq;
                     M[i * cols + q] = sn * mp + cs * mq;
                 }
@@ -273,15 +291,16 @@ RH_HD void jacobi_svals(double *M, int rows, int cols, double *sv)
         if (!rotated) break;
     }
     for (int j = 0; j < cols; j++) {
-        double a = 0;
+        T a = 0;
         for (int i = 0; i < rows; i++) a += M[i * cols + j] * M[i * cols + j];
-        sv[j] = sqrt(a);
+        sv[j] = rh_sqrt_t(a);
     }
 }
 
-RH_HD int matrix_rank(const double *A, int m, int n)   // rank(A): count(svdvals .> min(m,n)*eps*max)
+template <typename T>
+RH_HD int matrix_rank(const T *A, int m, int n)   // rank(A): count(svdvals .> min(m,n)*eps*max)
 {
-    double M[16], sv[4];
+    T M[16], sv[4];
     int rows, cols;
     if (m >= n) {
         rows = m; cols = n;
@@ -290,39 +309,40 @@ RH_HD int matrix_rank(const double *A, int m, int n)   // rank(A): count(svdvals
         rows = n; cols = m;
         for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) M[j * cols + i] = A[i * n + j];
     }
-    jacobi_svals(M, rows, cols, sv);
-    double smax = 0;
+    jacobi_svals<T>(M, rows, cols, sv);
+    T smax = 0;
     for (int j = 0; j < cols; j++) smax = sv[j] > smax ? sv[j] : smax;
-    const double tol = (double)(m < n ? m : n) * 2.220446049250313e-16 * smax;
+    const T tol = (T)(m < n ? m : n) * FitEps<T>::eps() * smax;
     int r = 0;
     for (int j = 0; j < cols; j++) r += sv[j] > tol;
     return r;
 }
 
-RH_HD bool lu_solve3(const double A0[9], const double b0[3], double x[3])   // A \ b, partial pivoting
+template <typename T>
+RH_HD bool lu_solve3(const T A0[9], const T b0[3], T x[3])   // A \ b, partial pivoting
 {
-    double A[9], b[3];
+    T A[9], b[3];
     for (int i = 0; i < 9; i++) A[i] = A0[i];
     for (int i = 0; i < 3; i++) b[i] = b0[i];
     for (int k = 0; k < 3; k++) {
         int piv = k;
-        double best = fabs(A[k * 3 + k]);
+        T best = rh_fabs_t(A[k * 3 + k]);
         for (int i = k + 1; i < 3; i++)
-            if (fabs(A[i * 3 + k]) > best) { best = fabs(A[i * 3 + k]); piv = i; }
-        if (best == 0.0) return false;
+            if (rh_fabs_t(A[i * 3 + k]) > best) { best = rh_fabs_t(A[i * 3 + k]); piv = i; }
+        if (best == T(0)) return false;
         if (piv != k) {
-            for (int j = 0; j < 3; j++) { const double t = A[k * 3 + j]; A[k * 3 + j] = A[piv * 3 + j]; A[piv * 3 + j] = t; }
-            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
+            for (int j = 0; j < 3; j++) { const T t = A[k * 3 + j]; A[k * 3 + j] = A[piv * 3 + j]; A[piv * 3 + j] = t; }
+            const T t = b[k]; b[k] = b[piv]; b[piv] = t;
         }
         for (int i = k + 1; i < 3; i++) {
-            const double l = A[i * 3 + k] / A[k * 3 + k];
+            const T l = A[i * 3 + k] / A[k * 3 + k];
             A[i * 3 + k] = l;
             for (int j = k + 1; j < 3; j++) A[i * 3 + j] -= l * A[k * 3 + j];
             b[i] -= l * b[k];
         }
     }
     for (int i = 2; i >= 0; i--) {
-        double acc = b[i];
+        T acc = b[i];
         for (int j = i + 1; j < 3; j++) acc -= A[i * 3 + j] * x[j];
         x[i] = acc / A[i * 3 + i];
     }
@@ -330,85 +350,91 @@ RH_HD bool lu_solve3(const double A0[9], const double b0[3], double x[3])   // A
 }
 
 // ---- cone.jl:68-85 (host twin of the device test, used by validatecone) ----
-RH_HD void project2cone(const rh_shape &cone, const Vec &p, double *dist, Vec *cn)
+template <typename T>
+RH_HD void project2cone(const rh_shape &cone, const VecT<T> &p, T *dist, VecT<T> *cn)
 {
-    const Vec apex(cone.v), axis(cone.v + 3);
-    const Vec to_point = apex - p;
-    const Vec to_pointn = normalize(to_point);
-    const Vec rot_ax = normalize(cross(axis, to_pointn));
-    const Vec comp_n = normalize(cross(axis, rot_ax));
-    const Vec v = normalize(rot_ax);   // rodriguesrad re-normalizes (utilities.jl:62)
-    const double c = cone.v[7], s = cone.v[8];
-    const double e[3] = { v.x, v.y, v.z };
-    double R[3][3];
+    const VecT<T> apex(cone.v), axis(cone.v + 3);
+    const VecT<T> to_point = apex - p;
+    const VecT<T> to_pointn = normalize(to_point);
+    const VecT<T> rot_ax = normalize(cross(axis, to_pointn));
+    const VecT<T> comp_n = normalize(cross(axis, rot_ax));
+    const VecT<T> v = normalize(rot_ax);   // rodriguesrad re-normalizes (utilities.jl:62)
+    const T c = (T)cone.v[7], s = (T)cone.v[8];
+    const T e[3] = { v.x, v.y, v.z };
+    T R[3][3];
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {
-            const double nn = e[i] * e[j];
-            R[i][j] = nn + c * ((i == j ? 1.0 : 0.0) - nn);
+            const T nn = e[i] * e[j];
+            R[i][j] = nn + c * ((i == j ? T(1) : T(0)) - nn);
         }
     R[0][1] -= s * e[2]; R[0][2] += s * e[1];   // pluscrossprod!: utilities.jl:32-43
     R[1][0] += s * e[2]; R[1][2] -= s * e[0];
     R[2][0] -= s * e[1]; R[2][1] += s * e[0];
-    const Vec rc((R[0][0] * comp_n.x + R[0][1] * comp_n.y) + R[0][2] * comp_n.z,
-                 (R[1][0] * comp_n.x + R[1][1] * comp_n.y) + R[1][2] * comp_n.z,
-                 (R[2][0] * comp_n.x + R[2][1] * comp_n.y) + R[2][2] * comp_n.z);
+    const VecT<T> rc((R[0][0] * comp_n.x + R[0][1] * comp_n.y) + R[0][2] * comp_n.z,
+                     (R[1][0] * comp_n.x + R[1][1] * comp_n.y) + R[1][2] * comp_n.z,
+                     (R[2][0] * comp_n.x + R[2][1] * comp_n.y) + R[2][2] * comp_n.z);
     *cn = normalize(rc);
     *dist = dot(-*cn, -to_point);
 }
 
-RH_HD double clamp_unit(double x) { return x < -1 ? -1 : (x > 1 ? 1 : x); }
+template <typename T> RH_HD T clamp_unit(T x) { return x < T(-1) ? T(-1) : (x > T(1) ? T(1) : x); }
 
 // ---- cone.jl:39-61 ----
-RH_HD bool fit3pointcone(const double *p, const double *n, rh_shape *cone)
+template <typename T>
+RH_HD bool fit3pointcone_t(const double *p, const double *n, rh_shape *cone)
 {
-    double r[9], rv[12], ds[3], ap[3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = n[3 * i + j];
-    if (matrix_rank(r, 3, 3) != 3) return false;
-    for (int i = 0; i < 3; i++) ds[i] = dot(Vec(p + 3 * i), Vec(n + 3 * i));
+    typedef VecT<T> V;
+    T r[9], rv[12], ds[3], ap[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = (T)n[3 * i + j];
+    if (matrix_rank<T>(r, 3, 3) != 3) return false;
+    for (int i = 0; i < 3; i++) ds[i] = dot(V(p + 3 * i), V(n + 3 * i));
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) rv[i * 4 + j] = r[i * 3 + j];
         rv[i * 4 + 3] = -1 * ds[i];
     }
-    if (matrix_rank(rv, 3, 4) != 3) return false;
-    if (!lu_solve3(r, ds, ap)) return false;
-    const Vec apex(ap);
-    Vec a3[3];
+    if (matrix_rank<T>(rv, 3, 4) != 3) return false;
+    if (!lu_solve3<T>(r, ds, ap)) return false;
+    const V apex(ap[0], ap[1], ap[2]);
+    V a3[3];
     for (int i = 0; i < 3; i++) {
-        const Vec d = Vec(p + 3 * i) - apex;
+        const V d = V(p + 3 * i) - apex;
         a3[i] = apex + d / norm(d);
     }
-    Vec ax = normalize(cross(a3[1] - a3[0], a3[2] - a3[0]));
-    const Vec midp = ((a3[0] + a3[1]) + a3[2]) / 3;
-    const Vec dirv = normalize(midp - apex);
-    if (dot(ax, dirv) < 0) ax = -1.0 * ax;
-    double ang[3];
-    for (int i = 0; i < 3; i++) ang[i] = rh_acos(clamp_unit(dot(normalize(Vec(p + 3 * i) - apex), ax)));
+    V ax = normalize(cross(a3[1] - a3[0], a3[2] - a3[0]));
+    const V midp = ((a3[0] + a3[1]) + a3[2]) / T(3);
+    const V dirv = normalize(midp - apex);
+    if (dot(ax, dirv) < 0) ax = T(-1) * ax;
+    T ang[3];
+    for (int i = 0; i < 3; i++) ang[i] = rh_acos_t(clamp_unit<T>(dot(normalize(V(p + 3 * i) - apex), ax)));
     for (int i = 0; i < 10; i++) cone->v[i] = 0.0;
     cone->kind = RH_CONE;
     cone->outwards = 1;
     apex.store(cone->v);
     ax.store(cone->v + 3);
-    cone->v[6] = 2 * ((ang[0] + ang[1]) + ang[2]) / 3;
-    cone_finalize(cone);
+    cone->v[6] = (double)(2 * ((ang[0] + ang[1]) + ang[2]) / 3);
+    if (sizeof(T) == sizeof(float)) cone_finalize32(cone); else cone_finalize(cone);
     return true;
 }
+RH_HD bool fit3pointcone(const double *p, const double *n, rh_shape *cone) { return fit3pointcone_t<double>(p, n, cone); }
 
 // ---- cone.jl:87-115, 123-128 ----
-RH_HD bool fit_cone(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
+template <typename T>
+RH_HD bool fit_cone_t(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out)
 {
+    typedef VecT<T> V;
     if (lp > 16) return false;
     rh_shape cone;
-    if (!fit3pointcone(p, n, &cone)) return false;
-    double dist[16];
-    Vec cn[16];
-    for (int i = 0; i < lp; i++) project2cone(cone, Vec(p + 3 * i), &dist[i], &cn[i]);
+    if (!fit3pointcone_t<T>(p, n, &cone)) return false;
+    T dist[16];
+    V cn[16];
+    for (int i = 0; i < lp; i++) project2cone<T>(cone, V(p + 3 * i), &dist[i], &cn[i]);
     for (int i = 0; i < lp; i++)
-        if (dist[i] > prm.eps[RH_CONE]) return false;   // no abs in the reference (cone.jl:93)
+        if (dist[i] > prm.eps[RH_CONE]) return false;   // no abs in the reference (cone.jl:93); a Float32 distance is promoted exactly
     if (cone.v[6] < prm.minconeopang) return false;
     const double thr = prm.cos_alpha[RH_CONE];
     bool same = true, opposite = true;
     for (int i = 0; i < lp; i++) {
-        const double dotp = dot(cn[i], Vec(n + 3 * i));
+        const T dotp = dot(cn[i], V(n + 3 * i));
         same = same && (dotp > thr);
         opposite = opposite && (dotp < -thr);
     }
@@ -417,6 +443,8 @@ RH_HD bool fit_cone(const double *p, const double *n, int lp, const rh_params &p
     out->outwards = same ? 1 : 0;
     return true;
 }
+RH_HD bool fit_cone(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_cone_t<double>(p, n, lp, prm, out); }
+RH_HD bool fit_cone32(const double *p, const double *n, int lp, const rh_params &prm, rh_shape *out) { return fit_cone_t<float>(p, n, lp, prm, out); }
 
 
 // ---- per-minimal-set random stream (sampling_streams = 1) ------------------------------------

@@ -718,6 +718,62 @@ __global__ void select_kernel(const uint64_t *__restrict__ enabled, const int32_
     out[i] = (lo << 6) + __ffsll((unsigned long long)m);
 }
 
+// samplepointcloud4! (fitting.jl:383-430) on the root cell for EVERY start position of a stream of raw 64-bit draws: thread
+// p plays the call that would begin at raw[p] -- first point by rejection on rand(1:n) (:388-395), the others as the
+// rand(1:count)-th enabled point with one redraw when it repeats the first (:414-423), all-different test (:425-428) -- and
+// leaves the points, whether the set is usable and how many draws the call consumed.  The host then follows the chain
+// p -> p + consumed[p]: k calls in a row cost one launch, and the result is what k sequential calls give, draw for draw.
+// rec[p]: drawN points (1-based int64; 0 = none), then consumed (0 = the draws ran out before the call finished) and ok.
+__global__ void __launch_bounds__(256)
+sample_sets_seq_kernel(const uint64_t *__restrict__ enabled, const int32_t *__restrict__ word_prefix, int64_t nwords, int64_t n,
+                       const int32_t *__restrict__ total_ptr, const uint64_t *__restrict__ raw, int32_t L, int32_t drawN,
+                       int64_t *__restrict__ rec)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    const int64_t count = *total_ptr;
+    int64_t *o = rec + (int64_t)p * (drawN + 2);
+    for (int q = 0; q < drawN + 2; q++) o[q] = 0;
+    auto range = [](uint64_t u, int64_t m) { return 1 + (int64_t)__umul64hi(u, (uint64_t)m); };   // rand(1:m), rh_rng_range
+    auto select = [&](int64_t r) -> int64_t {
+        int64_t lo = 0, hi = nwords;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (word_prefix[mid] < r) lo = mid; else hi = mid;
+        }
+        uint64_t m = enabled[lo];
+        const int rem = (int)(r - word_prefix[lo]);
+        for (int t = 1; t < rem; t++) m &= m - 1;
+        return (lo << 6) + __ffsll((unsigned long long)m);
+    };
+    int q = p;
+    int64_t sd[16];
+    if (count <= 0) return;
+    int64_t r1;
+    for (;;) {
+        if (q >= L) return;                                  // ran out: consumed stays 0
+        r1 = range(raw[q++], n);
+        if ((enabled[(r1 - 1) >> 6] >> ((r1 - 1) & 63)) & 1ULL) break;
+    }
+    if (count < drawN) { o[drawN] = q - p; return; }          // (false, ..): fitting.jl:409-411
+    sd[0] = r1;
+    for (int i = 1; i < drawN; i++) {
+        if (q >= L) return;
+        int64_t pick = select(range(raw[q++], count));
+        if (pick == sd[0]) {
+            if (q >= L) return;
+            pick = select(range(raw[q++], count));
+        }
+        sd[i] = pick;
+    }
+    bool distinct = true;
+    for (int a = 1; a < drawN; a++)
+        for (int b = 0; b < a; b++) distinct = distinct && sd[a] != sd[b];
+    for (int i = 0; i < drawN; i++) o[i] = sd[i];
+    o[drawN] = q - p;
+    o[drawN + 1] = distinct ? 1 : 0;
+}
+
 // AoS (Vector{SVector{3,Float64}}) -> SoA planes, optionally gathering through an index list
 __global__ void transpose_kernel(const double *__restrict__ xyz, const double *__restrict__ nrm,
                                  const int32_t *__restrict__ gather, int64_t count, double *__restrict__ dst,
@@ -1142,6 +1198,15 @@ int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out)
     if (k == 0) return RH_OK;
     hipLaunchKernelGGL(select_kernel, dim3(cdiv(k, 256)), dim3(256), 0, c->stream, c->enabled, c->word_prefix,
                        c->nwords, c->d_total, d_ranks, k, d_out);
+    RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+int rhk_sample_sets_seq(rh_cloud *c, const uint64_t *d_raw, int32_t L, int32_t drawN, int64_t *d_rec)
+{
+    if (L == 0) return RH_OK;
+    hipLaunchKernelGGL(sample_sets_seq_kernel, dim3(cdiv(L, 256)), dim3(256), 0, c->stream, c->enabled, c->word_prefix, c->nwords,
+                       c->n, c->d_total, d_raw, L, drawN, d_rec);
     RH_HIP(hipGetLastError());
     return RH_OK;
 }

@@ -145,7 +145,7 @@ extern "C" int rh_set_option(rh_cloud *c, const char *key, int64_t value)
         switch (d->id) {
         case RH_OPT_SCORE_PATH: ok = value >= 0 && value <= RH_SCORE_PATH_GROUPS; break;
         case RH_OPT_REFIT_PATH: ok = value >= 0 && value <= RH_REFIT_PATH_CULLED; break;
-        case RH_OPT_S4_ROWS: ok = value == 0 || value == 4 || value == 8 || value == 12 || value == 16; break;
+        case RH_OPT_S4_ROWS: ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 12 || value == 16; break;
         case RH_OPT_UNP_WORDS: ok = value >= 0 && value <= 16384; break;
         default: break;
         }

@@ -160,6 +160,7 @@ struct rh_cloud {
     float *dis_gb32 = nullptr;         // binary32 twins of dis_gb
     int32_t *zero_extra = nullptr;     // the next rhk_prep_binned launch also zeroes zero_extra_n ints from here (then forgets it)
     int32_t zero_extra_n = 0;
+    void *s4_stats = nullptr;          // diag build: event counters of the score launches (rh_dbg_s4_stats), 128 x u64 on the device
     bool s4_open_count = false;        // the candidate count of the score launches being queued is a guess (windows of the candidate loop)
     int32_t *oct_adv_tab = nullptr;    //   the (level, slot) table of rhk_oct_advance, its bitmap (kept zero) and the sorted scores
     unsigned long long *oct_adv_bits = nullptr;
@@ -323,6 +324,8 @@ int rhk_pack_live(rh_cloud *c, int32_t *d_flags, int32_t n_flags, int32_t *h_fla
 int rhk_build_select(rh_cloud *c);
 int rhk_select(rh_cloud *c, const int64_t *d_ranks, int32_t k, int64_t *d_out);
 int rhk_count_enabled(rh_cloud *c, int64_t *out);
+uint64_t rh_rng_next_raw(rh_rng *r);   // fit.cpp: the next raw 64-bit draw (an injected stream first)
+int rhk_sample_sets_seq(rh_cloud *c, const uint64_t *d_raw, int32_t L, int32_t drawN, int64_t *d_rec);   // rh_sample_sets
 int rhk_iota(rh_cloud *c, int32_t *d, int32_t n, int32_t base);
 int rhk_gather_prep(rh_cloud *c, const rh_prep *src, const int32_t *d_idx, int32_t n, rh_prep *dst);
 // removeinvalidshapes! (fitting.jl:209-221) on a device-managed store (driver.hip, chained octree windows): the store's

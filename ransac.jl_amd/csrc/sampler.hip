@@ -208,7 +208,7 @@ sample_sets_kernel(const double *__restrict__ rec, int64_t n, DevEnabled en, int
 
 
 // fit(T, p, n, pc, params) for one shape type on a gathered minimal set (forcefitshapes!, fitting.jl:165-173).  f32: the cloud
-// is a Float32 cloud -- plane / sphere / cylinder fits in binary32 (fit_shared.h); its cones are refused before a run starts.
+// is a Float32 cloud -- all four fits in binary32 (fit_shared.h).
 template <bool CONE>
 static __device__ __forceinline__ bool fit_kind(int kind, const double *fp, const double *fn, int drawN, const rh_params &prm, int f32, rh_shape *s)
 {
@@ -216,7 +216,7 @@ static __device__ __forceinline__ bool fit_kind(int kind, const double *fp, cons
     case RH_PLANE: return f32 ? rhfit::fit_plane32(fp, fn, drawN, prm, s) : rhfit::fit_plane(fp, fn, drawN, prm, s);
     case RH_SPHERE: return f32 ? rhfit::fit_sphere32(fp, fn, drawN, prm, s) : rhfit::fit_sphere(fp, fn, drawN, prm, s);
     case RH_CYLINDER: return f32 ? rhfit::fit_cylinder32(fp, fn, drawN, prm, s) : rhfit::fit_cylinder(fp, fn, drawN, prm, s);
-    case RH_CONE: return (CONE && !f32) ? rhfit::fit_cone(fp, fn, drawN, prm, s) : false;
+    case RH_CONE: return CONE ? (f32 ? rhfit::fit_cone32(fp, fn, drawN, prm, s) : rhfit::fit_cone(fp, fn, drawN, prm, s)) : false;
     default: return false;
     }
 }

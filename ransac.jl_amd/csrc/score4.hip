@@ -56,7 +56,7 @@ constexpr int S4_W = 4;                  // waves per block
 // grid would otherwise be a few hundred blocks
 template <int R, bool MASK = false>
 struct S4Shared {
-    static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && R % S4_W == 0, "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
+    static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && (R % S4_W == 0 || R < S4_W), "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
     rh_f32x2 pb[S4_TG][S4_ROW];          // (ny, nz)
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
@@ -102,7 +102,20 @@ struct S4AllArgs {
     uint64_t *masks;
     uint8_t *occ;
     int64_t mstride;
+    unsigned long long *stats;   // diag build: event counters of the launch (rh_dbg_s4_stats; layout at S4_STAT), else null
 };
+
+// ---- event counters (diag build only; tools/isa_account.py multiplies them with the static instruction histogram of the
+// kernel's regions): one add per WAVE-level event.  Per kind k at 24 k + ...: 0 segments entered, 1..4 chunk visits of the
+// wave's 1st..4th chunk, 5 candidates box-tested, 6 chunk visits without a survivor, 7 surviving pairs, 8 batches, 9 pairs
+// taken by the second (lane = point) pass, 10 undecided points queued for the exact test, 11 full ring drains, 12 final drains,
+// 13 points the exact test accepted, 14 pairs with a count > 0, 15 cone: compaction rounds.  Global at 96 + ...: 0 waves of
+// blocks with a tile, 1 stagings (per wave), 2 re-used stagings, 3 waves whose tile has no enabled point.
+#ifdef RH_DIAG
+#define S4_STAT(stats, idx, val) do { const unsigned long long v_ = (unsigned long long)(val); if ((stats) != nullptr && (threadIdx.x & 63) == 0) atomicAdd((stats) + (idx), v_); } while (0)
+#else
+#define S4_STAT(stats, idx, val) do { } while (0)
+#endif
 
 template <int KIND> struct S4Fields { static constexpr int NBOX = KIND == RH_PLANE || KIND == RH_SPHERE ? 5 : (KIND == RH_CYLINDER ? 9 : 11); };
 
@@ -132,8 +145,10 @@ static __device__ __forceinline__ void
 score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
-             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0)
+             uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0, unsigned long long *__restrict__ stats)
 {
+    (void)stats;
+    S4_STAT(stats, 24 * KIND + 8, 1);
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
     const int g = (int)(e & S4_GM), ci = cbase + (int)(e >> S4_GB);
@@ -164,6 +179,8 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
             r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
                                  pts[5 * stride + gi], eps, cosa);
         }
+        S4_STAT(stats, 24 * KIND + (k == 64 ? 11 : 12), 1);
+        S4_STAT(stats, 24 * KIND + 13, __popcll(r & (k >= 64 ? ~0ULL : ((1ULL << k) - 1ULL))));
         if (on && ((r >> lane) & 1ULL)) {
             atomicAdd(&sh.cntb[wv][slot], 1);
             if (MASK) atomicOr(&sh.maskb[wv][slot], 1ULL << (e2 & 63u));
@@ -207,6 +224,7 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         // 64 at a time through the ring, whatever pair they belong to.  (Round 3 ran the exact test on the whole group of every
         // such pair: 40 binary64 instructions per wave and pair, a tenth of the launch's issue cycles.)
         uint64_t redo = WB(amb);
+        S4_STAT(stats, 24 * KIND + 9, __popcll(redo));
         if (redo != 0) {
             sh.cntb[wv][lane] = 0;
             if (MASK) sh.maskb[wv][lane] = 0ULL;
@@ -232,6 +250,7 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
                 const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(und >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)und, 0));
                 if (has) sh.qb[wv][(qbh + qbn + rank) & 127] = (uint16_t)((k << 6) | lane);
                 qbn += __popcll(und);
+                S4_STAT(stats, 24 * KIND + 10, __popcll(und));
                 if (qbn >= 64) drain_b(64);
             }
             if (qbn > 0) drain_b(qbn);
@@ -281,6 +300,8 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
             const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
             if (has) sh.qb[wv][(qbh + qbn + rank) & 127] = (uint16_t)((lane << 6) | j);
             qbn += __popcll(mm);
+            S4_STAT(stats, 24 * KIND + 15, 1);
+            S4_STAT(stats, 24 * KIND + 10, __popcll(mm));
             if (qbn >= 64) drain_b(64);
         }
         if (qbn > 0) drain_b(qbn);
@@ -319,6 +340,7 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
             }
         }
     }
+    S4_STAT(stats, 24 * KIND + 14, __popcll(WB(act && total > 0)));
     // one global atomic per (candidate, tile) with inliers: the pairs of a candidate sit in adjacent lanes
     const int v = run_total(act ? total : 0, act ? ci : -1 - lane, lane);
     if (v != 0) atomicAdd(&counts[orig[ci]], v);
@@ -331,14 +353,17 @@ template <int KIND, int R, bool MASK, bool F32>
 static __device__ __forceinline__ void
 score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
-               int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride)
+               int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride,
+               unsigned long long *__restrict__ stats)
 {
+    (void)stats;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nk = *K.nk;
+    S4_STAT(stats, 24 * KIND + 0, 1);
     constexpr int NB = S4Fields<KIND>::NBOX;
     // (the culling records of the wave's chunks are requested together, before the first box test)
-    constexpr int CPW = R / S4_W;
+    constexpr int CPW = (R + S4_W - 1) / S4_W;   // (rows of 1 or 2 chunks: the waves without a chunk of their own go straight to the batches)
     float B[2][RH_BOX_FIELDS];
     // (unconditional loads from a clamped slot: a lane without a candidate reads slot 0 and is masked out below -- a
     // guarded load per field costs a scalar exec-mask save / branch / restore each, ~20 scalar instructions per chunk)
@@ -376,7 +401,10 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
         const int k = __popc(surv);
         const uint64_t b0 = WB(k & 1), b1 = WB(k & 2), b2 = WB(k & 4), b3 = WB(k & 8);
         const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
-        if (tot == 0) continue;
+        S4_STAT(stats, 24 * KIND + 1 + (h < 3 ? h : 3), 1);
+        S4_STAT(stats, 24 * KIND + 5, __popcll(WB(ci < nk)));
+        S4_STAT(stats, 24 * KIND + 7, tot);
+        if (tot == 0) { S4_STAT(stats, 24 * KIND + 6, 1); continue; }
         int base = 0;
         if (lane == 0) base = atomicAdd(&sh.npairs, tot);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -399,7 +427,7 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
         score4_batch<KIND, R, MASK, F32>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
-                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0);
+                                         K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, stats);
     }
 }
 
@@ -484,6 +512,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     if (tile >= A.ntiles) return;
     if (A.stop != nullptr && *A.stop != 0) return;
     const int64_t g0 = tile * S4_TG;
+    S4_STAT(A.stats, 96 + 0, 1);
     int nch[4], total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
@@ -499,13 +528,15 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             if (!ran || A.k[K].en != staged_en) {                                                                      \
                 s4_stage(sh, pts, stride, s, A.k[K].en, g0 * 64, A.gb32, A.ngroups);                                   \
                 staged_en = A.k[K].en;                                                                                 \
-            } else if (threadIdx.x == 0) { sh.npairs = 0; sh.next_batch = 0; }   /* same tile, same enabled words */   \
+                S4_STAT(A.stats, 96 + 1, 1);                                                                           \
+            } else { S4_STAT(A.stats, 96 + 2, 1); if (threadIdx.x == 0) { sh.npairs = 0; sh.next_batch = 0; } }   /* same tile, same enabled words */   \
             __syncthreads();                                                                                           \
             live = 0;                                                                                                  \
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             { int ww = 0; for (int g = 0; g < S4_TG; g++) ww |= sh.weirdw[g]; weird = __builtin_amdgcn_readfirstlane(ww) != 0; }  \
-            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride); \
+            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride, A.stats); \
+            else S4_STAT(A.stats, 96 + 3, 1);                                                                         \
             ran = true;                                                                                                \
         }                                                                                                              \
         base += nch[K];                                                                                                \
@@ -668,7 +699,17 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
     const uint64_t sin_ = WB(decided && cls_sure(t)) & valid;
     const uint64_t amb = (WB(!decided || (KIND == RH_CONE ? (!cls_sure(t) && cls_sure(t - 1.0f)) : cls_undecided(t)))) & valid;
     const uint64_t sout = valid & ~sin_ & ~amb;
+    // a "band point": its DISTANCE half alone is not surely failed (the normal half aside) -- a pair whose group holds one
+    // cannot be decided by any test on the group's position box: the floor of the necessary (candidate, group) work
+    float du, dn;
+    bool near_axis = false;
+    if (KIND == RH_PLANE) cls_plane_ab(Q.C, fx, fy, fz, fnx, fny, fnz, dn, du);
+    else if (KIND == RH_CONE) cls_cone_ab(Q.C, fx, fy, fz, fnx, fny, fnz, du, dn, near_axis);
+    else cls_round_ab<KIND == RH_SPHERE ? RH_SPHERE : RH_CYLINDER>(Q.C, fx, fy, fz, fnx, fny, fnz, du, dn);
+    const uint64_t band = WB(!decided || near_axis || !(du > 1.0f)) & valid;
     if (lane == 0) {
+        if (band != 0) atomicAdd(&out[40 + KIND], 1ULL);
+        if (ex != 0) atomicAdd(&out[44 + KIND], 1ULL);
         unsigned long long *o = out + KIND * 10;
         atomicAdd(&o[0], 1ULL);
         if (skip) atomicAdd(&o[1], 1ULL);
@@ -879,18 +920,26 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     A.masks = d_masks_int;
     A.occ = d_occ;
     A.mstride = mstride;
+    A.stats = nullptr;
+#ifdef RH_DIAG
+    A.stats = (unsigned long long *)c->s4_stats;   // (rh_dbg_s4_stats switched the counters on)
+#endif
     const int env_r = (int)rh_opt_int(c, RH_OPT_S4_ROWS, 0);   // rh_set_option(.., "s4_rows", ..), read on every launch: the fuzzers vary it from case to case
     // R = chunks of 64 candidates per block row.  A block's fixed work -- prologue, staging its tile, the four kinds' dispatch --
     // is a third of the launch's issue cycles at cfg3 and nearly half at cfg5 (profiles/r4/region_counters*.txt): longer rows pay
-    // it less often, as long as the grid still has a few blocks per slot.  Measured (round 4, counts only): cfg3 (1221 tiles)
-    // R = 8 0.0902 ms, 12 0.0880, 16 0.0930, 24 / 32 0.119; cfg5 (6104 tiles) 8 0.367, 12 0.330, 16 0.319, 24 0.343, 32 0.328;
-    // grids of a few hundred blocks (cfg2) stay at 4.  Open-ended windows keep 4 / 8 (their tail launch walks the same rows).
+    // it less often, as long as the grid still has a few blocks per slot -- and as long as the HEAVIEST block does not set the
+    // launch's time: on few tiles every candidate of a row meets the same dense tiles, and the time grows linearly with R
+    // (round 5, cfg2's 123 tiles: R = 1 / 2 / 4 / 8 / 16 -> 0.0428 / 0.0432 / 0.0588 / 0.0898 / 0.158 ms; the same 123 tiles of a
+    // sparse 1M-point scene 0.0383 / 0.0323 / 0.0334 / 0.0442; 367 tiles R = 2 / 4 / 8 / 12 -> 0.0589 / 0.0492 / 0.0576 / 0.0616;
+    // cfg3's 1221 tiles 4 / 8 / 12 / 16 -> 0.0969 / 0.0866 / 0.0855 / 0.0873; cfg5's 6104 tiles 8 / 12 / 16 / 24 / 32 -> 0.367 / 0.330 /
+    // 0.319 / 0.343 / 0.328).  Open-ended windows keep 4 / 8 (their tail launch walks the same rows).
     int R;
-    if (env_r == 4 || env_r == 8 || ((env_r == 12 || env_r == 16) && !open_count)) R = env_r;
+    if (env_r == 4 || env_r == 8 || ((env_r == 1 || env_r == 2 || env_r == 12 || env_r == 16) && !open_count)) R = env_r;
     else if (open_count) R = ntiles * ((nchunks + 7) / 8) < 3000 ? 4 : 8;
     else if (ntiles * ((nchunks + 15) / 16) >= 16384) R = 16;
     else if (ntiles * ((nchunks + 11) / 12) >= 3000) R = 12;
-    else R = 4;
+    else if (ntiles * ((nchunks + 3) / 4) >= 4000) R = 4;
+    else R = 2;
     int64_t rows = (nchunks + R - 1) / R;
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     // XCD-aware grid: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with an L2 of its own; with grid.x
@@ -903,7 +952,10 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     // (measured, round 4: cfg2 -- 123 tiles x 17 rows -- 0.0753 -> 0.0663 ms; cfg3 -- 1221 x 9 -- 0.0927 -> 0.1041: with every row
     // in flight at once the record gathers of stage 2 spread over all 4096 candidates instead of a row's 512; cfg5 0.388
     // either way.  So: small launches only.)
-    if (rows > 1 && ((ntiles + 7) / 8) * 8 * rows <= 4096) {
+#ifndef RH_S4_XROW_MAX
+#define RH_S4_XROW_MAX 4096
+#endif
+    if (rows > 1 && ((ntiles + 7) / 8) * 8 * rows <= RH_S4_XROW_MAX) {
         A.rows = (int)rows;
         grid = dim3((unsigned)(((ntiles + 7) / 8) * 8 * rows), 1);
     }
@@ -928,6 +980,8 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
 #define RH_S4_LAUNCH_R(MM, FF)                                                                                         \
     do {                                                                                                               \
         if (R == 4) RH_S4_LAUNCH(4, MM, FF);                                                                           \
+        else if (R == 1) RH_S4_LAUNCH(1, MM, FF);                                                                      \
+        else if (R == 2) RH_S4_LAUNCH(2, MM, FF);                                                                      \
         else if (R == 12) RH_S4_LAUNCH(12, MM, FF);                                                                    \
         else if (R == 16) RH_S4_LAUNCH(16, MM, FF);                                                                    \
         else RH_S4_LAUNCH(8, MM, FF);                                                                                  \
@@ -1055,7 +1109,7 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
 extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out)
 {
     if (c == nullptr || out == nullptr || p == nullptr || b < 0 || (b > 0 && shapes == nullptr)) { rh_set_error("rh_dbg_cls_soundness: bad arguments"); return RH_E_INVALID; }
-    for (int i = 0; i < 40; i++) out[i] = 0;
+    for (int i = 0; i < 48; i++) out[i] = 0;
     if (b == 0 || c->s == 0 || c->ngroups == 0 || c->gb32 == nullptr) return RH_OK;
     RH_HIP(hipSetDevice(c->device));
     std::vector<S4SoundCand> h((size_t)b);
@@ -1074,20 +1128,42 @@ extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t
     S4SoundCand *d_c = nullptr;
     unsigned long long *d_o = nullptr;
     RH_HIP(hipMalloc((void **)&d_c, sizeof(S4SoundCand) * (size_t)b));
-    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 40));
+    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 48));
     RH_HIP(hipMemcpyAsync(d_c, h.data(), sizeof(S4SoundCand) * (size_t)b, hipMemcpyHostToDevice, c->stream));
-    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 40, c->stream));
+    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 48, c->stream));
     hipLaunchKernelGGL(cls_sound_kernel, dim3((unsigned)c->ngroups, (unsigned)std::min<int32_t>(b, 64)), dim3(64), 0, c->stream, c->sub, c->s_pad, c->s,
                        c->gb32, d_c, b, A, d_o);
-    unsigned long long ho[40];
+    unsigned long long ho[48];
     RH_HIP(hipMemcpyAsync(ho, d_o, sizeof ho, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(d_c);
     (void)hipFree(d_o);
-    for (int i = 0; i < 40; i++) out[i] = (uint64_t)ho[i];
+    for (int i = 0; i < 48; i++) out[i] = (uint64_t)ho[i];
     return RH_OK;
 }
 
+#endif   // RH_DIAG
+
+#ifdef RH_DIAG
+// diagnostics: the event counters of the score launches on this cloud (layout: S4_STAT above).  mode 0: read (out[128], null:
+// nothing), 1: switch the counting on and zero the counters, 2: switch it off.  Synchronises the cloud's stream.
+extern "C" int rh_dbg_s4_stats(rh_cloud *c, int mode, uint64_t *out)
+{
+    if (c == nullptr || mode < 0 || mode > 2) { rh_set_error("rh_dbg_s4_stats: bad arguments"); return RH_E_INVALID; }
+    RH_HIP(hipSetDevice(c->device));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    if (mode == 1) {
+        if (c->s4_stats == nullptr) RH_HIP(hipMalloc((void **)&c->s4_stats, sizeof(unsigned long long) * 128));
+        RH_HIP(hipMemset(c->s4_stats, 0, sizeof(unsigned long long) * 128));
+    } else if (mode == 2) {
+        if (c->s4_stats != nullptr) (void)hipFree(c->s4_stats);
+        c->s4_stats = nullptr;
+    } else if (out != nullptr) {
+        for (int i = 0; i < 128; i++) out[i] = 0;
+        if (c->s4_stats != nullptr) RH_HIP(hipMemcpy(out, c->s4_stats, sizeof(unsigned long long) * 128, hipMemcpyDeviceToHost));
+    }
+    return RH_OK;
+}
 #endif   // RH_DIAG
 
 // the entry lists the v4 score kernel left (rows of mstride 16-byte entries, one cursor per row in d_occ) -> dense rows in

@@ -118,7 +118,7 @@ def test_fit_bit_identical_to_oracle(kind):
     assert nfit > 50
 
 
-@pytest.mark.parametrize("kind", [orc.PLANE, orc.SPHERE, orc.CYLINDER])
+@pytest.mark.parametrize("kind", [orc.PLANE, orc.SPHERE, orc.CYLINDER, orc.CONE])
 def test_fit_f32_bit_identical_to_oracle(kind):
     """fit on Float32 points (a Float32 cloud, octree.jl:102-109): rh_fit_f32 -- the binary32 instantiation of
     fit_shared.h, the same code the device fits of rh_ransac run -- against the oracle's own binary32 restatement
@@ -143,16 +143,12 @@ def test_fit_f32_bit_identical_to_oracle(kind):
             b = orc.fit(kind, pd, nd, po)
             ndiff += b is None or bytes(b) != bytes(a)
     assert nfit > 50 and ndiff > nfit // 2
-    # the mirror: fit() on float32 arrays is the Float32 fit; the cone is refused
+    # the mirror: fit() on float32 arrays is the Float32 fit
     for p, n in _minimal_sets(kind, rng, 5):
-        m = R.fit({orc.PLANE: R.FittedPlane, orc.SPHERE: R.FittedSphere, orc.CYLINDER: R.FittedCylinder}[kind],
+        m = R.fit({orc.PLANE: R.FittedPlane, orc.SPHERE: R.FittedSphere, orc.CYLINDER: R.FittedCylinder, orc.CONE: R.FittedCone}[kind],
                   p.astype(np.float32), n.astype(np.float32), None, pp)
         a = orc.fit32(kind, p, n, po)
         assert (m is None) == (a is None)
-    out, ok = L.Shape(), C.c_int32()
-    z = np.zeros(9)
-    assert R.lib().rh_fit_f32(orc.CONE, z.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double)), 3,
-                              C.byref(pp), C.byref(out), C.byref(ok)) != 0
 
 
 def test_estimatescore_prob_rng_match_oracle():

@@ -200,10 +200,8 @@ def test_f32_device_batch_and_unsupported_calls(scene32):
     L.check(R.lib().rh_cloud_sync(pc._h))
     assert np.array_equal(counts.cpu().numpy(), oc.score_batch(to_orc(arr, 300), orc.Params.from_buffer_copy(bytes(cp))))
     batch.free()
-    with pytest.raises(R.RansacHipError, match="FittedCone"):
-        R.ransac(pc, cp, seed=1)          # the default shape_types hold FittedCone: not available on a Float32 cloud
     with pytest.raises(R.RansacHipError):
-        R.refit_lsq(arr[0], pc, cp)
+        R.refit_lsq(arr[0], pc, cp)      # (the least-squares refit stays Float64-only)
 
 
 def test_f32_full_size_refit_halves_the_bytes():
@@ -284,12 +282,23 @@ def test_f32_ransac_multi_primitive(seed, env, monkeypatch):
     _same_run(got, st, exp, pc, oc)
 
 
-def test_f32_ransac_refuses_cones_on_both_sides():
-    c = synth.config("cfg1")
-    subs = synth.make_subsets(50000, c["r"], c["seed"])
-    pc = R.RANSACCloud(c["xyz"], c["nrm"], subs, force_eltype=np.float32)
-    oc = orc.Cloud(c["xyz"], c["nrm"], subs[0], f32=True)
-    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedCone]))
-    with pytest.raises(R.RansacHipError, match="FittedCone"):
-        R.ransac(pc, cp, seed=1)
-    assert oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=1)["rc"] == -3
+@pytest.mark.parametrize("streams,octree", [(0, False), (1, False), (1, True)])
+def test_f32_ransac_with_cones(streams, octree):
+    """ransac() on a Float32 cloud with FittedCone in shape_types (round 5: the cone's fit in binary32 -- a one-sided Jacobi SVD
+    and an LU in float for cone.jl:40-50's rank / \\, fit_shared.h fit_cone_t<float>; on the host for the sequential stream,
+    on the device for per-set streams) against the oracle's own binary32 loop: shapes, index lists, draws, bit for bit."""
+    prim = ["plane", "cone", "cylinder", "cone", "sphere"]
+    xyz, nrm, truth = synth.make_cloud(50_000, prim, 0.15, seed=77)
+    subs = synth.make_subsets(50_000, 2, seed=7)
+    pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
+    oc = orc.Cloud(xyz, nrm, subs[0], f32=True)
+    params = R.ransacparameters([R.FittedPlane, R.FittedCone, R.FittedCylinder, R.FittedSphere],
+                                iteration={"minsubsetN": 150, "itermax": 80, "τ": 300, "prob_det": 0.8})
+    cp = R.params_to_c(params, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=streams, octree_sampling=octree)
+    got, _, st = R.ransac(pc, cp, seed=31, return_stats=True)
+    exp = oc.ransac(orc.Params.from_buffer_copy(bytes(cp)), seed=31)
+    assert exp["rc"] == 0 and len(got) >= 3
+    assert any(g.c_shape.kind == L.CONE for g in got), [R.strt(g.shape) for g in got]
+    _same_run(got, st, exp, pc, oc)
+    for g in got:      # a Float32 shape holds binary32 numbers
+        assert all(float(np.float32(x)) == x for x in list(g.c_shape.v)[:9])

@@ -800,9 +800,9 @@ def test_subset_order_made_on_the_device_or_on_the_host_gives_the_same_results(m
         assert st["draws"] == exp["draws"] and len(got) == len(exp["shapes"])
         for g, e in zip(got, exp["shapes"]):
             assert bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
-        out = np.zeros(40, dtype=np.uint64)
+        out = np.zeros(48, dtype=np.uint64)
         L.check(R.lib().rh_dbg_cls_soundness(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        out = out.reshape(4, 10).astype(np.int64)
+        out = out[:40].reshape(4, 10).astype(np.int64)
         assert out[:, [2, 6, 7, 9]].sum() == 0
         radii[host] = out[:, 1].sum() / out[:, 0].sum()      # share of (candidate, group) pairs the box tests skip
     # the two orders cull alike (same tree, ties and binary32 keys aside)
@@ -953,11 +953,13 @@ def test_scorecandidates_and_removeinvalidshapes_mirror(small_scene):
     pc.enable_all()
 
 
-def _ransac_via_call_sites(pc, params, seed):
+def _ransac_via_call_sites(pc, params, seed, batched=False):
     """The reference's own loop (iterations.jl:35-162) written against the API mirrors, with ONLY the three
     hot calls going to the device -- scorecandidates! (batched), refit, invalidate_indexes! -- plus the
     k-th-enabled select; sampling, fits, score statistics and candidate bookkeeping stay on the host, as in
-    julia/RANSACHIP.jl's `ransac`.  Returns (extracted, iterations, draws)."""
+    julia/RANSACHIP.jl's `ransac`.  batched: the iteration's minsubsetN calls of samplepointcloud4! as ONE
+    rh_sample_sets launch on the same generator (instead of a select round trip per point).  Returns (extracted,
+    iterations, draws)."""
     lib = R.lib()
     it = params["iteration"]
     drawN, minsubsetN, tau, itermax, prob_det = it["drawN"], it["minsubsetN"], it["τ"], it["itermax"], it["prob_det"]
@@ -972,7 +974,13 @@ def _ransac_via_call_sites(pc, params, seed):
     for k in range(1, itermax + 1):
         if int(en.sum()) < tau:
             break
-        for _ in range(minsubsetN):
+        if batched:
+            sets, ok, _lev = R.sample_sets(pc, drawN, rng, minsubsetN)
+            for j in range(minsubsetN):
+                if ok[j]:
+                    idx = sets[j] - 1
+                    R.forcefitshapes(pc.vertices[idx], pc.normals[idx], params, candidates, levels, 1, pc)
+        for _ in range(0 if batched else minsubsetN):
             # samplepointcloud4! (fitting.jl:383-430), root cell
             first = rnd(pc.size)
             while not en[first - 1]:
@@ -1010,16 +1018,17 @@ def _ransac_via_call_sites(pc, params, seed):
     return extracted, iterations, rng.draws
 
 
-def test_reference_loop_with_three_call_sites_swapped():
+@pytest.mark.parametrize("batched", [False, True])
+def test_reference_loop_with_three_call_sites_swapped(batched):
     """Drop-in at the call sites INTEGRATION.md names: the reference's loop on the host with
-    scorecandidates! / refit / invalidate_indexes! (and the enabled select) served by the library gives
-    exactly the oracle's run -- shapes, index sets, iteration count, RNG draws."""
+    scorecandidates! / refit / invalidate_indexes! (and the enabled select, or the batched samplepointcloud4! of
+    rh_sample_sets) served by the library gives exactly the oracle's run -- shapes, index sets, iteration count, RNG draws."""
     xyz, nrm, truth = synth.make_cloud(9_000, ["plane", "sphere", "cylinder"], 0.1, seed=31)
     subs = synth.make_subsets(9_000, 2, seed=31)
     params = R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder],
                                 iteration={"minsubsetN": 12, "itermax": 25, "τ": 200, "prob_det": 0.7})
     pc = R.RANSACCloud(xyz, nrm, subs)
-    got, iters, draws = _ransac_via_call_sites(pc, params, seed=5)
+    got, iters, draws = _ransac_via_call_sites(pc, params, seed=5, batched=batched)
     oc = orc.Cloud(xyz, nrm, subs[0])
     exp = oc.ransac(to_orc_params(R.params_to_c(params)), seed=5)
     assert exp["rc"] == 0 and len(exp["shapes"]) >= 2
@@ -1029,3 +1038,53 @@ def test_reference_loop_with_three_call_sites_swapped():
         assert bytes(g.shape.to_c()) == bytes(e["shape"])
         assert np.array_equal(g.inpoints, e["inpoints"])
     assert np.array_equal(pc.enabled_chunks(), oc.get_enabled())
+
+
+@pytest.mark.parametrize("drawN,frac,inject", [(3, 1.0, False), (3, 0.4, True), (4, 0.02, False), (2, 0.5, True), (5, 0.0005, False)])
+def test_sample_sets_equals_sequential_calls(small_scene, drawN, frac, inject):
+    """rh_sample_sets = samplepointcloud4! k times in a row (fitting.jl:383-430) as one launch: the same sets, the same
+    accept / reject flags and the same number of draws as the per-point calls (rh_rng_range + rh_select_enabled) on the same
+    generator -- with few enabled points (long rejection runs for the first point, redraws, duplicate sets), fewer enabled
+    points than drawN, and an injected stream that runs out half way (the generator takes over, as in rh_rng_range)."""
+    pc, oc, truth = small_scene
+    lib = R.lib()
+    n = pc.size
+    rs = np.random.default_rng(int(1000 * frac) + drawN)
+    en = rs.random(n) < frac
+    if frac < 0.001:
+        en[:] = False
+        en[rs.choice(n, size=3, replace=False)] = True      # fewer enabled points than drawN = 5: every call fails after its first point
+    pc.set_enabled(en)
+    k = 300
+    stream = rs.integers(0, 2**64, size=400, dtype=np.uint64) if inject else None
+
+    def make_rng():
+        r = L.Rng()
+        lib.rh_rng_seed(C.byref(r), 99)
+        if stream is not None:
+            r.stream = stream.ctypes.data_as(C.POINTER(C.c_uint64))
+            r.stream_len = stream.size
+        return r
+    rng_a, rng_b = make_rng(), make_rng()
+    sets, ok, lev = R.sample_sets(pc, drawN, rng_a, k)
+    n_en = int(en.sum())
+    for j in range(k):
+        first = lib.rh_rng_range(C.byref(rng_b), n)
+        while not en[first - 1]:
+            first = lib.rh_rng_range(C.byref(rng_b), n)
+        if n_en < drawN:
+            assert not ok[j] and lev[j] == 0
+            continue
+        sd = [first]
+        for _q in range(1, drawN):
+            pick = int(R.select_enabled(pc, [lib.rh_rng_range(C.byref(rng_b), n_en)])[0])
+            if pick == first:
+                pick = int(R.select_enabled(pc, [lib.rh_rng_range(C.byref(rng_b), n_en)])[0])
+            sd.append(pick)
+        assert list(sets[j]) == sd, j
+        assert bool(ok[j]) == (len(set(sd)) == drawN) and lev[j] == int(ok[j])
+    assert rng_a.draws == rng_b.draws and rng_a.stream_pos == rng_b.stream_pos
+    assert [rng_a.s[i] for i in range(4)] == [rng_b.s[i] for i in range(4)]
+    if frac >= 0.02:
+        assert ok.sum() > 250
+    pc.enable_all()

@@ -51,9 +51,9 @@ def one(case, rng, f32=False):
     if f32:
         for i in range(b):
             R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
-    out = np.zeros(40, dtype=np.uint64)
+    out = np.zeros(48, dtype=np.uint64)
     L.check(R.lib().rh_dbg_cls_soundness(pc._h, arr, b, C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_uint64))))
-    out = out.reshape(4, 10).astype(np.int64)
+    out = out[:40].reshape(4, 10).astype(np.int64)
     ok = int(out[:, VIOL].sum()) == 0
     return ok, "n=%d r=%d scale=%g b=%d f32=%d viol=%s" % (n, r, scale, b, f32, out[:, VIOL].tolist()), out
 

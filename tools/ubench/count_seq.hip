@@ -9,9 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-enum { CMP_CND_ADDC, CMP_ADDC, SUB_ALIGNBIT, CLAMP_ADD, FMA6, CNDMASK_ONLY, CMP_ONLY, ADDC_ONLY, ALIGNBIT_ONLY, MIN3_ABS, SUBABS, SUB32, MIN2, MINABS, FMAC, FMANEG, MIN3, BCNT, LSHLOR, MAX2, MUL_E64, FMACLAMP, NOPS };
-static const char *names[NOPS] = { "cmp_cnd_addc/2", "cmp_addc", "sub_alignbit", "clamp_add", "fma6", "cndmask", "cmp_vcc", "addc_vcc", "alignbit", "min3_abs/2", "v_sub_e64_abs", "v_sub_e32", "v_min_e32", "v_min_e64_abs", "v_fmac_e32", "v_fma_neg_abs", "v_min3", "v_bcnt", "v_lshl_or", "v_max_e32", "v_mul_e64_neg", "v_fma_clamp" };
-static const double per[NOPS] = { 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1 };   // points per sequence
+enum { CMP_CND_ADDC, CMP_ADDC, SUB_ALIGNBIT, CLAMP_ADD, FMA6, CNDMASK_ONLY, CMP_ONLY, ADDC_ONLY, ALIGNBIT_ONLY, MIN3_ABS, SUBABS, SUB32, MIN2, MINABS, FMAC, FMANEG, MIN3, BCNT, LSHLOR, MAX2, MUL_E64, FMACLAMP, MOV, MBCNT, READLANE, READFIRST, AND32, LSHL32, ADDU32, ADD3, CNDMASK_SGPR, CVTF64, DPPMOV, NOPS };
+static const char *names[NOPS] = { "cmp_cnd_addc/2", "cmp_addc", "sub_alignbit", "clamp_add", "fma6", "cndmask", "cmp_vcc", "addc_vcc", "alignbit", "min3_abs/2", "v_sub_e64_abs", "v_sub_e32", "v_min_e32", "v_min_e64_abs", "v_fmac_e32", "v_fma_neg_abs", "v_min3", "v_bcnt", "v_lshl_or", "v_max_e32", "v_mul_e64_neg", "v_fma_clamp", "v_mov_b32", "v_mbcnt_lo+hi/2", "v_readlane", "v_readfirstlane", "v_and_b32", "v_lshlrev_b32", "v_add_u32", "v_add3_u32", "v_cndmask_sgpr", "v_cvt_f32_f64", "v_mov_dpp" };
+static const double per[NOPS] = { 2, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1 };   // points per sequence
 
 template <int OP> __device__ __forceinline__ void one(float &t, float &t2, unsigned &w, float &c, float k, float m)
 {
@@ -37,6 +37,18 @@ template <int OP> __device__ __forceinline__ void one(float &t, float &t2, unsig
     if constexpr (OP == MAX2) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(c) : "v"(t));
     if constexpr (OP == MUL_E64) asm volatile("v_mul_f32_e64 %0, -%1, %0" : "+v"(c) : "v"(t));
     if constexpr (OP == FMACLAMP) asm volatile("v_fma_f32 %0, %1, %2, %0 clamp" : "+v"(c) : "v"(t), "v"(t2));
+    // round 5: the classes tools/isa_account.py had priced by analogy (moves, lane operations, plain 32-bit integer)
+    if constexpr (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "v"(t));
+    if constexpr (OP == MBCNT) asm volatile("v_mbcnt_lo_u32_b32 %0, s10, 0\n v_mbcnt_hi_u32_b32 %0, s11, %0" : "=v"(w) : : "s10", "s11");
+    if constexpr (OP == READLANE) asm volatile("v_readlane_b32 s10, %0, 3" : : "v"(w) : "s10");
+    if constexpr (OP == READFIRST) asm volatile("v_readfirstlane_b32 s10, %0" : : "v"(w) : "s10");
+    if constexpr (OP == AND32) asm volatile("v_and_b32 %0, %1, %0" : "+v"(w) : "v"(t));
+    if constexpr (OP == LSHL32) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(w));
+    if constexpr (OP == ADDU32) asm volatile("v_add_u32 %0, %1, %0" : "+v"(w) : "v"(t));
+    if constexpr (OP == ADD3) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(w) : "v"(t), "v"(t2));
+    if constexpr (OP == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %1, %2, s[10:11]" : "=v"(w) : "v"(t), "v"(t2) : "s10", "s11");
+    if constexpr (OP == CVTF64) asm volatile("v_cvt_f32_f64 %0, v[100:101]" : "=v"(c) : : "v100", "v101");
+    if constexpr (OP == DPPMOV) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(w) : "v"(t));
 }
 
 template <int OP> __global__ void __launch_bounds__(256) kern(float *out, int iters)
