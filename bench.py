@@ -497,6 +497,7 @@ def main():
     L.check(lib.rh_timer_stop(tcloud._h, C.byref(ev_ms)))
     fence()
     dt = time.perf_counter() - t0
+    dt_rank = dt                      # this rank's own clock (the line quotes the maximum over the ranks)
     if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -543,6 +544,40 @@ def main():
                                  "torch.distributed (dist.ShardedScorer)") if multi else None),
     }
 
+    # ---- N > 1: what each rank saw, so that the first run on a real multi-GPU node can be read -- per rank the timed region's
+    # step, the score launch alone, the all-reduce alone (both with a host wait each: latencies, not the pipelined step)
+    per_rank = None
+    if multi:
+        try:
+            kd = max(5, min(20, args.steps))
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(kd):
+                if hi > lo:
+                    L.check(lib.rh_score_batch_dev(tcloud._h, (sbatch if points_mode else batch).slice_ptr(0 if points_mode else lo),
+                                                   (b_global if points_mode else hi - lo), C.byref(cp),
+                                                   C.c_void_p(counts.data_ptr() + (0 if points_mode else 4 * lo)), None))
+            L.check(lib.rh_cloud_sync(tcloud._h))
+            torch.cuda.synchronize()
+            t_score_alone = (time.perf_counter() - t1) / kd
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(kd):
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+            t_ar_alone = (time.perf_counter() - t1) / kd
+            mine = torch.tensor([float(rank), 1e3 * dt_rank / args.steps, 1e3 * t_score_alone, 1e3 * t_ar_alone], dtype=torch.float64, device="cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [{"rank": int(v[0].item()), "ms_per_step_timed_region": float(v[1].item()), "ms_score_launch_alone": float(v[2].item()),
+                         "ms_allreduce_alone": float(v[3].item())} for v in allr]
+            fence()
+        except Exception as e:   # diagnostics never take the headline down
+            per_rank = [{"error": repr(e)[:300]}]
+            fence()
+    out["per_rank"] = per_rank
+
     # ---- N > 1, end to end: ONE scene run by all ranks together (rh_ransac_mp: the minimal sets of every iteration are
     # dealt round-robin to the ranks, windows' candidate lists exchanged through host shared memory, extractions
     # replicated).  Strong scaling: the same scene, the same result as one GPU, bit for bit.
@@ -573,6 +608,10 @@ def main():
                 times.append(time.perf_counter() - t0)
             dm = digest(gm, sm)
             nshapes = len(gm)
+            split = torch.tensor([float(rank), times[-1], sm["seconds"], sm["seconds_score"], sm["seconds_extract"], sm["seconds_host"]],
+                                 dtype=torch.float64, device="cuda")
+            splits = [torch.zeros_like(split) for _ in range(world)]
+            dist.all_gather(splits, split)
             del gm
             grp.close()
             tt = torch.tensor(times, dtype=torch.float64, device="cuda")
@@ -591,6 +630,9 @@ def main():
                            "runs": len(times), "seconds_all_runs_slowest_rank": [float(x) for x in tt.tolist()],
                            "seconds_one_gpu_same_scene": t_one, "speedup_vs_one_gpu": t_one / tmed, "scaling": "strong",
                            "iterations": sm["iterations"], "candidates_scored": sm["candidates_scored"],
+                           "per_rank_last_run": [{"rank": int(v[0].item()), "wall_s": float(v[1].item()), "rh_ransac_s": float(v[2].item()),
+                                                  "windows_score_s": float(v[3].item()), "extractions_s": float(v[4].item()),
+                                                  "sample_fit_and_exchange_s": float(v[5].item())} for v in splits],
                            "note": "ONE scene, all ranks together (rh_ransac_mp): every rank returned the single-GPU result bit for "
                                    "bit (checked in this run); median over runs of the slowest rank's wall time"}
             pc.enable_all()

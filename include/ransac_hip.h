@@ -194,6 +194,15 @@ int rh_fit(int kind, const double *p, const double *n, int32_t lp, const rh_para
 int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm,
                rh_shape *out, int32_t *fitted);
 
+/* forcefitshapes! (src/fitting.jl:165-173) for the k minimal sets of an iteration in one call (what rh_sample_sets drew):
+ * fit(T, ...) for every type of p->shape_types, in that order, on every set with ok[j] != 0 (ok = NULL: every set); the shapes
+ * that fit are appended to shapes_out in (set, type) order -- the reference's candidate order -- with set_out[i] = the set a
+ * shape came from.  xyz_aos / nrm_aos: the cloud's host arrays (n x 3 doubles; for f32 != 0 they hold a Float32 cloud's values
+ * and the fits run in binary32, rh_fit_f32).  Host-side, O(1) per set.  RH_E_CAPACITY with *n_out = the needed size. */
+int rh_fit_sets(const double *xyz_aos, const double *nrm_aos, const int64_t *idx_1based, const int32_t *ok_or_null, int32_t k,
+                int32_t drawN, const rh_params *p, int32_t f32, rh_shape *shapes_out, int32_t *set_out_or_null, int32_t cap,
+                int32_t *n_out);
+
 /* estimatescore / ConfidenceInterval (src/confidenceintervals.jl:71-74, 53-59, 1-6) */
 int rh_estimatescore(int64_t S1length, int64_t Plength, int64_t sigma, int32_t score_mode,
                      double *ci_min, double *ci_max, double *ci_E);

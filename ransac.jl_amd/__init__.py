@@ -9,7 +9,7 @@ from .api import (DEFAULT_PARAMETERS, DEFAULT_SHAPE_DICT, ConfidenceInterval, E,
                   defaultcommonparameters, defaultiterationparameters, defaultparameters,
                   defaultshapeparameters, estimatescore, fit, invalidate_indexes, largestconncomp,
                   notsoconfident, params_to_c, prob, ransac, ransacparameters, MpGroup, refit, refit_lsq, score_batch,
-                  scorecandidate, select_enabled, sample_sets, shape_f32, shape_from_c, strt, buildoctree, octreedepth, findleaf,
+                  scorecandidate, select_enabled, sample_sets, fit_sets, shape_f32, shape_from_c, strt, buildoctree, octreedepth, findleaf,
                   getnthcell, iswithinrectangle, cell_enabled_points, OctreeCell, set_option, get_option, option)
 
 from .io import exportJSON, readconfig, toDict

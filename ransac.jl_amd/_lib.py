@@ -91,6 +91,7 @@ SIGNATURES = {
     "rh_invalidate": (C.c_int, [_vp, _i64p, C.c_int64]),
     "rh_select_enabled": (C.c_int, [_vp, _i64p, C.c_int32, _i64p]),
     "rh_sample_sets": (C.c_int, [_vp, C.c_int32, C.POINTER(Rng), C.c_int32, _i64p, _i32p, _i32p]),
+    "rh_fit_sets": (C.c_int, [_dp, _dp, _i64p, _i32p, C.c_int32, C.c_int32, _pp, C.c_int32, _sp, _i32p, C.c_int32, _i32p]),
     "rh_fit": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
     "rh_fit_f32": (C.c_int, [C.c_int, _dp, _dp, C.c_int32, _pp, _sp, _i32p]),
     "rh_estimatescore": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, _dp, _dp, _dp]),

@@ -754,6 +754,25 @@ def sample_sets(pc, drawN, rng, k):
     return idx[:k], ok[:k].astype(bool), lev[:k]
 
 
+def fit_sets(pc, sets, ok, params):
+    """forcefitshapes! (fitting.jl:165-173) over the minimal sets of an iteration in one call (rh_fit_sets): returns (list of
+    rh_shape in candidate order, index of the set each came from)."""
+    sets = np.ascontiguousarray(sets, dtype=np.int64)
+    k, drawN = sets.shape
+    okc = None if ok is None else np.ascontiguousarray(ok, dtype=np.int32)
+    cp = _cparams(params)
+    cap = max(1, k * max(1, cp.n_shape_types))
+    arr = (L.Shape * cap)()
+    so = np.zeros(cap, dtype=np.int32)
+    n = C.c_int32()
+    f32 = bool(getattr(pc, "is_f32", False))
+    xyz = pc.vertices if not f32 else np.ascontiguousarray(pc.vertices32, dtype=np.float64)
+    nrm = pc.normals if not f32 else np.ascontiguousarray(pc.normals32, dtype=np.float64)
+    check(lib().rh_fit_sets(_p(xyz, C.c_double), _p(nrm, C.c_double), _p(sets, C.c_int64), None if okc is None else _p(okc, C.c_int32),
+                            k, drawN, C.byref(cp), 1 if f32 else 0, arr, _p(so, C.c_int32), cap, C.byref(n)))
+    return [arr[i] for i in range(n.value)], so[: n.value]
+
+
 class _ResultOwner:
     """Keeps an rh_result (and with it the pinned block of index lists) alive; frees it on collection."""
 

@@ -124,7 +124,7 @@ def build(force=False, verbose=False, variant="product", out=None, extra_flags=N
         for (src, obj, cmd, _k, _v) in work:
             with open(obj + ".key", "w") as f:
                 f.write(_digest([src] + hdrs, " ".join(flags)) + "\n")
-    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [w[1] for w in work] + ["-ldl", "-o", so + ".tmp"]
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [w[1] for w in work] + ["-ldl", "-lpthread", "-o", so + ".tmp"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

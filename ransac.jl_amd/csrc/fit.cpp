@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "fit_shared.h"
@@ -91,7 +92,7 @@ extern "C" int rh_fit(int kind, const double *p, const double *n, int32_t lp, co
 }
 
 // fit on a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): p / n hold the Float32 values (as
-// doubles, exactly); the fit runs in binary32 (fit_shared.h) and its shape holds binary32 numbers.  Cones: not available
+// doubles, exactly); the fit runs in binary32 (fit_shared.h) and its shape holds binary32 numbers
 extern "C" int rh_fit_f32(int kind, const double *p, const double *n, int32_t lp, const rh_params *prm, rh_shape *out,
                           int32_t *fitted)
 {
@@ -165,6 +166,76 @@ static uint64_t rng_next(rh_rng *r)
     s[2] ^= t;
     s[3] = rotl64(s[3], 45);
     return result;
+}
+
+// forcefitshapes! (fitting.jl:165-173) for the minimal sets of an iteration in one call (the sets rh_sample_sets drew): fit for
+// every type of p->shape_types in order on every set with ok != 0; what fits is appended with the index of its set.  The sets
+// are independent: from 2048 sets on they are dealt to host threads in contiguous ranges and the ranges' results joined in
+// order, so the output does not depend on the number of threads.
+namespace {
+struct FitSetsOut { std::vector<rh_shape> shapes; std::vector<int32_t> sets; int rc = RH_OK; };
+void fit_sets_range(const double *xyz, const double *nrm, const int64_t *idx, const int32_t *ok, int32_t j0, int32_t j1, int32_t drawN,
+                    const rh_params *prm, int32_t f32, FitSetsOut *o)
+{
+    double fp[48], fn[48];
+    for (int32_t j = j0; j < j1; j++) {
+        if (ok != nullptr && ok[j] == 0) continue;
+        for (int q = 0; q < drawN; q++) {
+            const int64_t i = idx[(int64_t)j * drawN + q];
+            if (i < 1) { o->rc = RH_E_INVALID; return; }
+            for (int a = 0; a < 3; a++) { fp[3 * q + a] = xyz[3 * (i - 1) + a]; fn[3 * q + a] = nrm[3 * (i - 1) + a]; }
+        }
+        for (int t = 0; t < prm->n_shape_types; t++) {
+            rh_shape s;
+            memset(&s, 0, sizeof s);
+            bool fitted = false;
+            switch (prm->shape_types[t]) {
+            case RH_PLANE: fitted = f32 ? fit_plane32(fp, fn, drawN, *prm, &s) : fit_plane(fp, fn, drawN, *prm, &s); break;
+            case RH_SPHERE: fitted = f32 ? fit_sphere32(fp, fn, drawN, *prm, &s) : fit_sphere(fp, fn, drawN, *prm, &s); break;
+            case RH_CYLINDER: fitted = f32 ? fit_cylinder32(fp, fn, drawN, *prm, &s) : fit_cylinder(fp, fn, drawN, *prm, &s); break;
+            case RH_CONE: fitted = f32 ? fit_cone32(fp, fn, drawN, *prm, &s) : fit_cone(fp, fn, drawN, *prm, &s); break;
+            default: o->rc = RH_E_INVALID; return;
+            }
+            if (fitted) { o->shapes.push_back(s); o->sets.push_back(j); }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int rh_fit_sets(const double *xyz, const double *nrm, const int64_t *idx, const int32_t *ok, int32_t k, int32_t drawN,
+                           const rh_params *prm, int32_t f32, rh_shape *shapes_out, int32_t *set_out, int32_t cap, int32_t *n_out)
+{
+    if (!xyz || !nrm || (k > 0 && !idx) || !prm || !n_out || k < 0 || cap < 0 || (cap > 0 && !shapes_out)) { rh_set_error("rh_fit_sets: bad arguments"); return RH_E_INVALID; }
+    if (drawN < 3 || drawN > 16) { rh_set_error("rh_fit_sets: drawN=%d outside 3..16", drawN); return RH_E_INVALID; }
+    if (prm->n_shape_types < 0 || prm->n_shape_types > 8) { rh_set_error("rh_fit_sets: bad n_shape_types"); return RH_E_INVALID; }
+    *n_out = 0;
+    try {
+        unsigned nt = 1;
+        if (k >= 2048) { nt = std::thread::hardware_concurrency(); nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt); }
+        std::vector<FitSetsOut> outs(nt);
+        if (nt == 1) {
+            fit_sets_range(xyz, nrm, idx, ok, 0, k, drawN, prm, f32, &outs[0]);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) {
+                const int32_t j0 = (int32_t)((int64_t)k * t / nt), j1 = (int32_t)((int64_t)k * (t + 1) / nt);
+                th.emplace_back(fit_sets_range, xyz, nrm, idx, ok, j0, j1, drawN, prm, f32, &outs[t]);
+            }
+            for (auto &x : th) x.join();
+        }
+        int32_t nout = 0;
+        for (const FitSetsOut &o : outs) {
+            if (o.rc != RH_OK) { rh_set_error("rh_fit_sets: a set holds an index below 1, or shape_types an unknown kind"); return o.rc; }
+            for (size_t i = 0; i < o.shapes.size(); i++, nout++)
+                if (nout < cap) { shapes_out[nout] = o.shapes[i]; if (set_out) set_out[nout] = o.sets[i]; }
+        }
+        *n_out = nout;
+        if (nout > cap) { rh_set_error("rh_fit_sets: %d shapes fitted, capacity %d", nout, cap); return RH_E_CAPACITY; }
+    } catch (const std::exception &) {
+        rh_set_error("rh_fit_sets: out of host memory or threads");
+        return RH_E_NOMEM;
+    }
+    return RH_OK;
 }
 
 uint64_t rh_rng_next_raw(rh_rng *r) { return rng_next(r); }   // rh_sample_sets (cloud.hip): the raw draws rh_rng_range scales

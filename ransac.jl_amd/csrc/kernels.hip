@@ -1034,7 +1034,10 @@ int rhk_prep_binned(rh_cloud *c, const rh_shape *d_shapes, int32_t b, rh_prep *d
     int32_t *zx = c->zero_extra;
     const int32_t zxn = c->zero_extra_n;
     c->zero_extra = nullptr; c->zero_extra_n = 0;
-    hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, 256)), dim3(256), 0, c->stream, d_shapes, b, d_prep, d_orig,
+#ifndef RH_PREP_BLOCK
+#define RH_PREP_BLOCK 64   // (one wave per block: the launch is a latency chain -- shape, bin reservation, divisions, records -- and 64 blocks spread it over 64 CUs: cfg3 step 0.0860 -> 0.0846 ms, cfg2 0.0431 -> 0.0421; 128: the same; 256: round 4)
+#endif
+    hipLaunchKernelGGL(prep_binned_kernel, dim3(cdiv(b, RH_PREP_BLOCK)), dim3(RH_PREP_BLOCK), 0, c->stream, d_shapes, b, d_prep, d_orig,
                        d_nk, cap, d_counts_to_zero, d_nk_other, no_spread ? 1 : rh_spread_multiplier(b),
                        c->qpre_v4 ? (rh4::rh_cls *)c->d_qpre : (rh4::rh_cls *)nullptr, QA, zx, zxn);
     RH_HIP(hipGetLastError());

@@ -52,8 +52,8 @@ constexpr int S4_GB = 2;                 // bits of the group in a pair-list ent
 constexpr unsigned S4_GM = (1u << S4_GB) - 1u;
 constexpr int S4_ROW = 65;               // padded row length of the tile arrays (bank spread of the per-lane rows)
 constexpr int S4_W = 4;                  // waves per block
-// R: 64-candidate chunks per block -- 8 on large subsets (cfg3: 0.108 ms; 4: 0.120, 12: 0.107, 16: 0.116), 4 where the
-// grid would otherwise be a few hundred blocks
+// R: 64-candidate chunks per block row -- 16 / 12 / 4 / 2 by the size of the grid (rhk_score4_all holds the rule and the
+// measurements behind it)
 template <int R, bool MASK = false>
 struct S4Shared {
     static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && (R % S4_W == 0 || R < S4_W), "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
@@ -762,30 +762,36 @@ cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
 // a row of up to 8192 words (524 288 subset points) is ONE segment (64 KB of LDS); longer rows are cut into segments of 3072
 // words (cfg5, 24 415 words per row, masks step: 8192 -> 0.883 ms, 6144 0.851, 4096 0.848, 3072 0.828, 2560 0.839, 2048 0.847,
 // 1536 0.891: smaller segments mean more blocks per CU for a chain of dependent loads, and more passes over the entries)
-constexpr int S4_UNP_WORDS = 8192, S4_UNP_WORDS_MULTI = 3072;
+#ifndef RH_UNP_BLOCK
+#define RH_UNP_BLOCK 512      // threads per block of the multi-segment form
+#endif
+#ifndef RH_UNP_MULTI
+#define RH_UNP_MULTI 3072     // words per output segment of rows that need several
+#endif
+constexpr int S4_UNP_WORDS = 8192, S4_UNP_WORDS_MULTI = RH_UNP_MULTI;
 constexpr int S6_UNROLL = 4;
 
 // WAVEWORD (rows of one segment): a wave per entry, a lane per bit -- the word's 64 positions are one coalesced load and
 // every set bit lands in the block's segment; four entries in flight per wave (round 3's inner loop, fed from the list)
-template <bool WAVEWORD>
-__global__ void __launch_bounds__(512)
+template <bool WAVEWORD, int BLK = 512>
+__global__ void __launch_bounds__(BLK)
 unpermute6_kernel(const rh_u64x2 *__restrict__ ent, const int32_t *__restrict__ cursor, int64_t mstride, const int32_t *__restrict__ perm,
                   int64_t swords, int64_t seg_words, const uint64_t *__restrict__ segmask, int64_t smstride, uint64_t *__restrict__ out)
 {
     extern __shared__ unsigned long long seg[];
-    __shared__ uint32_t ring[8][128];
+    __shared__ uint32_t ring[BLK / 64][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t row = blockIdx.x;
     const int64_t w0 = (int64_t)blockIdx.y * seg_words;
     const int nw = (int)(swords - w0 < seg_words ? swords - w0 : seg_words);
-    for (int t = threadIdx.x; t < nw; t += 512) seg[t] = 0ULL;
+    for (int t = threadIdx.x; t < nw; t += BLK) seg[t] = 0ULL;
     const int n = min(cursor[row], (int32_t)mstride);
     __syncthreads();
     const int32_t lo = (int32_t)(w0 << 6), span = nw << 6;
     const rh_u64x2 *__restrict__ src = ent + row * mstride;
     const uint64_t *__restrict__ sm = segmask != nullptr ? segmask + (int64_t)blockIdx.y * smstride : nullptr;
     if (WAVEWORD) {
-        for (int i0 = wv * 4; i0 < n; i0 += 8 * 4) {
+        for (int i0 = wv * 4; i0 < n; i0 += (BLK / 64) * 4) {
             rh_u64x2 e[4];
             int32_t j[4];
 #pragma unroll
@@ -799,7 +805,7 @@ unpermute6_kernel(const rh_u64x2 *__restrict__ ent, const int32_t *__restrict__ 
         }
         __syncthreads();
         uint64_t *__restrict__ dstw = out + row * swords + w0;
-        for (int t = threadIdx.x; t < nw; t += 512) dstw[t] = seg[t];
+        for (int t = threadIdx.x; t < nw; t += BLK) dstw[t] = seg[t];
         return;
     }
     int head = 0, fill = 0;   // the wave's ring (wave-uniform)
@@ -813,11 +819,11 @@ unpermute6_kernel(const rh_u64x2 *__restrict__ ent, const int32_t *__restrict__ 
         head = (head + k) & 127;
         fill -= k;
     };
-    for (int i0 = threadIdx.x; i0 - lane < n; i0 += 512 * S6_UNROLL) {   // (whole waves stay in the loop: ballots)
+    for (int i0 = threadIdx.x; i0 - lane < n; i0 += BLK * S6_UNROLL) {   // (whole waves stay in the loop: ballots)
         rh_u64x2 e[S6_UNROLL];
 #pragma unroll
         for (int k = 0; k < S6_UNROLL; k++) {
-            const int i = i0 + k * 512;
+            const int i = i0 + k * BLK;
             e[k].x = 0; e[k].y = 0;
             if (i < n) e[k] = src[i];
         }
@@ -844,7 +850,7 @@ unpermute6_kernel(const rh_u64x2 *__restrict__ ent, const int32_t *__restrict__ 
     if (fill > 0) drain(fill);
     __syncthreads();
     uint64_t *__restrict__ dst = out + row * swords + w0;
-    for (int t = threadIdx.x; t < nw; t += 512) dst[t] = seg[t];
+    for (int t = threadIdx.x; t < nw; t += BLK) dst[t] = seg[t];
 }
 
 __global__ void clear_cursors_kernel(int32_t *__restrict__ cursor, int32_t b)
@@ -1176,7 +1182,7 @@ int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int6
     const int nseg = cdiv4(c->swords, seg_words);
     static bool attr_set = false;
     if (!attr_set) {
-        RH_HIP(hipFuncSetAttribute((const void *)unpermute6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
+        RH_HIP(hipFuncSetAttribute((const void *)unpermute6_kernel<false, RH_UNP_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
         RH_HIP(hipFuncSetAttribute((const void *)unpermute6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint64_t) * 16384)));
         attr_set = true;
     }
@@ -1198,7 +1204,7 @@ int rhk_unpermute_masks4(rh_cloud *c, const uint64_t *d_in, uint8_t *d_occ, int6
         hipLaunchKernelGGL(unpermute6_kernel<true>, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream,
                            (const rh_u64x2 *)d_in, (const int32_t *)d_occ, mstride, c->sub_perm, c->swords, seg_words, sm, c->ng_pad, d_out);
     else
-        hipLaunchKernelGGL(unpermute6_kernel<false>, dim3((unsigned)b, (unsigned)nseg), dim3(512), sizeof(uint64_t) * (size_t)seg_words, c->stream,
+        hipLaunchKernelGGL((unpermute6_kernel<false, RH_UNP_BLOCK>), dim3((unsigned)b, (unsigned)nseg), dim3(RH_UNP_BLOCK), sizeof(uint64_t) * (size_t)seg_words, c->stream,
                            (const rh_u64x2 *)d_in, (const int32_t *)d_occ, mstride, c->sub_perm, c->swords, seg_words, sm, c->ng_pad, d_out);
     hipLaunchKernelGGL(clear_cursors_kernel, dim3((unsigned)cdiv4(b, 256)), dim3(256), 0, c->stream, (int32_t *)d_occ, b);
     RH_HIP(hipGetLastError());

@@ -362,3 +362,46 @@ def test_diag_library_exports_the_diag_header_and_knows_the_switches():
         assert R.lib("product").rh_get_option(None, b"s4_rows", C.byref(v), C.byref(st)) == 0 and st.value == 0
     finally:
         del os.environ["RH_S4_R"]
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_fit_sets_equals_forcefitshapes_per_set(f32):
+    """rh_fit_sets = forcefitshapes! (fitting.jl:165-173) over the minimal sets of an iteration in one call: the shapes that fit, in
+    (set, type) order -- the reference's candidate order -- bit for bit what per-set rh_fit / rh_fit_f32 calls return."""
+    from ransac_jl_amd import synth
+    xyz, nrm, truth = synth.make_cloud(3000, ["plane", "sphere", "cylinder", "cone"], 0.1, seed=4)
+    if f32:
+        xyz, nrm = xyz.astype(np.float32).astype(np.float64), nrm.astype(np.float32).astype(np.float64)
+    rs = np.random.default_rng(1)
+    nsets = 2600                     # (from 2048 sets on the call deals them to host threads: the order must not change)
+    sets = rs.integers(1, 3001, size=(nsets, 3)).astype(np.int64)
+    for j in range(0, nsets, 2):    # neighbours in the cloud lie on one primitive: these sets fit often
+        b = int(rs.integers(1, 2900))
+        sets[j] = [b, b + 1, b + 2]
+    ok = (rs.random(nsets) < 0.9).astype(np.int32)
+    types = [R.FittedPlane, R.FittedCone, R.FittedCylinder, R.FittedSphere]
+    cp = R.params_to_c(R.ransacparameters(types))
+
+    class PC:
+        vertices, normals, is_f32 = xyz, nrm, f32
+        vertices32, normals32 = xyz.astype(np.float32), nrm.astype(np.float32)
+    shapes, so = R.fit_sets(PC, sets, ok, cp)
+    ref = []
+    fit = R.lib().rh_fit_f32 if f32 else R.lib().rh_fit
+    for j, sd in enumerate(sets):
+        if not ok[j]:
+            continue
+        p, n = np.ascontiguousarray(xyz[sd - 1]), np.ascontiguousarray(nrm[sd - 1])
+        for T in types:
+            out, okf = L.Shape(), C.c_int32()
+            L.check(fit(R.api._KIND_OF[T], p.ctypes.data_as(C.POINTER(C.c_double)), n.ctypes.data_as(C.POINTER(C.c_double)), 3, C.byref(cp), C.byref(out), C.byref(okf)))
+            if okf.value:
+                ref.append((j, bytes(out)))
+    assert len(ref) >= 10 and len(shapes) == len(ref)
+    assert [(int(so[i]), bytes(shapes[i])) for i in range(len(ref))] == ref
+    # capacity: the needed size comes back
+    n_out = C.c_int32()
+    arr = (L.Shape * 1)()
+    rc = R.lib().rh_fit_sets(xyz.ctypes.data_as(C.POINTER(C.c_double)), nrm.ctypes.data_as(C.POINTER(C.c_double)), sets.ctypes.data_as(C.POINTER(C.c_int64)),
+                             None, nsets, 3, C.byref(cp), 0, arr, None, 1, C.byref(n_out))
+    assert rc == L.RH_E_CAPACITY and n_out.value > 1

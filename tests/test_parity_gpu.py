@@ -2,6 +2,7 @@
 inputs.  Integer / index outputs must be bit-exact (counts, masks, inlier index lists)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1088,3 +1089,23 @@ def test_sample_sets_equals_sequential_calls(small_scene, drawN, frac, inject):
     if frac >= 0.02:
         assert ok.sum() > 250
     pc.enable_all()
+
+
+def test_reference_loop_with_call_sites_swapped_at_cfg3_scale(score_path, monkeypatch):
+    """The drop-in a RANSAC.jl maintainer would try first, at BASELINE configs[2] scale (tools/callsite_loop.py): the reference's
+    own loop on the host with scorecandidates! / refit / invalidate_indexes! served by the library and every iteration's 4096
+    minimal sets drawn by ONE rh_sample_sets launch and fitted by ONE rh_fit_sets call.  (With a select round trip per point
+    -- round 4 -- this loop ran at 1.6 shapes/s.)  All 40 primitives come out; the throughput is printed and held above a floor
+    that leaves room for a slow box."""
+    if score_path != "groups":
+        pytest.skip("one pass is enough for a throughput figure")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import callsite_loop
+    monkeypatch.setenv("MINSUBSET", "4096")
+    monkeypatch.setenv("ITERMAX", "300")
+    st = callsite_loop.main(quiet=True)
+    sys.stderr.write("\n[call-site loop, cfg3 scale] %d shapes in %.3f s = %.1f shapes/s (sampling %.3f, fits %.3f, scoring %.3f, extractions %.3f s)\n"
+                     % (st["shapes"], st["seconds"], st["shapes"] / st["seconds"], st["sample_s"], st["fit_s"], st["score_s"], st["extract_s"]))
+    assert st["shapes"] == 40 and st["inliers"] > 6_500_000
+    assert st["shapes"] / st["seconds"] > 40.0

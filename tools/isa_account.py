@@ -85,7 +85,9 @@ def classify(op):
         return "lane"
     if o.startswith("v_mov") or o.startswith("v_accvgpr") or o.startswith("v_swap"):
         return "mov"
-    if re.match(r"v_(and|or|xor|not|lshlrev|lshrrev|ashrrev|add|sub|subrev|add_co|sub_co|subrev_co)_(b32|u32|i32|nc_u32|u16|i16|b16)", o) or \
+    if re.match(r"v_(lshlrev|lshrrev|ashrrev)_(b32|i32|b16|i16)", o):
+        return "int_slow"                       # (shifts hold the port 4.1-4.2 cycles like the other slow integer operations: ubench_count_seq.txt)
+    if re.match(r"v_(and|or|xor|not|add|sub|subrev|add_co|sub_co|subrev_co)_(b32|u32|i32|nc_u32|u16|i16|b16)", o) or \
             re.match(r"v_(add|sub|subrev)_(co_)?u32", o) or o.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32")):
         return "int_fast"
     if o.startswith("v_"):
@@ -97,11 +99,13 @@ def classify(op):
 PRICE_GUIDE = {   # /opt/skills/guides/MI355X_MICROARCH.md: 32-bit VALU 2 (several waves per SIMD), FP64 4, transcendental 8 / 16
     "fma_f32": 2, "add_f32": 2, "mul_f32": 2, "minmax": 2, "cmp": 2, "cndmask": 2, "int_slow": 2, "int_fast": 2, "mbcnt": 2, "lane": 2, "mov": 2,
     "valu_other": 2, "cvt": 2, "trans_f32": 8, "fma_f64": 4, "mul_f64": 4, "add_f64": 4, "trans_f64": 16, "mfma": 16}
-PRICE_MEASURED = {   # tools/ubench/valu_rates.hip + count_seq.hip on this GPU, 8 waves per SIMD (profiles/r3/ubench_valu_rates.txt, r4/ubench_count_seq.txt)
-    "fma_f32": 2.45, "add_f32": 2.3, "mul_f32": 2.3, "minmax": 4.2, "cmp": 4.2, "cndmask": 4.3, "int_slow": 4.2, "int_fast": 2.3, "mbcnt": 4.2, "lane": 4.2,
-    "mov": 2.3, "valu_other": 4.2, "cvt": 4.3, "trans_f32": 8.15, "fma_f64": 4.75, "mul_f64": 4.3, "add_f64": 4.2, "trans_f64": 16.2, "mfma": 16}
-# classes measured directly on this GPU (the others -- mbcnt, lane, mov, valu_other -- are priced by analogy: the residual error bar)
-MEASURED_DIRECTLY = {"fma_f32", "add_f32", "mul_f32", "minmax", "cmp", "cndmask", "int_slow", "int_fast", "cvt", "trans_f32", "fma_f64", "mul_f64", "add_f64", "trans_f64"}
+PRICE_MEASURED = {   # tools/ubench/valu_rates.hip + count_seq.hip on this GPU, 8 waves per SIMD (profiles/r3/ubench_valu_rates.txt, r5/ubench_count_seq.txt)
+    "fma_f32": 2.45, "add_f32": 2.3, "mul_f32": 2.3, "minmax": 4.2, "cmp": 4.2, "cndmask": 4.2, "int_slow": 4.2, "int_fast": 2.45, "mbcnt": 4.2, "lane": 4.2,
+    "mov": 2.3, "valu_other": 4.2, "cvt": 4.2, "trans_f32": 8.15, "fma_f64": 4.75, "mul_f64": 4.3, "add_f64": 4.2, "trans_f64": 16.2, "mfma": 16}
+# classes measured directly on this GPU (round 5 added moves, v_mbcnt, v_readlane / v_readfirstlane, DPP moves, shifts, v_add3, v_and, v_add_u32 and
+# v_cvt_f32_f64 to count_seq.hip); `valu_other` -- whatever opcode none of the patterns above knows -- is priced by analogy: the residual error bar
+MEASURED_DIRECTLY = {"fma_f32", "add_f32", "mul_f32", "minmax", "cmp", "cndmask", "int_slow", "int_fast", "cvt", "trans_f32", "fma_f64", "mul_f64", "add_f64", "trans_f64",
+                     "mov", "mbcnt", "lane"}
 VALU_CLASSES = set(PRICE_GUIDE)
 SALU_PRICE = 4.2   # a scalar ALU instruction, per SIMD (one scalar unit per CU shared by four SIMDs): valu_rates.hip
 

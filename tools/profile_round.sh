@@ -6,6 +6,9 @@
 #            3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, three SQ passes of 8 counters
 #               (ONLY=sq3: the third one alone, the instruction classes).
 #   cfg5:    the same stats + PMC passes for `--workload cfg5` (50M points, cones; the 50M-point refit scan).
+#   cfg2:    the same for `--workload cfg2` (BASELINE configs[1]: 1M points, 6 dense primitives).
+#   stats:   the diag build's event counters of one score launch per workload (tools/s4_stats.py -> s4_stats_<wl>.json) and the
+#            issue-rate microbenchmark (tools/ubench/count_seq): the dynamic side and the prices of tools/isa_account.py.
 # The program itself follows `--` (no env / bash -c hop: the profiler's library has initialised the GPU by then).
 # Output: gpurun_out/prof_<round>/ (tools/collect_profiles.py copies what is to be judged into profiles/<round>/).
 set -e
@@ -17,9 +20,14 @@ mkdir -p "$OUT"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"
 SQ3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM"
 SQ2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+if [ "$WHAT" = "stats" ]; then
+    for w in cfg2 cfg3 cfg5; do WL=$w python tools/s4_stats.py > "$OUT/s4_stats_$w.log" 2>&1; cp gpurun_out/s4_stats_$w.json "$OUT/"; echo "stats $w done"; done
+    timeout -k 10 300 tools/ubench/count_seq > "$OUT/ubench_count_seq.txt" 2>&1
+    echo "ubench done"; exit 0
+fi
 if [ "$ONLY" = "sq3" ]; then
     cd /tmp && export TMPDIR=/tmp
-    if [ "$WHAT" = "default" ]; then B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"; SFX=""; else B="$ROOT/bench.py --workload cfg5 --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"; SFX="_cfg5"; fi
+    if [ "$WHAT" = "default" ]; then B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"; SFX=""; else B="$ROOT/bench.py --workload $WHAT --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"; SFX="_$WHAT"; fi
 elif [ "$WHAT" = "default" ]; then
     python bench.py --detail-out "$OUT/bench_default_detail.json" > "$OUT/bench_default_unprofiled.json" 2> "$OUT/bench_default.err"
     echo "bench done"
@@ -32,14 +40,19 @@ elif [ "$WHAT" = "default" ]; then
     echo "stats 2 done"
 else
     cd /tmp && export TMPDIR=/tmp
-    B="$ROOT/bench.py --workload cfg5 --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"
-    SFX="_cfg5"
+    B="$ROOT/bench.py --workload $WHAT --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"
+    SFX="_$WHAT"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only$SFX" -- python3 $B --no-e2e --steps 60 --warmup 10 --detail-out "$OUT/bench_score_only_under_rocprof${SFX}_detail.json" > "$OUT/bench_score_only_under_rocprof$SFX.json" 2> "$OUT/score_only$SFX.err"
-    echo "stats cfg5 done"
+    echo "stats $WHAT done"
 fi
 S="$B --no-e2e --steps 3 --warmup 1 --prewarm-ms 0 --detail-out $OUT/pmc_detail$SFX.json"
 rocprofv3 --kernel-trace --pmc $SQ3 --output-format csv -d "$OUT/pmc_sq3$SFX" -- python3 $S > "$OUT/pmc_sq3$SFX.json" 2> "$OUT/pmc_sq3$SFX.err"
 echo "pmc sq3 done"
+if [ "$WHAT" = "stats" ]; then
+    for w in cfg2 cfg3 cfg5; do WL=$w python tools/s4_stats.py > "$OUT/s4_stats_$w.log" 2>&1; cp gpurun_out/s4_stats_$w.json "$OUT/"; echo "stats $w done"; done
+    timeout -k 10 300 tools/ubench/count_seq > "$OUT/ubench_count_seq.txt" 2>&1
+    echo "ubench done"; exit 0
+fi
 if [ "$ONLY" = "sq3" ]; then find "$OUT" -name '*kernel_trace.csv' -delete; exit 0; fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch$SFX" -- python3 $S > "$OUT/pmc_fetch$SFX.json" 2> "$OUT/pmc_fetch$SFX.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write$SFX" -- python3 $S > "$OUT/pmc_write$SFX.json" 2> "$OUT/pmc_write$SFX.err"
