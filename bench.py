@@ -60,6 +60,9 @@ def parse():
                     help="N > 1 partitioning: candidates (each rank scores its 4096 of the N x 4096 batch on a replica "
                          "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
                          "on its 1/N slice of subset 1; the all-reduce is a true sum)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="N = 1: batches in flight (rh_set_option batches_in_flight): each batch's launches start while the previous "
+                         "batch's launch drains; 1 = one batch at a time")
     ap.add_argument("--spread-regions", type=int, default=5,
                     help="after the timed region, repeat the same K-step region this many times and report min / median / max of the "
                          "metric as `value_spread` (the headline `value` stays the first region)")
@@ -455,6 +458,13 @@ def main():
         torch.cuda.synchronize()
         lib_k = [0]
 
+    # N = 1: --in-flight F batches in flight, F count buffers in turn (batches_in_flight, include/ransac_hip.h)
+    in_flight = 1 if multi else max(1, min(4, args.in_flight))
+    ring = [counts] + [torch.zeros_like(counts) for _ in range(in_flight - 1)]
+    ring_k = [0]
+    if in_flight > 1:
+        R.set_option("batches_in_flight", in_flight, cloud=pc)
+
     def step():
         if libcomm is not None:
             buf = lib_bufs[lib_k[0] & 1]
@@ -467,8 +477,10 @@ def main():
         elif multi:
             rdist.score_batch_sharded(b_global, rank, world, local, counts, same_stream=same_stream)
         else:   # no collective, no host sync inside the timed region
+            buf = ring[ring_k[0] % in_flight]
+            ring_k[0] += 1
             L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp),
-                                           C.c_void_p(counts.data_ptr()), None))
+                                           C.c_void_p(buf.data_ptr()), None))
 
     def fence():
         if libcomm is not None:
@@ -483,12 +495,13 @@ def main():
         torch.cuda.synchronize()
 
     if args.prewarm_ms > 0:   # untimed, before the warm-up steps: bring the clocks up (reported as config.prewarm_ms)
-        for _ in range(int(args.prewarm_ms * 5)):   # ~0.2 ms per step; a fixed count, so every rank does the same
+        for _ in range(int(args.prewarm_ms * 14)):   # ~0.07 ms per step at N = 1 (more at N > 1); a fixed count, so every rank does the same
             step()
         fence()
     for _ in range(args.warmup):
         step()
     fence()
+    ring_k[0] = 0     # (a fence ends a run of batches in flight: the next call is slot 0 again)
     t0 = time.perf_counter()
     L.check(lib.rh_timer_start(tcloud._h))
     for _ in range(args.steps):
@@ -509,6 +522,7 @@ def main():
     spread_vals = []
     for _ in range(max(0, args.spread_regions)):
         fence()
+        ring_k[0] = 0
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -519,6 +533,23 @@ def main():
             dist.all_reduce(tm1, op=dist.ReduceOp.MAX)
             dt1 = float(tm1.item())
         spread_vals.append(b_global * args.steps / dt1)
+    one_in_flight = None
+    if in_flight > 1:   # every buffer of the ring holds the same batch's counts; then the same region one batch at a time
+        for r in ring[1:]:
+            if args.steps >= in_flight and not torch.equal(r, counts):
+                raise SystemExit("PARITY FAILURE: count buffers of the batches in flight differ")
+        R.set_option("batches_in_flight", 1, cloud=pc)
+        vals = []
+        for _ in range(3):
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(0), b_global, C.byref(cp), C.c_void_p(counts.data_ptr()), None))
+            fence()
+            vals.append(1e3 * (time.perf_counter() - t1) / args.steps)
+        one_in_flight = {"ms_per_step": sorted(vals)[1], "value": b_global / (1e-3 * sorted(vals)[1]),
+                         "note": "the same K-step region with batches_in_flight = 1 (median of 3): one batch's prepare + score launches at a time"}
+        R.set_option("batches_in_flight", in_flight, cloud=pc)
     counts_h = (lib_bufs[(lib_k[0] - 1) & 1] if libcomm is not None else
                 scorer.result(scorer.k - 1) if scorer is not None else counts).cpu().numpy()
 
@@ -530,11 +561,12 @@ def main():
                    "points": n, "subset_points": int(S), "candidates_per_step": b_global,
                    "kinds": "%s (cycled over the %d ground-truth primitives, 1%% jitter)"
                             % ("/".join(sorted(set(prim), key=KINDS.index)), len(prim)),
-                   "score_mode": "f64", "prewarm_ms": args.prewarm_ms,
+                   "score_mode": "f64", "prewarm_ms": args.prewarm_ms, "batches_in_flight": in_flight,
                    "parallelism": ("point-sharded x%d (1/%d of subset 1 per GPU, every GPU scores the whole batch), "
                                    "int32 sum all-reduce" % (world, world)) if points_mode
                    else "candidate-sharded x%d, int32 sum all-reduce" % world},
         "tests_per_sec": value * S,
+        "one_batch_in_flight": one_in_flight,
         "value_spread": ({"regions": len(spread_vals), "min": min(spread_vals), "median": sorted(spread_vals)[len(spread_vals) // 2],
                           "max": max(spread_vals), "note": "%d further timed regions of %d steps each, same fences; `value` is the first region"
                                                            % (len(spread_vals), args.steps)} if spread_vals else None),

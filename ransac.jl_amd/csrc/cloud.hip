@@ -178,6 +178,13 @@ static void cloud_free(rh_cloud *c)
     // a caller's stream (rh_cloud_set_stream) may be gone by now: wait for the device instead of the handle
     if (c->stream != c->own_stream) (void)hipDeviceSynchronize();
     else if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (rh_batch_slot &s : c->alt) {
+        if (!s.stream) continue;
+        (void)hipStreamSynchronize(s.stream);
+        (void)hipFree(s.d_shapes); (void)hipFree(s.d_prep); (void)hipFree(s.d_orig); (void)hipFree(s.d_counts); (void)hipFree(s.d_nk2);
+        (void)hipFree(s.d_qpre); (void)hipFree(s.d_prep32); (void)hipFree(s.d_box);
+        (void)hipEventDestroy(s.done); (void)hipEventDestroy(s.start); (void)hipStreamDestroy(s.stream);
+    }
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
@@ -661,11 +668,30 @@ extern "C" int rh_cloud_info(const rh_cloud *c, int64_t *n, int64_t *s, int *dev
     return RH_OK;
 }
 
-static int enter(rh_cloud *c)
+static int enter_nojoin(rh_cloud *c)
 {
     if (!c) { rh_set_error("cloud is NULL"); return RH_E_INVALID; }
     RH_HIP(hipSetDevice(c->device));
     return RH_OK;
+}
+
+// every entry point but the pipelined rh_score_batch_dev: the cloud's stream first waits for what the second batch slot
+// still has in flight ("batches_in_flight" = 2), so everything else sees one stream's order
+int rh_join_batches(rh_cloud *c)
+{
+    for (int i = 0; i < RH_MAX_IN_FLIGHT - 1; i++) {
+        if (c->alt_dirty[i]) RH_HIP(hipStreamWaitEvent(c->stream, c->alt[i].done, 0));
+        c->alt_dirty[i] = false;
+        c->alt_started[i] = false;
+    }
+    c->pipe_k = 0;
+    return RH_OK;
+}
+
+static int enter(rh_cloud *c)
+{
+    RH_TRY(enter_nojoin(c));
+    return rh_join_batches(c);
 }
 
 extern "C" int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t nchunks)
@@ -894,10 +920,19 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     return RH_OK;
 }
 
-static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
-                                int32_t *d_counts, uint64_t *d_masks, float *ms_kind)
+static void swap_batch_slot(rh_cloud *c, rh_batch_slot &s)
 {
-    RH_TRY(enter(c));
+    std::swap(c->stream, s.stream);
+    std::swap(c->batch_cap, s.batch_cap);
+    std::swap(c->d_shapes, s.d_shapes); std::swap(c->d_prep, s.d_prep); std::swap(c->d_orig, s.d_orig); std::swap(c->d_counts, s.d_counts);
+    std::swap(c->d_nk2, s.d_nk2); std::swap(c->d_qpre, s.d_qpre); std::swap(c->d_prep32, s.d_prep32); std::swap(c->d_box, s.d_box);
+    std::swap(c->nk2_flip, s.nk2_flip); std::swap(c->nk2_ready, s.nk2_ready); std::swap(c->qpre_v4, s.qpre_v4);
+}
+
+static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
+                                int32_t *d_counts, uint64_t *d_masks, float *ms_kind, bool joined = true)
+{
+    RH_TRY(joined ? enter(c) : enter_nojoin(c));
     RH_TRY(rh_validate_params(p));
     if (b < 0 || (b > 0 && (!d_shapes || !d_counts))) { rh_set_error("rh_score_batch_dev: bad arguments"); return RH_E_INVALID; }
     const bool product_only = ms_kind && ms_kind[0] < 0.f;   // (profiling passes: no per-kind launches beside the product's)
@@ -959,6 +994,36 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
 extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                                   int32_t *d_counts, uint64_t *d_masks)
 {
+    // "batches_in_flight" = F > 1 (rh_set_option): counts-only batches take turns on the cloud's stream and F - 1 more streams with
+    // workspaces of their own, so batch k + 1's prepare and score launches fill the chip while batch k's launch drains (the
+    // heaviest tile's block sets a launch's length: cfg2 0.042 -> 0.027 ms a batch, cfg3 0.085 -> 0.071 with F = 2).  The
+    // caller gives call k of a run buffer k mod F of F count buffers (the stream that wrote a buffer last writes it next); any other call on the cloud (and rh_cloud_sync /
+    // rh_timer_stop) first makes the cloud's stream wait for the others.
+    const int in_flight = c != nullptr && d_masks == nullptr && b > 0 && c->stream == c->own_stream ? rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) : 1;
+    if (in_flight > 1) {
+        RH_TRY(enter_nojoin(c));
+        const int slot = (int)(c->pipe_k++ % (uint32_t)in_flight);
+        if (slot == 0) return score_batch_dev_impl(c, d_shapes, b, p, d_counts, nullptr, nullptr, false);
+        rh_batch_slot &s = c->alt[slot - 1];
+        if (s.stream == nullptr) {
+            RH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            RH_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+            RH_HIP(hipEventCreateWithFlags(&s.start, hipEventDisableTiming));
+            RH_HIP(hipMalloc((void **)&s.d_nk2, 8 * sizeof(int32_t)));
+        }
+        if (!c->alt_started[slot - 1]) {   // once per pipelined stretch: the stream starts behind what the cloud's stream holds so far
+            RH_HIP(hipEventRecord(s.start, c->stream));
+            RH_HIP(hipStreamWaitEvent(s.stream, s.start, 0));
+            c->alt_started[slot - 1] = true;
+        }
+        swap_batch_slot(c, s);
+        const int rc = score_batch_dev_impl(c, d_shapes, b, p, d_counts, nullptr, nullptr, false);
+        swap_batch_slot(c, s);
+        if (rc != RH_OK) return rc;
+        RH_HIP(hipEventRecord(s.done, s.stream));
+        c->alt_dirty[slot - 1] = true;
+        return RH_OK;
+    }
     return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr);
 }
 

@@ -144,6 +144,7 @@ extern "C" int rh_score_batch_allreduce_dev(rh_cloud *c, rh_comm *m, const rh_sh
     Rccl *R = rccl();
     if (!R) { rh_set_error("librccl is not loaded"); return RH_E_NODEVICE; }
     RH_HIP(hipSetDevice(c->device));
+    RH_TRY(rh_join_batches(c));
     if (b_total == 0) return RH_OK;
     // a caller that keeps two batches in flight alternates two count buffers: this call's buffer was last read by the
     // collective of two calls ago, which the cloud's stream lets finish first (stream order, no host wait)

@@ -429,6 +429,7 @@ static int ransac_impl(rh_cloud *c, const double *xyz, const double *nrm, const 
         return RH_E_INVALID;
     }
     RH_HIP(hipSetDevice(c->device));
+    RH_TRY(rh_join_batches(c));
     const double t_start = now_s();
 
     bool device_sampler = p->sampling_streams != 0 && p->drawN <= 8 && p->minsubsetN > 0 && c->n > 0;

@@ -205,6 +205,7 @@ extern "C" int rh_refit_lsq(rh_cloud *c, const rh_shape *shape, const rh_params 
     if (shape->kind < 0 || shape->kind > 3) { rh_set_error("unknown shape kind %d", shape->kind); return RH_E_INVALID; }
     RH_TRY(rh_validate_params(p));
     RH_HIP(hipSetDevice(c->device));
+    RH_TRY(rh_join_batches(c));
     if (max_iter < 1) max_iter = 1;
     const int kind = shape->kind;
     // selection: compatible points within 3 eps (Schnabel et al. 2007, sec. 4.4)

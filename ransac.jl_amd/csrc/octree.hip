@@ -240,6 +240,7 @@ extern "C" int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t node, i
     const rh_octree_node &nd = t->nodes[(size_t)node];
     if (nd.count == 0) return RH_OK;
     RH_HIP(hipSetDevice(c->device));
+    RH_TRY(rh_join_batches(c));
     // the cell's own slice of the index lists goes up (not the tree's whole multi-level list: n x depth x 8 bytes), into
     // scratch the tree keeps for the next call: [cell list | enabled list | count]
     const int64_t ocap = cap < nd.count ? cap : nd.count;

@@ -33,6 +33,7 @@ enum rh_opt_id {
     RH_OPT_S4_ROWS,
     RH_OPT_UNP_WORDS,
     RH_OPT_REFIT_PATH,
+    RH_OPT_BATCHES_IN_FLIGHT,
     RH_OPT_N_PRODUCT,
     // A/B switches and diagnostics: alive in the diag build only (in the product build they read as unset)
     RH_OPT_CREATE_PROF = RH_OPT_N_PRODUCT, RH_OPT_AABB_HOST, RH_OPT_SUB_ORDER, RH_OPT_KD_HOST, RH_OPT_NO_SPREAD, RH_OPT_OCT_CHAIN_W,
@@ -86,6 +87,21 @@ struct rh_s4_points {   // what the v4 score kernel runs over (score4.hip): poin
     const double *pts;
     int64_t stride, s, ngroups;
     const float *gb32;
+};
+// rh_score_batch_dev with two batches in flight (rh_set_option "batches_in_flight" = 2): batches take turns on the cloud's own
+// workspaces and stream and on these, so its prepare + score launches fill the chip while the previous batch's launch drains
+#define RH_MAX_IN_FLIGHT 4
+struct rh_batch_slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr, start = nullptr;
+    int64_t batch_cap = 0;
+    rh_shape *d_shapes = nullptr;
+    rh_prep *d_prep = nullptr;
+    int32_t *d_orig = nullptr, *d_counts = nullptr, *d_nk2 = nullptr;
+    void *d_qpre = nullptr, *d_prep32 = nullptr;
+    float *d_box = nullptr;
+    int nk2_flip = 0;
+    bool nk2_ready = false, qpre_v4 = false;
 };
 struct rh_cloud {
     int64_t opt[RH_OPT_COUNT];         // rh_set_option on this cloud (RH_OPTION_UNSET: the process-wide value holds); rh_opt_init_cloud
@@ -229,6 +245,12 @@ struct rh_cloud {
 
     // rh_score_batch with host buffers: device twin of the pinned staging block of a small batch (one upload)
     void *d_stage = nullptr;
+
+    // two batches in flight (rh_score_batch_dev, "batches_in_flight" = 2)
+    rh_batch_slot alt[RH_MAX_IN_FLIGHT - 1];
+    uint32_t pipe_k = 0;               // batches since the pipeline (re)started
+    bool alt_dirty[RH_MAX_IN_FLIGHT - 1] = {};     // work on alt[i].stream the cloud's own stream has not waited for yet
+    bool alt_started[RH_MAX_IN_FLIGHT - 1] = {};   // alt[i].stream has been ordered behind the cloud's stream since the last join
 
     // pinned staging
     void *h_pin = nullptr;
@@ -423,6 +445,7 @@ int32_t rh_spread_multiplier(int32_t b);   // t -> (t * m) mod b: a permutation 
 
 // ---- host helpers (cloud.hip) -----------------------------------------------
 int rh_ensure_batch(rh_cloud *c, int64_t b);
+int rh_join_batches(rh_cloud *c);   // the cloud's stream waits for the second batch slot ("batches_in_flight")
 int rh_ensure_masks(rh_cloud *c, int64_t words);
 int rh_ensure_pin(rh_cloud *c, int64_t bytes);
 int rh_validate_params(const rh_params *p);

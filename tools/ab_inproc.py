@@ -4,7 +4,8 @@ same host arrays) score the same batch in alternating bursts, so that clock / th
 hit them alike.  Prints the median and the spread of the per-burst step time (HIP events on each cloud's stream) and checks
 that every build returns the same counts.
     python tools/ab_inproc.py variants/base.so ransac.jl_amd/libransac_hip.so        WL=cfg2|cfg3|cfg5  ROUNDS=12  STEPS=50
-    MASKS=1: the step with the inlier masks written;  OPTS="s4_rows=8,..." applied to every build (rh_set_option)"""
+    MASKS=1: the step with the inlier masks written;  OPTS="s4_rows=8,..." applied to every build (rh_set_option);
+    lib.so@batches_in_flight=2@...: options of that entry's cloud alone (the same library may be listed more than once)"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,7 @@ def load(path):
 
 
 def main():
-    paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+    paths = [a for a in sys.argv[1:] if ".so" in a]
     wl = os.environ.get("WL", "cfg3")
     rounds, steps = int(os.environ.get("ROUNDS", "12")), int(os.environ.get("STEPS", "50"))
     masks = bool(os.environ.get("MASKS"))
@@ -46,6 +47,7 @@ def main():
     swords = (S + 63) // 64
     builds = []
     for p in paths:
+        p, *own = p.split("@")
         lib = load(p)
         for kv in filter(None, os.environ.get("OPTS", "").split(",")):
             k, v = kv.split("=")
@@ -53,19 +55,25 @@ def main():
         h = C.c_void_p()
         rc = lib.rh_cloud_create(xyz.ctypes.data_as(dp), nrm.ctypes.data_as(dp), n, sub1.ctypes.data_as(i64p), S, 0, C.byref(h))
         assert rc == 0, (p, lib.rh_last_error())
+        for kv in own:
+            k, v = kv.split("=")
+            assert lib.rh_set_option(h, k.encode(), int(v)) == 0, kv
         d_sh, d_cn, d_mk = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        d_cnx = [C.c_void_p() for _ in range(3)]
+        for d in d_cnx:
+            assert lib.rh_dev_alloc(h, 4 * 4096, C.byref(d)) == 0
         assert lib.rh_dev_alloc(h, C.sizeof(L.Shape) * 4096, C.byref(d_sh)) == 0
         assert lib.rh_dev_alloc(h, 4 * 4096, C.byref(d_cn)) == 0
         if masks:
             assert lib.rh_dev_alloc(h, 8 * swords * 4096, C.byref(d_mk)) == 0
         assert lib.rh_dev_upload(h, d_sh, C.cast(arr, C.c_void_p), C.sizeof(L.Shape) * 4096) == 0
-        builds.append(dict(path=p, lib=lib, h=h, d_sh=d_sh, d_cn=d_cn, d_mk=d_mk, ms=[]))
+        builds.append(dict(path="@".join([p] + own), lib=lib, h=h, d_sh=d_sh, nbuf=max([int(kv.split("=")[1]) for kv in own if kv.startswith("batches_in_flight=")] + [2]), d_cn=d_cn, d_cn1=d_cnx[0], d_cn2=d_cnx[1], d_cn3=d_cnx[2], d_mk=d_mk, ms=[]))
 
     def burst(b, k):
         lib = b["lib"]
         assert lib.rh_timer_start(b["h"]) == 0
-        for _ in range(k):
-            rc = lib.rh_score_batch_dev(b["h"], b["d_sh"], 4096, C.byref(cp), b["d_cn"], b["d_mk"] if masks else None)
+        for i in range(k):   # (F count buffers in turn: what a caller with F batches in flight does)
+            rc = lib.rh_score_batch_dev(b["h"], b["d_sh"], 4096, C.byref(cp), b[("d_cn", "d_cn1", "d_cn2", "d_cn3")[i % b["nbuf"]]], b["d_mk"] if masks else None)
             assert rc == 0, lib.rh_last_error()
         ms = C.c_float()
         assert lib.rh_timer_stop(b["h"], C.byref(ms)) == 0
@@ -74,11 +82,12 @@ def main():
         burst(b, 200)
     ref = None
     for b in builds:
-        cn = np.zeros(4096, dtype=np.int32)
-        assert b["lib"].rh_dev_download(b["h"], cn.ctypes.data_as(C.c_void_p), b["d_cn"], 4 * 4096) == 0
-        if ref is None:
-            ref = cn
-        assert np.array_equal(cn, ref), "counts differ between builds: %s" % b["path"]
+        for key in ("d_cn", "d_cn1", "d_cn2", "d_cn3")[:b["nbuf"]]:
+            cn = np.zeros(4096, dtype=np.int32)
+            assert b["lib"].rh_dev_download(b["h"], cn.ctypes.data_as(C.c_void_p), b[key], 4 * 4096) == 0
+            if ref is None:
+                ref = cn
+            assert np.array_equal(cn, ref), "counts differ between builds: %s" % b["path"]
     for r in range(rounds):
         order = builds if r % 2 == 0 else builds[::-1]
         for b in order:
