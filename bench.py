@@ -190,6 +190,7 @@ def compact_line(out, detail_file=None):
                         "frac_upper": _num(rf.get("frac_upper"), 4), "frac_guide": _num(rf.get("frac_guide"), 4),
                         "frac_necessary": _num(rf.get("frac_necessary"), 4), "frac_necessary_guide": _num(rf.get("frac_necessary_guide"), 4),
                         "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
+                        "frac_over_step_in_flight": _num(rf.get("frac_over_step_in_flight"), 4),
                         "counters": rf.get("counters")}
     line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": cb.get("sample")} if cb else None)
@@ -197,6 +198,8 @@ def compact_line(out, detail_file=None):
     vs = out.get("value_spread") or {}
     if vs:
         line["value_spread"] = [_num(vs.get("min"), 5), _num(vs.get("median"), 5), _num(vs.get("max"), 5)]
+    line["batches_in_flight"] = cfg.get("batches_in_flight")
+    line["one_batch_in_flight_ms"] = _get(out, "one_batch_in_flight", "ms_per_step")
     flat = {
         "rccl_ranks_seen": out.get("rccl_ranks_seen"),
         "cpu_mt_value": _get(out, "cpu_baseline_mt", "value"), "cpu_mt_cores": _get(out, "cpu_baseline_mt", "cores"),
@@ -749,6 +752,12 @@ def main():
                 "priced_directly_share": m["priced_directly_share"], "model_vs_hardware_valu": 1.0 / scl,
                 "valu_insts_per_launch": scl * m["valu_instructions"], "salu_insts_per_launch": m["salu_instructions"],
                 "accounting": os.path.relpath(acc_file, ROOT), "accounting_is_stale": acc_stale})
+            if in_flight > 1 and not multi:
+                # the same priced cycles over the timed region's time per batch: launches of consecutive batches overlap there
+                # (batches_in_flight), so one batch costs less wall time than a launch on its own -- the chip's issue
+                # utilisation over the whole step, prepare launch and launch gaps included in the time (not in the work)
+                rf["frac_over_step_in_flight"] = scl * m["valu_issue_cycles_measured_lower"] / (ms_per_step * 1e-3 * simd_cycles_per_s)
+                rf["frac_over_step_in_flight_upper"] = scl * m["valu_issue_cycles_measured"] / (ms_per_step * 1e-3 * simd_cycles_per_s)
         src = acc_file or (os.path.join(ROOT, pmc["replayed_from"][0]) if pmc["replayed_from"] else None)
         rf.update({
             "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"), "sq_wait_any": sq.get("SQ_WAIT_ANY"),
@@ -790,34 +799,50 @@ def main():
         try:
             swords = (S + 63) // 64
             nb_m = hi - lo
-            dmask = torch.empty(nb_m * swords, dtype=torch.int64, device="cuda")
-            mcounts = torch.zeros(nb_m, dtype=torch.int32, device="cuda")
+            # (F batches in flight here too: batch k's un-permutation, HBM-bound, under batch k + 1's score launch, issue-bound)
+            dmasks = [torch.empty(nb_m * swords, dtype=torch.int64, device="cuda") for _ in range(in_flight)]
+            mcs = [torch.zeros(nb_m, dtype=torch.int32, device="cuda") for _ in range(in_flight)]
+            torch.cuda.synchronize()
+            dmask, mcounts = dmasks[0], mcs[0]
+            mreps = 60
 
-            def mstep():
-                L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(lo), nb_m, C.byref(cp),
-                                               C.c_void_p(mcounts.data_ptr()), C.c_void_p(dmask.data_ptr())))
-            for _ in range(5):
-                mstep()
+            def mregion(F):
+                for k in range(mreps):
+                    L.check(lib.rh_score_batch_dev(pc._h, batch.slice_ptr(lo), nb_m, C.byref(cp),
+                                                   C.c_void_p(mcs[k % F].data_ptr()), C.c_void_p(dmasks[k % F].data_ptr())))
+            mregion(in_flight)       # warm-up: every slot's lists allocated
             L.check(lib.rh_cloud_sync(pc._h))
-            mreps = 20
-            L.check(lib.rh_timer_start(pc._h))
-            for _ in range(mreps):
-                mstep()
             mev = C.c_float()
+            L.check(lib.rh_timer_start(pc._h))
+            mregion(in_flight)
             L.check(lib.rh_timer_stop(pc._h, C.byref(mev)))
-            mh = mcounts.cpu().numpy()
-            if not np.array_equal(mh, counts_h[lo:hi]):
-                raise SystemExit("PARITY FAILURE: counts of the mask-writing launch differ from the counts-only launch")
-            # popcount of the masks == the counts (checksum of checksums), on a slice to bound the host work
-            mslice = dmask[: 64 * swords].cpu().numpy().view(np.uint64).reshape(64, swords)
-            if not np.array_equal(np.bitwise_count(mslice).sum(axis=1, dtype=np.int64), mh[:64]):
-                raise SystemExit("PARITY FAILURE: mask popcounts differ from the counts")
             t_m = mev.value * 1e-3 / mreps
+            t_m1 = t_m
+            if in_flight > 1:
+                R.set_option("batches_in_flight", 1, cloud=pc)
+                mregion(1)
+                L.check(lib.rh_timer_start(pc._h))
+                mregion(1)
+                L.check(lib.rh_timer_stop(pc._h, C.byref(mev)))
+                t_m1 = mev.value * 1e-3 / mreps
+                R.set_option("batches_in_flight", in_flight, cloud=pc)
+            for mc_k, dm_k in zip(mcs, dmasks):
+                mh = mc_k.cpu().numpy()
+                if not np.array_equal(mh, counts_h[lo:hi]):
+                    raise SystemExit("PARITY FAILURE: counts of the mask-writing launch differ from the counts-only launch")
+                # popcount of the masks == the counts (checksum of checksums), on a slice to bound the host work
+                mslice = dm_k[: 64 * swords].cpu().numpy().view(np.uint64).reshape(64, swords)
+                if not np.array_equal(np.bitwise_count(mslice).sum(axis=1, dtype=np.int64), mh[:64]):
+                    raise SystemExit("PARITY FAILURE: mask popcounts differ from the counts")
+                if not torch.equal(dm_k, dmasks[0]):
+                    raise SystemExit("PARITY FAILURE: mask buffers of the batches in flight differ")
             out["masks_out"] = {"metric": "candidates_scored_per_sec_with_masks", "value": nb_m / t_m, "unit": "candidates/s",
-                                "ms_per_step": 1e3 * t_m, "mask_bytes_per_step": nb_m * swords * 8,
+                                "ms_per_step": 1e3 * t_m, "ms_per_step_one_in_flight": 1e3 * t_m1, "batches_in_flight": in_flight,
+                                "mask_bytes_per_step": nb_m * swords * 8,
                                 "note": "rh_score_batch_dev with d_masks: counts AND the per-candidate inlier bit masks over "
                                         "subset 1 in subset order, resident in HBM; HIP events over %d steps; counts equal the "
                                         "headline launch's, popcounts of 64 mask rows equal their counts" % mreps}
+            del dmasks, mcs
             del dmask, mcounts
         except SystemExit:
             raise

@@ -182,7 +182,7 @@ static void cloud_free(rh_cloud *c)
         if (!s.stream) continue;
         (void)hipStreamSynchronize(s.stream);
         (void)hipFree(s.d_shapes); (void)hipFree(s.d_prep); (void)hipFree(s.d_orig); (void)hipFree(s.d_counts); (void)hipFree(s.d_nk2);
-        (void)hipFree(s.d_qpre); (void)hipFree(s.d_prep32); (void)hipFree(s.d_box);
+        (void)hipFree(s.d_qpre); (void)hipFree(s.d_prep32); (void)hipFree(s.d_box); (void)hipFree(s.d_masks_int); (void)hipFree(s.d_occ);
         (void)hipEventDestroy(s.done); (void)hipEventDestroy(s.start); (void)hipStreamDestroy(s.stream);
     }
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
@@ -927,6 +927,8 @@ static void swap_batch_slot(rh_cloud *c, rh_batch_slot &s)
     std::swap(c->d_shapes, s.d_shapes); std::swap(c->d_prep, s.d_prep); std::swap(c->d_orig, s.d_orig); std::swap(c->d_counts, s.d_counts);
     std::swap(c->d_nk2, s.d_nk2); std::swap(c->d_qpre, s.d_qpre); std::swap(c->d_prep32, s.d_prep32); std::swap(c->d_box, s.d_box);
     std::swap(c->nk2_flip, s.nk2_flip); std::swap(c->nk2_ready, s.nk2_ready); std::swap(c->qpre_v4, s.qpre_v4);
+    std::swap(c->d_masks_int, s.d_masks_int); std::swap(c->masks_int_cap, s.masks_int_cap); std::swap(c->d_occ, s.d_occ);
+    std::swap(c->occ_cap, s.occ_cap); std::swap(c->mstride4, s.mstride4);
 }
 
 static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
@@ -994,16 +996,17 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
 extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                                   int32_t *d_counts, uint64_t *d_masks)
 {
-    // "batches_in_flight" = F > 1 (rh_set_option): counts-only batches take turns on the cloud's stream and F - 1 more streams with
+    // "batches_in_flight" = F > 1 (rh_set_option): batches take turns on the cloud's stream and F - 1 more streams with
     // workspaces of their own, so batch k + 1's prepare and score launches fill the chip while batch k's launch drains (the
     // heaviest tile's block sets a launch's length: cfg2 0.042 -> 0.027 ms a batch, cfg3 0.085 -> 0.071 with F = 2).  The
-    // caller gives call k of a run buffer k mod F of F count buffers (the stream that wrote a buffer last writes it next); any other call on the cloud (and rh_cloud_sync /
+    // caller gives call k of a run buffer k mod F of F count (and mask) buffers (the stream that wrote a buffer last writes it
+    // next; with masks the un-permutation of one batch, HBM-bound, runs under the next batch's score launch, issue-bound); any other call on the cloud (and rh_cloud_sync /
     // rh_timer_stop) first makes the cloud's stream wait for the others.
-    const int in_flight = c != nullptr && d_masks == nullptr && b > 0 && c->stream == c->own_stream ? rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) : 1;
+    const int in_flight = c != nullptr && b > 0 && c->stream == c->own_stream ? rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) : 1;
     if (in_flight > 1) {
         RH_TRY(enter_nojoin(c));
         const int slot = (int)(c->pipe_k++ % (uint32_t)in_flight);
-        if (slot == 0) return score_batch_dev_impl(c, d_shapes, b, p, d_counts, nullptr, nullptr, false);
+        if (slot == 0) return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr, false);
         rh_batch_slot &s = c->alt[slot - 1];
         if (s.stream == nullptr) {
             RH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
@@ -1017,7 +1020,7 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
             c->alt_started[slot - 1] = true;
         }
         swap_batch_slot(c, s);
-        const int rc = score_batch_dev_impl(c, d_shapes, b, p, d_counts, nullptr, nullptr, false);
+        const int rc = score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr, false);
         swap_batch_slot(c, s);
         if (rc != RH_OK) return rc;
         RH_HIP(hipEventRecord(s.done, s.stream));

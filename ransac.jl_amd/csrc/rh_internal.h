@@ -100,6 +100,9 @@ struct rh_batch_slot {
     int32_t *d_orig = nullptr, *d_counts = nullptr, *d_nk2 = nullptr;
     void *d_qpre = nullptr, *d_prep32 = nullptr;
     float *d_box = nullptr;
+    uint64_t *d_masks_int = nullptr;   // (batches with mask output: the entry lists and their cursors)
+    uint8_t *d_occ = nullptr;
+    int64_t masks_int_cap = 0, occ_cap = 0, mstride4 = 0;
     int nk2_flip = 0;
     bool nk2_ready = false, qpre_v4 = false;
 };

@@ -1,4 +1,4 @@
-"""rh_score_batch_dev with several batches in flight (rh_set_option "batches_in_flight", include/ransac_hip.h): batches take
+"""rh_score_batch_dev (counts, or counts and masks) with several batches in flight (rh_set_option "batches_in_flight", include/ransac_hip.h): batches take
 turns on the cloud's stream and on further streams with workspaces of their own.  Whatever the number in flight, every
 batch's counts must equal the counts of the same batch scored alone (and the oracle's), with other calls on the cloud --
 mask batches, disabling points, host-side scoring -- cut in between: those join the streams first."""
@@ -121,7 +121,48 @@ def test_other_calls_join_the_batches_in_flight(scene):
     pc.enable_all(); oc.enable_all()
 
 
-def test_option_is_ignored_for_mask_batches_and_refused_out_of_range(scene):
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_mask_batches_in_flight(scene, in_flight):
+    """batches WITH mask output in flight: every batch's dense subset-order masks equal those of the host-buffer call."""
+    import torch
+    pc, oc, cp, arrs, batches, b = scene
+    lib = R.lib()
+    pc.enable_all(); oc.enable_all()
+    sizes = [b, 900, b, 40, 1300, b]
+    want = [R.score_batch(pc, (L.Shape * nb).from_buffer_copy(bytes(arrs[i])[: C.sizeof(L.Shape) * nb]), cp, want_masks=True)
+            for i, nb in enumerate(sizes)]
+    sh = (orc.Shape * sizes[1])()
+    C.memmove(sh, arrs[1], C.sizeof(L.Shape) * sizes[1])
+    oc_counts, oc_masks = oc.score_batch(sh, orc.Params.from_buffer_copy(bytes(cp)), want_masks=True)
+    assert np.array_equal(want[1][0], oc_counts) and np.array_equal(want[1][1], oc_masks)
+    w = want[0][1].shape[1]
+    with R.option("batches_in_flight", in_flight, cloud=pc):
+        cn = [torch.zeros(b, dtype=torch.int32, device="cuda") for _ in range(in_flight)]
+        mk = [torch.zeros(b * w, dtype=torch.int64, device="cuda") for _ in range(in_flight)]
+        torch.cuda.synchronize()
+        for base in range(0, len(sizes), in_flight):
+            ks = list(range(base, min(base + in_flight, len(sizes))))
+            for j, k in enumerate(ks):
+                L.check(lib.rh_score_batch_dev(pc._h, batches[k].slice_ptr(0), sizes[k], C.byref(cp), C.c_void_p(cn[j].data_ptr()),
+                                               C.c_void_p(mk[j].data_ptr())))
+            L.check(lib.rh_cloud_sync(pc._h))
+            for j, k in enumerate(ks):
+                assert np.array_equal(cn[j].cpu().numpy()[:sizes[k]], want[k][0]), (in_flight, k)
+                got = mk[j].cpu().numpy().view(np.uint64)[: sizes[k] * w].reshape(sizes[k], w)
+                assert np.array_equal(got, want[k][1]), (in_flight, k)
+        # a long run without joins: the last F batches
+        for k in range(2 * len(sizes)):
+            i = k % len(sizes)
+            L.check(lib.rh_score_batch_dev(pc._h, batches[i].slice_ptr(0), sizes[i], C.byref(cp), C.c_void_p(cn[k % in_flight].data_ptr()),
+                                           C.c_void_p(mk[k % in_flight].data_ptr())))
+        L.check(lib.rh_cloud_sync(pc._h))
+        for k in range(2 * len(sizes) - in_flight, 2 * len(sizes)):
+            i = k % len(sizes)
+            got = mk[k % in_flight].cpu().numpy().view(np.uint64)[: sizes[i] * w].reshape(sizes[i], w)
+            assert np.array_equal(got, want[i][1]) and np.array_equal(cn[k % in_flight].cpu().numpy()[:sizes[i]], want[i][0])
+
+
+def test_option_is_refused_out_of_range_and_host_calls_ignore_it(scene):
     pc, oc, cp, arrs, batches, b = scene
     with pytest.raises(R.RansacHipError):
         R.set_option("batches_in_flight", 5, cloud=pc)

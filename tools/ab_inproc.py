@@ -64,16 +64,18 @@ def main():
             assert lib.rh_dev_alloc(h, 4 * 4096, C.byref(d)) == 0
         assert lib.rh_dev_alloc(h, C.sizeof(L.Shape) * 4096, C.byref(d_sh)) == 0
         assert lib.rh_dev_alloc(h, 4 * 4096, C.byref(d_cn)) == 0
+        d_mks = [C.c_void_p() for _ in range(4)]
         if masks:
-            assert lib.rh_dev_alloc(h, 8 * swords * 4096, C.byref(d_mk)) == 0
+            for d in d_mks:
+                assert lib.rh_dev_alloc(h, 8 * swords * 4096, C.byref(d)) == 0
         assert lib.rh_dev_upload(h, d_sh, C.cast(arr, C.c_void_p), C.sizeof(L.Shape) * 4096) == 0
-        builds.append(dict(path="@".join([p] + own), lib=lib, h=h, d_sh=d_sh, nbuf=max([int(kv.split("=")[1]) for kv in own if kv.startswith("batches_in_flight=")] + [2]), d_cn=d_cn, d_cn1=d_cnx[0], d_cn2=d_cnx[1], d_cn3=d_cnx[2], d_mk=d_mk, ms=[]))
+        builds.append(dict(path="@".join([p] + own), lib=lib, h=h, d_sh=d_sh, nbuf=max([int(kv.split("=")[1]) for kv in own if kv.startswith("batches_in_flight=")] + [2]), d_cn=d_cn, d_cn1=d_cnx[0], d_cn2=d_cnx[1], d_cn3=d_cnx[2], d_mks=d_mks, ms=[]))
 
     def burst(b, k):
         lib = b["lib"]
         assert lib.rh_timer_start(b["h"]) == 0
         for i in range(k):   # (F count buffers in turn: what a caller with F batches in flight does)
-            rc = lib.rh_score_batch_dev(b["h"], b["d_sh"], 4096, C.byref(cp), b[("d_cn", "d_cn1", "d_cn2", "d_cn3")[i % b["nbuf"]]], b["d_mk"] if masks else None)
+            rc = lib.rh_score_batch_dev(b["h"], b["d_sh"], 4096, C.byref(cp), b[("d_cn", "d_cn1", "d_cn2", "d_cn3")[i % b["nbuf"]]], b["d_mks"][i % b["nbuf"]] if masks else None)
             assert rc == 0, lib.rh_last_error()
         ms = C.c_float()
         assert lib.rh_timer_stop(b["h"], C.byref(ms)) == 0

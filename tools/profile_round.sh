@@ -2,7 +2,8 @@
 # Collects a round's profiles on a GPU box (run through gpurun from the repo root):
 #     tools/profile_round.sh r4 [default|cfg5]
 #   default: 1. the default bench line, un-profiled;
-#            2. rocprofv3 --kernel-trace --stats of the bench (score + masks legs only, and with the end-to-end legs);
+#            2. rocprofv3 --kernel-trace --stats of the bench (score + masks legs only with ONE batch in flight, so that a launch's
+#               duration is its own and not that of two launches sharing the chip; and the default line with the end-to-end legs);
 #            3. PMC passes, each in its own run with --kernel-trace only: FETCH_SIZE, WRITE_SIZE, three SQ passes of 8 counters
 #               (ONLY=sq3: the third one alone, the instruction classes).
 #   cfg5:    the same stats + PMC passes for `--workload cfg5` (50M points, cones; the 50M-point refit scan).
@@ -34,7 +35,7 @@ elif [ "$WHAT" = "default" ]; then
     cd /tmp && export TMPDIR=/tmp
     B="$ROOT/bench.py --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"
     SFX=""
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e --detail-out "$OUT/bench_score_only_under_rocprof_detail.json" > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only" -- python3 $B --no-e2e --in-flight 1 --detail-out "$OUT/bench_score_only_under_rocprof_detail.json" > "$OUT/bench_score_only_under_rocprof.json" 2> "$OUT/score_only.err"
     echo "stats 1 done"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/with_e2e" -- python3 $B --detail-out "$OUT/bench_under_rocprof_detail.json" > "$OUT/bench_under_rocprof.json" 2> "$OUT/with_e2e.err"
     echo "stats 2 done"
@@ -42,10 +43,10 @@ else
     cd /tmp && export TMPDIR=/tmp
     B="$ROOT/bench.py --workload $WHAT --no-cpu --no-cfg5 --no-cfg2 --no-f32 --no-per-kind"
     SFX="_$WHAT"
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only$SFX" -- python3 $B --no-e2e --steps 60 --warmup 10 --detail-out "$OUT/bench_score_only_under_rocprof${SFX}_detail.json" > "$OUT/bench_score_only_under_rocprof$SFX.json" 2> "$OUT/score_only$SFX.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/score_only$SFX" -- python3 $B --no-e2e --in-flight 1 --steps 60 --warmup 10 --detail-out "$OUT/bench_score_only_under_rocprof${SFX}_detail.json" > "$OUT/bench_score_only_under_rocprof$SFX.json" 2> "$OUT/score_only$SFX.err"
     echo "stats $WHAT done"
 fi
-S="$B --no-e2e --steps 3 --warmup 1 --prewarm-ms 0 --detail-out $OUT/pmc_detail$SFX.json"
+S="$B --no-e2e --in-flight 1 --steps 3 --warmup 1 --prewarm-ms 0 --detail-out $OUT/pmc_detail$SFX.json"
 rocprofv3 --kernel-trace --pmc $SQ3 --output-format csv -d "$OUT/pmc_sq3$SFX" -- python3 $S > "$OUT/pmc_sq3$SFX.json" 2> "$OUT/pmc_sq3$SFX.err"
 echo "pmc sq3 done"
 if [ "$WHAT" = "stats" ]; then
