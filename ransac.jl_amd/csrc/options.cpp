@@ -63,7 +63,6 @@ const OptDef kDefs[] = {
     RH_O(RH_OPT_G2_DBG, "g2_dbg", "RH_G2_DBG", T_INT),
     RH_O(RH_OPT_KREFIT_DBG, "krefit_dbg", "RH_KREFIT_DBG", T_FLAG),
     RH_O(RH_OPT_NO_FAST_EXTRACT, "no_fast_extract", "RH_NO_FAST_EXTRACT", T_FLAG),
-    RH_O(RH_OPT_NO_OCT_FUSE, "no_oct_fuse", "RH_NO_OCT_FUSE", T_FLAG),
 #endif
 };
 constexpr int kNDefs = (int)(sizeof(kDefs) / sizeof(kDefs[0]));

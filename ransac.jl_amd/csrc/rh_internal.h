@@ -40,7 +40,6 @@ enum rh_opt_id {
     RH_OPT_NO_MANAGED_STORE, RH_OPT_OCT_ONE_WINDOW, RH_OPT_OCT_WINDOW_ITERS, RH_OPT_NO_FUSED_SCORE, RH_OPT_NO_PIPELINE,
     RH_OPT_NO_OCT_CHAIN, RH_OPT_REFIT_BLOCKS, RH_OPT_NO_FUSED_SAMPLER, RH_OPT_NO_CREC, RH_OPT_LONG_WINDOW_SETS, RH_OPT_NO_OCT_TAB,
     RH_OPT_NO_DRIVER_CACHE, RH_OPT_HOST_SAMPLER, RH_OPT_DRIVER_PROF, RH_OPT_G2_DBG, RH_OPT_KREFIT_DBG, RH_OPT_NO_FAST_EXTRACT,
-    RH_OPT_NO_OCT_FUSE,
     RH_OPT_COUNT
 };
 struct rh_cloud;
