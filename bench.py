@@ -813,19 +813,25 @@ def main():
             mregion(in_flight)       # warm-up: every slot's lists allocated
             L.check(lib.rh_cloud_sync(pc._h))
             mev = C.c_float()
-            L.check(lib.rh_timer_start(pc._h))
-            mregion(in_flight)
-            L.check(lib.rh_timer_stop(pc._h, C.byref(mev)))
-            t_m = mev.value * 1e-3 / mreps
-            t_m1 = t_m
-            if in_flight > 1:
-                R.set_option("batches_in_flight", 1, cloud=pc)
-                mregion(1)
+
+            def mtimed(F):
+                R.set_option("batches_in_flight", F, cloud=pc)
                 L.check(lib.rh_timer_start(pc._h))
-                mregion(1)
+                mregion(F)
                 L.check(lib.rh_timer_stop(pc._h, C.byref(mev)))
-                t_m1 = mev.value * 1e-3 / mreps
-                R.set_option("batches_in_flight", in_flight, cloud=pc)
+                return mev.value * 1e-3 / mreps
+            # (the two forms in turn, twice: the faster region of each -- a 50M-point mask step moves 2.4 GB and the clocks move with it)
+            t_f, t_1 = [], []
+            for _ in range(2):
+                t_f.append(mtimed(in_flight))
+                if in_flight > 1:
+                    t_1.append(mtimed(1))
+            R.set_option("batches_in_flight", in_flight if in_flight > 1 else None, cloud=pc)
+            if in_flight > 1:   # (the count / mask buffers checked below: written by the last pipelined region's order again)
+                mregion(in_flight)
+                L.check(lib.rh_cloud_sync(pc._h))
+            t_m = min(t_f)
+            t_m1 = min(t_1) if t_1 else t_m
             for mc_k, dm_k in zip(mcs, dmasks):
                 mh = mc_k.cpu().numpy()
                 if not np.array_equal(mh, counts_h[lo:hi]):
@@ -840,8 +846,9 @@ def main():
                                 "ms_per_step": 1e3 * t_m, "ms_per_step_one_in_flight": 1e3 * t_m1, "batches_in_flight": in_flight,
                                 "mask_bytes_per_step": nb_m * swords * 8,
                                 "note": "rh_score_batch_dev with d_masks: counts AND the per-candidate inlier bit masks over "
-                                        "subset 1 in subset order, resident in HBM; HIP events over %d steps; counts equal the "
-                                        "headline launch's, popcounts of 64 mask rows equal their counts" % mreps}
+                                        "subset 1 in subset order, resident in HBM; HIP events over %d steps, the faster of two regions "
+                                        "per form (batches in flight / one at a time, in turn); counts equal the headline launch's, "
+                                        "popcounts of 64 mask rows equal their counts" % mreps}
             del dmasks, mcs
             del dmask, mcounts
         except SystemExit:

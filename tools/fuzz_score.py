@@ -99,7 +99,46 @@ def one(case, rng, f32=False):
     else:
         ok = np.array_equal(got, exp)
         tot = int(np.sum(exp))
-    return ok, "n=%d r=%d scale=%g path=%s R=%d b=%d masks=%d inliers=%d" % (n, r, scale, spath, rr, b, want_masks, tot)
+    # the same batch through the device-buffer entry with F batches in flight (rh_set_option batches_in_flight): slices of the
+    # batch, buffer k mod F for call k, no wait until the end -- every slice's counts (and masks) as the oracle has them
+    F = int(rng.choice([1, 1, 2, 3, 4]))
+    if F > 1 and ok:
+        lib = R.lib()
+        exp_c, exp_m = (exp if want_masks else (exp, None))
+        w = (subs[0].size + 63) // 64
+        d_sh = C.c_void_p()
+        L.check(lib.rh_dev_alloc(pc._h, C.sizeof(L.Shape) * b, C.byref(d_sh)))
+        L.check(lib.rh_dev_upload(pc._h, d_sh, C.cast(arr, C.c_void_p), C.sizeof(L.Shape) * b))
+        d_cn, d_mk = [C.c_void_p() for _ in range(F)], [C.c_void_p() for _ in range(F)]
+        for q in range(F):
+            L.check(lib.rh_dev_alloc(pc._h, 4 * b, C.byref(d_cn[q])))
+            if want_masks:
+                L.check(lib.rh_dev_alloc(pc._h, 8 * max(1, w) * b, C.byref(d_mk[q])))
+        R.set_option("batches_in_flight", F, cloud=pc)
+        ncall = int(rng.integers(F, 3 * F + 1))
+        sl = []
+        for k in range(ncall):
+            lo = int(rng.integers(0, b)); hi = int(rng.integers(lo + 1, b + 1))
+            sl.append((lo, hi))
+            L.check(lib.rh_score_batch_dev(pc._h, C.c_void_p(d_sh.value + lo * C.sizeof(L.Shape)), hi - lo, C.byref(cp), d_cn[k % F],
+                                           d_mk[k % F] if want_masks else None))
+        L.check(lib.rh_cloud_sync(pc._h))
+        for k in range(ncall - F, ncall):
+            lo, hi = sl[k]
+            cn = np.zeros(hi - lo, dtype=np.int32)
+            L.check(lib.rh_dev_download(pc._h, cn.ctypes.data_as(C.c_void_p), d_cn[k % F], 4 * (hi - lo)))
+            ok = ok and np.array_equal(cn, exp_c[lo:hi])
+            if want_masks and w > 0:
+                mk = np.zeros((hi - lo, w), dtype=np.uint64)
+                L.check(lib.rh_dev_download(pc._h, mk.ctypes.data_as(C.c_void_p), d_mk[k % F], 8 * w * (hi - lo)))
+                ok = ok and np.array_equal(mk, exp_m[lo:hi])
+        R.set_option("batches_in_flight", None, cloud=pc)
+        for q in range(F):
+            lib.rh_dev_free(pc._h, d_cn[q])
+            if want_masks:
+                lib.rh_dev_free(pc._h, d_mk[q])
+        lib.rh_dev_free(pc._h, d_sh)
+    return ok, "n=%d r=%d scale=%g path=%s R=%d b=%d masks=%d in_flight=%d inliers=%d" % (n, r, scale, spath, rr, b, want_masks, F, tot)
 
 
 def main():
