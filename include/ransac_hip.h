@@ -359,6 +359,11 @@ int rh_cloud_create_ms(const rh_cloud *c, double *out4);
  * returns (every sample comes from the root cell) and rh_ransac does not build it. */
 typedef struct rh_octree rh_octree;
 int rh_octree_build(const double *xyz_aos, int64_t n, rh_octree **out);                 /* buildoctree(vertices); host-side set-up */
+/* the tree of a Float32 cloud (RANSACCloud(...; force_eltype = Float32), octree.jl:102-109): findAABB, the divisions origin +
+ * widths / 2, the children's widths and the vmin < p <= vmax tests are binary32 operations there, so cells and their point lists
+ * can differ from the binary64 tree of the same (widened) points.  The queries below serve both kinds of tree (the geometry
+ * comes back widened to double, exactly). */
+int rh_octree_build_f32(const float *xyz_aos, int64_t n, rh_octree **out);
 int rh_octree_destroy(rh_octree *t);
 int rh_octree_info(const rh_octree *t, int32_t *n_cells, int32_t *octreedepth, int32_t *overflow);
 int rh_octree_findleaf(const rh_octree *t, const double *p3, int32_t *cell_out);        /* findleaf(pc.octree, p) */

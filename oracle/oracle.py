@@ -182,6 +182,7 @@ def _bind(L):
         "orc_findAABB": (None, [dp, C.c_int64, C.c_int, dp, dp]),
         "orc_iswithinrectangle": (C.c_int, [dp, dp, dp]),
         "orc_octree_build": (C.c_void_p, [dp, C.c_int64]),
+        "orc_octree_build_f32": (C.c_void_p, [C.POINTER(C.c_float), C.c_int64]),
         "orc_octree_destroy": (None, [C.c_void_p]),
         "orc_octree_depth": (C.c_int, [C.c_void_p]),
         "orc_octree_findleaf": (C.c_int, [C.c_void_p, dp, i32p, C.c_int]),
@@ -515,6 +516,11 @@ def bitmapparameters(params2d, compat, beta, idsource=None):
 
 class Octree:
     def __init__(self, xyz):
+        if np.asarray(xyz).dtype == np.float32:   # a Float32 cloud's tree
+            self.xyz32 = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+            self.xyz = self.xyz32.astype(np.float64)
+            self.h = lib().orc_octree_build_f32(self.xyz32.ctypes.data_as(C.POINTER(C.c_float)), self.xyz32.shape[0])
+            return
         self.xyz = _f64(xyz).reshape(-1, 3)
         self.h = lib().orc_octree_build(_dp(self.xyz), self.xyz.shape[0])
 

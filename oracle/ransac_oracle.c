@@ -1179,6 +1179,65 @@ orc_octree *orc_octree_build(const double *xyz, int64_t n)
     return t;
 }
 
+/* the same build on a Float32 cloud (octree.jl:102-109 converts the vertices; findAABB, RegionTrees' divisions and child
+ * boundaries and iswithinrectangle then run on Float32 values): every operation below rounds to binary32; the nodes keep
+ * the results widened to double */
+orc_octree *orc_octree_build_f32(const float *xyz, int64_t n)
+{
+    orc_octree *t = (orc_octree *)calloc(1, sizeof *t);
+    float minv[3] = { 0, 0, 0 }, maxv[3] = { 0, 0, 0 };
+    for (int j = 0; j < 3 && n > 0; j++) minv[j] = maxv[j] = xyz[j];          /* findAABB: utilities.jl:125-136 */
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) {
+            const float a = xyz[3 * i + j];
+            minv[j] = minv[j] > a ? a : minv[j];
+            maxv[j] = maxv[j] < a ? a : maxv[j];
+        }
+    int32_t root = new_node(t);
+    for (int i = 0; i < 3; i++) { t->nodes[root].origin[i] = minv[i]; t->nodes[root].widths[i] = maxv[i]; }
+    t->nodes[root].depth = 1;
+    t->nodes[root].parent = -1;
+    t->nodes[root].npts = n;
+    t->nodes[root].pts = (int64_t *)malloc(8 * (size_t)(n ? n : 1));
+    for (int64_t i = 0; i < n; i++) t->nodes[root].pts[i] = i + 1;
+    for (int32_t cur = 0; cur < t->n_nodes; cur++) {
+        if (!(t->nodes[cur].npts > 8)) continue;
+        if (t->nodes[cur].depth >= 48) { t->overflow = 1; continue; }
+        for (int i = 0; i < 3; i++) {
+            const float o = (float)t->nodes[cur].origin[i], w = (float)t->nodes[cur].widths[i];
+            const float half = w / 2.0f;
+            t->nodes[cur].div[i] = (float)(o + half);
+        }
+        for (int ci = 0; ci < 8; ci++) {
+            int32_t ch = new_node(t);
+            onode *par = &t->nodes[cur], *nd = &t->nodes[ch];
+            int idx[3] = { ci & 1, (ci >> 1) & 1, (ci >> 2) & 1 };
+            for (int i = 0; i < 3; i++) {
+                const float o = (float)par->origin[i], w = (float)par->widths[i], d = (float)par->div[i];
+                const float top = o + w;
+                nd->origin[i] = idx[i] == 0 ? o : d;
+                nd->widths[i] = idx[i] == 0 ? (float)(d - o) : (float)(top - d);
+            }
+            nd->depth = par->depth + 1;
+            nd->parent = cur;
+            nd->pts = (int64_t *)malloc(8 * (size_t)(par->npts ? par->npts : 1));
+            for (int64_t k = 0; k < par->npts; k++) {
+                const int64_t id = par->pts[k];
+                const float *p = &xyz[3 * (id - 1)];
+                int in = 1;
+                for (int i = 0; i < 3 && in; i++) {           /* iswithinrectangle: octree.jl:187-196, Float32 */
+                    const float vmin = (float)nd->origin[i];
+                    const float vmax = (float)nd->origin[i] + (float)nd->widths[i];
+                    if (!(vmin < p[i]) || !(vmax >= p[i])) in = 0;
+                }
+                if (in) nd->pts[nd->npts++] = id;
+            }
+            par->child[ci] = ch;
+        }
+    }
+    return t;
+}
+
 void orc_octree_destroy(orc_octree *t)
 {
     if (!t) return;

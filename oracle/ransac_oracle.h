@@ -183,6 +183,7 @@ int orc_iswithinrectangle(const double origin[3], const double widths[3], const 
 /* ---- octree (octree.jl:158-244, RegionTrees ^0.3 semantics) ---- */
 typedef struct orc_octree orc_octree;
 orc_octree *orc_octree_build(const double *xyz, int64_t n);
+orc_octree *orc_octree_build_f32(const float *xyz, int64_t n);   /* the tree of a Float32 cloud: binary32 geometry */
 void orc_octree_destroy(orc_octree *t);
 int orc_octree_depth(const orc_octree *t);
 /* findleaf(root, p): returns leaf depth; path[d-1] = node id at depth d (root = path[0]) */

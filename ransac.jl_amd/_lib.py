@@ -118,6 +118,7 @@ SIGNATURES = {
     "rh_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
     "rh_octree_build": (C.c_int, [_dp, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rh_octree_build_f32": (C.c_int, [C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_void_p)]),
     "rh_octree_destroy": (C.c_int, [_vp]),
     "rh_octree_info": (C.c_int, [_vp, _i32p, _i32p, _i32p]),
     "rh_octree_findleaf": (C.c_int, [_vp, _dp, _i32p]),
@@ -184,7 +185,7 @@ def lib(which=None):
     L = _libs.get(which)
     if L is None:
         path = SO_PATH if which == "product" else SO_PATH_DIAG
-        if which == "product" and os.environ.get("RH_LIB_PATH"):   # kernel A/B runs (tools/): another build of the product library
+        if os.environ.get("RH_LIB_PATH"):   # kernel A/B runs (tools/): another build of this variant of the library
             path = os.environ["RH_LIB_PATH"]
         if not os.path.exists(path):
             raise RuntimeError(

@@ -361,8 +361,13 @@ class OctreeCell:
 
 class _Octree:
     def __init__(self, vertices):
-        self.vertices = _f64(vertices).reshape(-1, 3)
         self._h = C.c_void_p()
+        v = np.asarray(vertices)
+        if v.dtype == np.float32:   # a Float32 cloud's tree: the geometry in binary32, as the reference computes it there
+            self.vertices = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+            check(lib().rh_octree_build_f32(_p(self.vertices, C.c_float), self.vertices.shape[0], C.byref(self._h)))
+            return
+        self.vertices = _f64(vertices).reshape(-1, 3)
         check(lib().rh_octree_build(_p(self.vertices, C.c_double), self.vertices.shape[0], C.byref(self._h)))
 
     def __del__(self):
@@ -376,7 +381,7 @@ class _Octree:
 
 
 def buildoctree(vertices):
-    """buildoctree(vertices) -> the root Cell (octree.jl:237-244)."""
+    """buildoctree(vertices) -> the root Cell (octree.jl:237-244).  float32 vertices: the binary32 tree (rh_octree_build_f32)."""
     return OctreeCell(_Octree(vertices), 0)
 
 
@@ -484,7 +489,7 @@ class RANSACCloud:
     def octree(self):
         """pc.octree (octree.jl:47, built by the constructor there; here on first use: rh_ransac never reads it)"""
         if getattr(self, "_octree", None) is None:
-            self._octree = buildoctree(self.vertices)
+            self._octree = buildoctree(self.vertices32 if self.is_f32 else self.vertices)   # (a Float32 cloud: the binary32 tree)
         return self._octree
 
     @property

@@ -42,10 +42,12 @@ struct rh_octree {
 
 namespace {
 
-inline bool within(const double o[3], const double w[3], const double *p)
+// (T = the cloud's element type: on a Float32 cloud the reference computes origin + widths in Float32, octree.jl:187-196)
+template <class T>
+inline bool within(const double o[3], const double w[3], const T *p)
 {
     for (int i = 0; i < 3; i++) {
-        const double vmin = o[i], vmax = o[i] + w[i];   // vertices(rect)[1,1,1], [2,2,2]
+        const T vmin = (T)o[i], vmax = (T)o[i] + (T)w[i];   // vertices(rect)[1,1,1], [2,2,2]
         if (!(vmin < p[i])) return false;
         if (!(vmax >= p[i])) return false;
     }
@@ -89,7 +91,10 @@ cell_enabled_kernel(const int64_t *__restrict__ idx, int64_t count, const uint64
 
 }  // namespace
 
-extern "C" int rh_octree_build(const double *xyz, int64_t n, rh_octree **out)
+// the build in the cloud's element type T: every corner, division and width is a T operation; the nodes keep the values
+// widened to double (exact), so that findleaf / node_info serve both kinds of tree
+template <class T>
+static int octree_build_impl(const T *xyz, int64_t n, rh_octree **out)
 {
     if (!out || n < 0 || (n > 0 && !xyz)) { rh_set_error("rh_octree_build: bad arguments"); return RH_E_INVALID; }
     *out = nullptr;
@@ -97,11 +102,11 @@ extern "C" int rh_octree_build(const double *xyz, int64_t n, rh_octree **out)
     if (!t) { rh_set_error("out of host memory"); return RH_E_NOMEM; }
     t->n = n;
     // findAABB: both corners start at the first point and move by plain comparisons
-    double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    T lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
     for (int j = 0; j < 3 && n > 0; j++) { lo[j] = xyz[j]; hi[j] = xyz[j]; }
     for (int64_t i = 0; i < n; i++)
         for (int j = 0; j < 3; j++) {
-            const double a = xyz[3 * i + j];
+            const T a = xyz[3 * i + j];
             lo[j] = lo[j] > a ? a : lo[j];
             hi[j] = hi[j] < a ? a : hi[j];
         }
@@ -121,14 +126,14 @@ extern "C" int rh_octree_build(const double *xyz, int64_t n, rh_octree **out)
             if (!(t->nodes[cur].count > 8)) continue;                          // needs_refinement
             if (t->nodes[cur].depth >= 48) { t->overflow = 1; continue; }
             rh_octree_node par = t->nodes[cur];
-            for (int j = 0; j < 3; j++) par.div[j] = par.origin[j] + par.widths[j] / 2;
+            for (int j = 0; j < 3; j++) par.div[j] = (T)par.origin[j] + (T)par.widths[j] / 2;
             for (int ci = 0; ci < 8; ci++) {
                 rh_octree_node ch;
                 memset(&ch, 0, sizeof ch);
                 for (int j = 0; j < 3; j++) {
                     const bool upper = (ci >> j) & 1;
                     ch.origin[j] = upper ? par.div[j] : par.origin[j];
-                    ch.widths[j] = upper ? par.origin[j] + par.widths[j] - par.div[j] : par.div[j] - par.origin[j];
+                    ch.widths[j] = upper ? (T)par.origin[j] + (T)par.widths[j] - (T)par.div[j] : (T)par.div[j] - (T)par.origin[j];
                 }
                 ch.depth = par.depth + 1;
                 ch.parent = (int32_t)cur;
@@ -153,6 +158,9 @@ extern "C" int rh_octree_build(const double *xyz, int64_t n, rh_octree **out)
     *out = t;
     return RH_OK;
 }
+
+extern "C" int rh_octree_build(const double *xyz, int64_t n, rh_octree **out) { return octree_build_impl<double>(xyz, n, out); }
+extern "C" int rh_octree_build_f32(const float *xyz, int64_t n, rh_octree **out) { return octree_build_impl<float>(xyz, n, out); }
 
 extern "C" int rh_octree_destroy(rh_octree *t)
 {

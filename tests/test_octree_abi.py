@@ -72,6 +72,47 @@ def test_octree_equals_the_oracles_cell_by_cell(seed, n, shift):
     assert len(on_min_face) >= 1 and not np.isin(on_min_face, kept).any()
 
 
+@pytest.mark.parametrize("seed,n,shift", [(4, 4000, 0.0), (5, 25000, 1000.0), (6, 800, -3.0)])
+def test_float32_octree_equals_the_oracles_binary32_tree(seed, n, shift):
+    """buildoctree on Float32 vertices (a Float32 cloud, octree.jl:102-109): corners, divisions, child widths and the
+    vmin < p <= vmax tests are binary32 operations -- cell by cell the oracle's binary32 tree, and (with the large shift,
+    where a binary32 division rounds visibly) NOT the binary64 tree of the same points widened"""
+    rng = np.random.default_rng(seed)
+    ps = (rng.uniform(0, 10, size=(n, 3)) * 1.2345 + shift * 1.0001).astype(np.float32)
+    ps[: n // 10] = np.round(ps[: n // 10], 1)
+    root = R.buildoctree(ps)
+    ot = orc.Octree(ps)
+    assert R.octreedepth(root) == ot.depth()
+    for q in rng.integers(0, n, 200):
+        d, path = ot.findleaf(ps[q].astype(np.float64))
+        leaf = R.findleaf(root, ps[q].astype(np.float64))
+        assert leaf.data.depth == d
+        cell = leaf
+        for node in reversed(path):
+            assert np.array_equal(cell.data.incellpoints, ot.node_points(node))
+            cell = cell.parent
+        assert cell is None
+    o, w = root.boundary
+    assert np.array_equal(np.asarray(o), ps.min(axis=0).astype(np.float64)) and np.array_equal(np.asarray(w), ps.max(axis=0).astype(np.float64))
+    if shift == 1000.0:   # the binary64 tree of the same points widened: its divisions carry bits a binary32 sum rounds away
+        wide = R.buildoctree(ps.astype(np.float64))
+        ndiff = 0
+        for q in rng.integers(0, n, 50):
+            a, b = R.findleaf(root, ps[q].astype(np.float64)), R.findleaf(wide, ps[q].astype(np.float64))
+            (oa, wa), (ob, wb) = a.boundary, b.boundary
+            ndiff += not (np.array_equal(np.asarray(oa), np.asarray(ob)) and np.array_equal(np.asarray(wa), np.asarray(wb)))
+        assert ndiff > 0
+
+
+def test_float32_cloud_carries_the_binary32_tree():
+    """(no device needed for the tree itself; the cloud is only built where there is one)"""
+    import ransac_jl_amd.api as api
+    ps = np.random.default_rng(2).uniform(0, 1, size=(300, 3)).astype(np.float32)
+    t32, t64 = api._Octree(ps), api._Octree(ps.astype(np.float64))
+    assert t32.vertices.dtype == np.float32 and t64.vertices.dtype == np.float64
+    assert R.lib().rh_octree_build_f32(None, 5, C.byref(C.c_void_p())) != 0
+
+
 def test_octree_pc_property_and_bad_arguments():
     import ransac_jl_amd.api as api
     ps = np.random.default_rng(0).uniform(0, 1, size=(100, 3))
