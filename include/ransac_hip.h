@@ -386,10 +386,15 @@ int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t cell, int64_t *idx
  *                 score kernel; read on every launch
  *   "unp_words"   0 (default) or the segment width, in 64-bit words, of the pass that turns the score kernel's inlier
  *                 lists into dense subset-order mask rows (inpoints, src/shapes/plane.jl:68); read on every call
+ *   "st_cull"     0 (default: by the launch's size) / 1 (whenever possible) / 2 (never) -- a small launch in front of the
+ *                 culled score kernel tests every candidate against the boxes of the SUPER-TILES (16 groups of 64 points)
+ *                 and leaves per super-tile the list of candidates that may meet it; the score kernel's blocks then walk
+ *                 those lists instead of every candidate of the batch.  Read on every launch.
  *   "batches_in_flight"  1 (default) .. 4 -- with F > 1, rh_score_batch_dev calls take turns on the cloud's
  *                 stream and F - 1 more with workspaces of their own, so one batch's prepare + score launches start while
  *                 the previous batches' launches drain.  The caller keeps F count (and mask) buffers and gives call k of a
- *                 run of such calls buffer k mod F (a buffer is written again only by the stream that wrote it last); every other call on the cloud, rh_cloud_sync and rh_timer_stop included, first lets the cloud's stream
+ *                 run of such calls buffer k mod F (a buffer is written again only by the stream that wrote it last);
+ *                 every other call on the cloud, rh_cloud_sync and rh_timer_stop included, first lets the cloud's stream
  *                 wait for the others, so whatever follows sees every batch's counts.  Ignored while the cloud runs on a
  *                 caller's stream (rh_cloud_set_stream).
  * Results never depend on any of them (tests/test_parity_gpu.py runs every parity test under both score paths).

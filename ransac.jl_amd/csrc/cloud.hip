@@ -182,14 +182,14 @@ static void cloud_free(rh_cloud *c)
         if (!s.stream) continue;
         (void)hipStreamSynchronize(s.stream);
         (void)hipFree(s.d_shapes); (void)hipFree(s.d_prep); (void)hipFree(s.d_orig); (void)hipFree(s.d_counts); (void)hipFree(s.d_nk2);
-        (void)hipFree(s.d_qpre); (void)hipFree(s.d_prep32); (void)hipFree(s.d_box); (void)hipFree(s.d_masks_int); (void)hipFree(s.d_occ);
+        (void)hipFree(s.d_qpre); (void)hipFree(s.d_prep32); (void)hipFree(s.d_box); (void)hipFree(s.d_masks_int); (void)hipFree(s.d_occ); (void)hipFree(s.d_stlist); (void)hipFree(s.d_stcount);
         (void)hipEventDestroy(s.done); (void)hipEventDestroy(s.start); (void)hipStreamDestroy(s.stream);
     }
     (void)hipFree(c->full); (void)hipFree(c->rec); (void)hipFree(c->crec); (void)hipFree(c->sel_list); (void)hipFree(c->set_ws); (void)hipFree(c->set_level); (void)hipFree(c->sub); (void)hipFree(c->dis);
     (void)hipFree(c->sub_idx0); (void)hipFree(c->enabled); (void)hipFree(c->sub_enabled);
     (void)hipFree(c->sub_perm); (void)hipFree(c->gb); (void)hipFree(c->d_masks_int);
     (void)hipFree(c->full32); (void)hipFree(c->sub32); (void)hipFree(c->d_prep32); (void)hipFree(c->d_qpre); (void)hipFree(c->d_zero);
-    (void)hipFree(c->s4_stats); (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
+    (void)hipFree(c->s4_stats); (void)hipFree(c->d_box); (void)hipFree(c->gb32); (void)hipFree(c->st32); (void)hipFree(c->d_stlist); (void)hipFree(c->d_stcount); (void)hipFree(c->d_occ); (void)hipFree(c->unp_segmask);
     (void)hipFree(c->oct_code); (void)hipFree(c->oct_perm); (void)hipFree(c->oct_pos); (void)hipFree(c->oct_men);
     (void)hipFree(c->oct_prefix); (void)hipFree(c->oct_P); (void)hipFree(c->oct_tab); (void)hipFree(c->oct_code_o);
     (void)hipFree(c->oct_state); (void)hipFree(c->oct_adv_tab); (void)hipFree(c->oct_adv_bits); (void)hipFree(c->oct_adv_E);
@@ -406,6 +406,8 @@ extern "C" int rh_cloud_create(const double *xyz, const double *nrm, int64_t n, 
     c->ng_pad = ((c->ngroups + RH_G2_TG - 1) / RH_G2_TG) * RH_G2_TG + RH_G2_TG;
     CK(dev_alloc(&c->gb, 7 * c->ng_pad));
     CK(dev_alloc(&c->gb32, 8 * c->ng_pad));
+    c->nst = (c->ngroups + 15) / 16;
+    CK(dev_alloc(&c->st32, 8 * std::max<int64_t>(1, c->nst)));
     CK(dev_alloc(&c->dis_gb, 7 * c->ng_pad));
     CK(dev_alloc(&c->dis_gb32, 8 * c->ng_pad));
     CKH(hipMemsetAsync(c->dis_gb, 0, sizeof(double) * 7 * (size_t)c->ng_pad, c->stream));
@@ -920,6 +922,52 @@ extern "C" int rh_score_batch(rh_cloud *c, const rh_shape *shapes, int32_t b, co
     return RH_OK;
 }
 
+// A stream that really runs beside the given ones.  The runtime deals its streams to a few hardware queues (the least used
+// one at creation), and two streams on one queue run one after the other -- which queue a new stream lands on depends on every
+// stream the process has made before (other clouds, torch, copy streams).  So: candidates are created until one of them gets
+// a kernel through while all the given streams are held busy by a spinning wave (~0.3 ms, once per slot and cloud).
+namespace {
+__global__ void spin_kernel(unsigned long long ticks)   // one wave, ~ticks of the 100 MHz clock
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void noop_kernel() {}
+}  // namespace
+
+static int pick_concurrent_stream(const hipStream_t *busy, int nbusy, hipStream_t *out)
+{
+    hipStream_t tried[8];
+    int ntried = 0, chosen = -1;
+    hipEvent_t eb[RH_MAX_IN_FLIGHT], ec;
+    for (int i = 0; i < nbusy; i++) RH_HIP(hipEventCreateWithFlags(&eb[i], hipEventDisableTiming));
+    RH_HIP(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+    int rc = RH_OK;
+    for (; ntried < 8 && chosen < 0 && rc == RH_OK; ntried++) {
+        if (hipStreamCreateWithFlags(&tried[ntried], hipStreamNonBlocking) != hipSuccess) { rc = RH_E_NODEVICE; rh_set_error("hipStreamCreateWithFlags failed"); break; }
+        for (int i = 0; i < nbusy; i++) {
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, busy[i], 30000ULL);   // 0.3 ms
+            (void)hipEventRecord(eb[i], busy[i]);
+        }
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, tried[ntried]);
+        (void)hipEventRecord(ec, tried[ntried]);
+        (void)hipEventSynchronize(ec);
+        bool beside = true;   // the candidate's kernel is through: are all the busy streams still spinning?
+        for (int i = 0; i < nbusy; i++) beside = beside && hipEventQuery(eb[i]) == hipErrorNotReady;
+        for (int i = 0; i < nbusy; i++) (void)hipEventSynchronize(eb[i]);
+        if (beside) chosen = ntried;
+    }
+    if (rc == RH_OK && chosen < 0) chosen = ntried - 1;   // (none found: the last one -- correct, only not concurrent)
+    for (int i = 0; i < ntried; i++)
+        if (i != chosen) (void)hipStreamDestroy(tried[i]);
+    for (int i = 0; i < nbusy; i++) (void)hipEventDestroy(eb[i]);
+    (void)hipEventDestroy(ec);
+    (void)hipGetLastError();
+    if (rc != RH_OK) return rc;
+    *out = tried[chosen];
+    return RH_OK;
+}
+
 static void swap_batch_slot(rh_cloud *c, rh_batch_slot &s)
 {
     std::swap(c->stream, s.stream);
@@ -929,6 +977,7 @@ static void swap_batch_slot(rh_cloud *c, rh_batch_slot &s)
     std::swap(c->nk2_flip, s.nk2_flip); std::swap(c->nk2_ready, s.nk2_ready); std::swap(c->qpre_v4, s.qpre_v4);
     std::swap(c->d_masks_int, s.d_masks_int); std::swap(c->masks_int_cap, s.masks_int_cap); std::swap(c->d_occ, s.d_occ);
     std::swap(c->occ_cap, s.occ_cap); std::swap(c->mstride4, s.mstride4);
+    std::swap(c->d_stlist, s.d_stlist); std::swap(c->d_stcount, s.d_stcount); std::swap(c->stlist_cap, s.stlist_cap); std::swap(c->stlist_nst, s.stlist_nst);
 }
 
 static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
@@ -1009,7 +1058,11 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
         if (slot == 0) return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr, false);
         rh_batch_slot &s = c->alt[slot - 1];
         if (s.stream == nullptr) {
-            RH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            hipStream_t busy[RH_MAX_IN_FLIGHT];
+            int nbusy = 0;
+            busy[nbusy++] = c->stream;
+            for (int q = 0; q < RH_MAX_IN_FLIGHT - 1; q++) if (q != slot - 1 && c->alt[q].stream != nullptr) busy[nbusy++] = c->alt[q].stream;
+            RH_TRY(pick_concurrent_stream(busy, nbusy, &s.stream));
             RH_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
             RH_HIP(hipEventCreateWithFlags(&s.start, hipEventDisableTiming));
             RH_HIP(hipMalloc((void **)&s.d_nk2, 8 * sizeof(int32_t)));

@@ -170,7 +170,7 @@ static uint64_t rng_next(rh_rng *r)
 
 // forcefitshapes! (fitting.jl:165-173) for the minimal sets of an iteration in one call (the sets rh_sample_sets drew): fit for
 // every type of p->shape_types in order on every set with ok != 0; what fits is appended with the index of its set.  The sets
-// are independent: from 2048 sets on they are dealt to host threads in contiguous ranges and the ranges' results joined in
+// are independent: from 512 sets on they are dealt to host threads in contiguous ranges and the ranges' results joined in
 // order, so the output does not depend on the number of threads.
 namespace {
 struct FitSetsOut { std::vector<rh_shape> shapes; std::vector<int32_t> sets; int rc = RH_OK; };
@@ -211,7 +211,11 @@ extern "C" int rh_fit_sets(const double *xyz, const double *nrm, const int64_t *
     *n_out = 0;
     try {
         unsigned nt = 1;
-        if (k >= 2048) { nt = std::thread::hardware_concurrency(); nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt); }
+        if (k >= 512) {   // (at least 128 sets per thread: a thread's start costs about as much as fitting fifty sets)
+            nt = std::thread::hardware_concurrency();
+            nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+            if (nt > (unsigned)k / 128) nt = (unsigned)k / 128;
+        }
         std::vector<FitSetsOut> outs(nt);
         if (nt == 1) {
             fit_sets_range(xyz, nrm, idx, ok, 0, k, drawN, prm, f32, &outs[0]);

@@ -37,6 +37,7 @@ const OptDef kDefs[] = {
     RH_O(RH_OPT_SCORE_PATH, "score_path", "RH_SCORE_PATH", T_ENUM_SCORE),
     RH_O(RH_OPT_S4_ROWS, "s4_rows", "RH_S4_R", T_INT),
     RH_O(RH_OPT_UNP_WORDS, "unp_words", "RH_UNP_WORDS", T_INT),
+    RH_O(RH_OPT_ST_CULL, "st_cull", "RH_ST_CULL", T_INT),
     RH_O(RH_OPT_REFIT_PATH, "refit_path", "RH_REFIT_PATH", T_ENUM_REFIT),
     RH_O(RH_OPT_BATCHES_IN_FLIGHT, "batches_in_flight", "RH_BATCHES_IN_FLIGHT", T_INT),
 #ifdef RH_DIAG
@@ -147,6 +148,7 @@ extern "C" int rh_set_option(rh_cloud *c, const char *key, int64_t value)
         case RH_OPT_REFIT_PATH: ok = value >= 0 && value <= RH_REFIT_PATH_CULLED; break;
         case RH_OPT_S4_ROWS: ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 12 || value == 16; break;
         case RH_OPT_UNP_WORDS: ok = value >= 0 && value <= 16384; break;
+        case RH_OPT_ST_CULL: ok = value >= 0 && value <= 2; break;
         case RH_OPT_BATCHES_IN_FLIGHT: ok = value >= 0 && value <= RH_MAX_IN_FLIGHT; break;
         default: break;
         }

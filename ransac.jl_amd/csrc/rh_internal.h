@@ -32,6 +32,7 @@ enum rh_opt_id {
     RH_OPT_SCORE_PATH = 0,      // product keys (rh_set_option, include/ransac_hip.h)
     RH_OPT_S4_ROWS,
     RH_OPT_UNP_WORDS,
+    RH_OPT_ST_CULL,
     RH_OPT_REFIT_PATH,
     RH_OPT_BATCHES_IN_FLIGHT,
     RH_OPT_N_PRODUCT,
@@ -99,6 +100,9 @@ struct rh_batch_slot {
     int32_t *d_orig = nullptr, *d_counts = nullptr, *d_nk2 = nullptr;
     void *d_qpre = nullptr, *d_prep32 = nullptr;
     float *d_box = nullptr;
+    uint16_t *d_stlist = nullptr;      // (the super-tile lists of the slot's batch)
+    int32_t *d_stcount = nullptr;
+    int64_t stlist_cap = 0, stlist_nst = 0;
     uint64_t *d_masks_int = nullptr;   // (batches with mask output: the entry lists and their cursors)
     uint8_t *d_occ = nullptr;
     int64_t masks_int_cap = 0, occ_cap = 0, mstride4 = 0;
@@ -146,6 +150,12 @@ struct rh_cloud {
     double nrm_mag = 0;                // max |normal component| over the subset (margins of the binary32 classifier)
     bool use_groups = false;           // culled scoring path available (s large enough)
     float *gb32 = nullptr;             // the same boxes in binary32, 8 floats per group (v4 score kernel: scalar loads)
+    float *st32 = nullptr;             // boxes of the super-tiles (16 consecutive groups = 4 tiles of the k-d leaf order), 8 floats each
+    int64_t nst = 0;
+    // per-super-tile candidate lists of the batch being scored (score4.hip, st_cull_kernel): [nst][4 kinds][stlist_cap] slots, [nst][4] counts
+    uint16_t *d_stlist = nullptr;
+    int32_t *d_stcount = nullptr;
+    int64_t stlist_cap = 0, stlist_nst = 0;
     double *dis_gb = nullptr;          // boxes of the dis segment in use (7 x ng_pad)
     int32_t *d_ndis = nullptr;         // device counter: entries in dis
     int64_t n_dis = 0;                 // host mirror

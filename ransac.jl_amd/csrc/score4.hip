@@ -52,9 +52,10 @@ constexpr int S4_GB = 2;                 // bits of the group in a pair-list ent
 constexpr unsigned S4_GM = (1u << S4_GB) - 1u;
 constexpr int S4_ROW = 65;               // padded row length of the tile arrays (bank spread of the per-lane rows)
 constexpr int S4_W = 4;                  // waves per block
+constexpr int S4_STG = 16;               // groups per super-tile (st_cull_kernel): 4 tiles = 1024 points of the k-d leaf order
 // R: 64-candidate chunks per block row -- 16 / 12 / 4 / 2 by the size of the grid (rhk_score4_all holds the rule and the
 // measurements behind it)
-template <int R, bool MASK = false>
+template <int R, bool MASK = false, bool LIST = false>
 struct S4Shared {
     static_assert(S4_TG == (1 << S4_GB) && R * 64 * S4_TG <= 65536 && (R % S4_W == 0 || R < S4_W), "entry encoding: S4_GB bits of group, the rest of 16 for the candidate");
     rh_f32x4 pa[S4_TG][S4_ROW];          // (x, y, z, nx); zeros for a disabled / out-of-range point
@@ -62,6 +63,7 @@ struct S4Shared {
     uint64_t len[S4_TG];                 // enabled & valid bits of the groups
     rh_f32x4 gbox[S4_TG][2];             // the groups' binary32 boxes (cx cy cz hx | hy hz hr 0): stage 1 reads them as broadcasts
     uint16_t plist[R * 64 * S4_TG + 2];  // the block's surviving pairs: candidate of the row << S4_GB | group (+ a dump slot)
+    uint16_t ctab[LIST ? R * 64 : 2];    // LIST: the bin slot of every candidate of the row (the row walks its super-tile's list)
     int32_t cntb[S4_W][64];              // cone: per-wave inlier counts of the batch's pairs
     unsigned long long maskb[S4_W][64];  // cone, masks wanted: per-wave inlier words of the batch's pairs
     uint16_t qb[S4_W][128];              // cone: per-wave ring (slot-in-batch << 6 | point-in-group) for the exact test
@@ -103,6 +105,11 @@ struct S4AllArgs {
     uint8_t *occ;
     int64_t mstride;
     unsigned long long *stats;   // diag build: event counters of the launch (rh_dbg_s4_stats; layout at S4_STAT), else null
+    // LIST launches: per super-tile (S4_STG groups) and kind the bin slots of the candidates whose culling record does not
+    // rule the super-tile's box out, ascending (st_cull_kernel), stcap apart, and their numbers
+    const uint16_t *stlist;
+    const int32_t *stcount;
+    int64_t stcap;
 };
 
 // ---- event counters (diag build only; tools/isa_account.py multiplies them with the static instruction histogram of the
@@ -140,9 +147,9 @@ static __device__ __forceinline__ int run_total(int v, int key, int lane)
 }
 
 // one batch: the 64 pairs of the block's list from `head` on (n of them valid), one per lane
-template <int KIND, int R, bool MASK, bool F32>
+template <int KIND, int R, bool MASK, bool F32, bool LIST>
 static __device__ __forceinline__ void
-score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
+score4_batch(S4Shared<R, MASK, LIST> &sh, const int wv, const int lane, const int head, const int n, const int cbase, const double *__restrict__ pts,
              int64_t stride, const int64_t p0, const rh_prep *__restrict__ prep, const rh_cls *__restrict__ cls,
              const int32_t *__restrict__ orig, double eps, double cosa, int32_t *__restrict__ counts, const bool weird,
              uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride, const int64_t g0, unsigned long long *__restrict__ stats)
@@ -151,7 +158,7 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
     S4_STAT(stats, 24 * KIND + 8, 1);
     const bool act = lane < n;
     const uint32_t e = sh.plist[head + (act ? lane : 0)];
-    const int g = (int)(e & S4_GM), ci = cbase + (int)(e >> S4_GB);
+    const int g = (int)(e & S4_GM), ci = LIST ? (int)sh.ctab[e >> S4_GB] : cbase + (int)(e >> S4_GB);
     const rh_f32x4 *__restrict__ rowa = &sh.pa[g][0];
     const rh_f32x2 *__restrict__ rowb = &sh.pb[g][0];
     const rh_cls *__restrict__ rec = &cls[ci];
@@ -170,12 +177,12 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
         const int64_t gi = p0 + (int)(pe & S4_GM) * 64 + (int)(e2 & 63u);
         uint64_t r;
         if (F32) {
-            const rh_prepf Pv = prepf_of<KIND>(prep[cbase + (int)(pe >> S4_GB)]);
+            const rh_prepf Pv = prepf_of<KIND>(prep[LIST ? (int)sh.ctab[pe >> S4_GB] : cbase + (int)(pe >> S4_GB)]);
             const rh_f32x4 a = sh.pa[pe & S4_GM][e2 & 63u];
             const rh_f32x2 b = sh.pb[pe & S4_GM][e2 & 63u];
             r = test_point32<KIND>(Pv, a.x, a.y, a.z, a.w, b.x, b.y, eps, cosa);
         } else {
-            const rh_prep Pv = prep[cbase + (int)(pe >> S4_GB)];
+            const rh_prep Pv = prep[LIST ? (int)sh.ctab[pe >> S4_GB] : cbase + (int)(pe >> S4_GB)];
             r = test_point<KIND>(Pv, pts[gi], pts[stride + gi], pts[2 * stride + gi], pts[3 * stride + gi], pts[4 * stride + gi],
                                  pts[5 * stride + gi], eps, cosa);
         }
@@ -232,7 +239,8 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
                 const int k = __builtin_ctzll(redo);
                 redo &= redo - 1;
                 const uint32_t ek = __builtin_amdgcn_readlane(e, k);
-                const int g2 = (int)(ek & S4_GM), ci2 = cbase + (int)(ek >> S4_GB);
+                const int g2 = (int)(ek & S4_GM);
+                const int ci2 = LIST ? __builtin_amdgcn_readfirstlane((int)sh.ctab[ek >> S4_GB]) : cbase + (int)(ek >> S4_GB);
                 const RH4_CONST_AS rh_cls *rk = (const RH4_CONST_AS rh_cls *)(uintptr_t)&cls[ci2];   // (wave-uniform: scalar loads)
                 rh_cls Ck;
 #pragma unroll
@@ -349,9 +357,9 @@ score4_batch(S4Shared<R, MASK> &sh, const int wv, const int lane, const int head
 // one kind segment of the block's row: chunks [lo, hi) of the kind (at most S4_R).  Stage 1: the waves share the
 // chunks out, lane = candidate, box tests, survivors -> the block's pair list.  Stage 2: the waves take batches of 64
 // pairs from the list until it is empty.
-template <int KIND, int R, bool MASK, bool F32>
+template <int KIND, int R, bool MASK, bool F32, bool LIST>
 static __device__ __forceinline__ void
-score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride, const int lo, const int hi,
+score4_segment(S4Shared<R, MASK, LIST> &sh, const S4KindArgs &K, const int32_t *__restrict__ nkp, const uint16_t *__restrict__ list, const int64_t bstride, const int lo, const int hi,
                const double *__restrict__ pts, int64_t stride, const int64_t g0, const unsigned live, const bool weird,
                int32_t *__restrict__ counts, int dbg, uint64_t *__restrict__ masks, uint8_t *__restrict__ occ, const int64_t mstride,
                unsigned long long *__restrict__ stats)
@@ -359,7 +367,7 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
     (void)stats;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nk = *K.nk;
+    const int nk = *nkp;
     S4_STAT(stats, 24 * KIND + 0, 1);
     constexpr int NB = S4Fields<KIND>::NBOX;
     // (the culling records of the wave's chunks are requested together, before the first box test)
@@ -367,9 +375,21 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
     float B[2][RH_BOX_FIELDS];
     // (unconditional loads from a clamped slot: a lane without a candidate reads slot 0 and is masked out below -- a
     // guarded load per field costs a scalar exec-mask save / branch / restore each, ~20 scalar instructions per chunk)
+    // LIST: the row's candidates come from the super-tile's list -- the bin slots of ALL the wave's chunks are requested
+    // together (one round trip in front of the record loads instead of one per chunk) and kept in LDS for stage 2
+    int slot[LIST ? CPW : 1];
+    auto clamped = [&](int h) { const int ci = ((lo + wv + h * S4_W) << 6) + lane; return (lo + wv + h * S4_W < hi && ci < nk) ? ci : 0; };
+    if (LIST) {
+#pragma unroll
+        for (int h = 0; h < CPW; h++) slot[h] = (int)list[clamped(h)];
+#pragma unroll
+        for (int h = 0; h < CPW; h++) {
+            const int ci = ((lo + wv + h * S4_W) << 6) + lane;
+            if (lo + wv + h * S4_W < hi && ci < nk) sh.ctab[ci - (lo << 6)] = (uint16_t)slot[h];
+        }
+    }
     {
-        const int ci = ((lo + wv) << 6) + lane;
-        const int cil = (lo + wv < hi && ci < nk) ? ci : 0;
+        const int cil = LIST ? slot[0] : clamped(0);
 #pragma unroll
         for (int f = 0; f < NB; f++) B[0][f] = K.box[(int64_t)f * bstride + cil];
     }
@@ -379,8 +399,7 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
         if (c >= hi) break;
         const int ci = (c << 6) + lane;
         if (h + 1 < CPW) {   // the next chunk's records: in flight during this chunk's tests
-            const int cin = ((c + S4_W) << 6) + lane;
-            const int cinl = (c + S4_W < hi && cin < nk) ? cin : 0;
+            const int cinl = LIST ? slot[h + 1 < CPW ? h + 1 : 0] : clamped(h + 1);
 #pragma unroll
             for (int f = 0; f < NB; f++) B[(h + 1) & 1][f] = K.box[(int64_t)f * bstride + cinl];
         }
@@ -426,7 +445,7 @@ score4_segment(S4Shared<R, MASK> &sh, const S4KindArgs &K, const int64_t bstride
         if (lane == 0) bt = atomicAdd(&sh.next_batch, 1);
         bt = __builtin_amdgcn_readfirstlane(bt);
         if (bt * 64 >= npairs) break;
-        score4_batch<KIND, R, MASK, F32>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
+        score4_batch<KIND, R, MASK, F32, LIST>(sh, wv, lane, bt * 64, min(64, npairs - bt * 64), lo << 6, pts, stride, g0 * 64, K.prep, K.cls, K.orig,
                                          K.eps, K.cosa, counts, weird, masks, occ, mstride, g0, stats);
     }
 }
@@ -482,13 +501,13 @@ static __device__ __forceinline__ void s4_stage(SH &sh, const double *__restrict
 // TAIL: the launch that picks up what a sized-before-the-count-was-known launch leaves over (rhk_score4_all, `open`):
 // its blocks walk the rows from A.row0 on grid-stride.  A separate instantiation -- the loop around the four per-kind
 // bodies costs the register allocation dearly (96 scalar + 40 vector registers spilled), the one-row form none.
-template <int R, bool MASK, bool F32, bool TAIL = false>
+template <int R, bool MASK, bool F32, bool TAIL = false, bool LIST = false>
 // 7 blocks of four waves per CU = 7 waves per SIMD = 72 vector registers (measured against 8 / 64 registers: cfg3 0.0816 ->
 // 0.0807 ms, cfg5 0.3006 -> 0.2973; 6 / 80 registers is slower: profiles/r4/experiments.txt)
 #ifndef RH_S4_MINBLK
 #define RH_S4_MINBLK 7
 #endif
-__global__ void __launch_bounds__(64 * S4_W, F32 ? 8 : RH_S4_MINBLK)   // (the Float32 instantiations: 8 / 64 registers, 0.0916 -> see experiments.txt)
+__global__ void __launch_bounds__(64 * S4_W, (F32 && !(LIST && R == 16)) ? 8 : RH_S4_MINBLK)   // (the Float32 instantiations: 8 / 64 registers, 0.0916 -> see experiments.txt; LIST rows of 16: 20.8 KB of LDS, seven blocks)
 score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S4AllArgs A, int32_t *__restrict__ counts, int dbg_arg)
 {
 #ifdef RH_DIAG
@@ -497,7 +516,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     constexpr int dbg = 0;     // the product kernel has no such switch
     (void)dbg_arg;
 #endif
-    __shared__ S4Shared<R, MASK> sh;
+    __shared__ S4Shared<R, MASK, LIST> sh;
     // Blocks go to the 8 XCDs round-robin by their linear id, each XCD with an L2 of its own.  With rows > 0 the id is
     // read as ((tile / 8) x rows + row) x 8 + tile % 8: the rows of one tile follow each other on ONE XCD, so the tile is
     // fetched from HBM once and staged from L2 by the other rows (cfg5, 9 rows over a 75-MB subset: the (tile, row) grid
@@ -513,9 +532,11 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
     if (A.stop != nullptr && *A.stop != 0) return;
     const int64_t g0 = tile * S4_TG;
     S4_STAT(A.stats, 96 + 0, 1);
+    static_assert(!(TAIL && LIST), "the row-walking launch takes its candidates in bin order");
     int nch[4], total = 0;
+    const int64_t st4 = LIST ? (tile / (S4_STG / S4_TG)) * 4 : 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { nch[k] = (*A.k[k].nk + 63) >> 6; total += nch[k]; }
+    for (int k = 0; k < 4; k++) { nch[k] = ((LIST ? A.stcount[st4 + k] : *A.k[k].nk) + 63) >> 6; total += nch[k]; }
     bool ran = false, weird = false;
     unsigned live = 0;
     const uint64_t *staged_en = nullptr;
@@ -535,7 +556,7 @@ score4_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const S
             for (int g = 0; g < S4_TG; g++) live |= sh.len[g] != 0 ? (1u << g) : 0u;                                   \
             live = __builtin_amdgcn_readfirstlane(live);                                                               \
             { int ww = 0; for (int g = 0; g < S4_TG; g++) ww |= sh.weirdw[g]; weird = __builtin_amdgcn_readfirstlane(ww) != 0; }  \
-            if (live != 0) score4_segment<K, R, MASK, F32>(sh, A.k[K], A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride, A.stats); \
+            if (live != 0) score4_segment<K, R, MASK, F32, LIST>(sh, A.k[K], LIST ? A.stcount + (st4 + K) : A.k[K].nk, LIST ? A.stlist + (st4 + K) * A.stcap : nullptr, A.bstride, slo, shi, pts, stride, g0, live, weird, counts, dbg, A.masks, A.occ, A.mstride, A.stats); \
             else S4_STAT(A.stats, 96 + 3, 1);                                                                         \
             ran = true;                                                                                                \
         }                                                                                                              \
@@ -888,6 +909,103 @@ __global__ void gb32_kernel(const double *__restrict__ gb, int64_t gstride, int6
     for (int k = 0; k < 8; k++) out[g * 8 + k] = o[k];
 }
 
+// boxes of the super-tiles: the union of S4_STG consecutive groups' boxes, widened by what the unions' own arithmetic can
+// lose, then made binary32 like a group's.  A group box that is not finite makes the super-tile's NaN: never skipped.
+__global__ void st32_kernel(const double *__restrict__ gb, int64_t gstride, int64_t ngroups, int64_t nst, float *__restrict__ out)
+{
+    const int64_t st = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (st >= nst) return;
+    double lo[3] = { __builtin_inf(), __builtin_inf(), __builtin_inf() }, hi[3] = { -__builtin_inf(), -__builtin_inf(), -__builtin_inf() };
+    bool bad = false;
+    for (int64_t g = st * S4_STG; g < (st + 1) * S4_STG && g < ngroups; g++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double cc = gb[k * gstride + g], hh = gb[(3 + k) * gstride + g];
+            bad |= !(fabs(cc) < __builtin_inf()) || !(fabs(hh) < __builtin_inf());
+            lo[k] = fmin(lo[k], cc - hh);
+            hi[k] = fmax(hi[k], cc + hh);
+        }
+    double c3[3], h3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        c3[k] = 0.5 * lo[k] + 0.5 * hi[k];
+        // (cc -+ hh above and the two differences below each round once: a few ulps of the LARGEST magnitude involved, not of h)
+        h3[k] = fmax(hi[k] - c3[k], c3[k] - lo[k]) * 1.000000000001 + (fabs(lo[k]) + fabs(hi[k])) * 1e-15;
+        bad |= !(fabs(c3[k]) < __builtin_inf()) || !(h3[k] < __builtin_inf());
+    }
+    float o[8];
+    box_to_f32(c3, h3, o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[st * 8 + k] = bad ? __builtin_nanf("") : o[k];
+}
+
+// ---- the super-tile lists of a batch.  One block per (super-tile, kind): the kind's candidates in bin order, 256 at a time,
+// lane = candidate, the culling record against the super-tile's box with the very test of stage 1 (box_skip32: a box that
+// holds all the points of its groups may be skipped only when none of them can pass) -- the survivors' bin slots, in order.
+struct StCullArgs {
+    const float *box[4];
+    const int32_t *nk[4];
+    int64_t bstride, stcap;
+    const float *st32;
+    uint16_t *stlist;
+    int32_t *stcount;
+};
+
+template <int KIND>
+static __device__ __forceinline__ void st_cull_kind(const StCullArgs &A, const int64_t st)
+{
+    __shared__ int32_t wsum[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nk = *A.nk[KIND];
+    int32_t *cnt = A.stcount + st * 4 + KIND;
+    if (nk <= 0) { if (tid == 0) *cnt = 0; return; }
+    rh_box32 G;
+    {
+        const float *b = A.st32 + st * 8;
+        G.cx = b[0]; G.cy = b[1]; G.cz = b[2]; G.hx = b[3]; G.hy = b[4]; G.hz = b[5]; G.hr = b[6];
+    }
+    uint16_t *__restrict__ list = A.stlist + (st * 4 + KIND) * A.stcap;
+    constexpr int NB = S4Fields<KIND>::NBOX;
+    const float *__restrict__ box = A.box[KIND];
+    float B[2][RH_BOX_FIELDS];
+    {
+        const int cl = tid < nk ? tid : 0;
+#pragma unroll
+        for (int f = 0; f < NB; f++) B[0][f] = box[(int64_t)f * A.bstride + cl];
+    }
+    int base = 0, it = 0;
+    for (int j0 = 0; j0 < nk; j0 += 256, it++) {
+        const int cand = j0 + tid;
+        if (j0 + 256 < nk) {   // the next 256 records: in flight during this round's tests and its barrier
+            const int cn = cand + 256 < nk ? cand + 256 : 0;
+#pragma unroll
+            for (int f = 0; f < NB; f++) B[(it + 1) & 1][f] = box[(int64_t)f * A.bstride + cn];
+        }
+        const bool keep = cand < nk && !box_skip32<KIND>(B[it & 1], G);
+        const uint64_t m = WB(keep);
+        if (lane == 0) wsum[it & 1][wv] = __popcll(m);
+        __syncthreads();   // (the sums alternate between two rows: one barrier per round)
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int v = wsum[it & 1][w]; off += w < wv ? v : 0; tot += v; }
+        if (keep) list[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint16_t)cand;
+        base += tot;
+    }
+    if (tid == 0) *cnt = base;
+}
+
+__global__ void __launch_bounds__(256)
+st_cull_kernel(const StCullArgs A)
+{
+    const int64_t st = blockIdx.x;
+    switch (blockIdx.y) {
+    case RH_PLANE: st_cull_kind<RH_PLANE>(A, st); break;
+    case RH_SPHERE: st_cull_kind<RH_SPHERE>(A, st); break;
+    case RH_CYLINDER: st_cull_kind<RH_CYLINDER>(A, st); break;
+    default: st_cull_kind<RH_CONE>(A, st); break;
+    }
+}
+
 inline int cdiv4(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -896,7 +1014,24 @@ int rhk_gb32_build(rh_cloud *c)
 {
     if (c->ngroups == 0 || c->gb32 == nullptr) return RH_OK;
     hipLaunchKernelGGL(gb32_kernel, dim3(cdiv4(c->ngroups, 256)), dim3(256), 0, c->stream, c->gb, c->ng_pad, c->ngroups, c->gb32);
+    if (c->st32 != nullptr && c->nst > 0)
+        hipLaunchKernelGGL(st32_kernel, dim3(cdiv4(c->nst, 64)), dim3(64), 0, c->stream, c->gb, c->ng_pad, c->ngroups, c->nst, c->st32);
     RH_HIP(hipGetLastError());
+    return RH_OK;
+}
+
+// the super-tile lists' workspace of the batch slot in place: [nst][4][cap] bin slots + [nst][4] counts
+static int ensure_stlists(rh_cloud *c, int64_t cap)
+{
+    if (c->d_stlist != nullptr && cap <= c->stlist_cap && c->stlist_nst == c->nst) return RH_OK;
+    RH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_stlist); (void)hipFree(c->d_stcount);
+    c->d_stlist = nullptr; c->d_stcount = nullptr; c->stlist_cap = 0;
+    const int64_t ncap = std::max<int64_t>(cap, 1024);
+    RH_HIP(hipMalloc((void **)&c->d_stlist, sizeof(uint16_t) * (size_t)c->nst * 4 * (size_t)ncap));
+    RH_HIP(hipMalloc((void **)&c->d_stcount, sizeof(int32_t) * (size_t)c->nst * 4));
+    c->stlist_cap = ncap;
+    c->stlist_nst = c->nst;
     return RH_OK;
 }
 
@@ -930,6 +1065,30 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
 #ifdef RH_DIAG
     A.stats = (unsigned long long *)c->s4_stats;   // (rh_dbg_s4_stats switched the counters on)
 #endif
+    // Super-tile lists (round 5): a candidate meets only ~13 / 3 / 10 % of the groups (plane / sphere / cylinder at cfg3), yet
+    // every block of every tile walks ALL the candidates of its row through stage 1 -- loads of their culling records, four box
+    // tests, the list bookkeeping: a third of the launch's issue cycles.  One small launch first tests every candidate against
+    // the boxes of the SUPER-TILES (16 groups = 4 tiles: 1/16 of the tests) and leaves per super-tile and kind the list of
+    // the candidates that may meet it (42 / 7 / 35 % of them at cfg3, 24 / 6 / 21 % at cfg5); the rows of a tile are then cut
+    // from its super-tile's lists.  Same culling rule, so the same counts and masks: a candidate the super-tile's box rules out
+    // has no inlier in any of its groups.  For launches whose candidate count the host knows, on subset 1.
+    A.stlist = nullptr; A.stcount = nullptr; A.stcap = 0;
+    const int64_t st_opt = rh_opt_int(c, RH_OPT_ST_CULL, 0);   // 0 = by size, 1 = whenever possible, 2 = never
+    bool use_lists = !open_count && c->s4_points == nullptr && dbg == 0 && c->st32 != nullptr && c->nst >= 2 && nk_total_bound <= 16384 && st_opt != 2;
+    // By size (measured, cfg3's mix on 10M / 20M / 30M / cfg5's on 50M points = 1221 / 2442 / 3662 / 6104 tiles, a batch of 4096): the
+    // lists cut the launch's instructions by a fifth, but its blocks become three times fewer and heavier, and a small grid then
+    // ends in a long tail -- one batch at a time +28 % / +5 % / -1 % / -10 %; with two batches in flight, where the next batch
+    // fills the tail, -0 % / -10 % / -15 % / -21 %.
+    if (use_lists && st_opt == 0)
+        use_lists = nk_total_bound >= 1024 && ntiles >= (rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) > 1 ? 2000 : 3500);
+    if (use_lists) {
+        RH_TRY(ensure_stlists(c, ((int64_t)nk_total_bound + 63) / 64 * 64));
+        StCullArgs SA;
+        for (int k = 0; k < 4; k++) { SA.box[k] = box[k]; SA.nk[k] = nk[k]; }
+        SA.bstride = bstride; SA.stcap = c->stlist_cap; SA.st32 = c->st32; SA.stlist = c->d_stlist; SA.stcount = c->d_stcount;
+        hipLaunchKernelGGL(st_cull_kernel, dim3((unsigned)c->nst, 4), dim3(256), 0, c->stream, SA);
+        A.stlist = c->d_stlist; A.stcount = c->d_stcount; A.stcap = c->stlist_cap;
+    }
     const int env_r = (int)rh_opt_int(c, RH_OPT_S4_ROWS, 0);   // rh_set_option(.., "s4_rows", ..), read on every launch: the fuzzers vary it from case to case
     // R = chunks of 64 candidates per block row.  A block's fixed work -- prologue, staging its tile, the four kinds' dispatch --
     // is a third of the launch's issue cycles at cfg3 and nearly half at cfg5 (profiles/r4/region_counters*.txt): longer rows pay
@@ -982,7 +1141,11 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         RH_HIP(hipGetLastError());
         return RH_OK;
     }
-#define RH_S4_LAUNCH(RR, MM, FF) hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg)
+#define RH_S4_LAUNCH(RR, MM, FF)                                                                                                              \
+    do {                                                                                                                                      \
+        if (use_lists) hipLaunchKernelGGL((score4_kernel<RR, MM, FF, false, true>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg); \
+        else hipLaunchKernelGGL((score4_kernel<RR, MM, FF>), grid, dim3(64 * S4_W), 0, c->stream, PS.pts, PS.stride, PS.s, A, d_counts, dbg);  \
+    } while (0)
 #define RH_S4_LAUNCH_R(MM, FF)                                                                                         \
     do {                                                                                                               \
         if (R == 4) RH_S4_LAUNCH(4, MM, FF);                                                                           \

@@ -373,7 +373,7 @@ def test_fit_sets_equals_forcefitshapes_per_set(f32):
     if f32:
         xyz, nrm = xyz.astype(np.float32).astype(np.float64), nrm.astype(np.float32).astype(np.float64)
     rs = np.random.default_rng(1)
-    nsets = 2600                     # (from 2048 sets on the call deals them to host threads: the order must not change)
+    nsets = 2600                     # (from 512 sets on the call deals them to host threads: the order must not change)
     sets = rs.integers(1, 3001, size=(nsets, 3)).astype(np.int64)
     for j in range(0, nsets, 2):    # neighbours in the cloud lie on one primitive: these sets fit often
         b = int(rs.integers(1, 2900))
