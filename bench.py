@@ -703,7 +703,7 @@ def main():
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
             # counts only, Float64: the timed step's launch (rows of 4, 8, 12 or 16 chunks, picked by the grid's size)
-            pmc_key = r"score4_kernel<\d+, false, false, false>"
+            pmc_key = r"score4_kernel<\d+, false, false, false, (false|true)>"
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom

@@ -27,8 +27,10 @@ int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_pa
  * (must be 0), 8 exact inliers, 9 candidates whose classifier takes the all-zero point (a disabled point as staged) for an
  * inlier (must be 0).  The soundness the bit-exact counts rest on, as a count (score4_device.h).  out[40 + k]: pairs whose
  * group holds a BAND point (one whose distance half alone is not surely failed: no test on the group's position box can
- * decide such a pair -- the floor of the necessary pair work, bench.py's frac_necessary); out[44 + k]: pairs with an exact inlier. */
-int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out /* [48] */);
+ * decide such a pair -- the floor of the necessary pair work, bench.py's frac_necessary); out[44 + k]: pairs with an exact inlier;
+ * out[48 + k]: pairs whose SUPER-TILE's box (16 groups: the lists of st_cull) rules the candidate out, out[52 + k]: VIOLATION: such
+ * a pair with an exact inlier (must be 0). */
+int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out /* [56] */);
 /* The device's octree sampler finds a point's cell and the r-th enabled point of a cell with a cell directory and
  * bracketed 8-ary searches (csrc/fit_shared.h: cell_bounds_code, lower_bound_in, select_in, select_in_many, select_bit)
  * where the host form uses plain binary searches.  Host-only self-check of those routines against the plain ones on a

@@ -698,7 +698,7 @@ struct S4SoundArgs { double eps[4], cosa[4]; int f32; };
 
 template <int KIND>
 static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4SoundArgs &A, double x, double y, double z, double nx, double ny,
-                                                 double nz, const uint64_t valid, const rh_box32 &G, const int lane, unsigned long long *__restrict__ out)
+                                                 double nz, const uint64_t valid, const rh_box32 &G, const rh_box32 &GS, const int lane, unsigned long long *__restrict__ out)
 {
     const double eps = A.eps[KIND], cosa = A.cosa[KIND];
     uint64_t ex;
@@ -706,6 +706,7 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
     else ex = test_point<KIND>(Q.P, x, y, z, nx, ny, nz, eps, cosa);
     ex &= valid;
     const bool skip = box_skip32<KIND>(Q.box, G);
+    const bool stskip = box_skip32<KIND>(Q.box, GS);   // the super-tile's box (st_cull_kernel): out[48 + k] such pairs, out[52 + k] VIOLATION: with an exact inlier
     const bool exact_only = is_nan_bits(Q.C.f[RH_CLS_FLAG]);
     const float fx = (float)x, fy = (float)y, fz = (float)z, fnx = (float)nx, fny = (float)ny, fnz = (float)nz;
     float t, t0;   // (the u of score4_device.h: sign bit = surely in, 0 <= u <= 1 undecided)
@@ -731,6 +732,8 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
     if (lane == 0) {
         if (band != 0) atomicAdd(&out[40 + KIND], 1ULL);
         if (ex != 0) atomicAdd(&out[44 + KIND], 1ULL);
+        if (stskip) atomicAdd(&out[48 + KIND], 1ULL);
+        if (stskip && ex != 0) atomicAdd(&out[52 + KIND], 1ULL);
         unsigned long long *o = out + KIND * 10;
         atomicAdd(&o[0], 1ULL);
         if (skip) atomicAdd(&o[1], 1ULL);
@@ -746,7 +749,7 @@ static __device__ __forceinline__ void sound_one(const S4SoundCand &Q, const S4S
 }
 
 __global__ void __launch_bounds__(64)
-cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const float *__restrict__ gb32, const S4SoundCand *__restrict__ cands,
+cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, const float *__restrict__ gb32, const float *__restrict__ st32, const S4SoundCand *__restrict__ cands,
                  int ncand, const S4SoundArgs A, unsigned long long *__restrict__ out)
 {
     const int lane = threadIdx.x;
@@ -759,13 +762,18 @@ cls_sound_kernel(const double *__restrict__ pts, int64_t stride, int64_t s, cons
     rh_box32 G;
     G.cx = gb32[g * 8 + 0]; G.cy = gb32[g * 8 + 1]; G.cz = gb32[g * 8 + 2]; G.hx = gb32[g * 8 + 3];
     G.hy = gb32[g * 8 + 4]; G.hz = gb32[g * 8 + 5]; G.hr = gb32[g * 8 + 6];
+    rh_box32 GS;
+    {
+        const float *b = st32 + (g / S4_STG) * 8;
+        GS.cx = b[0]; GS.cy = b[1]; GS.cz = b[2]; GS.hx = b[3]; GS.hy = b[4]; GS.hz = b[5]; GS.hr = b[6];
+    }
     for (int c = blockIdx.y; c < ncand; c += gridDim.y) {
         const S4SoundCand &Q = cands[c];
         switch (Q.kind) {
-        case RH_PLANE: sound_one<RH_PLANE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
-        case RH_SPHERE: sound_one<RH_SPHERE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
-        case RH_CYLINDER: sound_one<RH_CYLINDER>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
-        case RH_CONE: sound_one<RH_CONE>(Q, A, x, y, z, nx, ny, nz, valid, G, lane, out); break;
+        case RH_PLANE: sound_one<RH_PLANE>(Q, A, x, y, z, nx, ny, nz, valid, G, GS, lane, out); break;
+        case RH_SPHERE: sound_one<RH_SPHERE>(Q, A, x, y, z, nx, ny, nz, valid, G, GS, lane, out); break;
+        case RH_CYLINDER: sound_one<RH_CYLINDER>(Q, A, x, y, z, nx, ny, nz, valid, G, GS, lane, out); break;
+        case RH_CONE: sound_one<RH_CONE>(Q, A, x, y, z, nx, ny, nz, valid, G, GS, lane, out); break;
         default: break;
         }
     }
@@ -1274,12 +1282,12 @@ extern "C" int rh_dbg_cls_audit(rh_cloud *c, const rh_shape *shapes, int32_t b, 
 }
 
 // diagnostics (tests, tools/fuzz_score.py): the decisions of the box test and of the classifier against the exact test
-// on every (candidate, point) of a batch x subset 1 (all points taken as enabled): out[40], layout at cls_sound_kernel
+// on every (candidate, point) of a batch x subset 1 (all points taken as enabled): out[56], layout at sound_one
 extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t b, const rh_params *p, uint64_t *out)
 {
     if (c == nullptr || out == nullptr || p == nullptr || b < 0 || (b > 0 && shapes == nullptr)) { rh_set_error("rh_dbg_cls_soundness: bad arguments"); return RH_E_INVALID; }
-    for (int i = 0; i < 48; i++) out[i] = 0;
-    if (b == 0 || c->s == 0 || c->ngroups == 0 || c->gb32 == nullptr) return RH_OK;
+    for (int i = 0; i < 56; i++) out[i] = 0;
+    if (b == 0 || c->s == 0 || c->ngroups == 0 || c->gb32 == nullptr || c->st32 == nullptr) return RH_OK;
     RH_HIP(hipSetDevice(c->device));
     std::vector<S4SoundCand> h((size_t)b);
     for (int32_t i = 0; i < b; i++) {
@@ -1297,17 +1305,17 @@ extern "C" int rh_dbg_cls_soundness(rh_cloud *c, const rh_shape *shapes, int32_t
     S4SoundCand *d_c = nullptr;
     unsigned long long *d_o = nullptr;
     RH_HIP(hipMalloc((void **)&d_c, sizeof(S4SoundCand) * (size_t)b));
-    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 48));
+    RH_HIP(hipMalloc((void **)&d_o, sizeof(unsigned long long) * 56));
     RH_HIP(hipMemcpyAsync(d_c, h.data(), sizeof(S4SoundCand) * (size_t)b, hipMemcpyHostToDevice, c->stream));
-    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 48, c->stream));
+    RH_HIP(hipMemsetAsync(d_o, 0, sizeof(unsigned long long) * 56, c->stream));
     hipLaunchKernelGGL(cls_sound_kernel, dim3((unsigned)c->ngroups, (unsigned)std::min<int32_t>(b, 64)), dim3(64), 0, c->stream, c->sub, c->s_pad, c->s,
-                       c->gb32, d_c, b, A, d_o);
-    unsigned long long ho[48];
+                       c->gb32, c->st32, d_c, b, A, d_o);
+    unsigned long long ho[56];
     RH_HIP(hipMemcpyAsync(ho, d_o, sizeof ho, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(d_c);
     (void)hipFree(d_o);
-    for (int i = 0; i < 48; i++) out[i] = (uint64_t)ho[i];
+    for (int i = 0; i < 56; i++) out[i] = (uint64_t)ho[i];
     return RH_OK;
 }
 

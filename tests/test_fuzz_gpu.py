@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 _ENV = ("RH_NO_PIPELINE", "RH_NO_FUSED_SCORE", "RH_HOST_SAMPLER", "RH_NO_CREC", "RH_NO_FUSED_SAMPLER",
         "RH_LONG_WINDOW_SETS", "RH_NO_FAST_EXTRACT", "RH_NO_OCT_CHAIN", "RH_NO_MANAGED_STORE",
         "RH_NO_OCT_TAB", "RH_OCT_CHAIN_W", "RH_OCT_ONE_WINDOW", "RH_OCT_WINDOW_ITERS")
-_OPTS = ("score_path", "s4_rows", "refit_path")
+_OPTS = ("score_path", "s4_rows", "refit_path", "st_cull")
 
 
 @pytest.fixture(autouse=True)

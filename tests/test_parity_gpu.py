@@ -801,7 +801,7 @@ def test_subset_order_made_on_the_device_or_on_the_host_gives_the_same_results(m
         assert st["draws"] == exp["draws"] and len(got) == len(exp["shapes"])
         for g, e in zip(got, exp["shapes"]):
             assert bytes(g.c_shape) == bytes(e["shape"]) and np.array_equal(g.inpoints, e["inpoints"])
-        out = np.zeros(48, dtype=np.uint64)
+        out = np.zeros(56, dtype=np.uint64)
         L.check(R.lib().rh_dbg_cls_soundness(pc._h, arr, len(cands), C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_uint64))))
         out = out[:40].reshape(4, 10).astype(np.int64)
         assert out[:, [2, 6, 7, 9]].sum() == 0

@@ -67,6 +67,8 @@ def one(case, rng, f32=False):
     R.set_option("score_path", spath)               # rh_set_option: product and diag build alike
     rr = int(rng.choice([0, 0, 4, 8, 12, 16]))      # rows of the v4 kernel: the library's own choice, or every instantiation
     R.set_option("s4_rows", rr if rr else None)
+    stc = int(rng.choice([0, 1, 1, 2]))             # super-tile lists: by size (never, at these sizes), whenever possible, never
+    R.set_option("st_cull", stc if stc else None)
     if f32:   # a Float32 cloud: binary32 arithmetic on both sides (oracle/orc_f32.c)
         xyz, nrm = xyz.astype(np.float32), nrm.astype(np.float32)
         pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
@@ -138,7 +140,7 @@ def one(case, rng, f32=False):
             if want_masks:
                 lib.rh_dev_free(pc._h, d_mk[q])
         lib.rh_dev_free(pc._h, d_sh)
-    return ok, "n=%d r=%d scale=%g path=%s R=%d b=%d masks=%d in_flight=%d inliers=%d" % (n, r, scale, spath, rr, b, want_masks, F, tot)
+    return ok, "n=%d r=%d scale=%g path=%s R=%d lists=%d b=%d masks=%d in_flight=%d inliers=%d" % (n, r, scale, spath, rr, stc, b, want_masks, F, tot)
 
 
 def main():

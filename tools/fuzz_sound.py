@@ -51,11 +51,16 @@ def one(case, rng, f32=False):
     if f32:
         for i in range(b):
             R.lib().rh_shape_finalize_f32(C.byref(arr[i]))
-    out = np.zeros(48, dtype=np.uint64)
+    out = np.zeros(56, dtype=np.uint64)
     L.check(R.lib().rh_dbg_cls_soundness(pc._h, arr, b, C.byref(cp), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    st_skipped, st_viol = out[48:52].astype(np.int64), out[52:56].astype(np.int64)   # the super-tile boxes (st_cull)
     out = out[:40].reshape(4, 10).astype(np.int64)
-    ok = int(out[:, VIOL].sum()) == 0
-    return ok, "n=%d r=%d scale=%g b=%d f32=%d viol=%s" % (n, r, scale, b, f32, out[:, VIOL].tolist()), out
+    ok = int(out[:, VIOL].sum()) == 0 and int(st_viol.sum()) == 0
+    ST_TOT[0] += st_skipped; ST_TOT[1] += st_viol
+    return ok, "n=%d r=%d scale=%g b=%d f32=%d viol=%s st_viol=%s" % (n, r, scale, b, f32, out[:, VIOL].tolist(), st_viol.tolist()), out
+
+
+ST_TOT = [np.zeros(4, dtype=np.int64), np.zeros(4, dtype=np.int64)]
 
 
 def main():
@@ -74,6 +79,7 @@ def main():
         d = dict(zip(FIELDS, tot[k].tolist()))
         dec = (d["sure_in"] + d["sure_out"]) / max(1, d["points"])
         print("%-8s %s  decided=%.4f skipped=%.4f" % (name, d, dec, d["pairs_skipped"] / max(1, d["pairs"])))
+    print("super-tile boxes: pairs ruled out per kind %s, of them with an exact inlier (violations) %s" % (ST_TOT[0].tolist(), ST_TOT[1].tolist()))
     sys.exit(1 if bad else 0)
 
 

@@ -121,8 +121,8 @@ def build_isa():
     return open(out).read()
 
 
-def kernel_text(isa, rows, mask=False, f32=False, tail=False):
-    name = "score4_kernelILi%dELb%dELb%dELb%dE" % (rows, mask, f32, tail)
+def kernel_text(isa, rows, mask=False, f32=False, tail=False, lists=False):
+    name = "score4_kernelILi%dELb%dELb%dELb%dELb%dE" % (rows, mask, f32, tail, lists)
     m = re.search(r"^(\S*%s\S*):.*$" % re.escape(name), isa, flags=re.M)
     if not m:
         raise SystemExit("kernel %s not found in the ISA" % name)
@@ -282,8 +282,8 @@ def region_counts(stats, rows):
     return out
 
 
-def account(isa, stats, rows):
-    sym, text = kernel_text(isa, rows)
+def account(isa, stats, rows, lists=False):
+    sym, text = kernel_text(isa, rows, lists=lists)
     blocks = parse_blocks(text)
     reg = regions(blocks, rows)
     rc = region_counts(stats, rows)
@@ -371,21 +371,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats", required=True)
     ap.add_argument("--rows", type=int, required=True, help="R of the launch: 12 at cfg3, 16 at cfg5, 4 (or what the dispatch picks) at cfg2")
+    ap.add_argument("--lists", action="store_true", help="the LIST instantiation (the rows walk their super-tile's candidate list: st_cull)")
     ap.add_argument("--pmc", default=None, help="pmc_sq_counters*.json of the same launch (validation)")
     ap.add_argument("--ms", type=float, default=None, help="launch time in ms (rocprof / HIP events)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     stats = json.load(open(a.stats))
     isa = build_isa()
-    sym, dyn, per_region, point_loop, reg = account(isa, stats, a.rows)
+    sym, dyn, per_region, point_loop, reg = account(isa, stats, a.rows, lists=a.lists)
     pr = price(dyn)
     nec_g, nec_m, nec_detail = necessary(stats, point_loop, reg)
-    out = {"kernel": sym, "rows": a.rows, "workload": stats.get("workload"), "regions": per_region, "model": pr, "necessary": nec_detail,
+    out = {"kernel": sym, "rows": a.rows, "lists": bool(a.lists), "workload": stats.get("workload"), "regions": per_region, "model": pr, "necessary": nec_detail,
            "necessary_cycles_guide": nec_g, "necessary_cycles_measured": nec_m,
            "top_opcodes": dict(Counter({o: v for o, v in dyn.items()}).most_common(40))}
     hw = {}
     if a.pmc and os.path.exists(a.pmc):
-        pat = re.compile(r"score4_kernel<%d, false, false, false>" % a.rows)
+        pat = re.compile(r"score4_kernel<%d, false, false, false, %s>" % (a.rows, "true" if a.lists else "false"))
         for r in json.load(open(a.pmc)):
             if pat.search(r["kernel"]):
                 hw[r["counter"]] = r["mean"]

@@ -51,7 +51,7 @@ def main():
     L.check(lib.rh_dbg_s4_stats(pc._h, 0, st.ctypes.data_as(C.POINTER(C.c_uint64))))
     L.check(lib.rh_dbg_s4_stats(pc._h, 2, None))
     assert np.array_equal(counts.cpu().numpy(), ref)
-    snd = np.zeros(48, dtype=np.uint64)
+    snd = np.zeros(56, dtype=np.uint64)
     L.check(lib.rh_dbg_cls_soundness(pc._h, arr, 4096, C.byref(cp), snd.ctypes.data_as(C.POINTER(C.c_uint64))))
     S = int(subs[0].size)
     out = {"workload": wl, "subset_points": S, "groups": (S + 63) // 64, "candidates": {k: sum(1 for c in cands if c[0] == k) for k in KN},
