@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="N = 1: batches in flight (rh_set_option batches_in_flight): each batch's launches start while the previous "
                          "batch's launch drains; 1 = one batch at a time")
+    ap.add_argument("--lists", choices=["auto", "on", "off"], default="auto",
+                    help="rh_set_option st_cull on the scored cloud: super-tile candidate lists in front of the score kernel by the "
+                         "library's own rule (auto), always, never.  Profiling passes that run one batch at a time pass what the default run took")
     ap.add_argument("--spread-regions", type=int, default=5,
                     help="after the timed region, repeat the same K-step region this many times and report min / median / max of the "
                          "metric as `value_spread` (the headline `value` stays the first region)")
@@ -191,6 +194,7 @@ def compact_line(out, detail_file=None):
                         "frac_necessary": _num(rf.get("frac_necessary"), 4), "frac_necessary_guide": _num(rf.get("frac_necessary_guide"), 4),
                         "traffic": _num(rf.get("traffic")), "ms_per_launch": _num(rf.get("ms_per_launch")),
                         "frac_over_step_in_flight": _num(rf.get("frac_over_step_in_flight"), 4),
+                        "frac_necessary_over_step_in_flight": _num(rf.get("frac_necessary_over_step_in_flight"), 4),
                         "counters": rf.get("counters")}
     line["cpu_baseline"] = ({"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                              "sample": cb.get("sample")} if cb else None)
@@ -199,6 +203,7 @@ def compact_line(out, detail_file=None):
     if vs:
         line["value_spread"] = [_num(vs.get("min"), 5), _num(vs.get("median"), 5), _num(vs.get("max"), 5)]
     line["batches_in_flight"] = cfg.get("batches_in_flight")
+    line["score_lists"] = cfg.get("score_lists")
     line["one_batch_in_flight_ms"] = _get(out, "one_batch_in_flight", "ms_per_step")
     flat = {
         "rccl_ranks_seen": out.get("rccl_ranks_seen"),
@@ -467,6 +472,8 @@ def main():
     ring_k = [0]
     if in_flight > 1:
         R.set_option("batches_in_flight", in_flight, cloud=pc)
+    if args.lists != "auto":
+        R.set_option("st_cull", 1 if args.lists == "on" else 2, cloud=pc)
 
     def step():
         if libcomm is not None:
@@ -536,6 +543,10 @@ def main():
             dist.all_reduce(tm1, op=dist.ReduceOp.MAX)
             dt1 = float(tm1.item())
         spread_vals.append(b_global * args.steps / dt1)
+    # what the step's score launch looked like: rows of R chunks, with or without super-tile lists (the library's rule, or --lists)
+    linfo = (C.c_int32 * 4)()
+    L.check(lib.rh_score_launch_info(pc._h, linfo))
+    launch_R, lists_used = int(linfo[0]), bool(linfo[1])
     one_in_flight = None
     if in_flight > 1:   # every buffer of the ring holds the same batch's counts; then the same region one batch at a time
         for r in ring[1:]:
@@ -565,6 +576,7 @@ def main():
                    "kinds": "%s (cycled over the %d ground-truth primitives, 1%% jitter)"
                             % ("/".join(sorted(set(prim), key=KINDS.index)), len(prim)),
                    "score_mode": "f64", "prewarm_ms": args.prewarm_ms, "batches_in_flight": in_flight,
+                   "score_rows": launch_R, "score_lists": lists_used,
                    "parallelism": ("point-sharded x%d (1/%d of subset 1 per GPU, every GPU scores the whole batch), "
                                    "int32 sum all-reduce" % (world, world)) if points_mode
                    else "candidate-sharded x%d, int32 sum all-reduce" % world},
@@ -699,11 +711,13 @@ def main():
         forced_path = R.get_option("score_path")            # rh_set_option; None / 0: the library's own choice
         culled = forced_path in (None, 0, 2) and S >= 8192
         if culled:
-            kname = "score4_kernel (plane+sphere+cylinder%s in one launch)" % ("+cone" if "cone" in per_kind else "")
+            kname = "score4_kernel<%d%s> (plane+sphere+cylinder%s in one launch%s)" % (
+                launch_R, ", lists" if lists_used else "", "+cone" if "cone" in per_kind else "",
+                "; st_cull_kernel in front of it, inside ms_per_launch" if lists_used else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
             # counts only, Float64: the timed step's launch (rows of 4, 8, 12 or 16 chunks, picked by the grid's size)
-            pmc_key = r"score4_kernel<\d+, false, false, false, (false|true)>"
+            pmc_key = r"score4_kernel<\d+, false, false, false, %s>" % ("true" if lists_used else "false")
         else:   # per-kind launches: the dominant one
             dom = max(per_kind, key=lambda k: per_kind[k]["ms_separate_launch"])
             kname = "score kernel <%s>" % dom
@@ -728,6 +742,8 @@ def main():
         simd_cycles_per_s = 1024 * 2.4e9
         acc_file = _newest_profile("isa_account_%s.json" % args.workload) if pmc_ok else None
         acc = json.load(open(acc_file)) if acc_file else None
+        if acc is not None and bool(acc.get("lists")) != lists_used:   # the committed accounting is of the other instantiation
+            acc, acc_file = None, None
         acc_stale = None
         if acc_file:
             fm = os.path.join(os.path.dirname(acc_file), "pmc_meta.json")
@@ -758,6 +774,7 @@ def main():
                 # utilisation over the whole step, prepare launch and launch gaps included in the time (not in the work)
                 rf["frac_over_step_in_flight"] = scl * m["valu_issue_cycles_measured_lower"] / (ms_per_step * 1e-3 * simd_cycles_per_s)
                 rf["frac_over_step_in_flight_upper"] = scl * m["valu_issue_cycles_measured"] / (ms_per_step * 1e-3 * simd_cycles_per_s)
+                rf["frac_necessary_over_step_in_flight"] = acc["necessary_cycles_measured"] / (ms_per_step * 1e-3 * simd_cycles_per_s)
         src = acc_file or (os.path.join(ROOT, pmc["replayed_from"][0]) if pmc["replayed_from"] else None)
         rf.update({
             "sq_wave_cycles": sq.get("SQ_WAVE_CYCLES"), "sq_wait_any": sq.get("SQ_WAIT_ANY"),

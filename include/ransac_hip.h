@@ -407,6 +407,9 @@ enum { RH_REFIT_PATH_AUTO = 0, RH_REFIT_PATH_SCAN = 1, RH_REFIT_PATH_CULLED = 2 
 int rh_set_option(rh_cloud *c_or_null, const char *key, int64_t value);
 int rh_get_option(const rh_cloud *c_or_null, const char *key, int64_t *value_out, int32_t *is_set_out_or_null);
 int rh_build_variant(void);   /* 0 = product, 1 = diag (-DRH_DIAG) */
+/* what the cloud's last batch launch of the culled score kernel looked like (bench.py names the measured kernel with it):
+ * out4 = { chunks of 64 candidates per block row, 1 if the rows walked super-tile lists ("st_cull") else 0, rows, tiles } */
+int rh_score_launch_info(rh_cloud *c, int32_t *out4);
 
 #ifdef __cplusplus
 }

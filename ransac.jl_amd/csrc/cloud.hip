@@ -1083,6 +1083,13 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
     return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr);
 }
 
+extern "C" int rh_score_launch_info(rh_cloud *c, int32_t *out4)
+{
+    if (!c || !out4) { rh_set_error("rh_score_launch_info: bad arguments"); return RH_E_INVALID; }
+    for (int i = 0; i < 4; i++) out4[i] = c->last_s4[i];
+    return RH_OK;
+}
+
 extern "C" int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                                         int32_t *d_counts, uint64_t *d_masks, float *ms_kind_out)
 {

@@ -962,7 +962,8 @@ struct StCullArgs {
 template <int KIND>
 static __device__ __forceinline__ void st_cull_kind(const StCullArgs &A, const int64_t st)
 {
-    __shared__ int32_t wsum[2][4];
+    constexpr int Q = 4;                       // candidates per thread and round: 1024 per round, their records requested together
+    __shared__ int32_t wsum[2][Q * 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nk = *A.nk[KIND];
     int32_t *cnt = A.stcount + st * 4 + KIND;
@@ -975,29 +976,33 @@ static __device__ __forceinline__ void st_cull_kind(const StCullArgs &A, const i
     uint16_t *__restrict__ list = A.stlist + (st * 4 + KIND) * A.stcap;
     constexpr int NB = S4Fields<KIND>::NBOX;
     const float *__restrict__ box = A.box[KIND];
-    float B[2][RH_BOX_FIELDS];
-    {
-        const int cl = tid < nk ? tid : 0;
-#pragma unroll
-        for (int f = 0; f < NB; f++) B[0][f] = box[(int64_t)f * A.bstride + cl];
-    }
     int base = 0, it = 0;
-    for (int j0 = 0; j0 < nk; j0 += 256, it++) {
-        const int cand = j0 + tid;
-        if (j0 + 256 < nk) {   // the next 256 records: in flight during this round's tests and its barrier
-            const int cn = cand + 256 < nk ? cand + 256 : 0;
+    for (int j0 = 0; j0 < nk; j0 += Q * 256, it++) {
+        float B[Q][RH_BOX_FIELDS];
 #pragma unroll
-            for (int f = 0; f < NB; f++) B[(it + 1) & 1][f] = box[(int64_t)f * A.bstride + cn];
+        for (int q = 0; q < Q; q++) {
+            const int cand = j0 + q * 256 + tid, cl = cand < nk ? cand : 0;
+#pragma unroll
+            for (int f = 0; f < NB; f++) B[q][f] = box[(int64_t)f * A.bstride + cl];
         }
-        const bool keep = cand < nk && !box_skip32<KIND>(B[it & 1], G);
-        const uint64_t m = WB(keep);
-        if (lane == 0) wsum[it & 1][wv] = __popcll(m);
-        __syncthreads();   // (the sums alternate between two rows: one barrier per round)
-        int off = base, tot = 0;
+        uint64_t m[Q];
+        bool keep[Q];
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const int v = wsum[it & 1][w]; off += w < wv ? v : 0; tot += v; }
-        if (keep) list[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint16_t)cand;
-        base += tot;
+        for (int q = 0; q < Q; q++) {
+            keep[q] = j0 + q * 256 + tid < nk && !box_skip32<KIND>(B[q], G);
+            m[q] = WB(keep[q]);
+            if (lane == 0) wsum[it & 1][q * 4 + wv] = __popcll(m[q]);
+        }
+        __syncthreads();   // (the sums alternate between two rows: one barrier per round)
+        int run = base;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            int off = run;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const int v = wsum[it & 1][q * 4 + w]; off += w < wv ? v : 0; run += v; }
+            if (keep[q]) list[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[q], 0))] = (uint16_t)(j0 + q * 256 + tid);
+        }
+        base = run;
     }
     if (tid == 0) *cnt = base;
 }
@@ -1085,10 +1090,11 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     bool use_lists = !open_count && c->s4_points == nullptr && dbg == 0 && c->st32 != nullptr && c->nst >= 2 && nk_total_bound <= 16384 && st_opt != 2;
     // By size (measured, cfg3's mix on 10M / 20M / 30M / cfg5's on 50M points = 1221 / 2442 / 3662 / 6104 tiles, a batch of 4096): the
     // lists cut the launch's instructions by a fifth, but its blocks become three times fewer and heavier, and a small grid then
-    // ends in a long tail -- one batch at a time +28 % / +5 % / -1 % / -10 %; with two batches in flight, where the next batch
-    // fills the tail, -0 % / -10 % / -15 % / -21 %.
+    // ends in a long tail (and the list launch sits between the prepare and the score launch) -- one batch at a time +17 % / +0 % /
+    // -8 % / -13 %; with two batches in flight, where the next batch fills the tail, -8 % / -15 % / -15 % / -24 %; cfg2's 123
+    // tiles +50 % either way.
     if (use_lists && st_opt == 0)
-        use_lists = nk_total_bound >= 1024 && ntiles >= (rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) > 1 ? 2000 : 3500);
+        use_lists = nk_total_bound >= 1024 && ntiles >= (rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) > 1 ? 1000 : 3000);
     if (use_lists) {
         RH_TRY(ensure_stlists(c, ((int64_t)nk_total_bound + 63) / 64 * 64));
         StCullArgs SA;
@@ -1114,6 +1120,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
     else if (ntiles * ((nchunks + 3) / 4) >= 4000) R = 4;
     else R = 2;
     int64_t rows = (nchunks + R - 1) / R;
+    if (!open_count) { c->last_s4[0] = R; c->last_s4[1] = use_lists ? 1 : 0; c->last_s4[2] = (int32_t)rows; c->last_s4[3] = (int32_t)ntiles; }
     if (rows > 65535) { rh_set_error("batch of %d candidates is too large for one launch", nk_total_bound); return RH_E_INVALID; }
     // XCD-aware grid: the hardware deals consecutive block ids round-robin to the 8 XCDs, each with an L2 of its own; with grid.x
     // padded to a multiple of 8 a tile meets the same XCD in every row (only with >= 128 tiles per XCD: cfg2's 15 per XCD unbalance)

@@ -32,6 +32,8 @@ def main():
     xyz, nrm, truth = synth.make_cloud(n, prim, outl, seed=seed, scanner=scanner)
     subs = synth.make_subsets(n, 32, seed=seed)
     pc = R.RANSACCloud(xyz, nrm, subs)
+    if os.environ.get("LISTS") in ("on", "off"):   # the instantiation the default line's step launches (tools/profile_round.sh)
+        R.set_option("st_cull", 1 if os.environ["LISTS"] == "on" else 2, cloud=pc)
     cp = R.params_to_c(R.ransacparameters(types), score_mode=L.SCORE_F64)
     cands = synth.jittered_candidates(truth, 4096, seed=0)
     arr = bench.shapes_to_c(R, L, cands)
@@ -54,13 +56,15 @@ def main():
     snd = np.zeros(56, dtype=np.uint64)
     L.check(lib.rh_dbg_cls_soundness(pc._h, arr, 4096, C.byref(cp), snd.ctypes.data_as(C.POINTER(C.c_uint64))))
     S = int(subs[0].size)
-    out = {"workload": wl, "subset_points": S, "groups": (S + 63) // 64, "candidates": {k: sum(1 for c in cands if c[0] == k) for k in KN},
+    linfo = (C.c_int32 * 4)()
+    L.check(lib.rh_score_launch_info(pc._h, linfo))
+    out = {"workload": wl, "rows": int(linfo[0]), "lists": bool(linfo[1]), "subset_points": S, "groups": (S + 63) // 64, "candidates": {k: sum(1 for c in cands if c[0] == k) for k in KN},
            "global": {"blocks_with_tile": int(st[96]), "stagings": int(st[97]), "stagings_reused": int(st[98]), "blocks_tile_all_disabled": int(st[99])},
            "per_kind": {}, "census": {}}
     for k, name in enumerate(KN):
         out["per_kind"][name] = {f: int(st[24 * k + i]) for i, f in enumerate(FIELDS)}
         s10 = snd[10 * k:10 * k + 10]
-        out["census"][name] = {"pairs": int(s10[0]), "pairs_box_skips": int(s10[1]), "violations": int(s10[2] + s10[6] + s10[7] + s10[9]),
+        out["census"][name] = {"pairs_supertile_skips": int(snd[48 + k]), "supertile_violations": int(snd[52 + k]),"pairs": int(s10[0]), "pairs_box_skips": int(s10[1]), "violations": int(s10[2] + s10[6] + s10[7] + s10[9]),
                                "points": int(s10[3]), "surely_in": int(s10[4]), "surely_out": int(s10[5]), "exact_inliers": int(s10[8]),
                                "pairs_with_band_point": int(snd[40 + k]), "pairs_with_exact_inlier": int(snd[44 + k])}
     os.makedirs("gpurun_out", exist_ok=True)
