@@ -60,7 +60,7 @@ def parse():
                     help="N > 1 partitioning: candidates (each rank scores its 4096 of the N x 4096 batch on a replica "
                          "of subset 1; default, BASELINE north_star) or points (each rank scores all N x 4096 candidates "
                          "on its 1/N slice of subset 1; the all-reduce is a true sum)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="N = 1: batches in flight (rh_set_option batches_in_flight): each batch's launches start while the previous "
                          "batch's launch drains; 1 = one batch at a time")
     ap.add_argument("--lists", choices=["auto", "on", "off"], default="auto",

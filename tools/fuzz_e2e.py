@@ -56,6 +56,7 @@ def one(case, rng, f32=False):
         os.environ["RH_NO_FAST_EXTRACT"] = "1"
     # the culled refit scan (korder.hip) on these small clouds in two cases of three, the plain scan in the third
     R.set_option("refit_path", str(rng.choice(["culled", "culled", "scan"])))
+    R.set_option("st_cull", [None, 1, 2][int(rng.integers(0, 3))])   # super-tile lists for the loop's sized score launches: by size / whenever possible / never
     if f32:
         pc = R.RANSACCloud(xyz, nrm, subs, force_eltype=np.float32)
         oc = orc.Cloud(xyz, nrm, subs[0], f32=True)
