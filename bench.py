@@ -939,18 +939,30 @@ def main():
                 for i in range(b_global):
                     lib.rh_shape_finalize_f32(C.byref(arr32[i]))
                 batch32 = rdist.DeviceBatch(pc32, arr32, b_global)
-                c32 = torch.zeros(b_global, dtype=torch.int32, device="cuda")
+                # (the same batches in flight as the headline step: F count buffers in turn)
+                ring32 = [torch.zeros(b_global, dtype=torch.int32, device="cuda") for _ in range(in_flight)]
+                torch.cuda.synchronize()
+                c32 = ring32[0]
+                if in_flight > 1:
+                    R.set_option("batches_in_flight", in_flight, cloud=pc32)
+                k32 = [0]
 
                 def step32():
-                    L.check(lib.rh_score_batch_dev(pc32._h, batch32.slice_ptr(0), b_global, C.byref(cp), C.c_void_p(c32.data_ptr()), None))
+                    buf = ring32[k32[0] % in_flight]
+                    k32[0] += 1
+                    L.check(lib.rh_score_batch_dev(pc32._h, batch32.slice_ptr(0), b_global, C.byref(cp), C.c_void_p(buf.data_ptr()), None))
                 for _ in range(100):
                     step32()
                 L.check(lib.rh_cloud_sync(pc32._h))
+                k32[0] = 0
                 L.check(lib.rh_timer_start(pc32._h))
                 for _ in range(100):
                     step32()
                 ev32 = C.c_float()
                 L.check(lib.rh_timer_stop(pc32._h, C.byref(ev32)))
+                for r32 in ring32[1:]:
+                    if not torch.equal(r32, c32):
+                        raise SystemExit("PARITY FAILURE: Float32 count buffers of the batches in flight differ")
                 c32h = c32.cpu().numpy()
                 # oracle (binary32 twin) on a spread sample of the batch
                 sel = list(range(0, b_global, max(1, b_global // 256)))[:256]
