@@ -694,6 +694,7 @@ def main():
         per_kind = {}
         reps = 30
         acc = [0.0] * 5
+        list_ms_acc = 0.0
         msk = (C.c_float * 5)()
         for _ in range(reps):   # [4]: the launch of the timed steps (all kinds, one kernel); [0..3]: one launch per kind
             if args.no_per_kind:
@@ -702,6 +703,9 @@ def main():
                                                  C.c_void_p(counts.data_ptr() + 4 * lo), None, msk))
             for k in range(5):
                 acc[k] += msk[k]
+            lm = C.c_float()
+            L.check(lib.rh_last_list_launch_ms(pc._h, C.byref(lm)))
+            list_ms_acc += lm.value
         for ki, k in enumerate(KINDS):
             nk = sum(1 for c in cands[lo:hi] if c[0] == k)
             if nk:
@@ -713,7 +717,7 @@ def main():
         if culled:
             kname = "score4_kernel<%d%s> (plane+sphere+cylinder%s in one launch%s)" % (
                 launch_R, ", lists" if lists_used else "", "+cone" if "cone" in per_kind else "",
-                "; st_cull_kernel in front of it, inside ms_per_launch" if lists_used else "")
+                "; st_cull_kernel in front of it: list_launch_ms" if lists_used else "")
             sec = acc[4] / reps * 1e-3
             kinds_in = list(per_kind)
             # counts only, Float64: the timed step's launch (rows of 4, 8, 12 or 16 chunks, picked by the grid's size)
@@ -782,6 +786,7 @@ def main():
             "counters": None if src is None else ("replayed:" + os.path.dirname(os.path.relpath(src, ROOT)) + (" (stale)" if (acc_stale if acc_file else pmc["stale"]) else "")),
             "traffic_frac_of_hbm_peak": None if pmc["traffic"] is None else pmc["traffic"] / sec / 1e9 / HBM_PEAK_GBS,
             "ms_per_launch": sec * 1e3, "ms_source": "HIP events on the library's stream, this run",
+            "list_launch_ms": (list_ms_acc / reps) if culled and lists_used else None,
             "replayed_from": pmc["replayed_from"], "replay_is_stale": pmc["stale"],
             "effective_algorithmic": {
                 "GBs": alg_bytes / sec / 1e9, "bytes_per_launch": alg_bytes, "tests_per_launch": tests,

@@ -302,6 +302,9 @@ int rh_bitmapparameters(const double *params2d, const uint8_t *compat, const int
  * with an event before each and after the last -> ms_out[0..3] (0 for kinds without candidates
  * ~ an empty launch).  Waits for the batch.  ms_out[0] < 0 on entry: the first form only
  * (profiling passes that must see the product's launches alone). */
+/* (a launch that takes super-tile lists, "st_cull": ms_out[4] is the score launch alone; the list launch in front of it is
+ * returned by rh_last_list_launch_ms after the call, 0 when the launch took none) */
+int rh_last_list_launch_ms(rh_cloud *c, float *ms_out);
 int rh_score_batch_dev_timed(rh_cloud *c, const rh_shape *d_shapes, int32_t b, const rh_params *p,
                              int32_t *d_counts, uint64_t *d_masks_or_null, float *ms_out /* [5] */);
 /* device time of the most recent rh_refit on this cloud: the full-cloud scan kernel and the

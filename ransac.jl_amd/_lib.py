@@ -129,6 +129,7 @@ SIGNATURES = {
     "rh_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "rh_get_option": (C.c_int, [_vp, C.c_char_p, _i64p, _i32p]),
     "rh_score_launch_info": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "rh_last_list_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rh_build_variant": (C.c_int, []),
     "rh_cloud_create_ms": (C.c_int, [_vp, _dp]),
     "rh_comm_unique_id": (C.c_int, [_vp]),

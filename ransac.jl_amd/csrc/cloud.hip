@@ -204,6 +204,7 @@ static void cloud_free(rh_cloud *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (int k = 0; k < 5; k++)
         if (c->evk[k]) (void)hipEventDestroy(c->evk[k]);
+    if (c->ev_cull) (void)hipEventDestroy(c->ev_cull);
     c->stream = c->own_stream;   // (the deleter below waits on c->stream; everything has finished by now)
     if (c->drv_cache != nullptr && c->drv_cache_free != nullptr) c->drv_cache_free(c, c->drv_cache);
     c->drv_cache = nullptr;
@@ -1018,11 +1019,22 @@ static int score_batch_dev_impl(rh_cloud *c, const rh_shape *d_shapes, int32_t b
     c->f32_via_orig = 1;
     if (ms_kind) {   // the product launch (all kinds in one kernel) first, then the per-kind launches
         ms_kind[4] = 0.f;
+        if (c->ev_cull == nullptr) RH_HIP(hipEventCreate(&c->ev_cull));
         RH_HIP(hipEventRecord(c->evk[0], c->stream));
-        RH_TRY(score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, nullptr, d_cls, c->d_box, 4 * c->batch_cap));
+        c->time_cull = true;
+        c->last_s4[1] = 0;
+        const int rc_s = score_bins_subset(c, p, c->d_prep, c->d_orig, off, nk_cur, bound, b, d_counts, d_masks_int, nullptr, d_cls, c->d_box, 4 * c->batch_cap);
+        c->time_cull = false;
+        RH_TRY(rc_s);
         RH_HIP(hipEventRecord(c->evk[1], c->stream));
         RH_HIP(hipEventSynchronize(c->evk[1]));
-        RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
+        c->last_cull_ms = 0.f;
+        if (c->last_s4[1] != 0) {   // super-tile lists: the list launch and the score launch apart (ms_kind[4] = the score launch alone)
+            RH_HIP(hipEventElapsedTime(&c->last_cull_ms, c->evk[0], c->ev_cull));
+            RH_HIP(hipEventElapsedTime(&ms_kind[4], c->ev_cull, c->evk[1]));
+        } else {
+            RH_HIP(hipEventElapsedTime(&ms_kind[4], c->evk[0], c->evk[1]));
+        }
         if (!product_only) {
             RH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)b, c->stream));
             if (d_masks_int && c->masks4) RH_HIP(hipMemsetAsync(c->d_occ, 0, sizeof(int32_t) * (size_t)b, c->stream));   // (the lists' cursors)
@@ -1081,6 +1093,13 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
         return RH_OK;
     }
     return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr);
+}
+
+extern "C" int rh_last_list_launch_ms(rh_cloud *c, float *ms_out)
+{
+    if (!c || !ms_out) { rh_set_error("rh_last_list_launch_ms: bad arguments"); return RH_E_INVALID; }
+    *ms_out = c->last_cull_ms;
+    return RH_OK;
 }
 
 extern "C" int rh_score_launch_info(rh_cloud *c, int32_t *out4)

@@ -150,6 +150,9 @@ struct rh_cloud {
     double nrm_mag = 0;                // max |normal component| over the subset (margins of the binary32 classifier)
     bool use_groups = false;           // culled scoring path available (s large enough)
     float *gb32 = nullptr;             // the same boxes in binary32, 8 floats per group (v4 score kernel: scalar loads)
+    hipEvent_t ev_cull = nullptr;      // timed launches (rh_score_batch_dev_timed): behind the list launch, in front of the score launch
+    bool time_cull = false;
+    float last_cull_ms = 0.f;
     int32_t last_s4[4] = { 0, 0, 0, 0 };   // the last sized launch of the culled score kernel: R, lists taken (0 / 1), rows, tiles (rh_score_launch_info)
     float *st32 = nullptr;             // boxes of the super-tiles (16 consecutive groups = 4 tiles of the k-d leaf order), 8 floats each
     int64_t nst = 0;

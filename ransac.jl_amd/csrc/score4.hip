@@ -1102,6 +1102,7 @@ int rhk_score4_all(rh_cloud *c, const uint64_t *const en[4], const rh_prep *cons
         SA.bstride = bstride; SA.stcap = c->stlist_cap; SA.st32 = c->st32; SA.stlist = c->d_stlist; SA.stcount = c->d_stcount;
         hipLaunchKernelGGL(st_cull_kernel, dim3((unsigned)c->nst, 4), dim3(256), 0, c->stream, SA);
         A.stlist = c->d_stlist; A.stcount = c->d_stcount; A.stcap = c->stlist_cap;
+        if (c->time_cull && c->ev_cull != nullptr) RH_HIP(hipEventRecord(c->ev_cull, c->stream));
     }
     const int env_r = (int)rh_opt_int(c, RH_OPT_S4_ROWS, 0);   // rh_set_option(.., "s4_rows", ..), read on every launch: the fuzzers vary it from case to case
     // R = chunks of 64 candidates per block row.  A block's fixed work -- prologue, staging its tile, the four kinds' dispatch --
