@@ -1087,10 +1087,10 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
         swap_batch_slot(c, s);
         const int rc = score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr, false);
         swap_batch_slot(c, s);
-        if (rc != RH_OK) return rc;
+        // (also behind a failed call: whatever it did enqueue on the slot's stream is waited for at the next join)
         RH_HIP(hipEventRecord(s.done, s.stream));
         c->alt_dirty[slot - 1] = true;
-        return RH_OK;
+        return rc;
     }
     return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr);
 }
