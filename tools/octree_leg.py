@@ -3,7 +3,7 @@
 rh_ransac calls after a warm-up, with the driver's own breakdown (RH_DRIVER_PROF=1 prints it on stderr).  For rocprofv3
 --kernel-trace --stats runs of the leg and A/B runs of the window logic.   ITERS=256 python tools/octree_leg.py"""
 import os, sys, time
-_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
+_DIAG_ENV = [k for k in os.environ if k.startswith("RH_") and k not in ("RH_LIB_VARIANT", "RH_LIB_PATH", "RH_EXTRA_FLAGS", "RH_TYPES", "RH_SYSTEM_HIP") and not k.startswith("RH_BENCH")]
 if _DIAG_ENV:   # RH_* switches exist in the diag build only (the product library reads no environment variable)
     os.environ.setdefault("RH_LIB_VARIANT", "diag")
 import numpy as np
@@ -17,6 +17,8 @@ n = int(os.environ.get("POINTS", 10_000_000))
 xyz, nrm, truth = synth.make_cloud(n, prim, 0.30, seed=3)
 subs = synth.make_subsets(n, 32, seed=3)
 pc = R.RANSACCloud(xyz, nrm, subs)
+if os.environ.get("LISTS") in ("on", "off"):   # super-tile lists for the windows' score launches (rh_set_option st_cull)
+    R.set_option("st_cull", 1 if os.environ["LISTS"] == "on" else 2, cloud=pc)
 iters = int(os.environ.get("ITERS", "256"))
 e2e = R.ransacparameters(types, iteration={"minsubsetN": 4096, "itermax": iters, "τ": 900, "prob_det": 0.9})
 ocp = R.params_to_c(e2e, score_mode=L.SCORE_F64, sphere_uses_enabled=True, sampling_streams=1, octree_sampling=not os.environ.get("ROOT_CELL"))
