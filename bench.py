@@ -254,6 +254,8 @@ def compact_line(out, detail_file=None):
 
 
 def write_detail(out, path):
+    d = os.path.dirname(os.path.abspath(path))
+    os.makedirs(d, exist_ok=True)
     tmp = path + ".tmp"
     with open(tmp, "w") as f:
         json.dump(out, f, indent=1)
