@@ -396,7 +396,8 @@ int rh_octree_cell_enabled(rh_cloud *c, rh_octree *t, int32_t cell, int64_t *idx
  *   "batches_in_flight"  1 (default) .. 4 -- with F > 1, rh_score_batch_dev calls take turns on the cloud's
  *                 stream and F - 1 more with workspaces of their own, so one batch's prepare + score launches start while
  *                 the previous batches' launches drain.  The caller keeps F count (and mask) buffers and gives call k of a
- *                 run of such calls buffer k mod F (a buffer is written again only by the stream that wrote it last);
+ *                 run of such calls buffer k mod F (a buffer is written again only by the stream that wrote it last; a call
+ *                 that hands in a buffer another batch in flight is writing is simply run after it, alone);
  *                 every other call on the cloud, rh_cloud_sync and rh_timer_stop included, first lets the cloud's stream
  *                 wait for the others, so whatever follows sees every batch's counts.  Ignored while the cloud runs on a
  *                 caller's stream (rh_cloud_set_stream).

@@ -687,6 +687,7 @@ int rh_join_batches(rh_cloud *c)
         c->alt_dirty[i] = false;
         c->alt_started[i] = false;
     }
+    for (int i = 0; i < RH_MAX_IN_FLIGHT; i++) { c->slot_counts[i] = nullptr; c->slot_masks[i] = nullptr; }
     c->pipe_k = 0;
     return RH_OK;
 }
@@ -1066,7 +1067,18 @@ extern "C" int rh_score_batch_dev(rh_cloud *c, const rh_shape *d_shapes, int32_t
     const int in_flight = c != nullptr && b > 0 && c->stream == c->own_stream ? rh_opt_int(c, RH_OPT_BATCHES_IN_FLIGHT, 1) : 1;
     if (in_flight > 1) {
         RH_TRY(enter_nojoin(c));
-        const int slot = (int)(c->pipe_k++ % (uint32_t)in_flight);
+        int slot = (int)(c->pipe_k % (uint32_t)in_flight);
+        // a caller whose buffers are not F apart (the same count buffer call after call, say): never two batches in flight on
+        // one buffer -- the streams are joined first and the batch runs alone (correct, only not overlapped)
+        for (int t = 0; t < RH_MAX_IN_FLIGHT; t++)
+            if (t != slot && ((c->slot_counts[t] != nullptr && c->slot_counts[t] == d_counts) || (d_masks != nullptr && c->slot_masks[t] == d_masks))) {
+                RH_TRY(rh_join_batches(c));
+                slot = 0;
+                break;
+            }
+        c->pipe_k++;
+        c->slot_counts[slot] = d_counts;
+        c->slot_masks[slot] = d_masks;
         if (slot == 0) return score_batch_dev_impl(c, d_shapes, b, p, d_counts, d_masks, nullptr, false);
         rh_batch_slot &s = c->alt[slot - 1];
         if (s.stream == nullptr) {

@@ -265,6 +265,7 @@ struct rh_cloud {
     // two batches in flight (rh_score_batch_dev, "batches_in_flight" = 2)
     rh_batch_slot alt[RH_MAX_IN_FLIGHT - 1];
     uint32_t pipe_k = 0;               // batches since the pipeline (re)started
+    const void *slot_counts[RH_MAX_IN_FLIGHT] = {}, *slot_masks[RH_MAX_IN_FLIGHT] = {};   // the buffers the slots' batches in flight write (null: none)
     bool alt_dirty[RH_MAX_IN_FLIGHT - 1] = {};     // work on alt[i].stream the cloud's own stream has not waited for yet
     bool alt_started[RH_MAX_IN_FLIGHT - 1] = {};   // alt[i].stream has been ordered behind the cloud's stream since the last join
 

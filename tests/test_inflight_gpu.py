@@ -162,6 +162,35 @@ def test_mask_batches_in_flight(scene, in_flight):
             assert np.array_equal(got, want[i][1]) and np.array_equal(cn[k % in_flight].cpu().numpy()[:sizes[i]], want[i][0])
 
 
+def test_the_same_buffer_call_after_call_is_still_right(scene):
+    """a caller that ignores the buffer rule (one count buffer for every call): the library never overlaps two batches on one
+    buffer -- every batch's counts are those of the batch scored alone"""
+    import torch
+    pc, oc, cp, arrs, batches, b = scene
+    lib = R.lib()
+    pc.enable_all(); oc.enable_all()
+    ref = _alone(pc, cp, batches, b, [b] * len(batches))
+    with R.option("batches_in_flight", 3, cloud=pc):
+        one = torch.zeros(b, dtype=torch.int32, device="cuda")
+        other = torch.zeros(b, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        snaps = []
+        for k in range(6):
+            L.check(lib.rh_score_batch_dev(pc._h, batches[k].slice_ptr(0), b, C.byref(cp), C.c_void_p(one.data_ptr()), None))
+            if k == 2:   # (a second buffer in between: that batch may overlap, the next one on `one` may not)
+                L.check(lib.rh_score_batch_dev(pc._h, batches[8].slice_ptr(0), b, C.byref(cp), C.c_void_p(other.data_ptr()), None))
+            L.check(lib.rh_cloud_sync(pc._h))
+            snaps.append(one.cpu().numpy().copy())
+        for k in range(6):
+            assert np.array_equal(snaps[k], ref[k]), k
+        assert np.array_equal(other.cpu().numpy(), ref[8])
+        # without a sync in between: the last writer wins, and it is the last call
+        for k in range(6):
+            L.check(lib.rh_score_batch_dev(pc._h, batches[k].slice_ptr(0), b, C.byref(cp), C.c_void_p(one.data_ptr()), None))
+        L.check(lib.rh_cloud_sync(pc._h))
+        assert np.array_equal(one.cpu().numpy(), ref[5])
+
+
 def test_option_is_refused_out_of_range_and_host_calls_ignore_it(scene):
     pc, oc, cp, arrs, batches, b = scene
     with pytest.raises(R.RansacHipError):
