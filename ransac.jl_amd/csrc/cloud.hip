@@ -678,8 +678,8 @@ static int enter_nojoin(rh_cloud *c)
     return RH_OK;
 }
 
-// every entry point but the pipelined rh_score_batch_dev: the cloud's stream first waits for what the second batch slot
-// still has in flight ("batches_in_flight" = 2), so everything else sees one stream's order
+// every entry point but the pipelined rh_score_batch_dev: the cloud's stream first waits for what the other batch slots
+// still have in flight ("batches_in_flight" > 1), so everything else sees one stream's order
 int rh_join_batches(rh_cloud *c)
 {
     for (int i = 0; i < RH_MAX_IN_FLIGHT - 1; i++) {
@@ -697,6 +697,8 @@ static int enter(rh_cloud *c)
     RH_TRY(enter_nojoin(c));
     return rh_join_batches(c);
 }
+
+int rh_cloud_join(rh_cloud *c) { return enter(c); }
 
 extern "C" int rh_cloud_set_enabled(rh_cloud *c, const uint64_t *chunks, int64_t nchunks)
 {

@@ -158,8 +158,13 @@ extern "C" int rh_set_option(rh_cloud *c, const char *key, int64_t value)
         rh_set_error("rh_set_option: 'score_path' is fixed when a cloud is created (its point order depends on it): set it process-wide (cloud = NULL) before rh_cloud_create");
         return RH_E_INVALID;
     }
-    if (c != nullptr) c->opt[d->id] = value;
-    else g_opt[d->id] = value;
+    if (c != nullptr) {
+        // (a cloud with batches in flight: the number of streams they take turns on must not change under them)
+        if (d->id == RH_OPT_BATCHES_IN_FLIGHT) { const int rc = rh_cloud_join(c); if (rc != RH_OK) return rc; }
+        c->opt[d->id] = value;
+    } else {
+        g_opt[d->id] = value;
+    }
     return RH_OK;
 }
 

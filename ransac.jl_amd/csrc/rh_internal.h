@@ -462,6 +462,7 @@ int32_t rh_spread_multiplier(int32_t b);   // t -> (t * m) mod b: a permutation 
 
 // ---- host helpers (cloud.hip) -----------------------------------------------
 int rh_ensure_batch(rh_cloud *c, int64_t b);
+int rh_cloud_join(rh_cloud *c);     // the same with the cloud's device made current first (options.cpp)
 int rh_join_batches(rh_cloud *c);   // the cloud's stream waits for the second batch slot ("batches_in_flight")
 int rh_ensure_masks(rh_cloud *c, int64_t words);
 int rh_ensure_pin(rh_cloud *c, int64_t bytes);
