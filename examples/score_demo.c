@@ -1,6 +1,6 @@
 /* score_demo.c -- the C ABI of libransac_hip.so used from plain C (no Python, no torch).
  * Builds a small synthetic cloud (a noisy plane patch + uniform outliers), scores two plane
- * candidates in one batch, refits the better one, invalidates its points and runs the whole
+ * candidates in one batch (host buffers, then resident buffers with batches in flight), refits the better one, invalidates its points and runs the whole
  * ransac() loop.  Build (done by __graft_entry__.build()):
  *   gcc -O2 -Iinclude examples/score_demo.c -Lransac.jl_amd -lransac_hip -lm -Wl,-rpath,$PWD/ransac.jl_amd -o examples/score_demo
  * Needs an MI355X to run; prints "score_demo ok" on success, the rh_last_error() text otherwise. */
@@ -53,6 +53,26 @@ int main(void)
     CHECK(rh_score_batch(c, cand, 2, &p, counts, NULL));
     printf("counts on subset 1: %d %d (of %lld)\n", counts[0], counts[1], (long long)(n / 2));
     if (counts[0] != n_plane / 2 || counts[1] > 50) { fprintf(stderr, "unexpected counts\n"); return 1; }
+
+    /* the same batch with resident buffers, three batches in flight (rh_set_option "batches_in_flight"): call k writes count
+     * buffer k mod 3; rh_cloud_sync (like every other call on the cloud) joins the streams */
+    {
+        void *d_cand = NULL, *d_cnt[3] = { NULL, NULL, NULL };
+        CHECK(rh_dev_alloc(c, sizeof cand, &d_cand));
+        CHECK(rh_dev_upload(c, d_cand, cand, sizeof cand));
+        for (int k = 0; k < 3; k++) CHECK(rh_dev_alloc(c, sizeof counts, &d_cnt[k]));
+        CHECK(rh_set_option(c, "batches_in_flight", 3));
+        for (int k = 0; k < 6; k++) CHECK(rh_score_batch_dev(c, (const rh_shape *)d_cand, 2, &p, (int32_t *)d_cnt[k % 3], NULL));
+        CHECK(rh_cloud_sync(c));
+        for (int k = 0; k < 3; k++) {
+            int32_t got[2];
+            CHECK(rh_dev_download(c, got, d_cnt[k], sizeof got));
+            if (got[0] != counts[0] || got[1] != counts[1]) { fprintf(stderr, "batches in flight: unexpected counts\n"); return 1; }
+            CHECK(rh_dev_free(c, d_cnt[k]));
+        }
+        CHECK(rh_set_option(c, "batches_in_flight", RH_OPTION_UNSET));
+        CHECK(rh_dev_free(c, d_cand));
+    }
 
     int64_t *idx = malloc(sizeof(int64_t) * n), n_in = 0, left = 0;
     CHECK(rh_refit(c, &cand[0], &p, idx, n, &n_in));
