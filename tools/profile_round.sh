@@ -72,11 +72,6 @@ fi
 S="$B --no-e2e --in-flight 1 --lists $LI --steps 3 --warmup 1 --prewarm-ms 0 --detail-out $OUT/pmc_detail$SFX.json"
 rocprofv3 --kernel-trace --pmc $SQ3 --output-format csv -d "$OUT/pmc_sq3$SFX" -- python3 $S > "$OUT/pmc_sq3$SFX.json" 2> "$OUT/pmc_sq3$SFX.err"
 echo "pmc sq3 done"
-if [ "$WHAT" = "stats" ]; then
-    for w in cfg2 cfg3 cfg5; do WL=$w python tools/s4_stats.py > "$OUT/s4_stats_$w.log" 2>&1; cp gpurun_out/s4_stats_$w.json "$OUT/"; echo "stats $w done"; done
-    timeout -k 10 300 tools/ubench/count_seq > "$OUT/ubench_count_seq.txt" 2>&1
-    echo "ubench done"; exit 0
-fi
 if [ "$ONLY" = "sq3" ]; then find "$OUT" -name '*kernel_trace.csv' -delete; exit 0; fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch$SFX" -- python3 $S > "$OUT/pmc_fetch$SFX.json" 2> "$OUT/pmc_fetch$SFX.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write$SFX" -- python3 $S > "$OUT/pmc_write$SFX.json" 2> "$OUT/pmc_write$SFX.err"
