@@ -31,14 +31,17 @@ def canned(big=True):
         "ms_per_step": 0.09391234567, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg3: 10M-point 40-primitive cloud, 30% outliers, r=32 subsets, B=4096 candidates/GPU/step",
                    "points": 10_000_000, "subset_points": 312500, "candidates_per_step": 4096, "kinds": PROSE, "score_mode": "f64",
-                   "prewarm_ms": 40.0, "parallelism": "candidate-sharded x1, int32 sum all-reduce"},
+                   "prewarm_ms": 40.0, "batches_in_flight": 3, "score_rows": 12, "score_lists": True,
+                   "parallelism": "candidate-sharded x1, int32 sum all-reduce"},
         "tests_per_sec": 1.36e13, "rccl_ranks_seen": 1, "collective_backend": None, "collective_issued_by": None,
         "roofline": {"kernel": "score4_kernel (plane+sphere+cylinder in one launch)", "bound": "valu_issue", "achieved": 1.3e12,
                      "peak": 2.4576e12, "unit": "SIMD vector-issue cycles/s", "frac": 0.53123456, "frac_upper": 0.712345, "traffic": 27.7e6, "ms_per_launch": 0.0904,
+                     "frac_over_step_in_flight": 0.80123, "frac_necessary_over_step_in_flight": 0.5112, "list_launch_ms": 0.0088,
                      "counters": "replayed:profiles/r3", "replayed_from": [PROSE, PROSE], "note": PROSE,
                      "effective_algorithmic": {"GBs": 658000.0, "note": PROSE}},
         "cpu_baseline": {"value": 61.2, "unit": "candidates/s", "cores": 1, "kind": "port", "sample": PROSE, "host_cpus": 128},
         "cpu_baseline_mt": {"value": 900.0, "cores": 16, "sample": PROSE}, "oracle_checked": 4096,
+        "one_batch_in_flight": {"ms_per_step": 0.0866, "value": 4.7e7, "note": PROSE},
         "masks_out": {"ms_per_step": 0.166, "note": PROSE}, "pcie_inclusive": {"ms_per_step": 0.31, "note": PROSE},
         "roofline_refit": {"kernel": "refit_mask_kernel<plane>", "achieved": 6600.0, "frac": 0.825, "ms_per_launch": 0.0729, "note": PROSE},
         "refit_culled": {"ms_per_refit_scan": 0.021, "note": PROSE}, "float32": {"ms_per_step": 0.111, "note": PROSE},
@@ -112,3 +115,14 @@ def test_detail_file_round_trips(tmp_path):
     p = str(tmp_path / "d.json")
     b.write_detail(out, p)
     assert json.load(open(p)) == out
+
+
+def test_line_carries_the_batches_in_flight_and_the_list_launch(tmp_path):
+    """round 5: the line says how many batches were in flight, whether the score launch walked super-tile lists, what one
+    batch at a time costs, and the fractions over the timed step next to those of the launch on its own"""
+    b = _bench()
+    line = json.loads(b.compact_line(canned(), str(tmp_path / "bench_detail.json")))
+    assert line["batches_in_flight"] == 3 and line["score_lists"] is True
+    assert abs(line["one_batch_in_flight_ms"] - 0.0866) < 1e-9
+    rf = line["roofline"]
+    assert abs(rf["frac_over_step_in_flight"] - 0.8012) < 1e-3 and abs(rf["frac_necessary_over_step_in_flight"] - 0.5112) < 1e-3

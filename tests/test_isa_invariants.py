@@ -78,3 +78,19 @@ def test_score_kernel_register_budget(isa):
             assert v["vgpr_spill"] <= 24, (key, v)
         if not lst and not tail:   # the scalar registers of the plain sized launches stay in registers
             assert v["sgpr_spill"] <= 12, (key, v)
+
+
+def test_accounting_tool_finds_the_regions_of_both_instantiations(isa):
+    """tools/isa_account.py cuts the kernel's ISA into regions by LLVM's loop annotations: the four per-kind batch loops, their
+    point loops, the chunk visits in front of them.  Both forms of the timed launch (rows in bin order / rows walking super-tile
+    lists) must parse: the round's roofline object is built on it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_account as ia
+    for rows, lists in ((12, False), (12, True), (16, True), (2, False)):
+        sym, text = ia.kernel_text(isa, rows, lists=lists)
+        assert ("ELb1EE" in sym) == lists
+        reg = ia.regions(ia.parse_blocks(text), rows)
+        for kind in ("plane", "sphere", "cylinder", "cone"):
+            for part in ("visit_test_%s", "pl_%s", "batch_%s", "stage_%s"):
+                assert sum(len(b.ins) for b in reg[part % kind]) > 0, (rows, lists, part % kind)
+        assert sum(len(b.ins) for b in reg["prologue"]) > 0

@@ -131,3 +131,40 @@ def test_lists_with_batches_in_flight_at_full_size():
         C.memmove(C.byref(sub_arr[j]), C.byref(arr[int(i)]), C.sizeof(L.Shape))
     assert np.array_equal(oc.score_batch(sub_arr, orc.Params.from_buffer_copy(bytes(cp))), outs[None][sel])
     batch.free()
+
+
+def test_launch_info_and_the_list_launch_time():
+    """rh_score_launch_info names the last sized launch (rows, lists, grid); rh_score_batch_dev_timed times the score launch
+    alone and rh_last_list_launch_ms the list launch in front of it (0 when the launch took no lists)"""
+    from ransac_jl_amd import dist as rdist
+    n = 200_000
+    xyz, nrm, truth = synth.make_cloud(n, ["plane", "sphere", "cylinder"], 0.2, seed=2)
+    subs = synth.make_subsets(n, 2, seed=2)             # 100 000 subset points: 1563 groups, 391 tiles, 98 super-tiles
+    pc = R.RANSACCloud(xyz, nrm, subs)
+    cp = R.params_to_c(R.ransacparameters([R.FittedPlane, R.FittedSphere, R.FittedCylinder]))
+    b = 2048
+    arr = _cands(truth, b, seed=1)
+    batch = rdist.DeviceBatch(pc, arr, b)
+    lib = R.lib()
+    d_cn = C.c_void_p()
+    L.check(lib.rh_dev_alloc(pc._h, 4 * b, C.byref(d_cn)))
+    got = {}
+    for mode in (2, 1):
+        with R.option("st_cull", mode, cloud=pc):
+            ms = (C.c_float * 5)()
+            ms[0] = -1.0
+            L.check(lib.rh_score_batch_dev_timed(pc._h, batch.slice_ptr(0), b, C.byref(cp), d_cn, None, ms))
+            info = (C.c_int32 * 4)()
+            L.check(lib.rh_score_launch_info(pc._h, info))
+            lm = C.c_float()
+            L.check(lib.rh_last_list_launch_ms(pc._h, C.byref(lm)))
+            cn = np.zeros(b, dtype=np.int32)
+            L.check(lib.rh_dev_download(pc._h, cn.ctypes.data_as(C.c_void_p), d_cn, 4 * b))
+            got[mode] = (list(info), lm.value, ms[4], cn)
+    assert got[2][0][1] == 0 and got[1][0][1] == 1                       # lists off / on
+    assert got[2][0][3] == got[1][0][3] == (100_000 + 255) // 256        # tiles
+    assert got[2][0][0] in (2, 4, 8, 12, 16) and got[2][0][2] >= 1       # rows of R chunks
+    assert got[2][1] == 0.0 and got[1][1] > 0.0 and got[1][2] > 0.0 and got[2][2] > 0.0
+    assert np.array_equal(got[1][3], got[2][3])
+    lib.rh_dev_free(pc._h, d_cn)
+    batch.free()
